@@ -1,0 +1,57 @@
+"""Counter-based AWGN generator used in the library's *performance* noise mode, restated
+for the oracle (the reference's ``randn`` at basicRadarChannel.m:68 is MATLAB's
+mt19937ar+ziggurat stream and is not reproducible outside MATLAB -- SURVEY.md A.7).
+
+Philox4x32-10 (Salmon et al., SC'11; Random123 constants), one call per complex
+sample:  counter = (e_lo, e_hi, stream, 0) with e = t + T*a the column-major element
+index of rxWaveform(t, a);  key = (seed_lo, seed_hi).  Box-Muller on two 53-bit
+uniforms gives independent N(0,1) real and imaginary parts.
+TEST INFRASTRUCTURE ONLY.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M0 = np.uint64(0xD2511F53)
+_M1 = np.uint64(0xCD9E8D57)
+_W0 = np.uint32(0x9E3779B9)
+_W1 = np.uint32(0xBB67AE85)
+_MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10.  All inputs broadcastable uint32 arrays."""
+    c0 = np.asarray(c0, dtype=np.uint32).copy()
+    c1 = np.asarray(c1, dtype=np.uint32).copy()
+    c2 = np.asarray(c2, dtype=np.uint32).copy()
+    c3 = np.asarray(c3, dtype=np.uint32).copy()
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = np.uint32(k0)
+    k1 = np.uint32(k1)
+    with np.errstate(over="ignore"):
+        for r in range(10):
+            p0 = _M0 * c0.astype(np.uint64)
+            p1 = _M1 * c2.astype(np.uint64)
+            hi0 = (p0 >> np.uint64(32)).astype(np.uint32)
+            lo0 = (p0 & _MASK).astype(np.uint32)
+            hi1 = (p1 >> np.uint64(32)).astype(np.uint32)
+            lo1 = (p1 & _MASK).astype(np.uint32)
+            c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+            k0 = np.uint32((int(k0) + int(_W0)) & 0xFFFFFFFF)
+            k1 = np.uint32((int(k1) + int(_W1)) & 0xFFFFFFFF)
+    return c0, c1, c2, c3
+
+
+def philox_normal_pairs(elem_index, seed: int, stream: int = 0) -> np.ndarray:
+    """Complex N(0,1)+jN(0,1) sample for each 64-bit element index."""
+    e = np.asarray(elem_index, dtype=np.uint64)
+    x0, x1, x2, x3 = philox4x32_10((e & _MASK).astype(np.uint32), (e >> np.uint64(32)).astype(np.uint32),
+                                   np.uint32(stream), np.uint32(0),
+                                   np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
+    w0 = x0.astype(np.uint64) | (x1.astype(np.uint64) << np.uint64(32))
+    w1 = x2.astype(np.uint64) | (x3.astype(np.uint64) << np.uint64(32))
+    u1 = ((w0 >> np.uint64(11)).astype(np.float64) + 1.0) * 2.0 ** -53      # (0, 1]
+    u2 = (w1 >> np.uint64(11)).astype(np.float64) * 2.0 ** -53              # [0, 1)
+    r = np.sqrt(-2.0 * np.log(u1))
+    ang = 2.0 * np.pi * u2
+    return r * np.cos(ang) + 1j * (r * np.sin(ang))
