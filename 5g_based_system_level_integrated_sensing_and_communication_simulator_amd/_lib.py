@@ -1,0 +1,223 @@
+"""ctypes binding of libisac_hip.so (C ABI: include/isac.h).  Fails loudly when the
+HIP library is missing -- there is deliberately no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libisac_hip.so")
+_lib = None
+_lock = threading.Lock()
+
+ISAC_MAX_EST = 1024
+NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
+
+STATUS_NAMES = {0: "OK", 1: "INVALID_ARG", 2: "HIP", 3: "NO_LOS", 4: "NO_DETECTION", 5: "CFAR_WINDOW",
+                6: "CAPACITY", 7: "UNSUPPORTED", 8: "SHORT_WAVEFORM"}
+
+
+class IsacError(RuntimeError):
+    """Raised for every non-zero isac_status; ``.code`` / ``.name`` carry the status.
+
+    The reference's caller wraps fft2D in try/catch and maps any error to
+    ``senResults = NaN`` (cellSimulation.m:196-202); callers here keep that convention
+    by catching IsacError."""
+
+    def __init__(self, code: int, message: str):
+        self.code = int(code)
+        self.name = STATUS_NAMES.get(int(code), str(code))
+        super().__init__(f"isac[{self.name}]: {message}")
+
+
+class c64(C.Structure):
+    _fields_ = [("re", C.c_double), ("im", C.c_double)]
+
+
+class Carrier(C.Structure):
+    _fields_ = [("n_sc", C.c_int32), ("nfft", C.c_int32), ("scs_khz", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RadarChannelParams(C.Structure):
+    _fields_ = [("fc", C.c_double), ("fs", C.c_double), ("n0", C.c_double), ("n_ants", C.c_int32),
+                ("n_targets", C.c_int32), ("range", C.POINTER(C.c_double)), ("velocity", C.POINTER(C.c_double)),
+                ("large_scale_fading", C.POINTER(C.c_double)), ("rx_steering", C.c_void_p)]
+
+
+class CfarConfig(C.Structure):
+    _fields_ = [("pfa", C.c_double), ("guard", C.c_int32 * 2), ("train", C.c_int32 * 2),
+                ("row0", C.c_int32), ("row1", C.c_int32), ("col0", C.c_int32), ("col1", C.c_int32)]
+
+
+class EstParams(C.Structure):
+    _fields_ = [("n_ifft", C.c_int32), ("n_fft", C.c_int32), ("r_res", C.c_double), ("v_res", C.c_double),
+                ("array_is_upa", C.c_int32), ("n_ants_x", C.c_int32), ("n_ants_y", C.c_int32),
+                ("azimuth_scan_scale", C.c_double), ("azimuth_scan_granularity", C.c_double),
+                ("elevation_scan_scale", C.c_double), ("elevation_scan_granularity", C.c_double)]
+
+
+class EstResult(C.Structure):
+    _fields_ = [("n_rng", C.c_int32), ("n_vel", C.c_int32), ("n_azi", C.c_int32), ("num_dets", C.c_int32),
+                ("total_detections", C.c_int32), ("reserved", C.c_int32),
+                ("rng_est", C.c_double * ISAC_MAX_EST), ("vel_est", C.c_double * ISAC_MAX_EST),
+                ("azi_est", C.c_double * ISAC_MAX_EST), ("ele_est", C.c_double * ISAC_MAX_EST)]
+
+
+# every symbol include/isac.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "isac_abi_version", "isac_device_count", "isac_ctx_create", "isac_ctx_destroy", "isac_last_error",
+    "isac_ctx_get_stream", "isac_sync", "isac_dev_alloc", "isac_dev_free", "isac_memcpy_h2d", "isac_memcpy_d2h",
+    "isac_memset_dev", "isac_timer_start", "isac_timer_stop_ms",
+    "isac_basic_radar_channel_dev", "isac_basic_radar_channel", "isac_mono_static_sensing_dev",
+    "isac_mono_static_sensing", "isac_ofdm_symbol_count", "isac_ofdm_demodulate_dev", "isac_ofdm_modulate_dev",
+    "isac_ofdm_waveform_length", "isac_cfar2d_ca", "isac_fft2d_dev", "isac_fft2d", "isac_fft2d_get_detections",
+    "isac_fft2d_get_power_window", "isac_fft2d_get_covariance", "isac_fft2d_get_music_spectrum",
+    "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_eigh", "isac_synth_qpsk_grid_dev",
+]
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load libisac_hip.so once.  torch (if installed) is imported first so that both share one
+    HIP runtime (same SONAME libamdhip64.so.7); loading order the other way round would map two."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the sensing hot path.")
+        if "torch" not in sys.modules and os.environ.get("ISAC_NO_TORCH_PRELOAD") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
+        lib = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+        lib.isac_last_error.restype = C.c_char_p
+        for name in EXPORTS:
+            fn = getattr(lib, name)  # AttributeError here = ABI drift between isac.h and the .so
+            if name != "isac_last_error":
+                fn.restype = C.c_int
+        _lib = lib
+        return lib
+
+
+def _np_ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceArray:
+    """Column-major array resident in HBM, owned by a Context (freed with it or via .free())."""
+
+    def __init__(self, ctx: "Context", ptr: int, shape, dtype, owner: bool = True):
+        self.ctx, self.ptr, self.shape, self.dtype, self._owner = ctx, int(ptr), tuple(int(s) for s in shape), np.dtype(dtype), owner
+
+    @property
+    def nbytes(self) -> int:
+        return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=self.dtype, order="F")
+        self.ctx.check(self.ctx.lib.isac_memcpy_d2h(self.ctx.handle, _np_ptr(out), C.c_void_p(self.ptr), C.c_size_t(self.nbytes)))
+        return out
+
+    def free(self):
+        if self._owner and self.ptr:
+            self.ctx.lib.isac_dev_free(self.ctx.handle, C.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            if self.ctx.handle:
+                self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One device + one HIP stream + scratch (isac_ctx).  Not thread-safe."""
+
+    def __init__(self, device: int | None = None):
+        self.lib = load()
+        if device is None:
+            device = int(os.environ.get("ISAC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = C.c_int(0)
+        st = self.lib.isac_device_count(C.byref(n))
+        if st != 0 or n.value <= 0:
+            raise IsacError(2, "no HIP device visible: the sensing hot path needs an MI355X (no CPU fallback)")
+        h = C.c_void_p()
+        st = self.lib.isac_ctx_create(C.c_int(device % n.value), C.byref(h))
+        if st != 0:
+            raise IsacError(st, f"isac_ctx_create(device={device}) failed")
+        self.handle = h
+        self.device = device % n.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.isac_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, status: int):
+        if status != 0:
+            raise IsacError(status, (self.lib.isac_last_error(self.handle) or b"").decode())
+
+    def sync(self):
+        self.check(self.lib.isac_sync(self.handle))
+
+    def stream(self) -> int:
+        s = C.c_void_p()
+        self.check(self.lib.isac_ctx_get_stream(self.handle, C.byref(s)))
+        return int(s.value or 0)
+
+    def empty(self, shape, dtype=np.complex128) -> DeviceArray:
+        dt = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+        p = C.c_void_p()
+        self.check(self.lib.isac_dev_alloc(self.handle, C.c_size_t(nbytes), C.byref(p)))
+        return DeviceArray(self, p.value, shape, dt)
+
+    def to_device(self, a: np.ndarray) -> DeviceArray:
+        a = np.asfortranarray(a)
+        d = self.empty(a.shape, a.dtype)
+        self.check(self.lib.isac_memcpy_h2d(self.handle, C.c_void_p(d.ptr), _np_ptr(a), C.c_size_t(a.nbytes)))
+        return d
+
+    def timer_start(self):
+        self.check(self.lib.isac_timer_start(self.handle))
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_double(0)
+        self.check(self.lib.isac_timer_stop_ms(self.handle, C.byref(ms)))
+        return ms.value
+
+
+_default_ctx = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+def as_f64(x) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+
+
+def as_c128_f(x) -> np.ndarray:
+    return np.asfortranarray(np.asarray(x, dtype=np.complex128))

@@ -1,0 +1,652 @@
+// C ABI of libisac_hip.so: context, tables, host glue of the fft2D pipeline (gfx950 only).
+// Declarations and the reference functions each entry point replaces: include/isac.h.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <numeric>
+
+#include "isac_common.hpp"
+
+using namespace isac;
+
+// kernels / stages implemented in the other translation units
+int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, const c64* d_rx, const c64* d_tx,
+                          int K, int L, int A, int* nr_out, int* nc_out);
+int isac_cfar_window(isac_ctx* ctx, const isac_cfar_config* cf, int nr, int nc, int A, int cap);
+int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A);
+int isac_music_scan_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num_dets_host, const double* d_sind, int n_steps,
+                        double d_ratio, double* d_spec);
+
+namespace {
+
+// ---- host math mirrors of the MATLAB helpers the reference calls (product code, not the oracle)
+double bessel_i0(double x) {  // power series, converges to < 1 ulp for |x| <= 10
+  double q = 0.25 * x * x, term = 1.0, sum = 1.0;
+  for (int k = 1; k < 200; ++k) {
+    term *= q / ((double)k * (double)k);
+    sum += term;
+    if (term < 1e-18 * sum) break;
+  }
+  return sum;
+}
+
+std::vector<double> kaiser_window(int n, double beta) {  // Signal Processing Toolbox kaiser(n, beta); fft2D.m:135
+  std::vector<double> w((size_t)n, 1.0);
+  if (n == 1) return w;
+  const int odd = n % 2;
+  const double xind = (double)(n - 1) * (double)(n - 1);
+  const int half = (n + 1) / 2;
+  const double den = bessel_i0(std::fabs(beta));
+  std::vector<double> h((size_t)half);
+  for (int i = 0; i < half; ++i) {
+    double xi = (double)i + 0.5 * (1 - odd);
+    xi = 4.0 * xi * xi;
+    h[(size_t)i] = std::fabs(bessel_i0(std::fabs(beta) * std::sqrt(1.0 - xi / xind)) / den);
+  }
+  // w = [h(half:-1:odd+1) h]
+  int o = 0;
+  for (int i = half - 1; i >= odd; --i) w[(size_t)o++] = h[(size_t)i];
+  for (int i = 0; i < half; ++i) w[(size_t)o++] = h[(size_t)i];
+  return w;
+}
+
+double sind_deg(double x) {  // degree-domain reduction: exact at multiples of 90, sind(180-p) == sind(p) bitwise
+  x = std::fmod(x, 360.0);
+  if (x > 180.0) x -= 360.0;
+  if (x < -180.0) x += 360.0;
+  if (x > 90.0) x = 180.0 - x;
+  if (x < -90.0) x = -180.0 - x;
+  const double ax = std::fabs(x);
+  const double k = M_PI / 180.0;
+  if (ax <= 45.0) return std::sin(x * k);
+  const double c = std::cos((90.0 - ax) * k);
+  return x < 0 ? -c : c;
+}
+
+// findpeaks(y,'NPeaks',L,'SortStr','descend'): strict maxima, first sample of plateaus, no end points,
+// stable descending sort (music.m:102).  Returns 0-based locations.
+std::vector<int> findpeaks_desc(const std::vector<double>& y, int npeaks) {
+  std::vector<int> idx;
+  const int n = (int)y.size();
+  for (int i = 0; i < n; ++i)
+    if (i == 0 || y[(size_t)i] != y[(size_t)i - 1]) idx.push_back(i);
+  std::vector<int> locs;
+  for (size_t k = 1; k + 1 < idx.size(); ++k) {
+    double a = y[(size_t)idx[k - 1]], b = y[(size_t)idx[k]], c = y[(size_t)idx[k + 1]];
+    if (b > a && b > c) locs.push_back(idx[k]);
+  }
+  std::stable_sort(locs.begin(), locs.end(), [&](int p, int q) { return y[(size_t)p] > y[(size_t)q]; });
+  if ((int)locs.size() > npeaks) locs.resize((size_t)npeaks);
+  return locs;
+}
+
+int determine_num_targets(const std::vector<double>& v_ascending) {  // music.m:109-125 (on eig()'s ascending order)
+  const int n = (int)v_ascending.size() - 1;
+  if (n < 1) return 1;
+  std::vector<double> delta((size_t)n);
+  for (int i = 0; i < n; ++i) delta[(size_t)i] = -(v_ascending[(size_t)i + 1] - v_ascending[(size_t)i]);
+  const int start = (int)std::ceil((n + 1) / 2.0) - 1;
+  double sum = 0.0;
+  for (int i = start; i < n; ++i) sum += delta[(size_t)i];
+  const double half_mean = sum / (double)(n - start);
+  int best = 0;
+  double bv = delta[0] - 2.0 * half_mean;
+  for (int i = 1; i < n; ++i) {
+    double v = delta[(size_t)i] - 2.0 * half_mean;
+    if (v > bv) { bv = v; best = i; }
+  }
+  return best + 1;
+}
+
+int upload(isac_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+  ISAC_TRY(ensure(ctx, b, bytes));
+  ISAC_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  return ISAC_OK;
+}
+
+int scan_steps(const isac_est_params* ep) {
+  return (int)std::floor((ep->azimuth_scan_scale + 1.0) / ep->azimuth_scan_granularity);   // music.m:79
+}
+
+int get_sind_table(isac_ctx* ctx, const isac_est_params* ep, const double** out, int* n_steps) {
+  isac_ctx& t = *ctx;
+  auto key = std::make_pair((long long)std::llround(ep->azimuth_scan_scale * 1e6),
+                            (long long)std::llround(ep->azimuth_scan_granularity * 1e6));
+  const int n = scan_steps(ep);
+  if (n <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "empty azimuth scan");
+  auto it = t.sind.find(key);
+  if (it == t.sind.end()) {
+    std::vector<double> s((size_t)n);
+    for (int a = 0; a < n; ++a) s[(size_t)a] = sind_deg(a * ep->azimuth_scan_granularity - ep->azimuth_scan_scale / 2.0);   // music.m:88
+    DevBuf b;
+    ISAC_TRY(upload(ctx, b, s.data(), sizeof(double) * s.size()));
+    it = t.sind.emplace(key, b).first;
+  }
+  *out = (const double*)it->second.p;
+  *n_steps = n;
+  return ISAC_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ tables shared with the other TUs
+int isac_get_twiddles(isac_ctx* ctx, int n, const c64** out) {
+  isac_ctx& t = *ctx;
+  auto it = t.twiddles.find(n);
+  if (it == t.twiddles.end()) {
+    std::vector<c64> w((size_t)n);
+    for (int m = 0; m < n; ++m) {
+      // exact octant reduction in long double, rounded once
+      long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)n;
+      w[(size_t)m] = mk((double)cosl(ang), (double)sinl(ang));
+    }
+    // exact values on the axes
+    w[0] = mk(1.0, 0.0);
+    if (n % 4 == 0) { w[(size_t)n / 4] = mk(0.0, -1.0); w[(size_t)n / 2] = mk(-1.0, 0.0); w[(size_t)3 * n / 4] = mk(0.0, 1.0); }
+    DevBuf b;
+    ISAC_TRY(upload(ctx, b, w.data(), sizeof(c64) * w.size()));
+    it = t.twiddles.emplace(n, b).first;
+  }
+  *out = (const c64*)it->second.p;
+  return ISAC_OK;
+}
+int isac_get_twiddles2(isac_ctx* ctx, int n, const c64** out) { return isac_get_twiddles(ctx, n, out); }
+
+int isac_get_windows(isac_ctx* ctx, int K, int n_ifft, const double** win_k, const double** win_r) {
+  isac_ctx& t = *ctx;
+  auto get = [&](int n, int shifted, const double** out) -> int {
+    auto key = std::make_pair(n, shifted);
+    auto it = t.kaiser3.find(key);
+    if (it == t.kaiser3.end()) {
+      std::vector<double> w = kaiser_window(n, 3.0);            // fft2D.m:135 'kaiser', beta = 3
+      if (shifted) {                                            // fftshift: out[i] = in[(i + ceil(n/2)) mod n]
+        std::vector<double> s((size_t)n);
+        const int sh = (n + 1) / 2;
+        for (int i = 0; i < n; ++i) s[(size_t)i] = w[(size_t)((i + sh) % n)];
+        w.swap(s);
+      }
+      DevBuf b;
+      ISAC_TRY(upload(ctx, b, w.data(), sizeof(double) * w.size()));
+      it = t.kaiser3.emplace(key, b).first;
+    }
+    *out = (const double*)it->second.p;
+    return ISAC_OK;
+  };
+  ISAC_TRY(get(K, 0, win_k));
+  ISAC_TRY(get(n_ifft, 1, win_r));
+  return ISAC_OK;
+}
+
+// ------------------------------------------------------------------ context
+extern "C" int isac_abi_version(void) { return ISAC_ABI_VERSION; }
+
+extern "C" int isac_device_count(int* count) {
+  if (!count) return ISAC_ERR_INVALID_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return ISAC_ERR_HIP; }
+  *count = n;
+  return ISAC_OK;
+}
+
+extern "C" int isac_ctx_create(int device, isac_ctx** out) {
+  if (!out) return ISAC_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return ISAC_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return ISAC_ERR_HIP;
+  isac_ctx* ctx = new isac_ctx();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreate(&ctx->ev_t0) != hipSuccess || hipEventCreate(&ctx->ev_t1) != hipSuccess) {
+    delete ctx;
+    return ISAC_ERR_HIP;
+  }
+  *out = ctx;
+  return ISAC_OK;
+}
+
+extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  hipStreamSynchronize(ctx->stream2);
+  for (auto& kv : ctx->twiddles) hipFree(kv.second.p);
+  for (auto& kv : ctx->kaiser3) hipFree(kv.second.p);
+  for (auto& kv : ctx->sind) hipFree(kv.second.p);
+  DevBuf* bufs[] = {&ctx->beam, &ctx->coef, &ctx->phase_rx, &ctx->steer,
+                    &ctx->ymid, &ctx->pwin, &ctx->flags, &ctx->det_cut, &ctx->det_pow, &ctx->det_cnt, &ctx->cov_part,
+                    &ctx->cov, &ctx->eig_w, &ctx->eig_v, &ctx->spec, &ctx->misc, &ctx->stage_a, &ctx->stage_b,
+                    &ctx->stage_c, &ctx->sind_tab};
+  for (DevBuf* b : bufs)
+    if (b->p) hipFree(b->p);
+  if (ctx->pinned) hipHostFree(ctx->pinned);
+  hipEventDestroy(ctx->ev_fork);
+  hipEventDestroy(ctx->ev_join);
+  hipEventDestroy(ctx->ev_t0);
+  hipEventDestroy(ctx->ev_t1);
+  hipStreamDestroy(ctx->stream);
+  hipStreamDestroy(ctx->stream2);
+  delete ctx;
+  return ISAC_OK;
+}
+
+extern "C" const char* isac_last_error(const isac_ctx* ctx) { return ctx ? ctx->err.c_str() : "NULL context"; }
+
+extern "C" int isac_ctx_get_stream(isac_ctx* ctx, void** hip_stream) {
+  if (!ctx || !hip_stream) return ISAC_ERR_INVALID_ARG;
+  *hip_stream = (void*)ctx->stream;
+  return ISAC_OK;
+}
+
+extern "C" int isac_sync(isac_ctx* ctx) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream2));
+  return ISAC_OK;
+}
+
+extern "C" int isac_dev_alloc(isac_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return ISAC_ERR_INVALID_ARG;
+  ISAC_HIP(hipSetDevice(ctx->device));
+  ISAC_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+  return ISAC_OK;
+}
+extern "C" int isac_dev_free(isac_ctx* ctx, void* dptr) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!dptr) return ISAC_OK;
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  ISAC_HIP(hipFree(dptr));
+  return ISAC_OK;
+}
+extern "C" int isac_memcpy_h2d(isac_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+  if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return ISAC_ERR_INVALID_ARG;
+  ISAC_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  return ISAC_OK;
+}
+extern "C" int isac_memcpy_d2h(isac_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+  if (!ctx || (!dst_host && bytes) || (!src_dev && bytes)) return ISAC_ERR_INVALID_ARG;
+  ISAC_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  return ISAC_OK;
+}
+extern "C" int isac_memset_dev(isac_ctx* ctx, void* dst_dev, int value, size_t bytes) {
+  if (!ctx || (!dst_dev && bytes)) return ISAC_ERR_INVALID_ARG;
+  ISAC_HIP(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+  return ISAC_OK;
+}
+extern "C" int isac_timer_start(isac_ctx* ctx) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_HIP(hipEventRecord(ctx->ev_t0, ctx->stream));
+  return ISAC_OK;
+}
+extern "C" int isac_timer_stop_ms(isac_ctx* ctx, double* elapsed_ms) {
+  if (!ctx || !elapsed_ms) return ISAC_ERR_INVALID_ARG;
+  ISAC_HIP(hipEventRecord(ctx->ev_t1, ctx->stream));
+  ISAC_HIP(hipEventSynchronize(ctx->ev_t1));
+  float ms = 0.f;
+  ISAC_HIP(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
+  *elapsed_ms = (double)ms;
+  return ISAC_OK;
+}
+
+// ------------------------------------------------------------------ fft2D pipeline
+namespace {
+
+__global__ void pack_kernel(const int* __restrict__ det_cnt, const int* __restrict__ det_cut, const double* __restrict__ det_pow,
+                            const int* __restrict__ num_dets, int A, int cap, int* __restrict__ hdr /* [3 + A+1] */,
+                            int* __restrict__ full_cut, double* __restrict__ full_pow, int pack_first,
+                            int* __restrict__ first_cut, double* __restrict__ first_pow, const double* __restrict__ spec,
+                            int n_steps, double* __restrict__ spec_out) {
+  __shared__ int s_off[1025];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    int acc = 0, over = 0;
+    for (int a = 0; a < A; ++a) {
+      s_off[a] = acc;
+      int c = det_cnt[a];
+      over |= c > cap;
+      acc += c < cap ? c : cap;
+    }
+    s_off[A] = acc;
+    hdr[0] = acc;
+    hdr[1] = *num_dets;
+    hdr[2] = over;
+  }
+  __syncthreads();
+  for (int a = tid; a <= A; a += blockDim.x) hdr[3 + a] = s_off[a];
+  for (int i = tid; i < n_steps; i += blockDim.x) spec_out[i] = spec[i];
+  for (int a = 0; a < A; ++a) {
+    const int n = s_off[a + 1] - s_off[a];
+    for (int i = tid; i < n; i += blockDim.x) {
+      const int o = s_off[a] + i;
+      const int c = det_cut[(long long)a * cap + i];
+      const double p = det_pow[(long long)a * cap + i];
+      full_cut[o] = c;
+      full_pow[o] = p;
+      if (o < pack_first) { first_cut[o] = c; first_pow[o] = p; }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int isac_fft2d_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
+                              const isac_c64* d_rx_grid, const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A,
+                              isac_est_result* out) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!ep || !cfar || !d_rx_grid || !d_tx_grid || !out) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (K <= 0 || L <= 0 || A <= 0 || A > 1024) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad grid dimensions");
+  if (ep->n_ifft < K || (ep->n_ifft & (ep->n_ifft - 1)) || ep->n_fft <= 0 || (ep->n_fft & (ep->n_fft - 1)))
+    return fail(ctx, ISAC_ERR_INVALID_ARG, "nIFFT/nFFT must be powers of two with nIFFT >= K");
+  std::memset(out, 0, sizeof(*out));
+  ctx->last.valid = false;
+  const c64* rx = (const c64*)d_rx_grid;
+  const c64* tx = (const c64*)d_tx_grid;
+  int nr = 0, nc = 0;
+  ISAC_TRY(isac_rdm_power_window(ctx, ep, cfar, rx, tx, K, L, A, &nr, &nc));          // fft2D.m:37-46,61
+  const int n_cut_rows = cfar->row1 - cfar->row0 + 1, n_cut_cols = cfar->col1 - cfar->col0 + 1;
+  const long long n_cut = (long long)n_cut_rows * n_cut_cols;
+  const int cap = (int)std::min<long long>(n_cut, 4096);
+  ISAC_TRY(isac_cfar_window(ctx, cfar, nr, nc, A, cap));                                 // fft2D.m:62
+  // MUSIC branch: covariance -> eig -> scan with numDets taken from the device counter
+  ISAC_TRY(ensure(ctx, ctx->cov, sizeof(c64) * (size_t)A * A));
+  ISAC_TRY(isac_covariance_dev(ctx, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
+  const bool upa = ep->array_is_upa != 0;
+  int n_steps = 0;
+  const double* d_sind = nullptr;
+  if (!upa) {
+    ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A));                             // music.m:19
+    ISAC_TRY(get_sind_table(ctx, ep, &d_sind, &n_steps));
+    ISAC_TRY(ensure(ctx, ctx->spec, sizeof(double) * (size_t)n_steps));
+    ISAC_TRY(isac_music_scan_dev(ctx, A, (const int*)ctx->misc.p, 0, d_sind, n_steps, 0.5, (double*)ctx->spec.p));   // music.m:12,82-91
+  }
+  // pack + one device->host copy
+  const int pack_first = 4096;
+  const size_t hdr_ints = 3 + (size_t)A + 1;
+  const size_t off_spec = (hdr_ints * sizeof(int) + 15) & ~(size_t)15;
+  const size_t off_pow = off_spec + sizeof(double) * (size_t)(n_steps > 0 ? n_steps : 1);
+  const size_t off_cut = off_pow + sizeof(double) * (size_t)pack_first;
+  const size_t first_bytes = off_cut + sizeof(int) * (size_t)pack_first;
+  const size_t pack_cap = (size_t)A * cap;
+  const size_t full_bytes = off_pow + (sizeof(double) + sizeof(int)) * pack_cap + 64;
+  ISAC_TRY(ensure(ctx, ctx->stage_a, full_bytes));
+  ISAC_TRY(ensure_pinned(ctx, full_bytes));
+  char* dbase = (char*)ctx->stage_a.p;
+  // layout on the device: [hdr][spec][pow first][cut first] ... then the tails of pow / cut beyond pack_first
+  double* d_ppow_first = (double*)(dbase + off_pow);
+  int* d_pcut_first = (int*)(dbase + off_cut);
+  // a second full-size region for the overflow case keeps the fast path one small copy
+  ISAC_TRY(ensure(ctx, ctx->stage_b, (sizeof(double) + sizeof(int)) * pack_cap + 64));
+  double* d_ppow_full = (double*)ctx->stage_b.p;
+  int* d_pcut_full = (int*)((char*)ctx->stage_b.p + sizeof(double) * pack_cap);
+  hipLaunchKernelGGL(pack_kernel, dim3(1), dim3(256), 0, ctx->stream, (const int*)ctx->det_cnt.p, (const int*)ctx->det_cut.p,
+                     (const double*)ctx->det_pow.p, (const int*)ctx->misc.p, A, cap, (int*)dbase, d_pcut_full, d_ppow_full,
+                     pack_first, d_pcut_first, d_ppow_first, (const double*)ctx->spec.p, n_steps, (double*)(dbase + off_spec));
+  ISAC_HIP(hipGetLastError());
+  char* h = (char*)ctx->pinned;
+  ISAC_HIP(hipMemcpyAsync(h, dbase, first_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  const int* hdr = (const int*)h;
+  const int total = hdr[0];
+  const int num_dets_dev = hdr[1];
+  if (hdr[2]) return fail(ctx, ISAC_ERR_CAPACITY, "an antenna produced more CFAR detections than the per-antenna capacity (4096)");
+  std::vector<int> cut((size_t)total);
+  std::vector<double> pw((size_t)total);
+  if (total <= pack_first) {
+    std::memcpy(cut.data(), h + off_cut, sizeof(int) * (size_t)total);
+    std::memcpy(pw.data(), h + off_pow, sizeof(double) * (size_t)total);
+  } else {
+    ISAC_HIP(hipMemcpy(cut.data(), d_pcut_full, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost));
+    ISAC_HIP(hipMemcpy(pw.data(), d_ppow_full, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost));
+  }
+  const int* ant_off = hdr + 3;
+  // ---- host post-processing, fft2D.m:63-99
+  Fft2dLast& last = ctx->last;
+  last.A = A; last.nr = nr; last.nc = nc;
+  last.first_row = cfar->row0 - (cfar->guard[0] + cfar->train[0]);
+  last.first_col = cfar->col0 - (cfar->guard[1] + cfar->train[1]);
+  last.ant_off.assign(ant_off, ant_off + A + 1);
+  last.det_rc.resize((size_t)2 * total);
+  last.det_pow = pw;
+  std::vector<int> all_row, all_col;
+  all_row.reserve((size_t)total);
+  all_col.reserve((size_t)total);
+  std::vector<int> order;
+  for (int a = 0; a < A; ++a) {
+    const int b = ant_off[a], e = ant_off[a + 1];
+    for (int i = b; i < e; ++i) {
+      const int cr = cut[(size_t)i] % n_cut_rows, cc = cut[(size_t)i] / n_cut_rows;
+      last.det_rc[(size_t)2 * i] = cfar->row0 + cr;          // 1-based
+      last.det_rc[(size_t)2 * i + 1] = cfar->col0 + cc;
+    }
+    order.resize((size_t)(e - b));
+    std::iota(order.begin(), order.end(), b);
+    std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return pw[(size_t)p] > pw[(size_t)q]; });   // :89 sort(peaks,'descend')
+    for (int i : order) {
+      all_row.push_back(last.det_rc[(size_t)2 * i]);
+      all_col.push_back(last.det_rc[(size_t)2 * i + 1]);
+    }
+  }
+  auto unique_stable = [](const std::vector<int>& v) {      // unique(x,'stable') on the integer bin indices  :99
+    std::vector<int> out_;
+    std::vector<char> seen;
+    for (int x : v) {
+      if ((size_t)x >= seen.size()) seen.resize((size_t)x + 1, 0);
+      if (!seen[(size_t)x]) { seen[(size_t)x] = 1; out_.push_back(x); }
+    }
+    return out_;
+  };
+  const std::vector<int> urow = unique_stable(all_row), ucol = unique_stable(all_col);
+  out->total_detections = total;
+  out->num_dets = (int)urow.size();                           // :110
+  if ((int)urow.size() != num_dets_dev)
+    return fail(ctx, ISAC_ERR_HIP, "internal: device numDets disagrees with host unique() count");
+  if (urow.size() > ISAC_MAX_EST || ucol.size() > ISAC_MAX_EST)
+    return fail(ctx, ISAC_ERR_CAPACITY, "more unique estimates than ISAC_MAX_EST");
+  out->n_rng = (int)urow.size();
+  out->n_vel = (int)ucol.size();
+  for (size_t i = 0; i < urow.size(); ++i) out->rng_est[i] = (double)(urow[i] - 1) * ep->r_res;               // :77,:81
+  for (size_t i = 0; i < ucol.size(); ++i) out->vel_est[i] = ((double)ucol[i] - ep->n_fft / 2.0 - 1.0) * ep->v_res;   // :78,:82
+  last.valid = true;
+  last.spectrum_db.clear();
+  if (upa) return fail(ctx, ISAC_ERR_UNSUPPORTED, "UPA DoA: music.m:69 calls tools.find2DPeaks, which the reference does not define");
+  // ---- DoA, music.m:94-104
+  const double* spec = (const double*)(h + off_spec);
+  double mx = 0.0;
+  for (int i = 0; i < n_steps; ++i) mx = std::max(mx, std::fabs(spec[i]));
+  last.spectrum_db.resize((size_t)n_steps);
+  for (int i = 0; i < n_steps; ++i) last.spectrum_db[(size_t)i] = 20.0 * std::log10(std::fabs(spec[i]) / mx);   // :94-96
+  if (out->num_dets == 0)
+    return fail(ctx, ISAC_ERR_NO_DETECTION, "no CFAR detection: findpeaks 'NPeaks' must be a positive integer (music.m:102)");
+  const std::vector<int> locs = findpeaks_desc(last.spectrum_db, out->num_dets);                             // :102
+  out->n_azi = (int)std::min<size_t>(locs.size(), ISAC_MAX_EST);
+  for (int i = 0; i < out->n_azi; ++i) {
+    out->azi_est[i] = locs[(size_t)i] * ep->azimuth_scan_granularity - ep->azimuth_scan_scale / 2.0;           // :103
+    out->ele_est[i] = NAN;                                                                                  // :104
+  }
+  return ISAC_OK;
+}
+
+extern "C" int isac_fft2d(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar, const isac_c64* rx_grid,
+                          const isac_c64* tx_grid, int32_t K, int32_t L, int32_t A, isac_est_result* out) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!rx_grid || !tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL grid");
+  const size_t bytes = sizeof(c64) * (size_t)K * L * A;
+  void *d_rx = nullptr, *d_tx = nullptr;
+  ISAC_HIP(hipMalloc(&d_rx, bytes));
+  if (hipMalloc(&d_tx, bytes) != hipSuccess) { hipFree(d_rx); return fail(ctx, ISAC_ERR_HIP, "hipMalloc failed"); }
+  int st = ISAC_OK;
+  if (hipMemcpy(d_rx, rx_grid, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(d_tx, tx_grid, bytes, hipMemcpyHostToDevice) != hipSuccess)
+    st = fail(ctx, ISAC_ERR_HIP, "host->device copy failed");
+  if (st == ISAC_OK) st = isac_fft2d_dev(ctx, ep, cfar, (const isac_c64*)d_rx, (const isac_c64*)d_tx, K, L, A, out);
+  hipStreamSynchronize(ctx->stream);
+  hipFree(d_rx);
+  hipFree(d_tx);
+  return st;
+}
+
+extern "C" int isac_fft2d_get_detections(isac_ctx* ctx, int32_t* det_idx, double* det_pow, int32_t cap, int32_t* ant_offsets,
+                                         int32_t* n_total) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!ctx->last.valid) return fail(ctx, ISAC_ERR_INVALID_ARG, "no completed fft2D call on this context");
+  const int total = (int)ctx->last.det_pow.size();
+  if (n_total) *n_total = total;
+  if (ant_offsets) std::copy(ctx->last.ant_off.begin(), ctx->last.ant_off.end(), ant_offsets);
+  if (total > cap) return fail(ctx, ISAC_ERR_CAPACITY, "detection list larger than capacity");
+  if (det_idx) std::copy(ctx->last.det_rc.begin(), ctx->last.det_rc.end(), det_idx);
+  if (det_pow) std::copy(ctx->last.det_pow.begin(), ctx->last.det_pow.end(), det_pow);
+  return ISAC_OK;
+}
+
+extern "C" int isac_fft2d_get_power_window(isac_ctx* ctx, double* P, int64_t cap_elems, int32_t dims[3], int32_t* first_row,
+                                           int32_t* first_col) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!ctx->last.valid) return fail(ctx, ISAC_ERR_INVALID_ARG, "no completed fft2D call on this context");
+  const Fft2dLast& l = ctx->last;
+  if (dims) { dims[0] = l.nr; dims[1] = l.nc; dims[2] = l.A; }
+  if (first_row) *first_row = l.first_row;
+  if (first_col) *first_col = l.first_col;
+  const long long n = (long long)l.nr * l.nc * l.A;
+  if (!P) return ISAC_OK;
+  if (cap_elems < n) return fail(ctx, ISAC_ERR_CAPACITY, "power window larger than capacity");
+  ISAC_HIP(hipMemcpy(P, ctx->pwin.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return ISAC_OK;
+}
+
+extern "C" int isac_fft2d_get_covariance(isac_ctx* ctx, isac_c64* Ra, int32_t A) {
+  if (!ctx || !Ra) return ISAC_ERR_INVALID_ARG;
+  if (!ctx->last.valid || ctx->last.A != A) return fail(ctx, ISAC_ERR_INVALID_ARG, "no completed fft2D call with this A");
+  ISAC_HIP(hipMemcpy(Ra, ctx->cov.p, sizeof(c64) * (size_t)A * A, hipMemcpyDeviceToHost));
+  return ISAC_OK;
+}
+
+extern "C" int isac_fft2d_get_music_spectrum(isac_ctx* ctx, double* p_db, int32_t cap, int32_t* n_steps) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!ctx->last.valid) return fail(ctx, ISAC_ERR_INVALID_ARG, "no completed fft2D call on this context");
+  const int n = (int)ctx->last.spectrum_db.size();
+  if (n_steps) *n_steps = n;
+  if (!p_db) return ISAC_OK;
+  if (cap < n) return fail(ctx, ISAC_ERR_CAPACITY, "spectrum larger than capacity");
+  std::copy(ctx->last.spectrum_db.begin(), ctx->last.spectrum_db.end(), p_db);
+  return ISAC_OK;
+}
+
+// ------------------------------------------------------------------ stand-alone MUSIC / eig
+extern "C" int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w, isac_c64* V) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!H || !w || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)A * A));
+  ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, H, sizeof(c64) * (size_t)A * A, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A));
+  std::vector<double> wv((size_t)A);
+  std::vector<c64> vv((size_t)A * A);
+  ISAC_HIP(hipMemcpyAsync(wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipMemcpyAsync(vv.data(), ctx->eig_v.p, sizeof(c64) * (size_t)A * A, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<int> order((size_t)A);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return wv[(size_t)p] < wv[(size_t)q]; });
+  for (int i = 0; i < A; ++i) {
+    w[i] = wv[(size_t)order[(size_t)i]];
+    if (V) std::memcpy(V + (size_t)A * i, vv.data() + (size_t)A * order[(size_t)i], sizeof(c64) * (size_t)A);
+  }
+  return ISAC_OK;
+}
+
+extern "C" int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_params* ep, const isac_c64* Ra, int32_t A,
+                              int32_t* L_out, double* azi_est, double* ele_est, int32_t cap, int32_t* n_est) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!ep || !Ra || A <= 0 || !n_est) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  *n_est = 0;
+  ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)A * A));
+  ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, Ra, sizeof(c64) * (size_t)A * A, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A));                                    // music.m:19
+  int L = num_dets;
+  if (num_dets < 0) {                                                                              // music.m:21-22
+    std::vector<double> wv((size_t)A);
+    ISAC_HIP(hipMemcpyAsync(wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));
+    ISAC_HIP(hipStreamSynchronize(ctx->stream));
+    std::sort(wv.begin(), wv.end());
+    L = determine_num_targets(wv);
+  }
+  if (L_out) *L_out = L;
+  if (ep->array_is_upa) return fail(ctx, ISAC_ERR_UNSUPPORTED, "UPA DoA: music.m:69 calls tools.find2DPeaks, which the reference does not define");
+  int n_steps = 0;
+  const double* d_sind = nullptr;
+  ISAC_TRY(get_sind_table(ctx, ep, &d_sind, &n_steps));
+  ISAC_TRY(ensure(ctx, ctx->spec, sizeof(double) * (size_t)n_steps));
+  ISAC_TRY(isac_music_scan_dev(ctx, A, nullptr, L, d_sind, n_steps, 0.5, (double*)ctx->spec.p));
+  std::vector<double> spec((size_t)n_steps);
+  ISAC_HIP(hipMemcpyAsync(spec.data(), ctx->spec.p, sizeof(double) * (size_t)n_steps, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  double mx = 0.0;
+  for (double v : spec) mx = std::max(mx, std::fabs(v));
+  std::vector<double> db((size_t)n_steps);
+  for (int i = 0; i < n_steps; ++i) db[(size_t)i] = 20.0 * std::log10(std::fabs(spec[(size_t)i]) / mx);
+  ctx->last.spectrum_db = db;
+  if (L <= 0) return fail(ctx, ISAC_ERR_NO_DETECTION, "findpeaks 'NPeaks' must be a positive integer (music.m:102)");
+  const std::vector<int> locs = findpeaks_desc(db, L);
+  if ((int)locs.size() > cap) return fail(ctx, ISAC_ERR_CAPACITY, "more peaks than capacity");
+  *n_est = (int)locs.size();
+  for (size_t i = 0; i < locs.size(); ++i) {
+    if (azi_est) azi_est[i] = locs[i] * ep->azimuth_scan_granularity - ep->azimuth_scan_scale / 2.0;
+    if (ele_est) ele_est[i] = NAN;
+  }
+  return ISAC_OK;
+}
+
+// ------------------------------------------------------------------ host-pointer wrappers of the echo path
+extern "C" int isac_basic_radar_channel(isac_ctx* ctx, const isac_c64* tx_wave, int64_t T,
+                                        const isac_radar_channel_params* rp, const uint8_t* los, int noise_mode,
+                                        const isac_c64* noise_unit, uint64_t seed, isac_c64* rx_wave) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!tx_wave || !rp || !rx_wave || T <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  const size_t bytes = sizeof(c64) * (size_t)T * rp->n_ants;
+  void *d_tx = nullptr, *d_nz = nullptr, *d_rx = nullptr;
+  int st = ISAC_OK;
+  if (hipMalloc(&d_tx, bytes) != hipSuccess || hipMalloc(&d_rx, bytes) != hipSuccess) st = fail(ctx, ISAC_ERR_HIP, "hipMalloc failed");
+  if (st == ISAC_OK && noise_mode == ISAC_NOISE_INJECTED && noise_unit) {
+    if (hipMalloc(&d_nz, bytes) != hipSuccess || hipMemcpy(d_nz, noise_unit, bytes, hipMemcpyHostToDevice) != hipSuccess)
+      st = fail(ctx, ISAC_ERR_HIP, "noise upload failed");
+  }
+  if (st == ISAC_OK && hipMemcpy(d_tx, tx_wave, bytes, hipMemcpyHostToDevice) != hipSuccess) st = fail(ctx, ISAC_ERR_HIP, "upload failed");
+  if (st == ISAC_OK)
+    st = isac_basic_radar_channel_dev(ctx, (const isac_c64*)d_tx, T, rp, los, noise_mode, (const isac_c64*)d_nz, seed, (isac_c64*)d_rx);
+  if (st == ISAC_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(rx_wave, d_rx, bytes, hipMemcpyDeviceToHost) != hipSuccess))
+    st = fail(ctx, ISAC_ERR_HIP, "download failed");
+  hipFree(d_tx); hipFree(d_nz); hipFree(d_rx);
+  return st;
+}
+
+extern "C" int isac_mono_static_sensing(isac_ctx* ctx, const isac_c64* tx_wave, int64_t T, int32_t tx_dim_l,
+                                        const isac_carrier* carrier, const isac_radar_channel_params* rp, const uint8_t* los,
+                                        int noise_mode, const isac_c64* noise_unit, uint64_t seed, isac_c64* echo_grid,
+                                        int32_t* l_out) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!tx_wave || !rp || !carrier || !echo_grid || T <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  int32_t lw = 0;
+  ISAC_TRY(isac_ofdm_symbol_count(carrier, T, &lw));
+  const int L_out = lw < tx_dim_l ? tx_dim_l : lw;
+  const size_t wbytes = sizeof(c64) * (size_t)T * rp->n_ants;
+  const size_t gbytes = sizeof(c64) * (size_t)carrier->n_sc * (size_t)(L_out > 0 ? L_out : 1) * rp->n_ants;
+  void *d_tx = nullptr, *d_nz = nullptr, *d_g = nullptr;
+  int st = ISAC_OK;
+  if (hipMalloc(&d_tx, wbytes) != hipSuccess || hipMalloc(&d_g, gbytes) != hipSuccess) st = fail(ctx, ISAC_ERR_HIP, "hipMalloc failed");
+  if (st == ISAC_OK && noise_mode == ISAC_NOISE_INJECTED && noise_unit) {
+    if (hipMalloc(&d_nz, wbytes) != hipSuccess || hipMemcpy(d_nz, noise_unit, wbytes, hipMemcpyHostToDevice) != hipSuccess)
+      st = fail(ctx, ISAC_ERR_HIP, "noise upload failed");
+  }
+  if (st == ISAC_OK && hipMemcpy(d_tx, tx_wave, wbytes, hipMemcpyHostToDevice) != hipSuccess) st = fail(ctx, ISAC_ERR_HIP, "upload failed");
+  if (st == ISAC_OK)
+    st = isac_mono_static_sensing_dev(ctx, (const isac_c64*)d_tx, T, tx_dim_l, carrier, rp, los, noise_mode,
+                                      (const isac_c64*)d_nz, seed, (isac_c64*)d_g, l_out);
+  if (st == ISAC_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(echo_grid, d_g, gbytes, hipMemcpyDeviceToHost) != hipSuccess))
+    st = fail(ctx, ISAC_ERR_HIP, "download failed");
+  hipFree(d_tx); hipFree(d_nz); hipFree(d_g);
+  return st;
+}

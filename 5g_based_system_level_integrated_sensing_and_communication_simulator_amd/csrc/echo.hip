@@ -1,0 +1,486 @@
+// Echo synthesis + CP-OFDM (de)modulation kernels (gfx950).
+//
+// Reference path: sensing.monoStaticSensing (+sensing/monoStaticSensing.m:1-23) ->
+// sensing.channelModels.basicRadarChannel (+sensing/+channelModels/basicRadarChannel.m:1-76)
+// -> nrOFDMDemodulate.  The reference makes ~10 full passes over the [T x A] waveform;
+// here the rank-1 structure of basicRadarChannel.m:51  (e * a) * a.'  is used to read the
+// transmit waveform ONCE (beam-sum), build one length-T coefficient vector per LoS target,
+// and synthesise each receive antenna's samples directly inside the OFDM-demodulation
+// FFT's register file, so rxWaveform never touches HBM:
+//
+//   beam_q[t]   = sum_a tx[t,a] * a_q[a]                                   (1 read of tx)
+//   coef_q[t]   = lsf_q * e^{j wd_q t} * e^{j w (t-d_q)} * beam_q[t-d_q] * e^{-j w t}
+//   rx[t,r]     = sum_q coef_q[t] * a_q[r] + sqrt(N0/2) * noise[t,r] * e^{-j w t}
+//   echoGrid    = OFDM-demodulate(rx)                                      (1 write of grid)
+//
+// Carrier phase arguments are formed exactly like the reference forms them
+// ((2*pi*fc) * (n*Ts), all in fp64) so the ~1e-8 rad rounding of those huge arguments
+// is reproduced rather than "improved".
+#include "fft_lds.hpp"
+
+namespace isac {
+
+// ---------------------------------------------------------------- Philox4x32-10 (Random123)
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// complex N(0,1)+jN(0,1) for 64-bit element index e (Box-Muller on two 53-bit uniforms)
+__device__ __forceinline__ c64 philox_normal_pair(uint64_t e, uint64_t seed, uint32_t stream) {
+  uint32_t o[4];
+  philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  uint64_t w0 = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
+  uint64_t w1 = (uint64_t)o[2] | ((uint64_t)o[3] << 32);
+  double u1 = ((double)(w0 >> 11) + 1.0) * 0x1.0p-53;
+  double u2 = (double)(w1 >> 11) * 0x1.0p-53;
+  double r = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincospi(2.0 * u2, &s, &c);
+  return c64{r * c, r * s};
+}
+
+// ---------------------------------------------------------------- beam-sum: 1 read of tx
+template <int QT>
+__global__ __launch_bounds__(256) void beamsum_kernel(const c64* __restrict__ tx, long long T, int A,
+                                                      const c64* __restrict__ steer /* [A x QT] compacted LoS */,
+                                                      c64* __restrict__ beam /* [QT x T] */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* s_steer = reinterpret_cast<c64*>(smem_raw);
+  for (int i = threadIdx.x; i < A * QT; i += blockDim.x) s_steer[i] = steer[i];
+  __syncthreads();
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  c64 acc[QT];
+#pragma unroll
+  for (int q = 0; q < QT; ++q) acc[q] = mk(0.0, 0.0);
+  const c64* p = tx + t;
+  int a = 0;
+  for (; a + 8 <= A; a += 8) {
+    c64 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(long long)(a + u) * T];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int q = 0; q < QT; ++q) acc[q] = fma(v[u], s_steer[q * A + a + u], acc[q]);
+  }
+  for (; a < A; ++a) {
+    c64 v = p[(long long)a * T];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) acc[q] = fma(v, s_steer[q * A + a], acc[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < QT; ++q) beam[(long long)q * T + t] = acc[q];
+}
+
+// ---------------------------------------------------------------- per-target coefficient vectors
+struct TargetDesc {
+  double wd;      // (2*pi)*fd          basicRadarChannel.m:25,44
+  double lsf;     // largeScaleFading   basicRadarChannel.m:48
+  long long shift;  // ceil(pathDelay/Ts) basicRadarChannel.m:22
+};
+constexpr int kMaxTargets = 64;
+struct TargetTable {
+  TargetDesc t[kMaxTargets];
+};
+
+__global__ __launch_bounds__(256) void coef_kernel(const c64* __restrict__ beam, long long T, int Q,
+                                                   TargetTable tab, double w /* (2*pi)*fc */, double Ts,
+                                                   c64* __restrict__ coef /* [Q x T] */,
+                                                   c64* __restrict__ phase_rx /* [T] */) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  double tt = (double)t * Ts;
+  double s, c;
+  sincos(w * tt, &s, &c);
+  c64 prx = mk(c, -s);  // exp(-2j*pi*fc*t)   basicRadarChannel.m:73
+  phase_rx[t] = prx;
+  for (int q = 0; q < Q; ++q) {
+    long long d = tab.t[q].shift;
+    c64 out = mk(0.0, 0.0);
+    if (t >= d) {
+      double sd, cd, st, ct;
+      sincos(tab.t[q].wd * tt, &sd, &cd);                  // doppler phase at receive time  :43-44
+      sincos(w * ((double)(t - d) * Ts), &st, &ct);         // up-conversion phase at transmit time :29-31,42
+      c64 v = beam[(long long)q * T + (t - d)] * mk(ct, st);
+      v = v * mk(cd, sd);
+      v = v * tab.t[q].lsf;
+      out = v * prx;
+    }
+    coef[(long long)q * T + t] = out;
+  }
+}
+
+// rx[t,r] for one sample (shared by the fused demodulator and the waveform materialiser)
+__device__ __forceinline__ c64 rx_sample(long long t, int r, long long T, int Q, const c64* __restrict__ coef,
+                                         const c64* __restrict__ s_steer_r /* [Q] a_q[r] */,
+                                         const c64* __restrict__ phase_rx, int noise_mode,
+                                         const c64* __restrict__ noise, double n0s, uint64_t seed) {
+  c64 v = mk(0.0, 0.0);
+  for (int q = 0; q < Q; ++q) v = fma(coef[(long long)q * T + t], s_steer_r[q], v);
+  if (noise_mode != ISAC_NOISE_NONE) {
+    uint64_t e = (uint64_t)t + (uint64_t)T * (uint64_t)r;
+    c64 nz = (noise_mode == ISAC_NOISE_INJECTED) ? noise[e] : philox_normal_pair(e, seed, 0u);
+    v = v + (nz * n0s) * phase_rx[t];
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void radar_waveform_kernel(long long T, int A, int Q, const c64* __restrict__ coef,
+                                                             const c64* __restrict__ steer_rq /* [A x Q] row r: a_q[r] at r*Q+q */,
+                                                             const c64* __restrict__ phase_rx, int noise_mode,
+                                                             const c64* __restrict__ noise, double n0s, uint64_t seed,
+                                                             c64* __restrict__ rx) {
+  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  int r = blockIdx.y;
+  if (t >= T) return;
+  rx[t + T * r] = rx_sample(t, r, T, Q, coef, steer_rq + (long long)r * Q, phase_rx, noise_mode, noise, n0s, seed);
+}
+
+// ---------------------------------------------------------------- fused sample synthesis + OFDM demodulation
+struct OfdmGeom {
+  int nfft, n_sc, cp_base, cp_long, sym_per_half;
+};
+
+template <class FFT, bool SYNTH>
+__global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, int A, int L_whole, int L_out,
+                                                       const c64* __restrict__ tw,
+                                                       // SYNTH = true: synthesise rx samples
+                                                       int Q, const c64* __restrict__ coef,
+                                                       const c64* __restrict__ steer_rq, const c64* __restrict__ phase_rx,
+                                                       int noise_mode, const c64* __restrict__ noise, double n0s,
+                                                       uint64_t seed,
+                                                       // SYNTH = false: read them
+                                                       const c64* __restrict__ wave,
+                                                       c64* __restrict__ grid) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* lds = reinterpret_cast<c64*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int n_cols = L_whole * A;
+  FFT fft;
+  for (int col = blockIdx.x; col < n_cols; col += gridDim.x) {
+    const int l = col % L_whole, r = col / L_whole;
+    const int cp = cp_of_symbol(l, g.cp_base, g.cp_long, g.sym_per_half);
+    const int off = cp / 2;  // fix(cp * CyclicPrefixFraction), fraction 0.5
+    const long long w0 = symbol_start(l, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) + off;
+    const int dshift = cp - off;  // window leads the useful part by dshift samples
+    if constexpr (SYNTH) {
+      const c64* sr = steer_rq + (long long)r * Q;
+      fft.fill([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, noise_mode, noise, n0s, seed); }, tid);
+    } else {
+      const c64* src = wave + w0 + T * (long long)r;
+      fft.fill([&](int n) { return src[n]; }, tid);
+    }
+    fft.template transform<-1>(lds, tw, tid);
+    c64* dst = grid + (long long)g.n_sc * ((long long)l + (long long)L_out * r);
+    const int half = g.n_sc / 2;
+    fft.drain(
+        [&](int k, c64 v) {
+          int kb = (k < g.nfft / 2) ? k : k - g.nfft;  // signed bin
+          int row = kb + half;
+          if (row >= 0 && row < g.n_sc) {
+            int m = (int)(((long long)kb * dshift) % g.nfft);
+            if (m < 0) m += g.nfft;
+            dst[row] = v * conj(tw[m]);  // exp(+2 pi j kb dshift / nfft)
+          }
+        },
+        tid);
+    fft.release();
+  }
+}
+
+// ---------------------------------------------------------------- plain CP-OFDM modulator (no windowing)
+template <class FFT>
+__global__ __launch_bounds__(256, 2) void mod_kernel(OfdmGeom g, long long T, int A, int L, const c64* __restrict__ tw,
+                                                     const c64* __restrict__ grid, double scale /* amplitude / nfft */,
+                                                     c64* __restrict__ wave) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* lds = reinterpret_cast<c64*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int n_cols = L * A;
+  FFT fft;
+  for (int col = blockIdx.x; col < n_cols; col += gridDim.x) {
+    const int l = col % L, a = col / L;
+    const int cp = cp_of_symbol(l, g.cp_base, g.cp_long, g.sym_per_half);
+    const long long s0 = symbol_start(l, g.nfft, g.cp_base, g.cp_long, g.sym_per_half);
+    const c64* src = grid + (long long)g.n_sc * ((long long)l + (long long)L * a);
+    const int half = g.n_sc / 2;
+    fft.fill(
+        [&](int n) {
+          int kb = (n < g.nfft / 2) ? n : n - g.nfft;
+          int row = kb + half;
+          return (row >= 0 && row < g.n_sc) ? src[row] : mk(0.0, 0.0);
+        },
+        tid);
+    fft.template transform<+1>(lds, tw, tid);
+    c64* dst = wave + s0 + T * (long long)a;
+    fft.drain(
+        [&](int m, c64 v) {
+          v = v * scale;
+          dst[cp + m] = v;
+          if (m >= g.nfft - cp) dst[m - (g.nfft - cp)] = v;
+        },
+        tid);
+    fft.release();
+  }
+}
+
+// ---------------------------------------------------------------- synthetic QPSK grid
+__global__ __launch_bounds__(256) void synth_qpsk_kernel(c64* __restrict__ grid, int K, int L, int A, uint64_t seed,
+                                                         int zero_s_slots) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long n = (long long)K * L * A;
+  if (i >= n) return;
+  int l = (int)((i / K) % L);
+  int slot = l / 14;
+  c64 v = mk(0.0, 0.0);
+  if (!(zero_s_slots && (slot % 4) == 3)) {
+    uint32_t o[4];
+    philox4x32_10((uint32_t)i, (uint32_t)((uint64_t)i >> 32), 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    v = mk((o[0] & 1u) ? kR2 : -kR2, (o[1] & 1u) ? kR2 : -kR2);
+  }
+  grid[i] = v;
+}
+
+}  // namespace isac
+
+// ================================================================= host side
+using namespace isac;
+
+int isac_get_twiddles(isac_ctx* ctx, int n, const c64** out);  // capi.hip
+
+static int check_carrier(isac_ctx* ctx, const isac_carrier* c) {
+  if (!c) return fail(ctx, ISAC_ERR_INVALID_ARG, "carrier is NULL");
+  if (c->nfft < 64 || c->nfft > 4096 || (c->nfft & (c->nfft - 1)))
+    return fail(ctx, ISAC_ERR_UNSUPPORTED, "carrier.nfft must be a power of two in 64..4096");
+  if (c->n_sc <= 0 || c->n_sc > c->nfft || (c->n_sc & 1)) return fail(ctx, ISAC_ERR_INVALID_ARG, "carrier.n_sc invalid");
+  if (c->scs_khz != 15 && c->scs_khz != 30 && c->scs_khz != 60 && c->scs_khz != 120)
+    return fail(ctx, ISAC_ERR_INVALID_ARG, "carrier.scs_khz must be 15/30/60/120");
+  return ISAC_OK;
+}
+
+static OfdmGeom geom_of(const isac_carrier* c) {
+  Numerology n = numerology(c->nfft, c->scs_khz);
+  return OfdmGeom{c->nfft, c->n_sc, n.cp_base, n.cp_long, n.sym_per_half};
+}
+
+static int whole_symbols(const OfdmGeom& g, long long T) {
+  // largest L with symbol_start(L) <= T   (symbol_start(L) = end of symbol L-1)
+  long long lo = 0, hi = T / g.nfft + 1;
+  while (lo < hi) {
+    long long mid = (lo + hi + 1) / 2;
+    if (symbol_start((int)mid, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) <= T) lo = mid; else hi = mid - 1;
+  }
+  return (int)lo;
+}
+
+extern "C" int isac_ofdm_symbol_count(const isac_carrier* carrier, int64_t T, int32_t* n_symbols) {
+  if (!carrier || !n_symbols || T < 0) return ISAC_ERR_INVALID_ARG;
+  *n_symbols = whole_symbols(geom_of(carrier), T);
+  return ISAC_OK;
+}
+
+extern "C" int isac_ofdm_waveform_length(const isac_carrier* carrier, int32_t L, int64_t* T) {
+  if (!carrier || !T || L < 0) return ISAC_ERR_INVALID_ARG;
+  OfdmGeom g = geom_of(carrier);
+  *T = symbol_start(L, g.nfft, g.cp_base, g.cp_long, g.sym_per_half);
+  return ISAC_OK;
+}
+
+static unsigned fft_grid(int n_cols) {
+  // two 69 KB workgroups fit a CU; 256 CUs -> 512 resident; keep a few waves of work per slot
+  unsigned cap = 256u * 2u * 4u;
+  return n_cols < (int)cap ? (unsigned)n_cols : cap;
+}
+
+// Everything basicRadarChannel needs before samples can be synthesised: LoS compaction,
+// beam-sums, coefficient vectors.  Leaves coef [Q x T], phase_rx [T], steer_rq [A x Q] in ctx.
+static int prepare_echo(isac_ctx* ctx, const c64* d_tx, long long T, const isac_radar_channel_params* rp,
+                        const uint8_t* los, int* q_out) {
+  if (!d_tx || !rp || !los) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (T <= 0 || rp->n_ants <= 0 || rp->n_targets < 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad T / n_ants / n_targets");
+  if (!(rp->fs > 0)) return fail(ctx, ISAC_ERR_INVALID_ARG, "fs must be positive");
+  const int A = rp->n_ants;
+  const double c0 = 299792458.0;                    // physconst('Lightspeed')  basicRadarChannel.m:11
+  const double lambda = c0 / rp->fc;                // :13
+  const double Ts = 1.0 / rp->fs;                   // :15
+  const double two_pi = 2.0 * M_PI;
+  TargetTable tab{};
+  std::vector<c64> steer_aq, steer_rq;              // compacted LoS columns
+  int Q = 0;
+  for (int i = 0; i < rp->n_targets; ++i) {
+    if (los[i] != 1) continue;                      // :40
+    if (Q >= kMaxTargets) return fail(ctx, ISAC_ERR_CAPACITY, "more than 64 LoS targets");
+    double path_delay = 2.0 * rp->range[i] / c0;    // :21
+    tab.t[Q].shift = (long long)std::ceil(path_delay / Ts);   // :22
+    double fd = 2.0 * rp->velocity[i] / lambda;     // :25
+    tab.t[Q].wd = two_pi * fd;                      // 2j*pi*fd  :44
+    tab.t[Q].lsf = rp->large_scale_fading[i];
+    ++Q;
+  }
+  if (Q == 0) return fail(ctx, ISAC_ERR_NO_LOS, "no LoS target: rxWaveform is empty (basicRadarChannel.m:59,64)");
+  steer_aq.resize((size_t)A * Q);
+  steer_rq.resize((size_t)A * Q);
+  {
+    int q = 0;
+    for (int i = 0; i < rp->n_targets; ++i) {
+      if (los[i] != 1) continue;
+      for (int a = 0; a < A; ++a) {
+        const isac_c64 s = rp->rx_steering[(size_t)a + (size_t)A * i];
+        steer_aq[(size_t)q * A + a] = mk(s.re, s.im);
+        steer_rq[(size_t)a * Q + q] = mk(s.re, s.im);
+      }
+      ++q;
+    }
+  }
+  ISAC_TRY(ensure(ctx, ctx->steer, sizeof(c64) * (size_t)A * Q * 2));
+  ISAC_TRY(ensure(ctx, ctx->beam, sizeof(c64) * (size_t)Q * T));
+  ISAC_TRY(ensure(ctx, ctx->coef, sizeof(c64) * (size_t)Q * T));
+  ISAC_TRY(ensure(ctx, ctx->phase_rx, sizeof(c64) * (size_t)T));
+  c64* d_steer_aq = (c64*)ctx->steer.p;
+  c64* d_steer_rq = d_steer_aq + (size_t)A * Q;
+  ISAC_HIP(hipMemcpyAsync(d_steer_aq, steer_aq.data(), sizeof(c64) * steer_aq.size(), hipMemcpyHostToDevice, ctx->stream));
+  ISAC_HIP(hipMemcpyAsync(d_steer_rq, steer_rq.data(), sizeof(c64) * steer_rq.size(), hipMemcpyHostToDevice, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+  // beam-sums in tiles of up to 8 targets (tx is re-read only when Q > 8)
+  const unsigned gb = cdiv(T, 256);
+  for (int q0 = 0; q0 < Q;) {
+    int rem = Q - q0;
+    const c64* st = d_steer_aq + (size_t)q0 * A;
+    c64* bm = (c64*)ctx->beam.p + (size_t)q0 * T;
+    if (rem >= 8) { hipLaunchKernelGGL(beamsum_kernel<8>, dim3(gb), dim3(256), sizeof(c64) * A * 8, ctx->stream, d_tx, T, A, st, bm); q0 += 8; }
+    else if (rem >= 4) { hipLaunchKernelGGL(beamsum_kernel<4>, dim3(gb), dim3(256), sizeof(c64) * A * 4, ctx->stream, d_tx, T, A, st, bm); q0 += 4; }
+    else if (rem >= 2) { hipLaunchKernelGGL(beamsum_kernel<2>, dim3(gb), dim3(256), sizeof(c64) * A * 2, ctx->stream, d_tx, T, A, st, bm); q0 += 2; }
+    else { hipLaunchKernelGGL(beamsum_kernel<1>, dim3(gb), dim3(256), sizeof(c64) * A * 1, ctx->stream, d_tx, T, A, st, bm); q0 += 1; }
+  }
+  const double w = two_pi * rp->fc;                 // 2j*pi*fc  :30,:73
+  hipLaunchKernelGGL(coef_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const c64*)ctx->beam.p, T, Q, tab, w, Ts,
+                     (c64*)ctx->coef.p, (c64*)ctx->phase_rx.p);
+  ISAC_HIP(hipGetLastError());
+  *q_out = Q;
+  return ISAC_OK;
+}
+
+extern "C" int isac_basic_radar_channel_dev(isac_ctx* ctx, const isac_c64* d_tx_wave, int64_t T,
+                                            const isac_radar_channel_params* rp, const uint8_t* los, int noise_mode,
+                                            const isac_c64* d_noise_unit, uint64_t seed, isac_c64* d_rx_wave) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!d_rx_wave) return fail(ctx, ISAC_ERR_INVALID_ARG, "rx_wave is NULL");
+  if (noise_mode == ISAC_NOISE_INJECTED && !d_noise_unit) return fail(ctx, ISAC_ERR_INVALID_ARG, "noise buffer missing");
+  int Q = 0;
+  ISAC_TRY(prepare_echo(ctx, (const c64*)d_tx_wave, T, rp, los, &Q));
+  const int A = rp->n_ants;
+  const double n0s = std::sqrt(rp->n0 / 2.0);       // basicRadarChannel.m:67
+  hipLaunchKernelGGL(radar_waveform_kernel, dim3(cdiv(T, 256), A), dim3(256), 0, ctx->stream, (long long)T, A, Q,
+                     (const c64*)ctx->coef.p, (const c64*)ctx->steer.p + (size_t)A * Q, (const c64*)ctx->phase_rx.p,
+                     noise_mode, (const c64*)d_noise_unit, n0s, seed, (c64*)d_rx_wave);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+template <class FFT, bool SYNTH>
+static int launch_demod(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, int L_whole, int L_out, const c64* tw, int Q,
+                        int noise_mode, const c64* noise, double n0s, uint64_t seed, const c64* wave, c64* grid) {
+  size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
+  auto kern = demod_kernel<FFT, SYNTH>;
+  ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(fft_grid(L_whole * A)), dim3(256), lds, ctx->stream, g, T, A, L_whole, L_out, tw, Q,
+                     (const c64*)ctx->coef.p, SYNTH ? (const c64*)ctx->steer.p + (size_t)A * Q : nullptr,
+                     (const c64*)ctx->phase_rx.p, noise_mode, noise, n0s, seed, wave, grid);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+extern "C" int isac_mono_static_sensing_dev(isac_ctx* ctx, const isac_c64* d_tx_wave, int64_t T, int32_t tx_dim_l,
+                                            const isac_carrier* carrier, const isac_radar_channel_params* rp,
+                                            const uint8_t* los, int noise_mode, const isac_c64* d_noise_unit,
+                                            uint64_t seed, isac_c64* d_echo_grid, int32_t* l_out) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_TRY(check_carrier(ctx, carrier));
+  if (!d_echo_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "echo_grid is NULL");
+  if (noise_mode == ISAC_NOISE_INJECTED && !d_noise_unit) return fail(ctx, ISAC_ERR_INVALID_ARG, "noise buffer missing");
+  int Q = 0;
+  ISAC_TRY(prepare_echo(ctx, (const c64*)d_tx_wave, T, rp, los, &Q));   // monoStaticSensing.m:13
+  OfdmGeom g = geom_of(carrier);
+  const int A = rp->n_ants;
+  const int L_whole = whole_symbols(g, T);
+  if (L_whole <= 0) return fail(ctx, ISAC_ERR_SHORT_WAVEFORM, "waveform shorter than one OFDM symbol");
+  const int L_out = L_whole < tx_dim_l ? tx_dim_l : L_whole;            // monoStaticSensing.m:19-21
+  if (l_out) *l_out = L_out;
+  if (L_out > L_whole)
+    ISAC_HIP(hipMemsetAsync(d_echo_grid, 0, sizeof(c64) * (size_t)g.n_sc * L_out * A, ctx->stream));
+  const c64* tw = nullptr;
+  ISAC_TRY(isac_get_twiddles(ctx, g.nfft, &tw));
+  const double n0s = std::sqrt(rp->n0 / 2.0);
+  ISAC_FFT_DISPATCH(g.nfft, ISAC_TRY((launch_demod<FFT, true>(ctx, g, T, A, L_whole, L_out, tw, Q, noise_mode,
+                                                              (const c64*)d_noise_unit, n0s, seed, nullptr,
+                                                              (c64*)d_echo_grid))));
+  return ISAC_OK;
+}
+
+extern "C" int isac_ofdm_demodulate_dev(isac_ctx* ctx, const isac_c64* d_wave, int64_t T, int32_t A,
+                                        const isac_carrier* carrier, isac_c64* d_grid, int32_t L) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_TRY(check_carrier(ctx, carrier));
+  if (!d_wave || !d_grid || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  OfdmGeom g = geom_of(carrier);
+  const int L_whole = whole_symbols(g, T);
+  if (L_whole <= 0) return fail(ctx, ISAC_ERR_SHORT_WAVEFORM, "waveform shorter than one OFDM symbol");
+  if (L < L_whole) return fail(ctx, ISAC_ERR_CAPACITY, "grid has fewer symbol columns than the waveform holds");
+  if (L > L_whole) ISAC_HIP(hipMemsetAsync(d_grid, 0, sizeof(c64) * (size_t)g.n_sc * L * A, ctx->stream));
+  const c64* tw = nullptr;
+  ISAC_TRY(isac_get_twiddles(ctx, g.nfft, &tw));
+  ISAC_FFT_DISPATCH(g.nfft, ISAC_TRY((launch_demod<FFT, false>(ctx, g, T, A, L_whole, L, tw, 0, 0, nullptr, 0.0, 0,
+                                                               (const c64*)d_wave, (c64*)d_grid))));
+  return ISAC_OK;
+}
+
+template <class FFT>
+static int launch_mod(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, int L, const c64* tw, const c64* grid,
+                      double scale, c64* wave) {
+  size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
+  auto kern = mod_kernel<FFT>;
+  ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(fft_grid(L * A)), dim3(256), lds, ctx->stream, g, T, A, L, tw, grid, scale, wave);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+extern "C" int isac_ofdm_modulate_dev(isac_ctx* ctx, const isac_c64* d_grid, int32_t L, int32_t A,
+                                      const isac_carrier* carrier, double amplitude, isac_c64* d_wave, int64_t T) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_TRY(check_carrier(ctx, carrier));
+  if (!d_wave || !d_grid || A <= 0 || L <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  OfdmGeom g = geom_of(carrier);
+  long long need = symbol_start(L, g.nfft, g.cp_base, g.cp_long, g.sym_per_half);
+  if (T < need) return fail(ctx, ISAC_ERR_CAPACITY, "waveform buffer shorter than L symbols");
+  if (T > need) ISAC_HIP(hipMemsetAsync(d_wave, 0, sizeof(c64) * (size_t)T * A, ctx->stream));
+  const c64* tw = nullptr;
+  ISAC_TRY(isac_get_twiddles(ctx, g.nfft, &tw));
+  ISAC_FFT_DISPATCH(g.nfft, ISAC_TRY((launch_mod<FFT>(ctx, g, T, A, L, tw, (const c64*)d_grid, amplitude / g.nfft,
+                                                      (c64*)d_wave))));
+  return ISAC_OK;
+}
+
+extern "C" int isac_synth_qpsk_grid_dev(isac_ctx* ctx, isac_c64* d_grid, int32_t K, int32_t L, int32_t A, uint64_t seed,
+                                        int32_t zero_s_slots) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!d_grid || K <= 0 || L <= 0 || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  long long n = (long long)K * L * A;
+  hipLaunchKernelGGL(synth_qpsk_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (c64*)d_grid, K, L, A, seed,
+                     zero_s_slots);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}

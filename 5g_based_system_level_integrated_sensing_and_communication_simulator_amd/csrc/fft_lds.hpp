@@ -1,0 +1,221 @@
+// Workgroup-level complex fp64 FFTs for gfx950, 256 threads (4 wavefronts) per transform.
+//
+//  * Fft4096   -- the hot size (Nfft = nIFFT = 4096 for 100 MHz / 30 kHz / 273 PRB):
+//                 three radix-16 passes.  Each thread owns 16 points in registers
+//                 (n = tid + 256 j on entry, k = tid + 256 f on exit), so global loads
+//                 and stores of a column are coalesced without any LDS staging; the two
+//                 exchanges between passes go through a padded LDS image
+//                 (stride 273 / 17 complex) that keeps ds_read/ds_write_b128 lane groups
+//                 on distinct 16-byte slots.  69 888 B of LDS -> two workgroups per CU.
+//  * FftStockham<N> -- any power of two 8..4096 (other bandwidths / small test shapes):
+//                 radix-2 Stockham autosort in LDS (2 N complex), same ownership contract.
+//
+// Twiddles come from a device table tw[m] = exp(-2 pi j m / N) built in long double on
+// the host; DIR = -1 is the forward transform, DIR = +1 the (unscaled) inverse.
+#pragma once
+
+#include "isac_common.hpp"
+
+namespace isac {
+
+constexpr double kC1 = 0.92387953251128673848;  // cos(pi/8)
+constexpr double kS1 = 0.38268343236508978178;  // sin(pi/8)
+constexpr double kR2 = 0.70710678118654752440;  // sqrt(1/2)
+
+template <int DIR>
+__device__ __forceinline__ c64 tw_dir(c64 w) {
+  if (DIR > 0) w.im = -w.im;
+  return w;
+}
+
+template <int DIR>
+__device__ __forceinline__ void dft4(c64& a0, c64& a1, c64& a2, c64& a3) {
+  c64 s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+  c64 jd = (DIR < 0) ? mul_mi(d13) : mul_i(d13);
+  a0 = s02 + s13;
+  a2 = s02 - s13;
+  a1 = d02 + jd;
+  a3 = d02 - jd;
+}
+
+// multiply by W16^M (forward) or its conjugate (inverse), M in {0,1,2,3,4,6,9}
+template <int DIR, int M>
+__device__ __forceinline__ c64 mul_w16(c64 a) {
+  if constexpr (M == 0) {
+    return a;
+  } else if constexpr (M == 4) {
+    return (DIR < 0) ? mul_mi(a) : mul_i(a);
+  } else {
+    constexpr double wr = (M == 1) ? kC1 : (M == 2) ? kR2 : (M == 3) ? kS1 : (M == 6) ? -kR2 : -kC1;
+    constexpr double wi_f = (M == 1) ? -kS1 : (M == 2) ? -kR2 : (M == 3) ? -kC1 : (M == 6) ? -kR2 : kS1;
+    constexpr double wi = (DIR < 0) ? wi_f : -wi_f;
+    return c64{a.re * wr - a.im * wi, a.re * wi + a.im * wr};
+  }
+}
+
+// 16-point DFT in registers, natural order in and out.
+template <int DIR>
+__device__ __forceinline__ void dft16(c64 (&x)[16]) {
+  // step A: 4-point DFTs over n1 (stride 4), n = 4 n1 + n2
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) dft4<DIR>(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);
+  // twiddles W16^(n2 k1) on element (k1, n2) held at x[4 k1 + n2]
+  x[5] = mul_w16<DIR, 1>(x[5]);
+  x[9] = mul_w16<DIR, 2>(x[9]);
+  x[13] = mul_w16<DIR, 3>(x[13]);
+  x[6] = mul_w16<DIR, 2>(x[6]);
+  x[10] = mul_w16<DIR, 4>(x[10]);
+  x[14] = mul_w16<DIR, 6>(x[14]);
+  x[7] = mul_w16<DIR, 3>(x[7]);
+  x[11] = mul_w16<DIR, 6>(x[11]);
+  x[15] = mul_w16<DIR, 9>(x[15]);
+  // step B: 4-point DFTs over n2 -> k2; x[4 k1 + k2] = X[k1 + 4 k2]
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) dft4<DIR>(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
+  // transpose 4x4 register tile to natural order (compile-time renaming)
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+    for (int k2 = k1 + 1; k2 < 4; ++k2) {
+      c64 t = x[4 * k1 + k2];
+      x[4 * k1 + k2] = x[4 * k2 + k1];
+      x[4 * k2 + k1] = t;
+    }
+}
+
+struct Fft4096 {
+  static constexpr int N = 4096;
+  static constexpr int NT = 256;
+  static constexpr int PER = 16;
+  static constexpr int SK = 273;  // k1 stride (complex elements)
+  static constexpr int SE = 17;   // second-digit stride
+  static constexpr int LDS_ELEMS = 16 * SK;
+  c64 x[PER];
+
+  template <class F>
+  __device__ __forceinline__ void fill(F&& f, int tid) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) x[j] = f(tid + NT * j);
+  }
+  template <class G>
+  __device__ __forceinline__ void drain(G&& g, int tid) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) g(tid + NT * j, x[j]);
+  }
+
+  // x[j] = in[tid + 256 j]  ->  x[f] = OUT[tid + 256 f]
+  template <int DIR>
+  __device__ __forceinline__ void transform(c64* __restrict__ lds, const c64* __restrict__ tw, int tid) {
+    // ---- pass 1: n = 256 a + b (b = tid), DFT16 over a -> k1, twiddle W4096^(b k1)
+    dft16<DIR>(x);
+    {
+      const int pos = SE * (tid >> 4) + (tid & 15);
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) {
+        c64 v = x[k1];
+        if (k1) v = v * tw_dir<DIR>(tw[tid * k1]);
+        lds[k1 * SK + pos] = v;
+      }
+    }
+    __syncthreads();
+    // ---- pass 2: per k1 a 256-point DFT over b = 16 c + d; thread (k1, d): DFT16 over c -> e
+    {
+      const int k1 = tid >> 4, d = tid & 15;
+      c64* base = lds + k1 * SK + d;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) x[c] = base[SE * c];
+      dft16<DIR>(x);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        c64 v = x[e];
+        if (e) v = v * tw_dir<DIR>(tw[16 * d * e]);
+        base[SE * e] = v;  // in place: same address set this thread just read
+      }
+    }
+    __syncthreads();
+    // ---- pass 3: thread (k1 = tid & 15, e = tid >> 4): DFT16 over d -> f; k = k1 + 16 e + 256 f
+    {
+      const int k1 = tid & 15, e = tid >> 4;
+      const c64* base = lds + k1 * SK + SE * e;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) x[d] = base[d];
+      dft16<DIR>(x);
+    }
+  }
+  // call between two transforms that reuse the same LDS image
+  __device__ __forceinline__ void release() { __syncthreads(); }
+};
+
+template <int N_>
+struct FftStockham {
+  static constexpr int N = N_;
+  static constexpr int NT = 256;
+  static constexpr int PER = (N + NT - 1) / NT;
+  static constexpr int LDS_ELEMS = 2 * N;
+  c64 x[PER];
+
+  template <class F>
+  __device__ __forceinline__ void fill(F&& f, int tid) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      int n = tid + NT * j;
+      if (n < N) x[j] = f(n);
+    }
+  }
+  template <class G>
+  __device__ __forceinline__ void drain(G&& g, int tid) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      int k = tid + NT * j;
+      if (k < N) g(k, x[j]);
+    }
+  }
+
+  template <int DIR>
+  __device__ __forceinline__ void transform(c64* __restrict__ lds, const c64* __restrict__ tw, int tid) {
+    c64* a = lds;
+    c64* b = lds + N;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      int n = tid + NT * j;
+      if (n < N) a[n] = x[j];
+    }
+    __syncthreads();
+    for (int ns = 1; ns < N; ns <<= 1) {
+      for (int j = tid; j < N / 2; j += NT) {
+        int r = j & (ns - 1);
+        c64 w = tw_dir<DIR>(tw[r * (N / (2 * ns))]);
+        c64 v0 = a[j];
+        c64 v1 = a[j + N / 2] * w;
+        int j0 = ((j - r) << 1) + r;
+        b[j0] = v0 + v1;
+        b[j0 + ns] = v0 - v1;
+      }
+      __syncthreads();
+      c64* t = a;
+      a = b;
+      b = t;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      int k = tid + NT * j;
+      if (k < N) x[j] = a[k];
+    }
+  }
+  __device__ __forceinline__ void release() { __syncthreads(); }
+};
+
+// Dispatch a callable templated on the FFT policy for a runtime power-of-two length.
+#define ISAC_FFT_DISPATCH(nfft, CALL)                   \
+  switch (nfft) {                                       \
+    case 4096: { using FFT = isac::Fft4096; CALL; } break;          \
+    case 2048: { using FFT = isac::FftStockham<2048>; CALL; } break; \
+    case 1024: { using FFT = isac::FftStockham<1024>; CALL; } break; \
+    case 512: { using FFT = isac::FftStockham<512>; CALL; } break;   \
+    case 256: { using FFT = isac::FftStockham<256>; CALL; } break;   \
+    case 128: { using FFT = isac::FftStockham<128>; CALL; } break;   \
+    case 64: { using FFT = isac::FftStockham<64>; CALL; } break;     \
+    default: return isac::fail(ctx, ISAC_ERR_UNSUPPORTED, "FFT length must be a power of two in 64..4096"); \
+  }
+
+}  // namespace isac

@@ -1,0 +1,150 @@
+// Shared device/host helpers for libisac_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/isac.h"
+
+namespace isac {
+
+// ---------------------------------------------------------------- complex fp64 (interleaved)
+struct __attribute__((aligned(16))) c64 {
+  double re, im;
+};
+static_assert(sizeof(c64) == 16, "c64 must match isac_c64 / MATLAB interleaved complex");
+
+__host__ __device__ inline c64 mk(double r, double i) { return c64{r, i}; }
+__host__ __device__ inline c64 operator+(c64 a, c64 b) { return {a.re + b.re, a.im + b.im}; }
+__host__ __device__ inline c64 operator-(c64 a, c64 b) { return {a.re - b.re, a.im - b.im}; }
+__host__ __device__ inline c64 operator*(c64 a, c64 b) {
+  return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+__host__ __device__ inline c64 operator*(c64 a, double s) { return {a.re * s, a.im * s}; }
+__host__ __device__ inline c64 operator*(double s, c64 a) { return {a.re * s, a.im * s}; }
+__host__ __device__ inline c64 conj(c64 a) { return {a.re, -a.im}; }
+__host__ __device__ inline c64 mul_conj(c64 a, c64 b) {  // a * conj(b)
+  return {a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im};
+}
+__host__ __device__ inline c64 mul_i(c64 a) { return {-a.im, a.re}; }    // * (+j)
+__host__ __device__ inline c64 mul_mi(c64 a) { return {a.im, -a.re}; }   // * (-j)
+__host__ __device__ inline c64& operator+=(c64& a, c64 b) { a.re += b.re; a.im += b.im; return a; }
+__host__ __device__ inline c64 fma(c64 a, c64 b, c64 c) {  // a*b + c
+  return {::fma(a.re, b.re, ::fma(-a.im, b.im, c.re)), ::fma(a.re, b.im, ::fma(a.im, b.re, c.im))};
+}
+
+// ---------------------------------------------------------------- context
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct Fft2dLast {  // introspection of the last fft2D call (host copies)
+  bool valid = false;
+  int A = 0, nr = 0, nc = 0, first_row = 0, first_col = 0;
+  std::vector<int32_t> det_rc;      // [2 x total] 1-based, CUT order per antenna
+  std::vector<double> det_pow;
+  std::vector<int32_t> ant_off;     // [A+1]
+  std::vector<double> spectrum_db;
+  bool pow_on_device = false;
+};
+
+}  // namespace isac
+
+struct isac_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // MUSIC branch (covariance/eig) overlaps the RDM branch
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  std::string err;
+  // cached device tables
+  std::map<int, isac::DevBuf> twiddles;                             // n -> exp(-2 pi j m / n)
+  std::map<std::pair<int, int>, isac::DevBuf> kaiser3;              // (n, shifted) -> kaiser(n,3) / fftshift(kaiser(n,3))
+  std::map<std::pair<long long, long long>, isac::DevBuf> sind;     // (scale, granularity) -> sind(scan angles)
+  // scratch
+  isac::DevBuf beam, coef, phase_rx, steer, ymid, pwin, flags, det_cut, det_pow, det_cnt, cov_part, cov,
+      eig_w, eig_v, spec, misc, stage_a, stage_b, stage_c, sind_tab;
+  void* pinned = nullptr; size_t pinned_cap = 0;
+  isac::Fft2dLast last;
+};
+
+namespace isac {
+
+inline int fail(isac_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define ISAC_HIP(call)                                                                     \
+  do {                                                                                     \
+    hipError_t e__ = (call);                                                               \
+    if (e__ != hipSuccess)                                                                 \
+      return isac::fail(ctx, ISAC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+#define ISAC_TRY(call)              \
+  do {                              \
+    int s__ = (call);               \
+    if (s__ != ISAC_OK) return s__; \
+  } while (0)
+
+inline int ensure(isac_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (b.cap >= bytes && b.p) return ISAC_OK;
+  if (b.p) {
+    ISAC_HIP(hipStreamSynchronize(ctx->stream));
+    ISAC_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes < 256 ? 256 : bytes;
+  ISAC_HIP(hipMalloc(&b.p, want));
+  b.cap = want;
+  return ISAC_OK;
+}
+
+inline int ensure_pinned(isac_ctx* ctx, size_t bytes) {
+  if (ctx->pinned_cap >= bytes) return ISAC_OK;
+  if (ctx->pinned) ISAC_HIP(hipHostFree(ctx->pinned));
+  ctx->pinned = nullptr;
+  ctx->pinned_cap = 0;
+  ISAC_HIP(hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
+  ctx->pinned_cap = bytes;
+  return ISAC_OK;
+}
+
+// ---------------------------------------------------------------- OFDM numerology (TS 38.211 5.3.1)
+struct Numerology {
+  int nfft, mu, cp_base, cp_long, sym_per_half;  // long CP every sym_per_half symbols
+};
+inline Numerology numerology(int nfft, int scs_khz) {
+  Numerology n{};
+  n.nfft = nfft;
+  n.mu = 0;
+  for (int s = scs_khz / 15; s > 1; s >>= 1) n.mu++;
+  double scale = nfft / 2048.0;
+  n.cp_base = (int)std::lround(144.0 * scale);
+  n.cp_long = n.cp_base + (int)std::lround(16.0 * scale * (1 << n.mu));
+  n.sym_per_half = 7 * (1 << n.mu);
+  return n;
+}
+__host__ __device__ inline int cp_of_symbol(int l, int cp_base, int cp_long, int sym_per_half) {
+  return (l % sym_per_half) == 0 ? cp_long : cp_base;
+}
+// start sample (of the CP) of symbol l
+__host__ __device__ inline long long symbol_start(int l, int nfft, int cp_base, int cp_long, int sym_per_half) {
+  long long n_long = (l + sym_per_half - 1) / sym_per_half;  // long-CP symbols among 0..l-1
+  return (long long)l * (nfft + cp_base) + n_long * (cp_long - cp_base);
+}
+
+// host-side launch geometry helper
+inline unsigned cdiv(long long a, long long b) { return (unsigned)((a + b - 1) / b); }
+
+}  // namespace isac

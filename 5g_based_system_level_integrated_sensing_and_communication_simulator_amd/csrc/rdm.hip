@@ -1,0 +1,400 @@
+// Range-Doppler map + 2D CA-CFAR kernels (gfx950).
+//
+// Reference path: sensing.estimation.fft2D (+sensing/+estimation/fft2D.m:37-99) with the
+// phased.CFARDetector2D configured by sensing.detection.cfar2D (+sensing/+detection/cfar2D.m).
+//
+// fft2D.m:37-46 literally is
+//     C   = rx .* conj(tx) .* kaiser(K,3)            (range window, :37,:43)
+//     R   = ifftshift( ifft(C, nIFFT, 1) * sqrt(nIFFT) )   -- ifftshift over ALL dims (:44)
+//     R   = R .* kaiser(nIFFT,3)                    ("dopWin", applied on the range axis, :45)
+//     rdm = fftshift( fft(R, nFFT, 2) / sqrt(nFFT) )       -- fftshift over ALL dims (:46)
+// which is algebraically (oracle KAT-4, max abs diff 0):
+//     row n of rdm  = R[n] * fftshift(kaiser(nIFFT,3))[n]          (shifts cancel on dim 1 and 3)
+//     slow time     : half-rotate (ifftshift over L), zero-pad/truncate to nFFT, FFT, fftshift.
+// Only the rows/columns the CFAR stage can touch (CUT rectangle +- guard+training) are ever
+// formed: the range kernel keeps those rows of each column FFT (coalesced run), the Doppler
+// kernel evaluates just the needed Doppler bins, and |.|^2 is written as a small power window.
+#include "fft_lds.hpp"
+
+namespace isac {
+
+// ---------------------------------------------------------------- range: conj-multiply + window + IFFT, keep needed rows
+template <class FFT>
+__global__ __launch_bounds__(256, 2) void range_kernel(const c64* __restrict__ rx, const c64* __restrict__ tx, int K, int L,
+                                                       int A, const c64* __restrict__ tw, const double* __restrict__ win_k,
+                                                       const double* __restrict__ win_r /* fftshift(kaiser(nIFFT)) */,
+                                                       double inv_n, double sqrt_n, int row_lo, int n_rows,
+                                                       c64* __restrict__ ymid /* [n_rows x L x A], row fastest */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* lds = reinterpret_cast<c64*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int n_cols = L * A;
+  FFT fft;
+  for (int col = blockIdx.x; col < n_cols; col += gridDim.x) {
+    const c64* prx = rx + (long long)K * col;
+    const c64* ptx = tx + (long long)K * col;
+    fft.fill(
+        [&](int n) {
+          if (n >= K) return mk(0.0, 0.0);                       // ifft(., nIFFT, 1) zero-pads at the end
+          return mul_conj(prx[n], ptx[n]) * win_k[n];            // fft2D.m:37,:43
+        },
+        tid);
+    fft.template transform<+1>(lds, tw, tid);
+    c64* dst = ymid + (long long)n_rows * col;
+    fft.drain(
+        [&](int n, c64 v) {
+          int rr = n - row_lo;
+          if (rr >= 0 && rr < n_rows) dst[rr] = ((v * inv_n) * sqrt_n) * win_r[n];   // :44-45
+        },
+        tid);
+    fft.release();
+  }
+}
+
+// ---------------------------------------------------------------- Doppler: needed bins only, |.|^2 window
+// One workgroup: RT consecutive rows of one antenna.  The rows x L slab is staged (transposed)
+// in LDS, twiddles of the nFFT-point DFT sit beside it; thread (row, bin) accumulates its bin.
+constexpr int kDopRows = 16;
+
+__global__ __launch_bounds__(512) void doppler_pow_kernel(const c64* __restrict__ ymid, int n_rows, int L, int A, int n_fft,
+                                                          const c64* __restrict__ tw_d /* e^{-2 pi j m / n_fft} */,
+                                                          double sqrt_nfft, int col_lo /* 0-based first rdm column */,
+                                                          int n_cols, double* __restrict__ pwin /* [n_rows x n_cols x A] */,
+                                                          c64* __restrict__ rdm_win /* optional complex window */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* s_tw = reinterpret_cast<c64*>(smem_raw);                 // [n_fft]
+  c64* s_y = s_tw + n_fft;                                      // [Lu][kDopRows+1]
+  const int Lu = L < n_fft ? L : n_fft;                         // fft(., nFFT, 2) truncates when L > nFFT
+  const int a = blockIdx.y;
+  const int r0 = blockIdx.x * kDopRows;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n_fft; i += blockDim.x) s_tw[i] = tw_d[i];
+  const int half = L / 2;                                       // ifftshift: out[i] = in[(i + floor(L/2)) mod L]
+  for (int i = tid; i < Lu * kDopRows; i += blockDim.x) {
+    int rr = i % kDopRows, li = i / kDopRows;
+    int lsrc = li + half;
+    if (lsrc >= L) lsrc -= L;
+    int row = r0 + rr;
+    c64 v = mk(0.0, 0.0);
+    if (row < n_rows) v = ymid[(long long)row + (long long)n_rows * ((long long)lsrc + (long long)L * a)];
+    s_y[li * (kDopRows + 1) + rr] = v;
+  }
+  __syncthreads();
+  for (int o = tid; o < kDopRows * n_cols; o += blockDim.x) {
+    int rr = o % kDopRows, cc = o / kDopRows;
+    int row = r0 + rr;
+    if (row >= n_rows) continue;
+    int c = col_lo + cc;                                        // final column c <-> bin (c + nFFT/2) mod nFFT (fftshift)
+    int kbin = (c + n_fft / 2) % n_fft;
+    c64 acc = mk(0.0, 0.0);
+    int m = 0;
+    for (int li = 0; li < Lu; ++li) {
+      acc = fma(s_y[li * (kDopRows + 1) + rr], s_tw[m], acc);
+      m += kbin;
+      if (m >= n_fft) m -= n_fft;
+    }
+    double re = acc.re / sqrt_nfft, im = acc.im / sqrt_nfft;    // fft(.)/sqrt(nFFT)  fft2D.m:46
+    double h = hypot(re, im);                                   // abs(rdm)            fft2D.m:61
+    long long idx = (long long)row + (long long)n_rows * ((long long)cc + (long long)n_cols * a);
+    pwin[idx] = h * h;                                          // .^2
+    if (rdm_win) rdm_win[idx] = mk(re, im);
+  }
+}
+
+// ---------------------------------------------------------------- 2D CA-CFAR on the power window
+// One workgroup per antenna.  The window (CUT rectangle +- guard+training) is staged in LDS in
+// column panels; each thread sums its CUT's training cells in the ORACLE-DEFINED order
+// (column offset slowest, row offset fastest, guard block skipped; oracle/cfar.py) with
+// correctly-rounded adds so detection flags are bit-identical on identical power maps.
+// Detections are compacted in CUT order (rows fastest) with wavefront ballots.
+struct CfarGeom {
+  int nr, nc;          // window dims
+  int hr, hc;          // guard+training half sizes
+  int gr, gc;          // guard half sizes
+  int n_cut_rows, n_cut_cols;
+  int cap;             // per-antenna list capacity
+  double alpha;        // N (Pfa^(-1/N) - 1)
+  double n_train;
+};
+
+__global__ __launch_bounds__(1024) void cfar_window_kernel(const double* __restrict__ pwin, CfarGeom g, int panel_cols,
+                                                           int* __restrict__ det_cut /* [A x cap] CUT ordinal */,
+                                                           double* __restrict__ det_pow /* [A x cap] */,
+                                                           int* __restrict__ det_cnt /* [A] */,
+                                                           unsigned* __restrict__ row_seen /* [n_cut_rows] flags */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* s_p = reinterpret_cast<double*>(smem_raw);            // [nr x (panel_cols + 2 hc)]
+  __shared__ int s_wave_cnt[32];   // [0..15] per-wave counts, [16] running base (one object: keeps the dynamic LDS base 16-B aligned)
+  int& s_base = s_wave_cnt[16];
+  const int a = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, n_waves = blockDim.x >> 6;
+  const double* p = pwin + (long long)g.nr * g.nc * a;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int pc0 = 0; pc0 < g.n_cut_cols; pc0 += panel_cols) {
+    const int pcs = min(panel_cols, g.n_cut_cols - pc0);
+    const int wc = pcs + 2 * g.hc;                              // staged columns
+    for (int i = tid; i < g.nr * wc; i += blockDim.x) s_p[i] = p[(long long)pc0 * g.nr + i];   // contiguous run
+    __syncthreads();
+    const int n_cut = g.n_cut_rows * pcs;
+    for (int base = 0; base < n_cut; base += blockDim.x) {
+      const int i = base + tid;
+      bool det = false;
+      double pv = 0.0;
+      if (i < n_cut) {
+        const int cr = i % g.n_cut_rows, cc = i / g.n_cut_rows;   // CUT order: rows fastest (cfar2D.m:23-24)
+        const int r = cr + g.hr, c = cc + g.hc;                    // position inside the staged panel
+        double acc = 0.0;
+        for (int dc = -g.hc; dc <= g.hc; ++dc) {
+          const bool guard_col = (dc >= -g.gc && dc <= g.gc);
+          const double* colp = s_p + (c + dc) * g.nr + r;
+          for (int dr = -g.hr; dr <= g.hr; ++dr) {
+            if (guard_col && dr >= -g.gr && dr <= g.gr) continue;
+            acc = __dadd_rn(acc, colp[dr]);
+          }
+        }
+        const double noise = __ddiv_rn(acc, g.n_train);
+        const double thr = __dmul_rn(g.alpha, noise);
+        pv = s_p[c * g.nr + r];
+        det = pv > thr;                                            // strict
+      }
+      // ordered compaction: lane order == CUT order inside a wave, waves in order
+      const unsigned long long mask = __ballot(det);
+      if (lane == 0) s_wave_cnt[wid] = __popcll(mask);
+      __syncthreads();
+      int off = s_base;
+      for (int w = 0; w < wid; ++w) off += s_wave_cnt[w];
+      if (det) {
+        int pos = off + __popcll(mask & ((1ull << lane) - 1ull));
+        if (pos < g.cap) {
+          const int cr = i % g.n_cut_rows, cc = i / g.n_cut_rows + pc0;
+          det_cut[(long long)a * g.cap + pos] = cr + g.n_cut_rows * cc;
+          det_pow[(long long)a * g.cap + pos] = pv;
+          row_seen[cr] = 1u;
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int tot = 0;
+        for (int w = 0; w < n_waves; ++w) tot += s_wave_cnt[w];
+        s_base += tot;
+      }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) det_cnt[a] = s_base;   // may exceed cap: host reports ISAC_ERR_CAPACITY
+}
+
+// numDets = numel(unique(allRngEst)) = number of distinct detected rows (fft2D.m:99,110)
+__global__ void count_rows_kernel(const unsigned* __restrict__ row_seen, int n, int* __restrict__ num_dets) {
+  __shared__ int s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  int local = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) local += row_seen[i] ? 1 : 0;
+  atomicAdd(&s_cnt, local);
+  __syncthreads();
+  if (threadIdx.x == 0) *num_dets = s_cnt;
+}
+
+// ---------------------------------------------------------------- generic detector: arbitrary CUT list on an arbitrary map
+__global__ __launch_bounds__(256) void cfar_list_kernel(const double* __restrict__ P, int n_rows, int n_cols,
+                                                        const int* __restrict__ cut /* [2 x n_cut] 1-based */, int n_cut,
+                                                        int gr, int gc, int hr, int hc, double alpha, double n_train,
+                                                        unsigned char* __restrict__ flags) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cut) return;
+  int r = cut[2 * i] - 1, c = cut[2 * i + 1] - 1;
+  double acc = 0.0;
+  for (int dc = -hc; dc <= hc; ++dc) {
+    const bool guard_col = (dc >= -gc && dc <= gc);
+    for (int dr = -hr; dr <= hr; ++dr) {
+      if (guard_col && dr >= -gr && dr <= gr) continue;
+      acc = __dadd_rn(acc, P[(long long)(r + dr) + (long long)n_rows * (c + dc)]);
+    }
+  }
+  double thr = __dmul_rn(alpha, __ddiv_rn(acc, n_train));
+  flags[i] = P[(long long)r + (long long)n_rows * c] > thr ? 1 : 0;
+}
+
+// ---------------------------------------------------------------- full RDM plane (plot/debug path)
+__global__ __launch_bounds__(256) void doppler_full_kernel(const c64* __restrict__ ymid /* [n_ifft x L] one antenna */,
+                                                           int n_ifft, int L, int n_fft, const c64* __restrict__ tw_d,
+                                                           double sqrt_nfft, c64* __restrict__ rdm /* [n_ifft x n_fft] */) {
+  long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= (long long)n_ifft * n_fft) return;
+  int row = (int)(o % n_ifft), c = (int)(o / n_ifft);
+  int kbin = (c + n_fft / 2) % n_fft;
+  const int Lu = L < n_fft ? L : n_fft;
+  const int half = L / 2;
+  c64 acc = mk(0.0, 0.0);
+  int m = 0;
+  for (int li = 0; li < Lu; ++li) {
+    int lsrc = li + half;
+    if (lsrc >= L) lsrc -= L;
+    acc = fma(ymid[(long long)row + (long long)n_ifft * lsrc], tw_d[m], acc);
+    m += kbin;
+    if (m >= n_fft) m -= n_fft;
+  }
+  rdm[o] = mk(acc.re / sqrt_nfft, acc.im / sqrt_nfft);
+}
+
+}  // namespace isac
+
+// ================================================================= host side
+using namespace isac;
+
+int isac_get_twiddles(isac_ctx* ctx, int n, const c64** out);        // capi.hip
+int isac_get_twiddles2(isac_ctx* ctx, int n, const c64** out);       // capi.hip (second slot)
+int isac_get_windows(isac_ctx* ctx, int K, int n_ifft, const double** win_k, const double** win_r);   // capi.hip
+
+static double cfar_alpha(int n_train, double pfa) { return n_train * (std::pow(pfa, -1.0 / n_train) - 1.0); }
+
+static unsigned fft_grid2(int n_cols) {
+  unsigned cap = 256u * 2u * 4u;
+  return n_cols < (int)cap ? (unsigned)n_cols : cap;
+}
+
+template <class FFT>
+static int launch_range(isac_ctx* ctx, hipStream_t st, const c64* rx, const c64* tx, int K, int L, int A, const c64* tw,
+                        const double* wk, const double* wr, int n_ifft, int row_lo, int n_rows, c64* ymid) {
+  size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
+  auto kern = range_kernel<FFT>;
+  ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(fft_grid2(L * A)), dim3(256), lds, st, rx, tx, K, L, A, tw, wk, wr, 1.0 / n_ifft,
+                     std::sqrt((double)n_ifft), row_lo, n_rows, ymid);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+// Range + Doppler + power window for the CUT rectangle.  Leaves pwin [nr x nc x A] in ctx->pwin.
+int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, const c64* d_rx,
+                          const c64* d_tx, int K, int L, int A, int* nr_out, int* nc_out) {
+  const int n_ifft = ep->n_ifft, n_fft = ep->n_fft;
+  const int hr = cf->guard[0] + cf->train[0], hc = cf->guard[1] + cf->train[1];
+  const int row_lo = cf->row0 - 1 - hr, row_hi = cf->row1 - 1 + hr;   // 0-based inclusive
+  const int col_lo = cf->col0 - 1 - hc, col_hi = cf->col1 - 1 + hc;
+  if (cf->row1 < cf->row0 || cf->col1 < cf->col0) return fail(ctx, ISAC_ERR_INVALID_ARG, "empty CUT rectangle");
+  if (row_lo < 0 || row_hi >= n_ifft || col_lo < 0 || col_hi >= n_fft)
+    return fail(ctx, ISAC_ERR_CFAR_WINDOW, "CUT training window exceeds the range-Doppler map");
+  const int nr = row_hi - row_lo + 1, nc = col_hi - col_lo + 1;
+  const c64 *tw = nullptr, *twd = nullptr;
+  const double *wk = nullptr, *wr = nullptr;
+  ISAC_TRY(isac_get_twiddles(ctx, n_ifft, &tw));
+  ISAC_TRY(isac_get_twiddles2(ctx, n_fft, &twd));
+  ISAC_TRY(isac_get_windows(ctx, K, n_ifft, &wk, &wr));
+  ISAC_TRY(ensure(ctx, ctx->ymid, sizeof(c64) * (size_t)nr * L * A));
+  ISAC_TRY(ensure(ctx, ctx->pwin, sizeof(double) * (size_t)nr * nc * A));
+  ISAC_FFT_DISPATCH(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, d_rx, d_tx, K, L, A, tw, wk, wr, n_ifft, row_lo, nr,
+                                                        (c64*)ctx->ymid.p))));
+  const int Lu = L < n_fft ? L : n_fft;
+  size_t lds = sizeof(c64) * ((size_t)n_fft + (size_t)Lu * (kDopRows + 1));
+  ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(doppler_pow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL(doppler_pow_kernel, dim3(cdiv(nr, kDopRows), A), dim3(512), lds, ctx->stream, (const c64*)ctx->ymid.p, nr,
+                     L, A, n_fft, twd, std::sqrt((double)n_fft), col_lo, nc, (double*)ctx->pwin.p, (c64*)nullptr);
+  ISAC_HIP(hipGetLastError());
+  *nr_out = nr;
+  *nc_out = nc;
+  return ISAC_OK;
+}
+
+// CFAR over the window in ctx->pwin; leaves compact lists in ctx->det_* and numDets in ctx->misc[0].
+int isac_cfar_window(isac_ctx* ctx, const isac_cfar_config* cf, int nr, int nc, int A, int cap) {
+  CfarGeom g{};
+  g.nr = nr; g.nc = nc;
+  g.gr = cf->guard[0]; g.gc = cf->guard[1];
+  g.hr = cf->guard[0] + cf->train[0]; g.hc = cf->guard[1] + cf->train[1];
+  g.n_cut_rows = cf->row1 - cf->row0 + 1;
+  g.n_cut_cols = cf->col1 - cf->col0 + 1;
+  g.cap = cap;
+  const int n_train = (2 * g.hr + 1) * (2 * g.hc + 1) - (2 * g.gr + 1) * (2 * g.gc + 1);
+  if (n_train <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "TrainingBandSize must be positive");
+  g.alpha = cfar_alpha(n_train, cf->pfa);
+  g.n_train = (double)n_train;
+  // column panels: as many CUT columns as fit ~128 KB of LDS with full rows
+  const size_t budget = 128 * 1024;
+  int panel = (int)(budget / (sizeof(double) * (size_t)nr)) - 2 * g.hc;
+  if (panel < 1) return fail(ctx, ISAC_ERR_UNSUPPORTED, "CUT zone has too many rows for the LDS-staged detector");
+  if (panel > g.n_cut_cols) panel = g.n_cut_cols;
+  size_t lds = sizeof(double) * (size_t)nr * (panel + 2 * g.hc);
+  ISAC_TRY(ensure(ctx, ctx->det_cut, sizeof(int) * (size_t)A * cap));
+  ISAC_TRY(ensure(ctx, ctx->det_pow, sizeof(double) * (size_t)A * cap));
+  ISAC_TRY(ensure(ctx, ctx->det_cnt, sizeof(int) * (size_t)A));
+  ISAC_TRY(ensure(ctx, ctx->flags, sizeof(unsigned) * (size_t)g.n_cut_rows));
+  ISAC_TRY(ensure(ctx, ctx->misc, 256));
+  ISAC_HIP(hipMemsetAsync(ctx->flags.p, 0, sizeof(unsigned) * (size_t)g.n_cut_rows, ctx->stream));
+  ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cfar_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  hipLaunchKernelGGL(cfar_window_kernel, dim3(A), dim3(1024), lds, ctx->stream, (const double*)ctx->pwin.p, g, panel,
+                     (int*)ctx->det_cut.p, (double*)ctx->det_pow.p, (int*)ctx->det_cnt.p, (unsigned*)ctx->flags.p);
+  ISAC_HIP(hipGetLastError());
+  hipLaunchKernelGGL(count_rows_kernel, dim3(1), dim3(256), 0, ctx->stream, (const unsigned*)ctx->flags.p, g.n_cut_rows,
+                     (int*)ctx->misc.p);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+extern "C" int isac_cfar2d_ca(isac_ctx* ctx, const double* P, int32_t n_rows, int32_t n_cols, const int32_t* cut_idx,
+                              int32_t n_cut, const int32_t guard[2], const int32_t train[2], double pfa, int32_t* det_idx,
+                              int32_t cap, int32_t* n_det) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!P || !cut_idx || !guard || !train || !n_det || n_rows <= 0 || n_cols <= 0 || n_cut < 0)
+    return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  const int gr = guard[0], gc = guard[1], hr = guard[0] + train[0], hc = guard[1] + train[1];
+  const int n_train = (2 * hr + 1) * (2 * hc + 1) - (2 * gr + 1) * (2 * gc + 1);
+  if (n_train <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "TrainingBandSize must be positive");
+  for (int i = 0; i < n_cut; ++i) {
+    int r = cut_idx[2 * i] - 1, c = cut_idx[2 * i + 1] - 1;
+    if (r - hr < 0 || r + hr >= n_rows || c - hc < 0 || c + hc >= n_cols)
+      return fail(ctx, ISAC_ERR_CFAR_WINDOW, "CUT training window exceeds the input matrix");
+  }
+  *n_det = 0;
+  if (n_cut == 0) return ISAC_OK;
+  size_t pb = sizeof(double) * (size_t)n_rows * n_cols, cb = sizeof(int) * 2 * (size_t)n_cut;
+  ISAC_TRY(ensure(ctx, ctx->stage_a, pb));
+  ISAC_TRY(ensure(ctx, ctx->stage_b, cb));
+  ISAC_TRY(ensure(ctx, ctx->stage_c, (size_t)n_cut));
+  ISAC_HIP(hipMemcpyAsync(ctx->stage_a.p, P, pb, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_HIP(hipMemcpyAsync(ctx->stage_b.p, cut_idx, cb, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(cfar_list_kernel, dim3(cdiv(n_cut, 256)), dim3(256), 0, ctx->stream, (const double*)ctx->stage_a.p, n_rows,
+                     n_cols, (const int*)ctx->stage_b.p, n_cut, gr, gc, hr, hc, cfar_alpha(n_train, pfa), (double)n_train,
+                     (unsigned char*)ctx->stage_c.p);
+  ISAC_HIP(hipGetLastError());
+  std::vector<unsigned char> flags((size_t)n_cut);
+  ISAC_HIP(hipMemcpyAsync(flags.data(), ctx->stage_c.p, (size_t)n_cut, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  int n = 0;
+  for (int i = 0; i < n_cut; ++i)
+    if (flags[i]) {
+      if (n < cap && det_idx) {
+        det_idx[2 * n] = cut_idx[2 * i];
+        det_idx[2 * n + 1] = cut_idx[2 * i + 1];
+      }
+      ++n;
+    }
+  *n_det = n;
+  if (n > cap) return fail(ctx, ISAC_ERR_CAPACITY, "more detections than det_idx capacity");
+  return ISAC_OK;
+}
+
+extern "C" int isac_rdm_plane_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_c64* d_rx_grid,
+                                  const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A, int32_t ant, isac_c64* d_rdm) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!ep || !d_rx_grid || !d_tx_grid || !d_rdm || ant < 0 || ant >= A) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  const int n_ifft = ep->n_ifft, n_fft = ep->n_fft;
+  const c64 *tw = nullptr, *twd = nullptr;
+  const double *wk = nullptr, *wr = nullptr;
+  ISAC_TRY(isac_get_twiddles(ctx, n_ifft, &tw));
+  ISAC_TRY(isac_get_twiddles2(ctx, n_fft, &twd));
+  ISAC_TRY(isac_get_windows(ctx, K, n_ifft, &wk, &wr));
+  ISAC_TRY(ensure(ctx, ctx->stage_a, sizeof(c64) * (size_t)n_ifft * L));
+  const c64* rx = (const c64*)d_rx_grid + (size_t)K * L * ant;
+  const c64* tx = (const c64*)d_tx_grid + (size_t)K * L * ant;
+  ISAC_FFT_DISPATCH(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, rx, tx, K, L, 1, tw, wk, wr, n_ifft, 0, n_ifft,
+                                                        (c64*)ctx->stage_a.p))));
+  hipLaunchKernelGGL(doppler_full_kernel, dim3(cdiv((long long)n_ifft * n_fft, 256)), dim3(256), 0, ctx->stream,
+                     (const c64*)ctx->stage_a.p, n_ifft, L, n_fft, twd, std::sqrt((double)n_fft), (c64*)d_rdm);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}

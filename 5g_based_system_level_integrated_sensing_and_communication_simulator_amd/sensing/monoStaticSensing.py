@@ -1,0 +1,51 @@
+"""sensing.monoStaticSensing (+sensing/monoStaticSensing.m:1-23)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib as L
+from ._marshal import ChannelBlock, carrier_block, los_array
+
+
+def monoStaticSensing(txWaveform, txDimension, carrierInfo, radarParams, targetLoSConditions, *,
+                      noise=None, seed=None, nfft=None, ctx=None):
+    """echoGrid = monoStaticSensing(txWaveform, txDimension, carrierInfo, radarParams, targetLoSConditions).
+
+    Radar channel (:13) + OFDM demodulation (:16) + zero-padding of the symbol dimension up to
+    ``txDimension(2)`` (:19-21), fused on the device: the time-domain echo is never written to HBM.
+    numpy in -> numpy out; DeviceArray in -> DeviceArray out.  ``noise`` / ``seed`` as in
+    basicRadarChannel."""
+    dev = isinstance(txWaveform, L.DeviceArray)
+    ctx = ctx or (txWaveform.ctx if dev else L.default_context())
+    T, A = (txWaveform.shape if dev else np.shape(txWaveform))
+    cb = ChannelBlock(radarParams)
+    if A != cb.block.n_ants:
+        raise ValueError("txWaveform antenna dimension differs from radarParams.nTxAnts")
+    los = los_array(targetLoSConditions, cb.block.n_targets)
+    car = carrier_block(carrierInfo, nfft)
+    mode = L.NOISE_INJECTED if noise is not None else (L.NOISE_PHILOX if seed is not None else L.NOISE_NONE)
+    lib = ctx.lib
+    lw = C.c_int32(0)
+    st = lib.isac_ofdm_symbol_count(C.byref(car), C.c_int64(T), C.byref(lw))
+    if st != 0:
+        raise L.IsacError(st, "isac_ofdm_symbol_count failed")
+    l_out = max(int(lw.value), int(txDimension[1]))
+    lo = C.c_int32(0)
+    if dev:
+        nz = noise if (noise is None or isinstance(noise, L.DeviceArray)) else ctx.to_device(L.as_c128_f(noise))
+        out = ctx.empty((car.n_sc, max(l_out, 1), A))
+        ctx.check(lib.isac_mono_static_sensing_dev(ctx.handle, C.c_void_p(txWaveform.ptr), C.c_int64(T), C.c_int32(int(txDimension[1])),
+                                                   C.byref(car), C.byref(cb.block), los.ctypes.data_as(C.c_void_p), C.c_int(mode),
+                                                   C.c_void_p(nz.ptr if nz is not None else 0), C.c_uint64(seed or 0),
+                                                   C.c_void_p(out.ptr), C.byref(lo)))
+        return out
+    tx = L.as_c128_f(txWaveform)
+    nz = None if noise is None else L.as_c128_f(noise)
+    out = np.empty((car.n_sc, max(l_out, 1), A), dtype=np.complex128, order="F")
+    ctx.check(lib.isac_mono_static_sensing(ctx.handle, tx.ctypes.data_as(C.c_void_p), C.c_int64(T), C.c_int32(int(txDimension[1])),
+                                           C.byref(car), C.byref(cb.block), los.ctypes.data_as(C.c_void_p), C.c_int(mode),
+                                           nz.ctypes.data_as(C.c_void_p) if nz is not None else C.c_void_p(0),
+                                           C.c_uint64(seed or 0), out.ctypes.data_as(C.c_void_p), C.byref(lo)))
+    return out

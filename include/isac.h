@@ -1,0 +1,232 @@
+/*
+ * isac.h -- C ABI of libisac_hip.so, the MI355X (gfx950) implementation of the
+ * sensing hot path of xds0112/5G_based_System_level_Integrated_Sensing_and_Communication_Simulator.
+ *
+ * The reference is pure MATLAB and has no FFI of its own; the entry points below are
+ * what a MEX gateway for its +sensing package functions binds (INTEGRATION.md shows
+ * the gateway).  Each entry point cites the reference function it replaces.
+ *
+ * Conventions:
+ *   - every function returns an isac_status (0 = OK); it never throws, never exits;
+ *     isac_last_error() gives the message for the last failing call on that context;
+ *   - arrays are MATLAB column-major, complex data is interleaved double (re, im)
+ *     exactly as mxGetComplexDoubles() hands it over:
+ *        txWaveform(t,a)  at  t + T*a
+ *        grid(k,l,a)      at  k + K*(l + L*a)
+ *   - indices returned to the caller are 1-based like MATLAB's;
+ *   - "_dev" entry points take DEVICE pointers (HBM resident, caller-owned) and are
+ *     asynchronous on the context's stream unless they return host results; the
+ *     un-suffixed entry points take HOST pointers and stage through the context;
+ *   - inputs are borrowed read-only and never retained past the call;
+ *   - one context = one device + one HIP stream + scratch; a context is not
+ *     thread-safe, distinct contexts are independent.
+ */
+#ifndef ISAC_H
+#define ISAC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISAC_ABI_VERSION 1
+#define ISAC_MAX_EST 1024 /* capacity of the estimate vectors in isac_est_result */
+
+typedef struct isac_ctx isac_ctx;
+
+typedef struct { double re, im; } isac_c64; /* interleaved complex double */
+
+typedef enum {
+  ISAC_OK = 0,
+  ISAC_ERR_INVALID_ARG = 1,
+  ISAC_ERR_HIP = 2,          /* HIP runtime / no device / kernel failure */
+  ISAC_ERR_NO_LOS = 3,       /* every target NLoS -> empty rxWaveform (basicRadarChannel.m:59,64) */
+  ISAC_ERR_NO_DETECTION = 4, /* zero CFAR detections -> findpeaks 'NPeaks'=0 error (music.m:102);
+                                cellSimulation.m:196-202 maps it to senResults = NaN */
+  ISAC_ERR_CFAR_WINDOW = 5,  /* a CUT's training window leaves the map (phased.CFARDetector2D error) */
+  ISAC_ERR_CAPACITY = 6,     /* more results than the caller's capacity */
+  ISAC_ERR_UNSUPPORTED = 7,  /* e.g. UPA DoA: music.m:69 calls the non-existent tools.find2DPeaks */
+  ISAC_ERR_SHORT_WAVEFORM = 8 /* waveform shorter than one OFDM symbol (nrOFDMDemodulate error) */
+} isac_status;
+
+/* ------------------------------------------------------------------ context */
+int isac_abi_version(void);
+int isac_device_count(int* count);
+int isac_ctx_create(int device, isac_ctx** out);
+int isac_ctx_destroy(isac_ctx* ctx);
+const char* isac_last_error(const isac_ctx* ctx);
+/* The HIP stream (hipStream_t as void*) every launch of this context goes to.  */
+int isac_ctx_get_stream(isac_ctx* ctx, void** hip_stream);
+int isac_sync(isac_ctx* ctx);
+
+/* device memory + copies (so a host language needs nothing but this library) */
+int isac_dev_alloc(isac_ctx* ctx, size_t bytes, void** dptr);
+int isac_dev_free(isac_ctx* ctx, void* dptr);
+int isac_memcpy_h2d(isac_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int isac_memcpy_d2h(isac_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int isac_memset_dev(isac_ctx* ctx, void* dst_dev, int value, size_t bytes);
+
+/* GPU timing of the context's stream with HIP events (bench.py roofline leg). */
+int isac_timer_start(isac_ctx* ctx);
+int isac_timer_stop_ms(isac_ctx* ctx, double* elapsed_ms); /* synchronises */
+
+/* ------------------------------------------------------------------ parameter blocks */
+
+/* carrier = nrCarrierConfig fields monoStaticSensing.m:8-10 sets, + nrOFDMInfo() */
+typedef struct {
+  int32_t n_sc;      /* 12 * NRBsDL                              */
+  int32_t nfft;      /* nrOFDMInfo.Nfft (power of two, <= 4096)  */
+  int32_t scs_khz;   /* 15 / 30 / 60 / 120                       */
+  int32_t reserved;
+} isac_carrier;
+
+/* the radarParams fields basicRadarChannel.m:10-35 reads (host pointers) */
+typedef struct {
+  double fc;                        /* radarParams.fc                          */
+  double fs;                        /* radarParams.fs                          */
+  double n0;                        /* radarParams.N0 (noise power, W)         */
+  int32_t n_ants;                   /* radarParams.nTxAnts (Tx = Rx array)     */
+  int32_t n_targets;                /* radarParams.nTargets                    */
+  const double* range;              /* [Q] m                                   */
+  const double* velocity;           /* [Q] m/s                                 */
+  const double* large_scale_fading; /* [Q]                                     */
+  const isac_c64* rx_steering;      /* RxSteeringVec [A x Q] column-major      */
+} isac_radar_channel_params;
+
+typedef enum {
+  ISAC_NOISE_NONE = 0,   /* noiseless (tests)                                                     */
+  ISAC_NOISE_INJECTED = 1, /* caller supplies randn()+1j*randn() [T x A]; parity mode              */
+  ISAC_NOISE_PHILOX = 2  /* on-device Philox4x32-10 + Box-Muller, counter = t + T*a; perf mode    */
+} isac_noise_mode;
+
+/* cfar2D.m:27-33 detector configuration + the CUT rectangle cfar2D.m:17-24 builds */
+typedef struct {
+  double pfa;             /* ProbabilityFalseAlarm                     */
+  int32_t guard[2];       /* GuardBandSize    [rows cols]              */
+  int32_t train[2];       /* TrainingBandSize [rows cols]              */
+  int32_t row0, row1;     /* CUT rows  row0..row1 (1-based, inclusive) */
+  int32_t col0, col1;     /* CUT cols  col0..col1 (1-based, inclusive) */
+} isac_cfar_config;
+
+/* the radarEstParams fields fft2D.m / music.m read */
+typedef struct {
+  int32_t n_ifft;         /* radarEstParams.nIFFT                      */
+  int32_t n_fft;          /* radarEstParams.nFFT                       */
+  double r_res;           /* rRes                                      */
+  double v_res;           /* vRes                                      */
+  int32_t array_is_upa;   /* antennaType: 0 = ULA, 1 = UPA             */
+  int32_t n_ants_x, n_ants_y; /* UPA only                              */
+  double azimuth_scan_scale;        /* 360 */
+  double azimuth_scan_granularity;  /* 1   */
+  double elevation_scan_scale;      /* 180 */
+  double elevation_scan_granularity;/* 1   */
+} isac_est_params;
+
+/* estResults of fft2D.m:102,114-115 (+ bookkeeping) */
+typedef struct {
+  int32_t n_rng, n_vel, n_azi;
+  int32_t num_dets;            /* numel(uniqueRngEst), fft2D.m:110                */
+  int32_t total_detections;    /* sum over antennas of CFAR detections           */
+  int32_t reserved;
+  double rng_est[ISAC_MAX_EST];
+  double vel_est[ISAC_MAX_EST];
+  double azi_est[ISAC_MAX_EST];
+  double ele_est[ISAC_MAX_EST]; /* NaN for ULA (music.m:104)                       */
+} isac_est_result;
+
+/* ------------------------------------------------------------------ hot path */
+
+/* sensing.channelModels.basicRadarChannel(txWaveform, radarParams, targetLoSConditions)
+ * (+sensing/+channelModels/basicRadarChannel.m:1).  rxWave [T x A]. */
+int isac_basic_radar_channel_dev(isac_ctx* ctx, const isac_c64* d_tx_wave, int64_t T,
+                                 const isac_radar_channel_params* rp, const uint8_t* los,
+                                 int noise_mode, const isac_c64* d_noise_unit, uint64_t seed,
+                                 isac_c64* d_rx_wave);
+int isac_basic_radar_channel(isac_ctx* ctx, const isac_c64* tx_wave, int64_t T,
+                             const isac_radar_channel_params* rp, const uint8_t* los,
+                             int noise_mode, const isac_c64* noise_unit, uint64_t seed,
+                             isac_c64* rx_wave);
+
+/* sensing.monoStaticSensing(txWaveform, txDimension, carrierInfo, radarParams, targetLoSConditions)
+ * (+sensing/monoStaticSensing.m:1).  The time-domain echo is never materialised: beam-sum,
+ * per-target coefficient vectors, sample synthesis + OFDM demodulation are fused.
+ * echoGrid [n_sc x max(L_whole, tx_dim_l) x A]; *l_out receives its 2nd dimension. */
+int isac_mono_static_sensing_dev(isac_ctx* ctx, const isac_c64* d_tx_wave, int64_t T, int32_t tx_dim_l,
+                                 const isac_carrier* carrier, const isac_radar_channel_params* rp,
+                                 const uint8_t* los, int noise_mode, const isac_c64* d_noise_unit,
+                                 uint64_t seed, isac_c64* d_echo_grid, int32_t* l_out);
+int isac_mono_static_sensing(isac_ctx* ctx, const isac_c64* tx_wave, int64_t T, int32_t tx_dim_l,
+                             const isac_carrier* carrier, const isac_radar_channel_params* rp,
+                             const uint8_t* los, int noise_mode, const isac_c64* noise_unit,
+                             uint64_t seed, isac_c64* echo_grid, int32_t* l_out);
+/* number of whole OFDM symbols in T samples (size query for the call above) */
+int isac_ofdm_symbol_count(const isac_carrier* carrier, int64_t T, int32_t* n_symbols);
+
+/* nrOFDMDemodulate(carrier, waveform) as monoStaticSensing.m:16 uses it (NSlot = 0,
+ * CyclicPrefixFraction 0.5) and the plain CP-OFDM modulator that builds senTxWave
+ * (gNBPhy.m:599-608, no windowing).  wave [T x A], grid [n_sc x L x A]. */
+int isac_ofdm_demodulate_dev(isac_ctx* ctx, const isac_c64* d_wave, int64_t T, int32_t A,
+                             const isac_carrier* carrier, isac_c64* d_grid, int32_t L);
+int isac_ofdm_modulate_dev(isac_ctx* ctx, const isac_c64* d_grid, int32_t L, int32_t A,
+                           const isac_carrier* carrier, double amplitude, isac_c64* d_wave, int64_t T);
+int isac_ofdm_waveform_length(const isac_carrier* carrier, int32_t L, int64_t* T);
+
+/* phased.CFARDetector2D step (fft2D.m:62) on an arbitrary power map and CUT list.
+ * P [n_rows x n_cols] column-major, cut_idx [2 x n_cut] 1-based; det_idx [2 x cap]. */
+int isac_cfar2d_ca(isac_ctx* ctx, const double* P, int32_t n_rows, int32_t n_cols,
+                   const int32_t* cut_idx, int32_t n_cut, const int32_t guard[2], const int32_t train[2],
+                   double pfa, int32_t* det_idx, int32_t cap, int32_t* n_det);
+
+/* sensing.estimation.fft2D(radarEstParams, cfar, rxGrid, txGrid) (+sensing/+estimation/fft2D.m:1):
+ * range-Doppler map, per-antenna CA-CFAR, estimate lists, covariance, MUSIC DoA. */
+int isac_fft2d_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
+                   const isac_c64* d_rx_grid, const isac_c64* d_tx_grid,
+                   int32_t K, int32_t L, int32_t A, isac_est_result* out);
+int isac_fft2d(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
+               const isac_c64* rx_grid, const isac_c64* tx_grid,
+               int32_t K, int32_t L, int32_t A, isac_est_result* out);
+
+/* Introspection of the LAST isac_fft2d[_dev] call on this context (parity tests, plots):
+ *  - per-antenna detection indices in CUT order (before the peak sort), det_idx [2 x cap] 1-based,
+ *    ant_offsets [A+1] prefix offsets into det_idx;
+ *  - the |rdm|^2 window the detector saw: rows row0-hr..row1+hr, cols col0-hc..col1+hc, [nr x nc x A];
+ *  - Ra [A x A], the MUSIC spectrum in dB [n_steps]. */
+int isac_fft2d_get_detections(isac_ctx* ctx, int32_t* det_idx, double* det_pow, int32_t cap,
+                              int32_t* ant_offsets, int32_t* n_total);
+int isac_fft2d_get_power_window(isac_ctx* ctx, double* P, int64_t cap_elems, int32_t dims[3],
+                                int32_t* first_row, int32_t* first_col);
+int isac_fft2d_get_covariance(isac_ctx* ctx, isac_c64* Ra, int32_t A);
+int isac_fft2d_get_music_spectrum(isac_ctx* ctx, double* p_db, int32_t cap, int32_t* n_steps);
+
+/* Full range-Doppler map (fft2D.m:37-46) for one antenna plane, rdm [n_ifft x n_fft]; the
+ * reference plots antenna 1 (fft2D.m:119).  Debug/plot path, not on the hot path. */
+int isac_rdm_plane_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_c64* d_rx_grid,
+                       const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A, int32_t ant,
+                       isac_c64* d_rdm);
+
+/* Array covariance of fft2D.m:106-107: Ra = X*X'/N with X = reshape(G, N, A)' (conjugate
+ * transpose!), i.e. Ra[a,b] = sum_n conj(G[n,a]) G[n,b] / N.  fp64 MFMA. */
+int isac_covariance_dev(isac_ctx* ctx, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra);
+
+/* sensing.estimation.doaEstimation.music(numDets, radarEstParams, Ra) (music.m:1), ULA branch.
+ * num_dets < 0 means [] (model order from determineNumTargets, music.m:109-125). */
+int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_params* ep, const isac_c64* Ra,
+                   int32_t A, int32_t* L_out, double* azi_est, double* ele_est, int32_t cap, int32_t* n_est);
+
+/* Hermitian eigendecomposition used by MUSIC (eig(Ra), music.m:19): ascending real
+ * eigenvalues w [A], orthonormal eigenvectors V [A x A] column-major.  One-workgroup
+ * cyclic Jacobi on the device. */
+int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w, isac_c64* V);
+
+/* ------------------------------------------------------------------ synthetic inputs (bench/tests) */
+/* QPSK txGrid [K x L x A] (unit modulus, zero planes for 'S' slots: every 4th grid slot when
+ * zero_s_slots != 0) generated on the device from a Philox stream. */
+int isac_synth_qpsk_grid_dev(isac_ctx* ctx, isac_c64* d_grid, int32_t K, int32_t L, int32_t A,
+                             uint64_t seed, int32_t zero_s_slots);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISAC_H */
