@@ -372,9 +372,8 @@ extern "C" int isac_fft2d_dev(isac_ctx* ctx, const isac_est_params* ep, const is
   const size_t off_cut = off_pow + sizeof(double) * (size_t)pack_first;
   const size_t first_bytes = off_cut + sizeof(int) * (size_t)pack_first;
   const size_t pack_cap = (size_t)A * cap;
-  const size_t full_bytes = off_pow + (sizeof(double) + sizeof(int)) * pack_cap + 64;
-  ISAC_TRY(ensure(ctx, ctx->stage_a, full_bytes));
-  ISAC_TRY(ensure_pinned(ctx, full_bytes));
+  ISAC_TRY(ensure(ctx, ctx->stage_a, first_bytes));
+  ISAC_TRY(ensure_pinned(ctx, first_bytes));
   char* dbase = (char*)ctx->stage_a.p;
   // layout on the device: [hdr][spec][pow first][cut first] ... then the tails of pow / cut beyond pack_first
   double* d_ppow_first = (double*)(dbase + off_pow);

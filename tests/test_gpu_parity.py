@@ -205,7 +205,8 @@ def test_covariance_mfma(pkg, ctx, n, a):
     g = np.asfortranarray(rng.standard_normal((n, a)) + 1j * rng.standard_normal((n, a)))
     g[:, 0] *= 3.0                                           # asymmetric: catches row/col swaps
     d_ra = ctx.empty((a, a))
-    ctx.check(ctx.lib.isac_covariance_dev(ctx.handle, C.c_void_p(ctx.to_device(g).ptr), C.c_int64(n), C.c_int32(a), C.c_void_p(d_ra.ptr)))
+    d_g = ctx.to_device(g)                                   # keep alive until the result is read back
+    ctx.check(ctx.lib.isac_covariance_dev(ctx.handle, C.c_void_p(d_g.ptr), C.c_int64(n), C.c_int32(a), C.c_void_p(d_ra.ptr)))
     ra = d_ra.numpy()
     want = g.conj().T @ g / n
     assert rel(ra, want) < 1e-12 and np.array_equal(ra, ra.conj().T)
@@ -240,7 +241,8 @@ def test_music_doa_kat_and_mirror_ties(pkg, ctx):
     # two sources + model-order estimate ([] -> determineNumTargets)
     a1 = np.exp(-2j * np.pi * m * 0.5 * float(O.sind(15)))
     a2 = np.exp(-2j * np.pi * m * 0.5 * float(O.sind(-40)))
-    ra = 4 * np.outer(a1, a1.conj()) + np.outer(a2, a2.conj()) + 1e-2 * np.eye(16)
+    # distinct noise eigenvalues: with a flat floor the model-order rule argmaxes over rounding noise
+    ra = 4 * np.outer(a1, a1.conj()) + np.outer(a2, a2.conj()) + np.diag(np.random.default_rng(3).uniform(0.01, 0.03, 16))
     want = O.music_doa(None, sc.rp, ra)
     got = pkg.sensing.estimation.doaEstimation.music(None, rp, ra)
     assert got[0] == want[0] and np.array_equal(got[1], want[1])
