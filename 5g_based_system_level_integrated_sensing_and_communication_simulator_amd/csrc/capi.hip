@@ -13,9 +13,10 @@ using namespace isac;
 int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, const c64* d_rx, const c64* d_tx,
                           int K, int L, int A, int* nr_out, int* nc_out);
 int isac_cfar_window(isac_ctx* ctx, const isac_cfar_config* cf, int nr, int nc, int A, int cap);
-int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A);
+int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st);
 int isac_music_scan_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num_dets_host, const double* d_sind, int n_steps,
-                        double d_ratio, double* d_spec);
+                        double d_ratio, double* d_spec, hipStream_t st);
+int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra);
 
 namespace {
 
@@ -200,6 +201,7 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
       hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_cfar, hipEventDisableTiming) != hipSuccess ||
       hipEventCreate(&ctx->ev_t0) != hipSuccess || hipEventCreate(&ctx->ev_t1) != hipSuccess) {
     delete ctx;
     return ISAC_ERR_HIP;
@@ -225,6 +227,7 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   if (ctx->pinned) hipHostFree(ctx->pinned);
   hipEventDestroy(ctx->ev_fork);
   hipEventDestroy(ctx->ev_join);
+  hipEventDestroy(ctx->ev_cfar);
   hipEventDestroy(ctx->ev_t0);
   hipEventDestroy(ctx->ev_t1);
   hipStreamDestroy(ctx->stream);
@@ -302,12 +305,15 @@ __global__ void pack_kernel(const int* __restrict__ det_cnt, const int* __restri
                             int* __restrict__ first_cut, double* __restrict__ first_pow, const double* __restrict__ spec,
                             int n_steps, double* __restrict__ spec_out) {
   __shared__ int s_off[1025];
+  __shared__ int s_cnt[1024];
   const int tid = threadIdx.x;
+  for (int a = tid; a < A; a += blockDim.x) s_cnt[a] = det_cnt[a];
+  __syncthreads();
   if (tid == 0) {
     int acc = 0, over = 0;
     for (int a = 0; a < A; ++a) {
       s_off[a] = acc;
-      int c = det_cnt[a];
+      int c = s_cnt[a];
       over |= c > cap;
       acc += c < cap ? c : cap;
     }
@@ -346,24 +352,33 @@ extern "C" int isac_fft2d_dev(isac_ctx* ctx, const isac_est_params* ep, const is
   ctx->last.valid = false;
   const c64* rx = (const c64*)d_rx_grid;
   const c64* tx = (const c64*)d_tx_grid;
+  const bool upa = ep->array_is_upa != 0;
+  int n_steps = 0;
+  const double* d_sind = nullptr;
+  // MUSIC branch on the second stream, concurrent with the range-Doppler/CFAR branch:
+  //   stream2: covariance (fp64 MFMA) -> eig (one CU)      stream: range IFFT -> Doppler -> CFAR
+  ISAC_TRY(ensure(ctx, ctx->cov, sizeof(c64) * (size_t)A * A));
+  ISAC_TRY(ensure(ctx, ctx->misc, 256));
+  if (!upa) {
+    ISAC_TRY(get_sind_table(ctx, ep, &d_sind, &n_steps));
+    ISAC_TRY(ensure(ctx, ctx->spec, sizeof(double) * (size_t)n_steps));
+  }
+  ISAC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+  ISAC_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  ISAC_TRY(isac_covariance_on(ctx, ctx->stream2, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
+  if (!upa) ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, ctx->stream2));                         // music.m:19
   int nr = 0, nc = 0;
   ISAC_TRY(isac_rdm_power_window(ctx, ep, cfar, rx, tx, K, L, A, &nr, &nc));          // fft2D.m:37-46,61
   const int n_cut_rows = cfar->row1 - cfar->row0 + 1, n_cut_cols = cfar->col1 - cfar->col0 + 1;
   const long long n_cut = (long long)n_cut_rows * n_cut_cols;
   const int cap = (int)std::min<long long>(n_cut, 4096);
-  ISAC_TRY(isac_cfar_window(ctx, cfar, nr, nc, A, cap));                                 // fft2D.m:62
-  // MUSIC branch: covariance -> eig -> scan with numDets taken from the device counter
-  ISAC_TRY(ensure(ctx, ctx->cov, sizeof(c64) * (size_t)A * A));
-  ISAC_TRY(isac_covariance_dev(ctx, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
-  const bool upa = ep->array_is_upa != 0;
-  int n_steps = 0;
-  const double* d_sind = nullptr;
-  if (!upa) {
-    ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A));                             // music.m:19
-    ISAC_TRY(get_sind_table(ctx, ep, &d_sind, &n_steps));
-    ISAC_TRY(ensure(ctx, ctx->spec, sizeof(double) * (size_t)n_steps));
-    ISAC_TRY(isac_music_scan_dev(ctx, A, (const int*)ctx->misc.p, 0, d_sind, n_steps, 0.5, (double*)ctx->spec.p));   // music.m:12,82-91
-  }
+  ISAC_TRY(isac_cfar_window(ctx, cfar, nr, nc, A, cap));                                 // fft2D.m:62 (+ numDets on device)
+  ISAC_HIP(hipEventRecord(ctx->ev_cfar, ctx->stream));
+  ISAC_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_cfar, 0));
+  if (!upa)   // numDets comes from the CFAR branch, still on the device                   music.m:12,82-91
+    ISAC_TRY(isac_music_scan_dev(ctx, A, (const int*)ctx->misc.p, 0, d_sind, n_steps, 0.5, (double*)ctx->spec.p, ctx->stream2));
+  ISAC_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
+  ISAC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   // pack + one device->host copy
   const int pack_first = 4096;
   const size_t hdr_ints = 3 + (size_t)A + 1;
@@ -541,7 +556,7 @@ extern "C" int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w,
   if (!H || !w || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)A * A));
   ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, H, sizeof(c64) * (size_t)A * A, hipMemcpyHostToDevice, ctx->stream));
-  ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A));
+  ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));
   std::vector<double> wv((size_t)A);
   std::vector<c64> vv((size_t)A * A);
   ISAC_HIP(hipMemcpyAsync(wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));
@@ -564,7 +579,7 @@ extern "C" int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_pa
   *n_est = 0;
   ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)A * A));
   ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, Ra, sizeof(c64) * (size_t)A * A, hipMemcpyHostToDevice, ctx->stream));
-  ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A));                                    // music.m:19
+  ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));                                    // music.m:19
   int L = num_dets;
   if (num_dets < 0) {                                                                              // music.m:21-22
     std::vector<double> wv((size_t)A);
@@ -579,7 +594,7 @@ extern "C" int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_pa
   const double* d_sind = nullptr;
   ISAC_TRY(get_sind_table(ctx, ep, &d_sind, &n_steps));
   ISAC_TRY(ensure(ctx, ctx->spec, sizeof(double) * (size_t)n_steps));
-  ISAC_TRY(isac_music_scan_dev(ctx, A, nullptr, L, d_sind, n_steps, 0.5, (double*)ctx->spec.p));
+  ISAC_TRY(isac_music_scan_dev(ctx, A, nullptr, L, d_sind, n_steps, 0.5, (double*)ctx->spec.p, nullptr));
   std::vector<double> spec((size_t)n_steps);
   ISAC_HIP(hipMemcpyAsync(spec.data(), ctx->spec.p, sizeof(double) * (size_t)n_steps, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));

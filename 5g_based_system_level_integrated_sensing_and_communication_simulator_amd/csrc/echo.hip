@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
   const int tid = threadIdx.x;
   const int n_cols = L_whole * A;
   FFT fft;
-  for (int col = blockIdx.x; col < n_cols; col += gridDim.x) {
+  fft.init(lds, tw, tid);
+  {
+    const int col = blockIdx.x;                    // one (symbol, antenna) column per workgroup
     const int l = col % L_whole, r = col / L_whole;
     const int cp = cp_of_symbol(l, g.cp_base, g.cp_long, g.sym_per_half);
     const int off = cp / 2;  // fix(cp * CyclicPrefixFraction), fraction 0.5
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
     const int dshift = cp - off;  // window leads the useful part by dshift samples
     if constexpr (SYNTH) {
       const c64* sr = steer_rq + (long long)r * Q;
-      fft.fill([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, noise_mode, noise, n0s, seed); }, tid);
+      fft.template fill<4>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, noise_mode, noise, n0s, seed); }, tid);
     } else {
       const c64* src = wave + w0 + T * (long long)r;
       fft.fill([&](int n) { return src[n]; }, tid);
@@ -188,16 +190,12 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
     const int half = g.n_sc / 2;
     fft.drain(
         [&](int k, c64 v) {
-          int kb = (k < g.nfft / 2) ? k : k - g.nfft;  // signed bin
-          int row = kb + half;
-          if (row >= 0 && row < g.n_sc) {
-            int m = (int)(((long long)kb * dshift) % g.nfft);
-            if (m < 0) m += g.nfft;
-            dst[row] = v * conj(tw[m]);  // exp(+2 pi j kb dshift / nfft)
-          }
+          const int kb = (k < g.nfft / 2) ? k : k - g.nfft;  // signed bin
+          const int row = kb + half;
+          const c64 ph = fft.phase_ramp(lds, tw, kb, dshift);   // exp(+2 pi j kb dshift / nfft), fetched unconditionally
+          if (row >= 0 && row < g.n_sc) dst[row] = v * ph;
         },
         tid);
-    fft.release();
   }
 }
 
@@ -211,7 +209,9 @@ __global__ __launch_bounds__(256, 2) void mod_kernel(OfdmGeom g, long long T, in
   const int tid = threadIdx.x;
   const int n_cols = L * A;
   FFT fft;
-  for (int col = blockIdx.x; col < n_cols; col += gridDim.x) {
+  fft.init(lds, tw, tid);
+  {
+    const int col = blockIdx.x;                    // one (symbol, antenna) column per workgroup
     const int l = col % L, a = col / L;
     const int cp = cp_of_symbol(l, g.cp_base, g.cp_long, g.sym_per_half);
     const long long s0 = symbol_start(l, g.nfft, g.cp_base, g.cp_long, g.sym_per_half);
@@ -221,7 +221,9 @@ __global__ __launch_bounds__(256, 2) void mod_kernel(OfdmGeom g, long long T, in
         [&](int n) {
           int kb = (n < g.nfft / 2) ? n : n - g.nfft;
           int row = kb + half;
-          return (row >= 0 && row < g.n_sc) ? src[row] : mk(0.0, 0.0);
+          const bool ok = (row >= 0 && row < g.n_sc);
+          c64 v = src[ok ? row : 0];                   // unconditional load, select afterwards
+          return ok ? v : mk(0.0, 0.0);
         },
         tid);
     fft.template transform<+1>(lds, tw, tid);
@@ -233,7 +235,6 @@ __global__ __launch_bounds__(256, 2) void mod_kernel(OfdmGeom g, long long T, in
           if (m >= g.nfft - cp) dst[m - (g.nfft - cp)] = v;
         },
         tid);
-    fft.release();
   }
 }
 
@@ -299,11 +300,7 @@ extern "C" int isac_ofdm_waveform_length(const isac_carrier* carrier, int32_t L,
   return ISAC_OK;
 }
 
-static unsigned fft_grid(int n_cols) {
-  // two 69 KB workgroups fit a CU; 256 CUs -> 512 resident; keep a few waves of work per slot
-  unsigned cap = 256u * 2u * 4u;
-  return n_cols < (int)cap ? (unsigned)n_cols : cap;
-}
+static unsigned fft_grid(int n_cols) { return (unsigned)n_cols; }   // one column per workgroup (two 72 KB workgroups per CU)
 
 // Everything basicRadarChannel needs before samples can be synthesised: LoS compaction,
 // beam-sums, coefficient vectors.  Leaves coef [Q x T], phase_rx [T], steer_rq [A x Q] in ctx.
@@ -395,7 +392,7 @@ static int launch_demod(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, in
                         int noise_mode, const c64* noise, double n0s, uint64_t seed, const c64* wave, c64* grid) {
   size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
   auto kern = demod_kernel<FFT, SYNTH>;
-  ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
   hipLaunchKernelGGL(kern, dim3(fft_grid(L_whole * A)), dim3(256), lds, ctx->stream, g, T, A, L_whole, L_out, tw, Q,
                      (const c64*)ctx->coef.p, SYNTH ? (const c64*)ctx->steer.p + (size_t)A * Q : nullptr,
                      (const c64*)ctx->phase_rx.p, noise_mode, noise, n0s, seed, wave, grid);
@@ -452,7 +449,7 @@ static int launch_mod(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, int 
                       double scale, c64* wave) {
   size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
   auto kern = mod_kernel<FFT>;
-  ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
   hipLaunchKernelGGL(kern, dim3(fft_grid(L * A)), dim3(256), lds, ctx->stream, g, T, A, L, tw, grid, scale, wave);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;

@@ -89,18 +89,42 @@ struct Fft4096 {
   static constexpr int PER = 16;
   static constexpr int SK = 273;  // k1 stride (complex elements)
   static constexpr int SE = 17;   // second-digit stride
-  static constexpr int LDS_ELEMS = 16 * SK;
+  static constexpr int IMG = 16 * SK;          // data image
+  static constexpr int LDS_ELEMS = IMG + 256;  // + W256 table (second-pass twiddles and OFDM phase ramps)
   c64 x[PER];
+  c64 wb[4];  // W4096^(tid * {1,2,4,8}); the other first-pass twiddles are products of at most 4 of these
 
-  template <class F>
+  // once per workgroup
+  __device__ __forceinline__ void init(c64* __restrict__ lds, const c64* __restrict__ tw, int tid) {
+    wb[0] = tw[tid];
+    wb[1] = tw[2 * tid];
+    wb[2] = tw[4 * tid];
+    wb[3] = tw[8 * tid];
+    lds[IMG + tid] = tw[16 * tid];  // W256^tid
+    __syncthreads();
+  }
+  // exp(+2 pi j kb dshift / 4096) for the OFDM window offset; dshift is a multiple of 16 at Nfft = 4096
+  __device__ __forceinline__ c64 phase_ramp(const c64* __restrict__ lds, const c64* __restrict__, int kb, int dshift) const {
+    return conj(lds[IMG + ((kb * (dshift >> 4)) & 255)]);
+  }
+
+  // GROUP bounds how many element producers the scheduler may interleave (register pressure:
+  // each in-flight producer holds its loads; w1 + x already pin ~124 VGPRs of the 256 budget)
+  template <int GROUP = 8, class F>
   __device__ __forceinline__ void fill(F&& f, int tid) {
 #pragma unroll
-    for (int j = 0; j < PER; ++j) x[j] = f(tid + NT * j);
+    for (int j = 0; j < PER; ++j) {
+      x[j] = f(tid + NT * j);
+      if ((j % GROUP) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+    }
   }
-  template <class G>
+  template <int GROUP = 8, class G>
   __device__ __forceinline__ void drain(G&& g, int tid) {
 #pragma unroll
-    for (int j = 0; j < PER; ++j) g(tid + NT * j, x[j]);
+    for (int j = 0; j < PER; ++j) {
+      g(tid + NT * j, x[j]);
+      if ((j % GROUP) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // x[j] = in[tid + 256 j]  ->  x[f] = OUT[tid + 256 f]
@@ -109,13 +133,25 @@ struct Fft4096 {
     // ---- pass 1: n = 256 a + b (b = tid), DFT16 over a -> k1, twiddle W4096^(b k1)
     dft16<DIR>(x);
     {
-      const int pos = SE * (tid >> 4) + (tid & 15);
-#pragma unroll
-      for (int k1 = 0; k1 < 16; ++k1) {
-        c64 v = x[k1];
-        if (k1) v = v * tw_dir<DIR>(tw[tid * k1]);
-        lds[k1 * SK + pos] = v;
-      }
+      c64* o = lds + SE * (tid >> 4) + (tid & 15);
+      const c64 w1 = tw_dir<DIR>(wb[0]), w2 = tw_dir<DIR>(wb[1]), w4 = tw_dir<DIR>(wb[2]), w8 = tw_dir<DIR>(wb[3]);
+      const c64 w3 = w1 * w2, w5 = w4 * w1, w6 = w4 * w2, w7 = w4 * w3;
+      o[0] = x[0];
+      o[1 * SK] = x[1] * w1;
+      o[2 * SK] = x[2] * w2;
+      o[3 * SK] = x[3] * w3;
+      o[4 * SK] = x[4] * w4;
+      o[5 * SK] = x[5] * w5;
+      o[6 * SK] = x[6] * w6;
+      o[7 * SK] = x[7] * w7;
+      o[8 * SK] = x[8] * w8;
+      o[9 * SK] = x[9] * (w8 * w1);
+      o[10 * SK] = x[10] * (w8 * w2);
+      o[11 * SK] = x[11] * (w8 * w3);
+      o[12 * SK] = x[12] * (w8 * w4);
+      o[13 * SK] = x[13] * (w8 * w5);
+      o[14 * SK] = x[14] * (w8 * w6);
+      o[15 * SK] = x[15] * (w8 * w7);
     }
     __syncthreads();
     // ---- pass 2: per k1 a 256-point DFT over b = 16 c + d; thread (k1, d): DFT16 over c -> e
@@ -125,12 +161,9 @@ struct Fft4096 {
 #pragma unroll
       for (int c = 0; c < 16; ++c) x[c] = base[SE * c];
       dft16<DIR>(x);
+      base[0] = x[0];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        c64 v = x[e];
-        if (e) v = v * tw_dir<DIR>(tw[16 * d * e]);
-        base[SE * e] = v;  // in place: same address set this thread just read
-      }
+      for (int e = 1; e < 16; ++e) base[SE * e] = x[e] * tw_dir<DIR>(lds[IMG + d * e]);  // in place
     }
     __syncthreads();
     // ---- pass 3: thread (k1 = tid & 15, e = tid >> 4): DFT16 over d -> f; k = k1 + 16 e + 256 f
@@ -154,7 +187,14 @@ struct FftStockham {
   static constexpr int LDS_ELEMS = 2 * N;
   c64 x[PER];
 
-  template <class F>
+  __device__ __forceinline__ void init(c64* __restrict__, const c64* __restrict__, int) {}
+  __device__ __forceinline__ c64 phase_ramp(const c64* __restrict__, const c64* __restrict__ tw, int kb, int dshift) const {
+    int m = (int)(((long long)kb * dshift) % N);
+    if (m < 0) m += N;
+    return conj(tw[m]);
+  }
+
+  template <int GROUP = 8, class F>
   __device__ __forceinline__ void fill(F&& f, int tid) {
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -162,7 +202,7 @@ struct FftStockham {
       if (n < N) x[j] = f(n);
     }
   }
-  template <class G>
+  template <int GROUP = 8, class G>
   __device__ __forceinline__ void drain(G&& g, int tid) {
 #pragma unroll
     for (int j = 0; j < PER; ++j) {

@@ -63,7 +63,7 @@ struct isac_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // MUSIC branch (covariance/eig) overlaps the RDM branch
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cfar = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   std::string err;
   // cached device tables
   std::map<int, isac::DevBuf> twiddles;                             // n -> exp(-2 pi j m / n)

@@ -90,24 +90,36 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_kernel(const c64* __restrict_
   }
 }
 
-// fixed-order reduction over workgroup partials + Hermitian fill + 1/N
-__global__ __launch_bounds__(256) void cov_reduce_kernel(const double* __restrict__ part, int n_wg, int n_tiles, int A,
-                                                         double inv_n, c64* __restrict__ Ra /* [A x A] column-major */) {
+// fixed-order reduction over workgroup partials + Hermitian fill + 1/N.
+// blockDim = (256, 4): the 4 y-slices each sum a contiguous quarter of the partials, then combine in order.
+__global__ __launch_bounds__(1024) void cov_reduce_kernel(const double* __restrict__ part, int n_wg, int n_tiles, int A,
+                                                          double inv_n, c64* __restrict__ Ra /* [A x A] column-major */) {
+  __shared__ double s_sum[3][4][256];
   const int t = blockIdx.x;
   const int nb = (A + 15) / 16;
   int I, J;
   tile_ij(t, nb, I, J);
   const int e = threadIdx.x;            // r*64 + lane
+  const int g = threadIdx.y;
   const int r = e >> 6, lane = e & 63;
   const int row = (lane >> 4) + 4 * r;  // f64 MFMA C/D layout: row = (lane>>4) + 4*reg, col = lane&15
   const int col = lane & 15;
+  const int per = (n_wg + 3) / 4;
+  const int w0 = g * per, w1 = min(n_wg, w0 + per);
   double sr = 0.0, sp = 0.0, sm = 0.0;
-  for (int w = 0; w < n_wg; ++w) {
+#pragma unroll 8
+  for (int w = w0; w < w1; ++w) {
     const double* o = part + (((long long)w * n_tiles + t) * 3) * 256;
     sr += o[e];
     sp += o[256 + e];
     sm += o[512 + e];
   }
+  s_sum[0][g][e] = sr; s_sum[1][g][e] = sp; s_sum[2][g][e] = sm;
+  __syncthreads();
+  if (g != 0) return;
+  sr = ((s_sum[0][0][e] + s_sum[0][1][e]) + s_sum[0][2][e]) + s_sum[0][3][e];
+  sp = ((s_sum[1][0][e] + s_sum[1][1][e]) + s_sum[1][2][e]) + s_sum[1][3][e];
+  sm = ((s_sum[2][0][e] + s_sum[2][1][e]) + s_sum[2][2][e]) + s_sum[2][3][e];
   const int a = I * 16 + row, b = J * 16 + col;
   if (a < A && b < A) {
     c64 v = mk(sr * inv_n, (sp - sm) * inv_n);
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
         rp[tid] = p; rq[tid] = q;
         c64 beta = H[p + n * q];
         double alpha = H[p + n * p].re, gamma = H[q + n * q].re;
-        double ab = hypot(beta.re, beta.im);
+        double ab = sqrt(beta.re * beta.re + beta.im * beta.im);
         double c = 1.0, s = 0.0;
         c64 ph = mk(1.0, 0.0);                       // e^{j phi}
         if (ab > 0.0 && ab > 1e-300) {
@@ -219,7 +231,7 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
       __syncthreads();
       // row update  H <- J^H H : row_p' = c row_p - s e^{+j phi} row_q ; row_q' = s row_p + c e^{+j phi} row_q
       for (int j = tid; j < (n / 2) * n; j += nt) {
-        int k = j / n, col = j % n;
+        int k = j % (n / 2), col = j / (n / 2);     // pair index fastest: lanes touch distinct rows of one column
         int p = rp[k], q = rq[k];
         double c = rot[k].re, s = rot[k].im;
         c64 ep = rph[k];
@@ -296,8 +308,12 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const double* __restric
 // ================================================================= host side
 using namespace isac;
 
+int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra);
 extern "C" int isac_covariance_dev(isac_ctx* ctx, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra) {
   if (!ctx) return ISAC_ERR_INVALID_ARG;
+  return isac_covariance_on(ctx, ctx->stream, d_grid, N, A, d_Ra);
+}
+int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra) {
   if (!d_grid || !d_Ra || N <= 0 || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   const int nb = (A + 15) / 16;
   const int n_tiles = nb * (nb + 1) / 2;
@@ -310,26 +326,26 @@ extern "C" int isac_covariance_dev(isac_ctx* ctx, const isac_c64* d_grid, int64_
   const long long steps_per_wg = (total_steps + gx - 1) / gx;
   gx = (total_steps + steps_per_wg - 1) / steps_per_wg;
   ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * (size_t)gx * n_tiles * 3 * 256));
-  hipLaunchKernelGGL(cov_mfma_kernel, dim3((unsigned)gx, gy), dim3(256), 0, ctx->stream, (const c64*)d_grid, (long long)N, A,
+  hipLaunchKernelGGL(cov_mfma_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, (const c64*)d_grid, (long long)N, A,
                      n_tiles, steps_per_wg, (double*)ctx->cov_part.p);
   ISAC_HIP(hipGetLastError());
-  hipLaunchKernelGGL(cov_reduce_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, (const double*)ctx->cov_part.p, (int)gx,
+  hipLaunchKernelGGL(cov_reduce_kernel, dim3(n_tiles), dim3(256, 4), 0, st, (const double*)ctx->cov_part.p, (int)gx,
                      n_tiles, A, 1.0 / (double)N, (c64*)d_Ra);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }
 
 // device eig: H [A x A] (device) -> ctx->eig_w [A], ctx->eig_v [A x A] (unsorted)
-int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A) {
+int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
+  if (!st) st = ctx->stream;
   if (A > kJacobiMaxA) return fail(ctx, ISAC_ERR_UNSUPPORTED, "device eigensolver supports up to 64 antennas in this build");
   const int n = (A + 1) & ~1;
   ISAC_TRY(ensure(ctx, ctx->eig_w, sizeof(double) * (size_t)A + 64));
   ISAC_TRY(ensure(ctx, ctx->eig_v, sizeof(c64) * (size_t)A * A));
   size_t lds = sizeof(c64) * ((size_t)2 * n * n + n) + sizeof(int) * n + 64;
-  ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
   int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
-  hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(1024), lds, ctx->stream, d_H, A, 40, (double*)ctx->eig_w.p,
+  hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(1024), lds, st, d_H, A, 40, (double*)ctx->eig_w.p,
                      (c64*)ctx->eig_v.p, info);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
@@ -337,8 +353,9 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A) {
 
 // scan: uses ctx->eig_w / eig_v; L from device pointer (fused pipeline) or host value
 int isac_music_scan_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num_dets_host, const double* d_sind, int n_steps,
-                        double d_ratio, double* d_spec) {
-  hipLaunchKernelGGL(music_scan_kernel, dim3(n_steps), dim3(256), sizeof(c64) * (size_t)A, ctx->stream,
+                        double d_ratio, double* d_spec, hipStream_t st) {
+  if (!st) st = ctx->stream;
+  hipLaunchKernelGGL(music_scan_kernel, dim3(n_steps), dim3(256), sizeof(c64) * (size_t)A, st,
                      (const double*)ctx->eig_w.p, (const c64*)ctx->eig_v.p, A, d_num_dets, num_dets_host, d_sind, d_ratio,
                      2.220446049250313e-16, d_spec);
   ISAC_HIP(hipGetLastError());

@@ -30,13 +30,16 @@ __global__ __launch_bounds__(256, 2) void range_kernel(const c64* __restrict__ r
   const int tid = threadIdx.x;
   const int n_cols = L * A;
   FFT fft;
-  for (int col = blockIdx.x; col < n_cols; col += gridDim.x) {
+  fft.init(lds, tw, tid);
+  {
+    const int col = blockIdx.x;                    // one (symbol, antenna) column per workgroup
     const c64* prx = rx + (long long)K * col;
     const c64* ptx = tx + (long long)K * col;
     fft.fill(
         [&](int n) {
-          if (n >= K) return mk(0.0, 0.0);                       // ifft(., nIFFT, 1) zero-pads at the end
-          return mul_conj(prx[n], ptx[n]) * win_k[n];            // fft2D.m:37,:43
+          const int nc = n < K ? n : K - 1;                      // unconditional loads, select afterwards
+          c64 v = mul_conj(prx[nc], ptx[nc]) * win_k[nc];        // fft2D.m:37,:43
+          return n < K ? v : mk(0.0, 0.0);                       // ifft(., nIFFT, 1) zero-pads at the end
         },
         tid);
     fft.template transform<+1>(lds, tw, tid);
@@ -44,10 +47,10 @@ __global__ __launch_bounds__(256, 2) void range_kernel(const c64* __restrict__ r
     fft.drain(
         [&](int n, c64 v) {
           int rr = n - row_lo;
-          if (rr >= 0 && rr < n_rows) dst[rr] = ((v * inv_n) * sqrt_n) * win_r[n];   // :44-45
+          const double wr = win_r[n];
+          if (rr >= 0 && rr < n_rows) dst[rr] = ((v * inv_n) * sqrt_n) * wr;         // :44-45
         },
         tid);
-    fft.release();
   }
 }
 
@@ -250,17 +253,14 @@ int isac_get_windows(isac_ctx* ctx, int K, int n_ifft, const double** win_k, con
 
 static double cfar_alpha(int n_train, double pfa) { return n_train * (std::pow(pfa, -1.0 / n_train) - 1.0); }
 
-static unsigned fft_grid2(int n_cols) {
-  unsigned cap = 256u * 2u * 4u;
-  return n_cols < (int)cap ? (unsigned)n_cols : cap;
-}
+static unsigned fft_grid2(int n_cols) { return (unsigned)n_cols; }   // one column per workgroup
 
 template <class FFT>
 static int launch_range(isac_ctx* ctx, hipStream_t st, const c64* rx, const c64* tx, int K, int L, int A, const c64* tw,
                         const double* wk, const double* wr, int n_ifft, int row_lo, int n_rows, c64* ymid) {
   size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
   auto kern = range_kernel<FFT>;
-  ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
   hipLaunchKernelGGL(kern, dim3(fft_grid2(L * A)), dim3(256), lds, st, rx, tx, K, L, A, tw, wk, wr, 1.0 / n_ifft,
                      std::sqrt((double)n_ifft), row_lo, n_rows, ymid);
   ISAC_HIP(hipGetLastError());
@@ -289,8 +289,7 @@ int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_c
                                                         (c64*)ctx->ymid.p))));
   const int Lu = L < n_fft ? L : n_fft;
   size_t lds = sizeof(c64) * ((size_t)n_fft + (size_t)Lu * (kDopRows + 1));
-  ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(doppler_pow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(doppler_pow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
   hipLaunchKernelGGL(doppler_pow_kernel, dim3(cdiv(nr, kDopRows), A), dim3(512), lds, ctx->stream, (const c64*)ctx->ymid.p, nr,
                      L, A, n_fft, twd, std::sqrt((double)n_fft), col_lo, nc, (double*)ctx->pwin.p, (c64*)nullptr);
   ISAC_HIP(hipGetLastError());
@@ -322,10 +321,8 @@ int isac_cfar_window(isac_ctx* ctx, const isac_cfar_config* cf, int nr, int nc, 
   ISAC_TRY(ensure(ctx, ctx->det_pow, sizeof(double) * (size_t)A * cap));
   ISAC_TRY(ensure(ctx, ctx->det_cnt, sizeof(int) * (size_t)A));
   ISAC_TRY(ensure(ctx, ctx->flags, sizeof(unsigned) * (size_t)g.n_cut_rows));
-  ISAC_TRY(ensure(ctx, ctx->misc, 256));
   ISAC_HIP(hipMemsetAsync(ctx->flags.p, 0, sizeof(unsigned) * (size_t)g.n_cut_rows, ctx->stream));
-  ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cfar_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds));
+  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cfar_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
   hipLaunchKernelGGL(cfar_window_kernel, dim3(A), dim3(1024), lds, ctx->stream, (const double*)ctx->pwin.p, g, panel,
                      (int*)ctx->det_cut.p, (double*)ctx->det_pow.p, (int*)ctx->det_cnt.p, (unsigned*)ctx->flags.p);
   ISAC_HIP(hipGetLastError());

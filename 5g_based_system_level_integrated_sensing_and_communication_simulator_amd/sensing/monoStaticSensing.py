@@ -10,13 +10,13 @@ from ._marshal import ChannelBlock, carrier_block, los_array
 
 
 def monoStaticSensing(txWaveform, txDimension, carrierInfo, radarParams, targetLoSConditions, *,
-                      noise=None, seed=None, nfft=None, ctx=None):
+                      noise=None, seed=None, nfft=None, ctx=None, out=None):
     """echoGrid = monoStaticSensing(txWaveform, txDimension, carrierInfo, radarParams, targetLoSConditions).
 
     Radar channel (:13) + OFDM demodulation (:16) + zero-padding of the symbol dimension up to
     ``txDimension(2)`` (:19-21), fused on the device: the time-domain echo is never written to HBM.
-    numpy in -> numpy out; DeviceArray in -> DeviceArray out.  ``noise`` / ``seed`` as in
-    basicRadarChannel."""
+    numpy in -> numpy out; DeviceArray in -> DeviceArray out (``out``: optional pre-allocated
+    DeviceArray to reuse between CPIs).  ``noise`` / ``seed`` as in basicRadarChannel."""
     dev = isinstance(txWaveform, L.DeviceArray)
     ctx = ctx or (txWaveform.ctx if dev else L.default_context())
     T, A = (txWaveform.shape if dev else np.shape(txWaveform))
@@ -35,7 +35,11 @@ def monoStaticSensing(txWaveform, txDimension, carrierInfo, radarParams, targetL
     lo = C.c_int32(0)
     if dev:
         nz = noise if (noise is None or isinstance(noise, L.DeviceArray)) else ctx.to_device(L.as_c128_f(noise))
-        out = ctx.empty((car.n_sc, max(l_out, 1), A))
+        shape = (car.n_sc, max(l_out, 1), A)
+        if out is None:
+            out = ctx.empty(shape)
+        elif tuple(out.shape) != shape:
+            raise ValueError(f"out must have shape {shape}")
         ctx.check(lib.isac_mono_static_sensing_dev(ctx.handle, C.c_void_p(txWaveform.ptr), C.c_int64(T), C.c_int32(int(txDimension[1])),
                                                    C.byref(car), C.byref(cb.block), los.ctypes.data_as(C.c_void_p), C.c_int(mode),
                                                    C.c_void_p(nz.ptr if nz is not None else 0), C.c_uint64(seed or 0),

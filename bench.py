@@ -85,19 +85,19 @@ class Cell:
         ctx.check(ctx.lib.isac_ofdm_modulate_dev(ctx.handle, C.c_void_p(self.tx_grid.ptr), self.Lsym, self.A, C.byref(car),
                                                  C.c_double(amp), C.c_void_p(self.tx_wave.ptr), C.c_int64(self.T)))
         self.los = np.ones(n_targets, dtype=np.uint8)
+        self.echo = ctx.empty((self.K, self.Lsym, self.A))      # reused every CPI
         self.seed = 0x5EED0002 + cell_id
         ctx.sync()
 
     def step(self):
         echo = self.pkg.sensing.monoStaticSensing(self.tx_wave, (self.K, self.Lsym, self.A), self.carrier, self.rp, self.los,
-                                                  seed=self.seed, nfft=4096)
+                                                  seed=self.seed, nfft=4096, out=self.echo)
         try:
             est = self.pkg.sensing.estimation.fft2D(self.rp, self.cfar, echo, self.tx_grid)
         except self.pkg.IsacError as e:           # reference: try/catch -> senResults = NaN (cellSimulation.m:196-202)
             if e.name != "NO_DETECTION":
                 raise
             est = None
-        echo.free()
         return est
 
     def algorithmic_bytes(self):
