@@ -202,6 +202,7 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_cfar, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_h2d, hipEventDisableTiming) != hipSuccess ||
       hipEventCreate(&ctx->ev_t0) != hipSuccess || hipEventCreate(&ctx->ev_t1) != hipSuccess) {
     delete ctx;
     return ISAC_ERR_HIP;
@@ -228,6 +229,8 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   hipEventDestroy(ctx->ev_fork);
   hipEventDestroy(ctx->ev_join);
   hipEventDestroy(ctx->ev_cfar);
+  hipEventDestroy(ctx->ev_h2d);
+  if (ctx->pinned_in) hipHostFree(ctx->pinned_in);
   hipEventDestroy(ctx->ev_t0);
   hipEventDestroy(ctx->ev_t1);
   hipStreamDestroy(ctx->stream);
@@ -344,11 +347,19 @@ extern "C" int isac_fft2d_dev(isac_ctx* ctx, const isac_est_params* ep, const is
                               const isac_c64* d_rx_grid, const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A,
                               isac_est_result* out) {
   if (!ctx) return ISAC_ERR_INVALID_ARG;
-  if (!ep || !cfar || !d_rx_grid || !d_tx_grid || !out) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (!out) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  ISAC_TRY(isac_fft2d_submit_dev(ctx, ep, cfar, d_rx_grid, d_tx_grid, K, L, A));
+  return isac_fft2d_collect(ctx, out);
+}
+
+extern "C" int isac_fft2d_submit_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
+                                     const isac_c64* d_rx_grid, const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ctx->pending.active = false;
+  if (!ep || !cfar || !d_rx_grid || !d_tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
   if (K <= 0 || L <= 0 || A <= 0 || A > 1024) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad grid dimensions");
   if (ep->n_ifft < K || (ep->n_ifft & (ep->n_ifft - 1)) || ep->n_fft <= 0 || (ep->n_fft & (ep->n_fft - 1)))
     return fail(ctx, ISAC_ERR_INVALID_ARG, "nIFFT/nFFT must be powers of two with nIFFT >= K");
-  std::memset(out, 0, sizeof(*out));
   ctx->last.valid = false;
   const c64* rx = (const c64*)d_rx_grid;
   const c64* tx = (const c64*)d_tx_grid;
@@ -363,10 +374,12 @@ extern "C" int isac_fft2d_dev(isac_ctx* ctx, const isac_est_params* ep, const is
     ISAC_TRY(get_sind_table(ctx, ep, &d_sind, &n_steps));
     ISAC_TRY(ensure(ctx, ctx->spec, sizeof(double) * (size_t)n_steps));
   }
+  static const bool single_stream = std::getenv("ISAC_SINGLE_STREAM") != nullptr;   // profiling aid: isolate kernel times
+  hipStream_t s2 = single_stream ? ctx->stream : ctx->stream2;
   ISAC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-  ISAC_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  ISAC_TRY(isac_covariance_on(ctx, ctx->stream2, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
-  if (!upa) ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, ctx->stream2));                         // music.m:19
+  ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+  ISAC_TRY(isac_covariance_on(ctx, s2, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
+  if (!upa) ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, s2));                         // music.m:19
   int nr = 0, nc = 0;
   ISAC_TRY(isac_rdm_power_window(ctx, ep, cfar, rx, tx, K, L, A, &nr, &nc));          // fft2D.m:37-46,61
   const int n_cut_rows = cfar->row1 - cfar->row0 + 1, n_cut_cols = cfar->col1 - cfar->col0 + 1;
@@ -374,10 +387,10 @@ extern "C" int isac_fft2d_dev(isac_ctx* ctx, const isac_est_params* ep, const is
   const int cap = (int)std::min<long long>(n_cut, 4096);
   ISAC_TRY(isac_cfar_window(ctx, cfar, nr, nc, A, cap));                                 // fft2D.m:62 (+ numDets on device)
   ISAC_HIP(hipEventRecord(ctx->ev_cfar, ctx->stream));
-  ISAC_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_cfar, 0));
+  ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_cfar, 0));
   if (!upa)   // numDets comes from the CFAR branch, still on the device                   music.m:12,82-91
-    ISAC_TRY(isac_music_scan_dev(ctx, A, (const int*)ctx->misc.p, 0, d_sind, n_steps, 0.5, (double*)ctx->spec.p, ctx->stream2));
-  ISAC_HIP(hipEventRecord(ctx->ev_join, ctx->stream2));
+    ISAC_TRY(isac_music_scan_dev(ctx, A, (const int*)ctx->misc.p, 0, d_sind, n_steps, 0.5, (double*)ctx->spec.p, s2));
+  ISAC_HIP(hipEventRecord(ctx->ev_join, s2));
   ISAC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   // pack + one device->host copy
   const int pack_first = 4096;
@@ -403,6 +416,32 @@ extern "C" int isac_fft2d_dev(isac_ctx* ctx, const isac_est_params* ep, const is
   ISAC_HIP(hipGetLastError());
   char* h = (char*)ctx->pinned;
   ISAC_HIP(hipMemcpyAsync(h, dbase, first_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  // everything the host half needs later
+  Fft2dPending& pd = ctx->pending;
+  pd.ep = *ep; pd.cfar = *cfar;
+  pd.A = A; pd.nr = nr; pd.nc = nc; pd.n_steps = n_steps; pd.pack_first = pack_first;
+  pd.off_spec = off_spec; pd.off_pow = off_pow; pd.off_cut = off_cut;
+  pd.d_pcut_full = d_pcut_full; pd.d_ppow_full = d_ppow_full;
+  pd.active = true;
+  return ISAC_OK;
+}
+
+extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!out) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  Fft2dPending& pd = ctx->pending;
+  if (!pd.active) return fail(ctx, ISAC_ERR_INVALID_ARG, "isac_fft2d_collect without a pending isac_fft2d_submit_dev");
+  pd.active = false;
+  std::memset(out, 0, sizeof(*out));
+  const isac_est_params* ep = &pd.ep;
+  const isac_cfar_config* cfar = &pd.cfar;
+  const int A = pd.A, nr = pd.nr, nc = pd.nc, n_steps = pd.n_steps, pack_first = pd.pack_first;
+  const size_t off_spec = pd.off_spec, off_pow = pd.off_pow, off_cut = pd.off_cut;
+  int* d_pcut_full = pd.d_pcut_full;
+  double* d_ppow_full = pd.d_ppow_full;
+  const bool upa = ep->array_is_upa != 0;
+  const int n_cut_rows = cfar->row1 - cfar->row0 + 1;
+  char* h = (char*)ctx->pinned;
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   const int* hdr = (const int*)h;
   const int total = hdr[0];
@@ -562,6 +601,11 @@ extern "C" int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w,
   ISAC_HIP(hipMemcpyAsync(wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipMemcpyAsync(vv.data(), ctx->eig_v.p, sizeof(c64) * (size_t)A * A, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  if (std::getenv("ISAC_DEBUG")) {
+    int sweeps = -1;
+    ISAC_HIP(hipMemcpy(&sweeps, (char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(int), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "[isac] jacobi eigh A=%d sweeps=%d\n", A, sweeps);
+  }
   std::vector<int> order((size_t)A);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return wv[(size_t)p] < wv[(size_t)q]; });

@@ -16,6 +16,8 @@
 // Carrier phase arguments are formed exactly like the reference forms them
 // ((2*pi*fc) * (n*Ts), all in fp64) so the ~1e-8 rad rounding of those huge arguments
 // is reproduced rather than "improved".
+#include <cstring>
+
 #include "fft_lds.hpp"
 
 namespace isac {
@@ -348,9 +350,22 @@ static int prepare_echo(isac_ctx* ctx, const c64* d_tx, long long T, const isac_
   ISAC_TRY(ensure(ctx, ctx->phase_rx, sizeof(c64) * (size_t)T));
   c64* d_steer_aq = (c64*)ctx->steer.p;
   c64* d_steer_rq = d_steer_aq + (size_t)A * Q;
-  ISAC_HIP(hipMemcpyAsync(d_steer_aq, steer_aq.data(), sizeof(c64) * steer_aq.size(), hipMemcpyHostToDevice, ctx->stream));
-  ISAC_HIP(hipMemcpyAsync(d_steer_rq, steer_rq.data(), sizeof(c64) * steer_rq.size(), hipMemcpyHostToDevice, ctx->stream));
-  ISAC_HIP(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+  {
+    // pinned staging so the upload is truly asynchronous; the event guards reuse of the staging buffer
+    const size_t bytes = sizeof(c64) * (size_t)A * Q * 2;
+    if (ctx->pinned_in_cap < bytes) {
+      if (ctx->pinned_in) { ISAC_HIP(hipEventSynchronize(ctx->ev_h2d)); ISAC_HIP(hipHostFree(ctx->pinned_in)); }
+      ctx->pinned_in = nullptr; ctx->pinned_in_cap = 0;
+      ISAC_HIP(hipHostMalloc(&ctx->pinned_in, bytes < 4096 ? 4096 : bytes, hipHostMallocDefault));
+      ctx->pinned_in_cap = bytes < 4096 ? 4096 : bytes;
+    } else {
+      ISAC_HIP(hipEventSynchronize(ctx->ev_h2d));
+    }
+    std::memcpy(ctx->pinned_in, steer_aq.data(), bytes / 2);
+    std::memcpy((char*)ctx->pinned_in + bytes / 2, steer_rq.data(), bytes / 2);
+    ISAC_HIP(hipMemcpyAsync(d_steer_aq, ctx->pinned_in, bytes, hipMemcpyHostToDevice, ctx->stream));
+    ISAC_HIP(hipEventRecord(ctx->ev_h2d, ctx->stream));
+  }
   // beam-sums in tiles of up to 8 targets (tx is re-read only when Q > 8)
   const unsigned gb = cdiv(T, 256);
   for (int q0 = 0; q0 < Q;) {

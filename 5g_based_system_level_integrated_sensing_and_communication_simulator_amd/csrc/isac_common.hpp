@@ -57,6 +57,16 @@ struct Fft2dLast {  // introspection of the last fft2D call (host copies)
   bool pow_on_device = false;
 };
 
+struct Fft2dPending {  // state between isac_fft2d_submit_dev and isac_fft2d_collect
+  bool active = false;
+  isac_est_params ep{};
+  isac_cfar_config cfar{};
+  int A = 0, nr = 0, nc = 0, n_steps = 0, pack_first = 0;
+  size_t off_spec = 0, off_pow = 0, off_cut = 0;
+  int* d_pcut_full = nullptr;
+  double* d_ppow_full = nullptr;
+};
+
 }  // namespace isac
 
 struct isac_ctx {
@@ -74,6 +84,9 @@ struct isac_ctx {
       eig_w, eig_v, spec, misc, stage_a, stage_b, stage_c, sind_tab;
   void* pinned = nullptr; size_t pinned_cap = 0;
   isac::Fft2dLast last;
+  isac::Fft2dPending pending;
+  hipEvent_t ev_h2d = nullptr;       // completion of the last pinned->device parameter upload
+  void* pinned_in = nullptr; size_t pinned_in_cap = 0;
 };
 
 namespace isac {

@@ -152,19 +152,25 @@ __device__ __forceinline__ void rr_pair(int round, int k, int n /* even */, int&
   q = a < b ? b : a;
 }
 
+// Two barriers per round:
+//   P: lanes k < n/2 read the pivot 2x2 of pair k and derive the complex rotation
+//        J_k = [[c, g], [-conj(g), c]],  g = s e^{j phi}      (no |beta| needed:
+//        u = sign(d) 2 / (|d| + sqrt(d^2 + 4|beta|^2)),  c = 1/sqrt(1 + u^2 |beta|^2),  g = c u beta)
+//   U: thread (a, b) owns the 2x2 block (pair a) x (pair b) of H and applies  J_a^H B J_b  in place
+//      (a one-phase two-sided update -- nobody else touches that block this round); the same
+//      threads rotate two (row, pair) column pairs of V.
 __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict__ Hin, int A, int max_sweeps,
                                                            double* __restrict__ w_out, c64* __restrict__ V_out,
                                                            int* __restrict__ info /* [0]=sweeps used */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int n = (A + 1) & ~1;                      // pad to even with an isolated zero row/col
+  const int h = n / 2;
   c64* H = reinterpret_cast<c64*>(smem_raw);       // [n x n] column-major
   c64* V = H + n * n;                              // [n x n]
-  c64* rot = V + n * n;                            // [n/2] (c, s) and phase e^{j phi}
-  c64* rph = rot + n / 2;
-  int* rp = reinterpret_cast<int*>(rph + n / 2);   // [n/2] p
-  int* rq = rp + n / 2;
-  __shared__ double s_red[16];
-  __shared__ double s_off, s_tot;
+  c64* rg = V + n * n;                             // [h] g_k
+  double* rc = reinterpret_cast<double*>(rg + h);  // [h] c_k
+  int* rp = reinterpret_cast<int*>(rc + h);        // [h] p_k
+  int* rq = rp + h;                                // [h] q_k
   const int tid = threadIdx.x, nt = blockDim.x;
   for (int i = tid; i < n * n; i += nt) {
     int r = i % n, c = i / n;
@@ -172,85 +178,70 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
     V[i] = mk(r == c ? 1.0 : 0.0, 0.0);
   }
   __syncthreads();
+  // Convergence: a sweep in which every pivot satisfied |h_pq|^2 <= tol^2 |h_pp h_qq| (relative to the
+  // diagonal pair, Demmel-Veselic style -- keeps the tiny noise eigen-pairs accurate next to a
+  // 60 dB stronger signal eigenvalue; a Frobenius-relative test would stop far too early for them).
+  const double tol2 = 1e-28;
+  int& s_dirty = rq[h];                            // lives in the dynamic LDS carve (keeps its base 16-B aligned)
   int sweep = 0;
   for (; sweep < max_sweeps; ++sweep) {
-    // off-diagonal and total Frobenius norms
-    double off = 0.0, tot = 0.0;
-    for (int i = tid; i < n * n; i += nt) {
-      int r = i % n, c = i / n;
-      double m2 = H[i].re * H[i].re + H[i].im * H[i].im;
-      tot += m2;
-      if (r != c) off += m2;
-    }
-    for (int o = 32; o > 0; o >>= 1) { off += __shfl_down(off, o); tot += __shfl_down(tot, o); }
-    if ((tid & 63) == 0) s_red[tid >> 6] = off;
+    if (tid == 0) s_dirty = 0;
     __syncthreads();
-    if (tid == 0) { double s = 0; for (int w = 0; w < nt / 64; ++w) s += s_red[w]; s_off = s; }
-    __syncthreads();
-    if ((tid & 63) == 0) s_red[tid >> 6] = tot;
-    __syncthreads();
-    if (tid == 0) { double s = 0; for (int w = 0; w < nt / 64; ++w) s += s_red[w]; s_tot = s; }
-    __syncthreads();
-    if (s_off <= 1e-30 * s_tot || s_tot == 0.0) break;
     for (int round = 0; round < n - 1; ++round) {
-      // rotation parameters for the n/2 disjoint pairs
-      if (tid < n / 2) {
+      // ---- P: rotation parameters of the h disjoint pairs
+      if (tid < h) {
         int p, q;
         rr_pair(round, tid, n, p, q);
         rp[tid] = p; rq[tid] = q;
-        c64 beta = H[p + n * q];
-        double alpha = H[p + n * p].re, gamma = H[q + n * q].re;
-        double ab = sqrt(beta.re * beta.re + beta.im * beta.im);
-        double c = 1.0, s = 0.0;
-        c64 ph = mk(1.0, 0.0);                       // e^{j phi}
-        if (ab > 0.0 && ab > 1e-300) {
-          ph = mk(beta.re / ab, beta.im / ab);
-          double tau = (gamma - alpha) / (2.0 * ab);
-          double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-          c = 1.0 / sqrt(1.0 + t * t);
-          s = t * c;
+        const c64 beta = H[p + n * q];
+        const double d = H[q + n * q].re - H[p + n * p].re;
+        const double m2 = beta.re * beta.re + beta.im * beta.im;
+        double c = 1.0;
+        c64 g = mk(0.0, 0.0);
+        if (m2 > tol2 * fabs(H[q + n * q].re * H[p + n * p].re)) s_dirty = 1;
+        if (m2 > 0.0) {
+          const double rt = sqrt(d * d + 4.0 * m2);
+          const double u = copysign(2.0, d) / (fabs(d) + rt);
+          c = 1.0 / sqrt(1.0 + u * u * m2);
+          const double cu = c * u;
+          g = mk(cu * beta.re, cu * beta.im);
         }
-        rot[tid] = mk(c, s);
-        rph[tid] = ph;
+        rc[tid] = c;
+        rg[tid] = g;
       }
       __syncthreads();
-      // column update  H <- H J,  V <- V J  with J[:,p] = (c, -s e^{-j phi}), J[:,q] = (s, c e^{-j phi})
-      for (int i = tid; i < (n / 2) * n * 2; i += nt) {
-        int which = i / ((n / 2) * n);              // 0: H, 1: V
-        int j = i % ((n / 2) * n);
-        int k = j / n, row = j % n;
-        c64* M = which ? V : H;
-        int p = rp[k], q = rq[k];
-        double c = rot[k].re, s = rot[k].im;
-        c64 em = conj(rph[k]);                       // e^{-j phi}
-        c64 hp = M[row + n * p], hq = M[row + n * q];
-        c64 hqe = hq * em;
-        M[row + n * p] = mk(c * hp.re - s * hqe.re, c * hp.im - s * hqe.im);
-        M[row + n * q] = mk(s * hp.re + c * hqe.re, s * hp.im + c * hqe.im);
+      // ---- U: two-sided 2x2 block updates of H, column rotations of V
+      if (tid < h * h) {
+        const int a = tid % h, b = tid / h;
+        const int pa = rp[a], qa = rq[a], pb = rp[b], qb = rq[b];
+        const double ca = rc[a], cb = rc[b];
+        const c64 ga = rg[a], gb = rg[b];
+        const c64 h00 = H[pa + n * pb], h01 = H[pa + n * qb], h10 = H[qa + n * pb], h11 = H[qa + n * qb];
+        // T = B J_b
+        const c64 gbc = conj(gb);
+        const c64 t00 = h00 * cb - h01 * gbc, t01 = h00 * gb + h01 * cb;
+        const c64 t10 = h10 * cb - h11 * gbc, t11 = h10 * gb + h11 * cb;
+        // B' = J_a^H T,  J_a^H = [[ca, -ga], [conj(ga), ca]]
+        const c64 gac = conj(ga);
+        c64 b00 = t00 * ca - ga * t10, b01 = t01 * ca - ga * t11;
+        c64 b10 = gac * t00 + t10 * ca, b11 = gac * t01 + t11 * ca;
+        if (a == b) { b01 = mk(0.0, 0.0); b10 = mk(0.0, 0.0); b00.im = 0.0; b11.im = 0.0; }
+        H[pa + n * pb] = b00; H[pa + n * qb] = b01; H[qa + n * pb] = b10; H[qa + n * qb] = b11;
       }
-      __syncthreads();
-      // row update  H <- J^H H : row_p' = c row_p - s e^{+j phi} row_q ; row_q' = s row_p + c e^{+j phi} row_q
-      for (int j = tid; j < (n / 2) * n; j += nt) {
-        int k = j % (n / 2), col = j / (n / 2);     // pair index fastest: lanes touch distinct rows of one column
-        int p = rp[k], q = rq[k];
-        double c = rot[k].re, s = rot[k].im;
-        c64 ep = rph[k];
-        c64 hp = H[p + n * col], hq = H[q + n * col];
-        c64 hqe = hq * ep;
-        H[p + n * col] = mk(c * hp.re - s * hqe.re, c * hp.im - s * hqe.im);
-        H[q + n * col] = mk(s * hp.re + c * hqe.re, s * hp.im + c * hqe.im);
-      }
-      __syncthreads();
-      // clean the annihilated entries and keep the diagonal real
-      if (tid < n / 2) {
-        int p = rp[tid], q = rq[tid];
-        H[p + n * q] = mk(0.0, 0.0);
-        H[q + n * p] = mk(0.0, 0.0);
-        H[p + n * p].im = 0.0;
-        H[q + n * q].im = 0.0;
+      for (int it = tid; it < n * h; it += nt) {
+        const int row = it % n, k = it / n;
+        const int p = rp[k], q = rq[k];
+        const double c = rc[k];
+        const c64 g = rg[k];
+        const c64 vp = V[row + n * p], vq = V[row + n * q];
+        V[row + n * p] = vp * c - vq * conj(g);
+        V[row + n * q] = vp * g + vq * c;
       }
       __syncthreads();
     }
+    const int dirty = s_dirty;
+    __syncthreads();                      // everyone has read the flag before thread 0 clears it again
+    if (!dirty) { ++sweep; break; }
   }
   for (int i = tid; i < A; i += nt) w_out[i] = H[i + n * i].re;
   for (int i = tid; i < A * A; i += nt) {
@@ -342,7 +333,7 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
   const int n = (A + 1) & ~1;
   ISAC_TRY(ensure(ctx, ctx->eig_w, sizeof(double) * (size_t)A + 64));
   ISAC_TRY(ensure(ctx, ctx->eig_v, sizeof(c64) * (size_t)A * A));
-  size_t lds = sizeof(c64) * ((size_t)2 * n * n + n) + sizeof(int) * n + 64;
+  size_t lds = sizeof(c64) * ((size_t)2 * n * n + n / 2) + sizeof(double) * (n / 2) + sizeof(int) * (n + 1) + 64;
   { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
   int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
   hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(1024), lds, st, d_H, A, 40, (double*)ctx->eig_w.p,

@@ -375,6 +375,28 @@ extern "C" int isac_cfar2d_ca(isac_ctx* ctx, const double* P, int32_t n_rows, in
   return ISAC_OK;
 }
 
+// Range stage alone (conj-multiply + Kaiser window + nIFFT-point IFFT + row selection + range-axis
+// window, fft2D.m:37-45) for every (symbol, antenna) column -- the dominant HBM-bound kernel of fft2D;
+// exposed so bench.py can time exactly this launch with HIP events for the roofline entry.
+extern "C" int isac_fft2d_range_stage_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf,
+                                          const isac_c64* d_rx_grid, const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!ep || !cf || !d_rx_grid || !d_tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  const int n_ifft = ep->n_ifft;
+  const int hr = cf->guard[0] + cf->train[0];
+  const int row_lo = cf->row0 - 1 - hr, row_hi = cf->row1 - 1 + hr;
+  if (row_lo < 0 || row_hi >= n_ifft) return fail(ctx, ISAC_ERR_CFAR_WINDOW, "CUT training window exceeds the range-Doppler map");
+  const int nr = row_hi - row_lo + 1;
+  const c64* tw = nullptr;
+  const double *wk = nullptr, *wr = nullptr;
+  ISAC_TRY(isac_get_twiddles(ctx, n_ifft, &tw));
+  ISAC_TRY(isac_get_windows(ctx, K, n_ifft, &wk, &wr));
+  ISAC_TRY(ensure(ctx, ctx->ymid, sizeof(c64) * (size_t)nr * L * A));
+  ISAC_FFT_DISPATCH(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, (const c64*)d_rx_grid, (const c64*)d_tx_grid, K, L, A, tw,
+                                                        wk, wr, n_ifft, row_lo, nr, (c64*)ctx->ymid.p))));
+  return ISAC_OK;
+}
+
 extern "C" int isac_rdm_plane_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_c64* d_rx_grid,
                                   const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A, int32_t ant, isac_c64* d_rdm) {
   if (!ctx) return ISAC_ERR_INVALID_ARG;

@@ -59,6 +59,39 @@ def fft2D(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None, return_debug=False)
     return est
 
 
+def fft2D_submit(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None):
+    """Asynchronous half of fft2D for device-resident grids: enqueues every kernel and the result
+    copy on ``ctx`` without waiting (isac_fft2d_submit_dev).  Pair with fft2D_collect(ctx).  Lets a
+    host loop keep several cells / CPIs in flight on different contexts."""
+    if not (isinstance(rxGrid, L.DeviceArray) and isinstance(txGrid, L.DeviceArray)):
+        raise ValueError("fft2D_submit needs DeviceArray grids")
+    ctx = ctx or rxGrid.ctx
+    K, Lsym, A = rxGrid.shape
+    if tuple(txGrid.shape) != (K, Lsym, A):
+        raise ValueError("rxGrid and txGrid must have identical [nSc x nSym x nAnts] shape")
+    det = cfar.cfarDetector2D
+    key = id(cfar.CUTIdx)
+    rect = getattr(cfar, "_rect", None)
+    if rect is None or rect[0] != key:
+        rect = (key, _cut_rectangle(cfar.CUTIdx))
+        cfar._rect = rect
+    r0, r1, c0, c1 = rect[1]
+    cf = L.CfarConfig(float(det.ProbabilityFalseAlarm), (C.c_int32 * 2)(*det.GuardBandSize), (C.c_int32 * 2)(*det.TrainingBandSize),
+                      r0, r1, c0, c1)
+    ep = est_block(radarEstParams)
+    ctx.check(ctx.lib.isac_fft2d_submit_dev(ctx.handle, C.byref(ep), C.byref(cf), C.c_void_p(rxGrid.ptr), C.c_void_p(txGrid.ptr),
+                                            C.c_int32(K), C.c_int32(Lsym), C.c_int32(A)))
+    return ctx
+
+
+def fft2D_collect(ctx):
+    """Waits for the submitted fft2D on ``ctx`` and returns estResults (raises IsacError like fft2D)."""
+    res = L.EstResult()
+    ctx.check(ctx.lib.isac_fft2d_collect(ctx.handle, C.byref(res)))
+    return SimpleNamespace(rngEst=np.array(res.rng_est[: res.n_rng]), velEst=np.array(res.vel_est[: res.n_vel]),
+                           aziEst=np.array(res.azi_est[: res.n_azi]), eleEst=np.array(res.ele_est[: res.n_azi]))
+
+
 def fft2D_debug(ctx, A):
     """Detection lists (CUT order, per antenna), the |rdm|^2 window, Ra and the MUSIC spectrum of the
     last fft2D call on ``ctx`` -- what the parity tests compare against the oracle."""

@@ -187,6 +187,21 @@ int isac_fft2d_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_con
 int isac_fft2d(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
                const isac_c64* rx_grid, const isac_c64* tx_grid,
                int32_t K, int32_t L, int32_t A, isac_est_result* out);
+/* The same call split in two so that a host loop can keep several CPIs / cells in flight on
+ * different contexts: submit enqueues every kernel and the result copy without waiting;
+ * collect waits for that context's stream and runs the host half (fft2D.m:63-99, music.m:94-104).
+ * isac_fft2d_dev == submit + collect.  d_rx_grid / d_tx_grid must stay valid until collect. */
+int isac_fft2d_submit_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
+                          const isac_c64* d_rx_grid, const isac_c64* d_tx_grid,
+                          int32_t K, int32_t L, int32_t A);
+int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out);
+
+/* Range stage of fft2D alone (fft2D.m:37-45: conj-multiply, Kaiser window, nIFFT-point IFFT per
+ * (symbol, antenna) column, CUT-row selection, range-axis window).  One kernel launch on the
+ * context stream; lets a benchmark time the dominant HBM-bound kernel with HIP events. */
+int isac_fft2d_range_stage_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
+                               const isac_c64* d_rx_grid, const isac_c64* d_tx_grid,
+                               int32_t K, int32_t L, int32_t A);
 
 /* Introspection of the LAST isac_fft2d[_dev] call on this context (parity tests, plots):
  *  - per-antenna detection indices in CUT order (before the peak sort), det_idx [2 x cap] 1-based,

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace:  python tools/prof_summary.py <results.db> [--csv out.csv]
+Prints per-kernel count / avg / total / share, like `rocprofv3 --stats` does for csv output."""
+import sqlite3
+import sys
+
+
+def summarise(path):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    q = (f"select s.kernel_name, count(*), avg(d.end-d.start), sum(d.end-d.start), min(d.end-d.start), max(d.end-d.start) "
+         f"from {kd} d join {ks} s on d.kernel_id=s.id group by s.kernel_name order by 4 desc")
+    rows = list(cur.execute(q))
+    tot = sum(r[3] for r in rows) or 1
+    return [(r[0], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[3] / tot) for r in rows]
+
+
+if __name__ == "__main__":
+    rows = summarise(sys.argv[1])
+    lines = ["kernel,calls,avg_us,total_us,min_us,max_us,pct"]
+    for r in rows:
+        lines.append(f"\"{r[0]}\",{r[1]},{r[2]:.2f},{r[3]:.2f},{r[4]:.2f},{r[5]:.2f},{r[6]:.2f}")
+    if "--csv" in sys.argv:
+        open(sys.argv[sys.argv.index("--csv") + 1], "w").write("\n".join(lines) + "\n")
+    for r in rows[:24]:
+        print(f"{r[0][:84]:84s} n={r[1]:5d} avg={r[2]:9.1f}us tot={r[3]:10.1f}us {r[6]:5.1f}%")
