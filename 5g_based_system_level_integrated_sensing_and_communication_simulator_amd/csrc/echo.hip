@@ -182,7 +182,10 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
     const int dshift = cp - off;  // window leads the useful part by dshift samples
     if constexpr (SYNTH) {
       const c64* sr = steer_rq + (long long)r * Q;
-      fft.template fill<4>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, noise_mode, noise, n0s, seed); }, tid);
+      if (noise_mode == ISAC_NOISE_PHILOX)   // Box-Muller per sample is register hungry: interleave at most 4 producers
+        fft.template fill<4>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, ISAC_NOISE_PHILOX, noise, n0s, seed); }, tid);
+      else
+        fft.template fill<8>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, noise_mode, noise, n0s, seed); }, tid);
     } else {
       const c64* src = wave + w0 + T * (long long)r;
       fft.fill([&](int n) { return src[n]; }, tid);

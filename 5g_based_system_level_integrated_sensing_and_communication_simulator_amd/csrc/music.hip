@@ -12,6 +12,8 @@
 // (4 complex samples) of column a0+i per macro-step and feeds them to 4 consecutive MFMA
 // k-steps; the k index is only a summation label, so no transposition is needed.
 // Per-workgroup partial tiles are reduced in a fixed order (deterministic).
+#include <type_traits>
+
 #include "isac_common.hpp"
 
 namespace isac {
@@ -63,10 +65,12 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_kernel(const c64* __restrict_
       c64 xa[4], xb[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const long long n = n0 + e;
+        long long n = n0 + e;
         const bool ok = n < N;
-        xa[e] = (ok && ca < A) ? G[n + N * ca] : mk(0.0, 0.0);
-        xb[e] = (ok && cb < A) ? G[n + N * cb] : mk(0.0, 0.0);
+        if (!ok) n = N - 1;
+        const c64 va = G[n + N * (long long)(ca < A ? ca : 0)], vb = G[n + N * (long long)(cb < A ? cb : 0)];   // unconditional loads
+        xa[e] = (ok && ca < A) ? va : mk(0.0, 0.0);
+        xb[e] = (ok && cb < A) ? vb : mk(0.0, 0.0);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -90,8 +94,126 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_kernel(const c64* __restrict_
   }
 }
 
+// ---- specialised schedule for A <= 64 (NB = ceil(A/16) <= 4 antenna blocks): every wave keeps ALL blocks'
+// operands of its samples in registers and owns a static group of <= 5 output tiles, so the four waves of a
+// workgroup issue exactly the same number of MFMAs (balanced SIMDs), share one 16-sample x A slab through
+// L1, and the next slab is prefetched under the current slab's MFMAs.
+//   wave = (tile group g, sample phase s):  NB=4: 2 groups x 2 phases,  NB=3: 2 x 2,  NB=2: 1 x 4,  NB=1: 1 x 4
+//   lane (i = lane&15, kq = lane>>4) holds samples  n0 + (16/S) ... see smp() below.
+template <int NB>
+struct CovPlan {
+  static constexpr int kTiles = NB * (NB + 1) / 2;
+  static constexpr int kGroups = (kTiles + 4) / 5;              // <= 5 tiles per wave
+  static constexpr int kPerGroup = (kTiles + kGroups - 1) / kGroups;
+  static constexpr int kPhases = 4 / kGroups;                   // waves per workgroup = kGroups * kPhases = 4
+  static constexpr int kSamplesPerLane = 4 / kPhases;           // k-steps a wave runs per 16-sample slab
+};
+
+constexpr int cov_tile_i(int nb, int t) {
+  int i = 0;
+  while (t >= nb - i) { t -= nb - i; ++i; }
+  return i;
+}
+constexpr int cov_tile_j(int nb, int t) {
+  int i = 0;
+  while (t >= nb - i) { t -= nb - i; ++i; }
+  return i + t;
+}
+template <int U, int NT, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (U < NT) {
+    f(std::integral_constant<int, U>{});
+    static_for<U + 1, NT>(f);
+  }
+}
+
+template <int NB, int GRP>
+__device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long long N, int A, int n_tiles, int phase, int lane,
+                                               long long s_begin, long long s_end, int part_index,
+                                               double* __restrict__ part) {
+  using P = CovPlan<NB>;
+  constexpr int T0 = GRP * P::kPerGroup;
+  constexpr int NT = (T0 + P::kPerGroup <= P::kTiles) ? P::kPerGroup : (P::kTiles - T0);
+  constexpr int SPL = P::kSamplesPerLane;
+  const int li = lane & 15, kq = lane >> 4;
+  v4f64 re[NT], imp[NT], imm[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) re[u] = imp[u] = imm[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+  // column pointers of this lane's antenna in each block (clamped: loads stay unconditional)
+  const c64* colp[NB];
+  bool colok[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int a = b * 16 + li;
+    colok[b] = a < A;
+    colp[b] = G + N * (long long)(colok[b] ? a : 0);
+  }
+  const long long lane_off = 4 * kq + SPL * phase;              // first sample of this lane inside a slab
+  c64 cur[NB][SPL], nxt[NB][SPL];
+  auto load = [&](c64 (&dst)[NB][SPL], long long slab) {
+    const long long n0 = slab * 16 + lane_off;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int e = 0; e < SPL; ++e) {
+        long long n = n0 + e;
+        const bool ok = (n < N) && colok[b];
+        if (n >= N) n = N - 1;
+        c64 v = colp[b][n];
+        dst[b][e] = ok ? v : mk(0.0, 0.0);
+      }
+  };
+  if (s_begin < s_end) load(cur, s_begin);
+  for (long long slab = s_begin; slab < s_end; ++slab) {
+    if (slab + 1 < s_end) load(nxt, slab + 1);
+    static_for<0, NT>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);   // row-major upper-triangular tile order
+#pragma unroll
+      for (int e = 0; e < SPL; ++e) {
+        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].re, re[u], 0, 0, 0);
+        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].im, re[u], 0, 0, 0);
+        imp[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].im, imp[u], 0, 0, 0);
+        imm[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].re, imm[u], 0, 0, 0);
+      }
+    });
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int e = 0; e < SPL; ++e) cur[b][e] = nxt[b][e];
+  }
+#pragma unroll
+  for (int u = 0; u < NT; ++u) {
+    double* o = part + (((long long)part_index * n_tiles + (T0 + u)) * 3) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[0 * 256 + r * 64 + lane] = re[u][r];
+      o[1 * 256 + r * 64 + lane] = imp[u][r];
+      o[2 * 256 + r * 64 + lane] = imm[u][r];
+    }
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void cov_mfma_small_kernel(const c64* __restrict__ G, long long N, int A,
+                                                                long long slabs_per_wg,
+                                                                double* __restrict__ part /* [gridX*kPhases][kTiles][3][256] */) {
+  using P = CovPlan<NB>;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wid / P::kPhases, phase = wid % P::kPhases;
+  const long long total = (N + 15) / 16;
+  const long long s_begin = (long long)blockIdx.x * slabs_per_wg;
+  long long s_end = s_begin + slabs_per_wg;
+  if (s_end > total) s_end = total;
+  const int pidx = blockIdx.x * P::kPhases + phase;
+  if (grp == 0) cov_group_body<NB, 0>(G, N, A, P::kTiles, phase, lane, s_begin, s_end, pidx, part);
+  if constexpr (P::kGroups > 1) {
+    if (grp == 1) cov_group_body<NB, 1>(G, N, A, P::kTiles, phase, lane, s_begin, s_end, pidx, part);
+  }
+}
+
 // fixed-order reduction over workgroup partials + Hermitian fill + 1/N.
-// blockDim = (256, 4): the 4 y-slices each sum a contiguous quarter of the partials, then combine in order.
 __global__ __launch_bounds__(1024) void cov_reduce_kernel(const double* __restrict__ part, int n_wg, int n_tiles, int A,
                                                           double inv_n, c64* __restrict__ Ra /* [A x A] column-major */) {
   __shared__ double s_sum[3][4][256];
@@ -304,9 +426,35 @@ extern "C" int isac_covariance_dev(isac_ctx* ctx, const isac_c64* d_grid, int64_
   if (!ctx) return ISAC_ERR_INVALID_ARG;
   return isac_covariance_on(ctx, ctx->stream, d_grid, N, A, d_Ra);
 }
+template <int NB>
+static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long long N, int A, c64* Ra) {
+  using P = CovPlan<NB>;
+  const long long total = (N + 15) / 16;
+  long long gx = 512;
+  if (gx > total) gx = total;
+  const long long per = (total + gx - 1) / gx;
+  gx = (total + per - 1) / per;
+  const int n_part = (int)gx * P::kPhases;
+  ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * (size_t)n_part * P::kTiles * 3 * 256));
+  hipLaunchKernelGGL(cov_mfma_small_kernel<NB>, dim3((unsigned)gx), dim3(256), 0, st, G, N, A, per, (double*)ctx->cov_part.p);
+  ISAC_HIP(hipGetLastError());
+  hipLaunchKernelGGL(cov_reduce_kernel, dim3(P::kTiles), dim3(256, 4), 0, st, (const double*)ctx->cov_part.p, n_part, P::kTiles, A,
+                     1.0 / (double)N, Ra);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
 int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra) {
   if (!d_grid || !d_Ra || N <= 0 || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   const int nb = (A + 15) / 16;
+  if (nb <= 4 && !std::getenv("ISAC_COV_GENERIC")) {
+    switch (nb) {
+      case 1: return launch_cov_small<1>(ctx, st, (const c64*)d_grid, N, A, (c64*)d_Ra);
+      case 2: return launch_cov_small<2>(ctx, st, (const c64*)d_grid, N, A, (c64*)d_Ra);
+      case 3: return launch_cov_small<3>(ctx, st, (const c64*)d_grid, N, A, (c64*)d_Ra);
+      default: return launch_cov_small<4>(ctx, st, (const c64*)d_grid, N, A, (c64*)d_Ra);
+    }
+  }
   const int n_tiles = nb * (nb + 1) / 2;
   const int tiles_per_wg = kCovWaves * kCovTPW;
   const int gy = (n_tiles + tiles_per_wg - 1) / tiles_per_wg;
