@@ -201,7 +201,7 @@ def main():
     ap.add_argument("--slots", type=int, default=16)
     ap.add_argument("--targets", type=int, default=1)
     ap.add_argument("--cells-per-gpu", type=int, default=1)
-    ap.add_argument("--inflight", type=int, default=3, help="CPIs in flight per cell (contexts)")
+    ap.add_argument("--inflight", type=int, default=2, help="CPIs in flight per cell (contexts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -245,18 +245,11 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     range_ms = cells[0].time_range_kernel() if rank == 0 else 0.0
-    # per-cell result record gather (the only collective: KB-scale, RCCL over xGMI)
-    rec = torch.zeros(8, dtype=torch.float64, device=f"cuda:{local_rank}")
-    if last is not None:
-        rec[0] = last.rngEst.size
-        rec[1] = float(last.rngEst[0]) if last.rngEst.size else float("nan")
-        rec[2] = float(last.velEst[0]) if last.velEst.size else float("nan")
-        rec[3] = float(last.aziEst[0]) if last.aziEst.size else float("nan")
-    rec[7] = dt
-    if dist is not None:
-        out = [torch.zeros_like(rec) for _ in range(world)]
-        dist.all_gather(out, rec)
-        dt = max(float(o[7]) for o in out)
+    # per-cell result record gather -- the only collective (KB-scale, RCCL over xGMI); max over ranks of the timed region
+    d = importlib.import_module(PKG + "._dist")
+    recs = np.array([d.make_record(rank * args.cells_per_gpu + i, cell.last, dt) for i, cell in enumerate(cells)])
+    allr = d.gather_records(recs, dist, torch.device("cuda", local_rank) if dist is not None else None)
+    dt = float(np.nanmax(allr[:, 6])) if allr.size else dt
     n_cpi = args.steps * args.cells_per_gpu * world
     slots = n_cpi * args.slots
     if rank == 0:
@@ -278,7 +271,10 @@ def main():
                                        "achieved_GBps": round((echo_b + rdm_b) / 1e9 / (per_cpi_ms / 1e3), 1),
                                        "frac": round((echo_b + rdm_b) / 1e9 / (per_cpi_ms / 1e3) / HBM_PEAK_GBS, 4)}},
         }
-        if not args.no_cpu_baseline:
+        res["cells"] = [{"cell": int(r[0]), "nRng": None if np.isnan(r[1]) else int(r[1]), "rngEst0": None if np.isnan(r[2]) else round(float(r[2]), 6),
+                         "velEst0": None if np.isnan(r[3]) else round(float(r[3]), 6), "aziEst0": None if np.isnan(r[4]) else float(r[4])}
+                        for r in allr[:8]]
+        if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.ants)
         print(json.dumps(res))
     if dist is not None:
