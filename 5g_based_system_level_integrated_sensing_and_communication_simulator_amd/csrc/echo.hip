@@ -174,8 +174,11 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
   FFT fft;
   fft.init(lds, tw, tid);
   {
-    const int col = blockIdx.x;                    // one (symbol, antenna) column per workgroup
-    const int l = col % L_whole, r = col / L_whole;
+    // one (symbol, antenna) column per workgroup; antenna fastest so that the workgroups resident at the
+    // same time share one symbol's 64 KB window of coef/phase_rx in their XCD's L2 (reuse distance 64 KB
+    // instead of the whole 31 MB coefficient set -- rocprof FETCH_SIZE 1.45 GB -> see profiles/)
+    const int col = blockIdx.x;
+    const int r = col % A, l = col / A;
     const int cp = cp_of_symbol(l, g.cp_base, g.cp_long, g.sym_per_half);
     const int off = cp / 2;  // fix(cp * CyclicPrefixFraction), fraction 0.5
     const long long w0 = symbol_start(l, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) + off;
@@ -202,6 +205,76 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
         },
         tid);
   }
+}
+
+// ---------------------------------------------------------------- fused: echo column -> OFDM demod -> range stage of fft2D
+// While a demodulated echo column is still on chip it is also pushed through the range stage of the
+// following fft2D call (fft2D.m:37-45): multiply by conj(txGrid) and the Kaiser window, nIFFT-point IFFT,
+// keep the CUT rows.  echoGrid is still written (covariance + API output) but never re-read by the
+// range kernel: saves K*L*A*16 B of HBM reads per CPI and lets the VALU-bound noise synthesis of one
+// workgroup overlap the HBM-bound loads of another inside the same launch.  Requires Nfft == nIFFT.
+template <class FFT>
+__global__ __launch_bounds__(256, 2) void demod_range_kernel(OfdmGeom g, long long T, int A, int L_whole, int L_out,
+                                                             const c64* __restrict__ tw, int Q, const c64* __restrict__ coef,
+                                                             const c64* __restrict__ steer_rq, const c64* __restrict__ phase_rx,
+                                                             int noise_mode, const c64* __restrict__ noise, double n0s,
+                                                             uint64_t seed, c64* __restrict__ grid,
+                                                             const c64* __restrict__ txg, const double* __restrict__ win_k,
+                                                             const double* __restrict__ win_r, double inv_n, double sqrt_n,
+                                                             int row_lo, int n_rows, c64* __restrict__ ymid) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* lds = reinterpret_cast<c64*>(smem_raw);
+  const int tid = threadIdx.x;
+  FFT fft;
+  fft.init(lds, tw, tid);
+  const int col = blockIdx.x;
+  const int r = col % A, l = col / A;              // antenna fastest: L2 reuse of the symbol's coef window
+  const int cp = cp_of_symbol(l, g.cp_base, g.cp_long, g.sym_per_half);
+  const int off = cp / 2;
+  const long long w0 = symbol_start(l, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) + off;
+  const int dshift = cp - off;
+  const c64* sr = steer_rq + (long long)r * Q;
+  if (noise_mode == ISAC_NOISE_PHILOX)
+    fft.template fill<4>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, ISAC_NOISE_PHILOX, noise, n0s, seed); }, tid);
+  else
+    fft.template fill<8>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, noise_mode, noise, n0s, seed); }, tid);
+  fft.template transform<-1>(lds, tw, tid);
+  const long long colg = (long long)l + (long long)L_out * r;
+  c64* dst = grid + (long long)g.n_sc * colg;
+  const int half = g.n_sc / 2;
+  fft.release();                                   // pass-3 reads of every thread are done: the image can be reused
+  fft.drain(
+      [&](int k, c64 v) {
+        const int kb = (k < g.nfft / 2) ? k : k - g.nfft;
+        const int row = kb + half;
+        const c64 ph = fft.phase_ramp(lds, tw, kb, dshift);
+        if (row >= 0 && row < g.n_sc) {
+          const c64 e = v * ph;
+          dst[row] = e;                                // echoGrid(row, l, r)
+          lds[row] = e;                                // staged in subcarrier order for the range stage
+        }
+      },
+      tid);
+  __syncthreads();
+  const c64* ptx = txg + (long long)g.n_sc * colg;
+  const int K = g.n_sc;
+  fft.fill(
+      [&](int n) {
+        const int nc = n < K ? n : K - 1;
+        c64 v = mul_conj(lds[nc], ptx[nc]) * win_k[nc];    // fft2D.m:37,:43
+        return n < K ? v : mk(0.0, 0.0);
+      },
+      tid);
+  __syncthreads();                                 // staging reads done before pass 1 overwrites the image
+  fft.template transform<+1>(lds, tw, tid);
+  c64* yd = ymid + (long long)n_rows * colg;
+  fft.drain(
+      [&](int n, c64 v) {
+        const int rr = n - row_lo;
+        const double wr = win_r[n];
+        if (rr >= 0 && rr < n_rows) yd[rr] = ((v * inv_n) * sqrt_n) * wr;   // fft2D.m:44-45
+      },
+      tid);
 }
 
 // ---------------------------------------------------------------- plain CP-OFDM modulator (no windowing)
@@ -423,6 +496,7 @@ extern "C" int isac_mono_static_sensing_dev(isac_ctx* ctx, const isac_c64* d_tx_
                                             const uint8_t* los, int noise_mode, const isac_c64* d_noise_unit,
                                             uint64_t seed, isac_c64* d_echo_grid, int32_t* l_out) {
   if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ctx->range_cache.valid = false;
   ISAC_TRY(check_carrier(ctx, carrier));
   if (!d_echo_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "echo_grid is NULL");
   if (noise_mode == ISAC_NOISE_INJECTED && !d_noise_unit) return fail(ctx, ISAC_ERR_INVALID_ARG, "noise buffer missing");
@@ -442,6 +516,65 @@ extern "C" int isac_mono_static_sensing_dev(isac_ctx* ctx, const isac_c64* d_tx_
   ISAC_FFT_DISPATCH(g.nfft, ISAC_TRY((launch_demod<FFT, true>(ctx, g, T, A, L_whole, L_out, tw, Q, noise_mode,
                                                               (const c64*)d_noise_unit, n0s, seed, nullptr,
                                                               (c64*)d_echo_grid))));
+  return ISAC_OK;
+}
+
+int isac_get_windows(isac_ctx* ctx, int K, int n_ifft, const double** win_k, const double** win_r);   // capi.hip
+
+template <class FFT>
+static int launch_demod_range(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, int L_whole, int L_out, const c64* tw, int Q,
+                              int noise_mode, const c64* noise, double n0s, uint64_t seed, c64* grid, const c64* txg,
+                              const double* wk, const double* wr, int n_ifft, int row_lo, int nr, c64* ymid) {
+  size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
+  auto kern = demod_range_kernel<FFT>;
+  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(L_whole * A)), dim3(256), lds, ctx->stream, g, T, A, L_whole, L_out, tw, Q,
+                     (const c64*)ctx->coef.p, (const c64*)ctx->steer.p + (size_t)A * Q, (const c64*)ctx->phase_rx.p, noise_mode,
+                     noise, n0s, seed, grid, txg, wk, wr, 1.0 / n_ifft, std::sqrt((double)n_ifft), row_lo, nr, ymid);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64* d_tx_wave, int64_t T, int32_t tx_dim_l,
+                                                  const isac_carrier* carrier, const isac_radar_channel_params* rp,
+                                                  const uint8_t* los, int noise_mode, const isac_c64* d_noise_unit,
+                                                  uint64_t seed, isac_c64* d_echo_grid, int32_t* l_out,
+                                                  const isac_est_params* ep, const isac_cfar_config* cf,
+                                                  const isac_c64* d_tx_grid) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ctx->range_cache.valid = false;
+  ISAC_TRY(check_carrier(ctx, carrier));
+  if (!d_echo_grid || !ep || !cf || !d_tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (noise_mode == ISAC_NOISE_INJECTED && !d_noise_unit) return fail(ctx, ISAC_ERR_INVALID_ARG, "noise buffer missing");
+  OfdmGeom g = geom_of(carrier);
+  const int hr = cf->guard[0] + cf->train[0];
+  const int row_lo = cf->row0 - 1 - hr, row_hi = cf->row1 - 1 + hr;
+  const bool fusable = (g.nfft == 4096 && ep->n_ifft == g.nfft && row_lo >= 0 && row_hi < ep->n_ifft && cf->row1 >= cf->row0);
+  if (!fusable)   // other numerologies: plain path, fft2D will run its own range stage
+    return isac_mono_static_sensing_dev(ctx, d_tx_wave, T, tx_dim_l, carrier, rp, los, noise_mode, d_noise_unit, seed, d_echo_grid, l_out);
+  int Q = 0;
+  ISAC_TRY(prepare_echo(ctx, (const c64*)d_tx_wave, T, rp, los, &Q));
+  const int A = rp->n_ants;
+  const int L_whole = whole_symbols(g, T);
+  if (L_whole <= 0) return fail(ctx, ISAC_ERR_SHORT_WAVEFORM, "waveform shorter than one OFDM symbol");
+  const int L_out = L_whole < tx_dim_l ? tx_dim_l : L_whole;
+  if (l_out) *l_out = L_out;
+  const int nr = row_hi - row_lo + 1;
+  ISAC_TRY(ensure(ctx, ctx->ymid, sizeof(c64) * (size_t)nr * L_out * A));
+  if (L_out > L_whole) {
+    ISAC_HIP(hipMemsetAsync(d_echo_grid, 0, sizeof(c64) * (size_t)g.n_sc * L_out * A, ctx->stream));
+    ISAC_HIP(hipMemsetAsync(ctx->ymid.p, 0, sizeof(c64) * (size_t)nr * L_out * A, ctx->stream));
+  }
+  const c64* tw = nullptr;
+  const double *wk = nullptr, *wr = nullptr;
+  ISAC_TRY(isac_get_twiddles(ctx, g.nfft, &tw));
+  ISAC_TRY(isac_get_windows(ctx, g.n_sc, ep->n_ifft, &wk, &wr));
+  const double n0s = std::sqrt(rp->n0 / 2.0);
+  ISAC_TRY((launch_demod_range<Fft4096>(ctx, g, T, A, L_whole, L_out, tw, Q, noise_mode, (const c64*)d_noise_unit, n0s, seed,
+                                        (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, ep->n_ifft, row_lo, nr, (c64*)ctx->ymid.p)));
+  RangeCache& rc = ctx->range_cache;
+  rc.rx = d_echo_grid; rc.tx = d_tx_grid; rc.K = g.n_sc; rc.L = L_out; rc.A = A; rc.n_ifft = ep->n_ifft; rc.row_lo = row_lo; rc.nr = nr;
+  rc.valid = true;
   return ISAC_OK;
 }
 

@@ -57,6 +57,13 @@ struct Fft2dLast {  // introspection of the last fft2D call (host copies)
   bool pow_on_device = false;
 };
 
+struct RangeCache {  // range rows pre-computed by the fused monoStaticSensing call for the next fft2D
+  bool valid = false;
+  const void* rx = nullptr;
+  const void* tx = nullptr;
+  int K = 0, L = 0, A = 0, n_ifft = 0, row_lo = 0, nr = 0;
+};
+
 struct Fft2dPending {  // state between isac_fft2d_submit_dev and isac_fft2d_collect
   bool active = false;
   isac_est_params ep{};
@@ -85,6 +92,7 @@ struct isac_ctx {
   void* pinned = nullptr; size_t pinned_cap = 0;
   isac::Fft2dLast last;
   isac::Fft2dPending pending;
+  isac::RangeCache range_cache;
   hipEvent_t ev_h2d = nullptr;       // completion of the last pinned->device parameter upload
   void* pinned_in = nullptr; size_t pinned_in_cap = 0;
 };

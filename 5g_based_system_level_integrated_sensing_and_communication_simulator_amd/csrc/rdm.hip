@@ -285,8 +285,15 @@ int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_c
   ISAC_TRY(isac_get_windows(ctx, K, n_ifft, &wk, &wr));
   ISAC_TRY(ensure(ctx, ctx->ymid, sizeof(c64) * (size_t)nr * L * A));
   ISAC_TRY(ensure(ctx, ctx->pwin, sizeof(double) * (size_t)nr * nc * A));
-  ISAC_FFT_DISPATCH(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, d_rx, d_tx, K, L, A, tw, wk, wr, n_ifft, row_lo, nr,
-                                                        (c64*)ctx->ymid.p))));
+  {
+    RangeCache& rc = ctx->range_cache;   // range rows already produced by isac_mono_static_sensing_fused_dev?
+    const bool hit = rc.valid && rc.rx == (const void*)d_rx && rc.tx == (const void*)d_tx && rc.K == K && rc.L == L && rc.A == A &&
+                     rc.n_ifft == n_ifft && rc.row_lo == row_lo && rc.nr == nr;
+    rc.valid = false;                    // single use
+    if (!hit)
+      ISAC_FFT_DISPATCH(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, d_rx, d_tx, K, L, A, tw, wk, wr, n_ifft, row_lo, nr,
+                                                            (c64*)ctx->ymid.p))));
+  }
   const int Lu = L < n_fft ? L : n_fft;
   size_t lds = sizeof(c64) * ((size_t)n_fft + (size_t)Lu * (kDopRows + 1));
   { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(doppler_pow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
@@ -382,6 +389,7 @@ extern "C" int isac_fft2d_range_stage_dev(isac_ctx* ctx, const isac_est_params* 
                                           const isac_c64* d_rx_grid, const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A) {
   if (!ctx) return ISAC_ERR_INVALID_ARG;
   if (!ep || !cf || !d_rx_grid || !d_tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  ctx->range_cache.valid = false;
   const int n_ifft = ep->n_ifft;
   const int hr = cf->guard[0] + cf->train[0];
   const int row_lo = cf->row0 - 1 - hr, row_hi = cf->row1 - 1 + hr;

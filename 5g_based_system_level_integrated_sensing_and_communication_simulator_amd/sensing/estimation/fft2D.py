@@ -23,6 +23,19 @@ def _cut_rectangle(cut: np.ndarray):
     return r0, r1, c0, c1
 
 
+def _cfar_block(cfar) -> L.CfarConfig:
+    """cfarConfig (CUTIdx + detector) -> isac_cfar_config; the rectangle recovery is cached on the object."""
+    det = cfar.cfarDetector2D
+    key = id(cfar.CUTIdx)
+    rect = getattr(cfar, "_rect", None)
+    if rect is None or rect[0] != key:
+        rect = (key, _cut_rectangle(cfar.CUTIdx))
+        cfar._rect = rect
+    r0, r1, c0, c1 = rect[1]
+    return L.CfarConfig(float(det.ProbabilityFalseAlarm), (C.c_int32 * 2)(*det.GuardBandSize), (C.c_int32 * 2)(*det.TrainingBandSize),
+                        r0, r1, c0, c1)
+
+
 def fft2D(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None, return_debug=False):
     """estResults = sensing.estimation.fft2D(radarEstParams, cfar, rxGrid, txGrid).
 
@@ -37,10 +50,7 @@ def fft2D(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None, return_debug=False)
     K, Lsym, A = (rxGrid.shape if dev else np.shape(rxGrid))
     if tuple(txGrid.shape) != (K, Lsym, A):
         raise ValueError("rxGrid and txGrid must have identical [nSc x nSym x nAnts] shape")
-    det = cfar.cfarDetector2D
-    r0, r1, c0, c1 = _cut_rectangle(cfar.CUTIdx)
-    cf = L.CfarConfig(float(det.ProbabilityFalseAlarm), (C.c_int32 * 2)(*det.GuardBandSize), (C.c_int32 * 2)(*det.TrainingBandSize),
-                      r0, r1, c0, c1)
+    cf = _cfar_block(cfar)
     ep = est_block(radarEstParams)
     res = L.EstResult()
     lib = ctx.lib
@@ -69,15 +79,7 @@ def fft2D_submit(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None):
     K, Lsym, A = rxGrid.shape
     if tuple(txGrid.shape) != (K, Lsym, A):
         raise ValueError("rxGrid and txGrid must have identical [nSc x nSym x nAnts] shape")
-    det = cfar.cfarDetector2D
-    key = id(cfar.CUTIdx)
-    rect = getattr(cfar, "_rect", None)
-    if rect is None or rect[0] != key:
-        rect = (key, _cut_rectangle(cfar.CUTIdx))
-        cfar._rect = rect
-    r0, r1, c0, c1 = rect[1]
-    cf = L.CfarConfig(float(det.ProbabilityFalseAlarm), (C.c_int32 * 2)(*det.GuardBandSize), (C.c_int32 * 2)(*det.TrainingBandSize),
-                      r0, r1, c0, c1)
+    cf = _cfar_block(cfar)
     ep = est_block(radarEstParams)
     ctx.check(ctx.lib.isac_fft2d_submit_dev(ctx.handle, C.byref(ep), C.byref(cf), C.c_void_p(rxGrid.ptr), C.c_void_p(txGrid.ptr),
                                             C.c_int32(K), C.c_int32(Lsym), C.c_int32(A)))

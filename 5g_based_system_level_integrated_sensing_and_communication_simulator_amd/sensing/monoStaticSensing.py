@@ -10,13 +10,18 @@ from ._marshal import ChannelBlock, carrier_block, los_array
 
 
 def monoStaticSensing(txWaveform, txDimension, carrierInfo, radarParams, targetLoSConditions, *,
-                      noise=None, seed=None, nfft=None, ctx=None, out=None):
+                      noise=None, seed=None, nfft=None, ctx=None, out=None, fuse_fft2d=None):
     """echoGrid = monoStaticSensing(txWaveform, txDimension, carrierInfo, radarParams, targetLoSConditions).
 
     Radar channel (:13) + OFDM demodulation (:16) + zero-padding of the symbol dimension up to
     ``txDimension(2)`` (:19-21), fused on the device: the time-domain echo is never written to HBM.
     numpy in -> numpy out; DeviceArray in -> DeviceArray out (``out``: optional pre-allocated
-    DeviceArray to reuse between CPIs).  ``noise`` / ``seed`` as in basicRadarChannel."""
+    DeviceArray to reuse between CPIs).  ``noise`` / ``seed`` as in basicRadarChannel.
+
+    ``fuse_fft2d=(radarEstParams, cfar, txGrid)`` (device path): also run the range stage of the
+    ``fft2D(radarEstParams, cfar, echoGrid, txGrid)`` call that follows while each echo column is still
+    on chip (isac_mono_static_sensing_fused_dev); that fft2D call then skips re-reading echoGrid.
+    Results are identical to the unfused sequence."""
     dev = isinstance(txWaveform, L.DeviceArray)
     ctx = ctx or (txWaveform.ctx if dev else L.default_context())
     T, A = (txWaveform.shape if dev else np.shape(txWaveform))
@@ -40,6 +45,18 @@ def monoStaticSensing(txWaveform, txDimension, carrierInfo, radarParams, targetL
             out = ctx.empty(shape)
         elif tuple(out.shape) != shape:
             raise ValueError(f"out must have shape {shape}")
+        if fuse_fft2d is not None:
+            from .estimation.fft2D import _cfar_block
+            from ._marshal import est_block
+            est_params, cfar, tx_grid = fuse_fft2d
+            if not isinstance(tx_grid, L.DeviceArray) or tuple(tx_grid.shape) != shape:
+                raise ValueError("fuse_fft2d needs a DeviceArray txGrid with the echo grid's shape")
+            ep, cf = est_block(est_params), _cfar_block(cfar)
+            ctx.check(lib.isac_mono_static_sensing_fused_dev(ctx.handle, C.c_void_p(txWaveform.ptr), C.c_int64(T), C.c_int32(int(txDimension[1])),
+                                                             C.byref(car), C.byref(cb.block), los.ctypes.data_as(C.c_void_p), C.c_int(mode),
+                                                             C.c_void_p(nz.ptr if nz is not None else 0), C.c_uint64(seed or 0),
+                                                             C.c_void_p(out.ptr), C.byref(lo), C.byref(ep), C.byref(cf), C.c_void_p(tx_grid.ptr)))
+            return out
         ctx.check(lib.isac_mono_static_sensing_dev(ctx.handle, C.c_void_p(txWaveform.ptr), C.c_int64(T), C.c_int32(int(txDimension[1])),
                                                    C.byref(car), C.byref(cb.block), los.ctypes.data_as(C.c_void_p), C.c_int(mode),
                                                    C.c_void_p(nz.ptr if nz is not None else 0), C.c_uint64(seed or 0),

@@ -62,8 +62,9 @@ class Cell:
     branch of CPI i (covariance -> eig -> scan, latency-bound on one CU) runs under the echo / range
     kernels of CPI i+1.  Results are collected in submission order."""
 
-    def __init__(self, pkg, device, cell_id, n_ants, n_slots, n_targets, inflight=1):
+    def __init__(self, pkg, device, cell_id, n_ants, n_slots, n_targets, inflight=1, fuse=True):
         L = pkg._lib
+        self.fuse = fuse
         self.pkg, self.L = pkg, L
         self.ctxs = [pkg.Context(device) for _ in range(max(1, inflight))]
         ctx = self.ctx = self.ctxs[0]
@@ -116,7 +117,8 @@ class Cell:
         self._collect(slot)
         c = self.ctxs[slot]
         echo = self.pkg.sensing.monoStaticSensing(self.tx_wave, (self.K, self.Lsym, self.A), self.carrier, self.rp, self.los,
-                                                  seed=self.seed + self.n_sub, nfft=4096, out=self.echo[slot], ctx=c)
+                                                  seed=self.seed + self.n_sub, nfft=4096, out=self.echo[slot], ctx=c,
+                                                  fuse_fft2d=(self.rp, self.cfar, self.tx_grid) if self.fuse else None)
         self.pkg.sensing.estimation.fft2D_submit(self.rp, self.cfar, echo, self.tx_grid, ctx=c)
         self.pending[slot] = True
         self.n_sub += 1
@@ -171,7 +173,7 @@ def cpu_baseline(n_ants, budget_s=25.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as O
     from conftest import make_scene
-    a_s = 4
+    a_s = 16
     sc = make_scene(n_ants=a_s, n_slots=16, nrb=273, targets=((100.0, 20.0, 1.5),), velocity=(7.0,), seed=3)
     cf = O.cfar2d_config(sc.rp)
     t0 = time.perf_counter()
@@ -183,7 +185,7 @@ def cpu_baseline(n_ants, budget_s=25.0):
         except ValueError:
             pass
         reps += 1
-        if time.perf_counter() - t0 > budget_s or reps >= 5:
+        if time.perf_counter() - t0 > budget_s or reps >= 8:
             break
     dt = (time.perf_counter() - t0) / reps
     cpi_s = dt * (n_ants / a_s)
@@ -202,6 +204,7 @@ def main():
     ap.add_argument("--targets", type=int, default=1)
     ap.add_argument("--cells-per-gpu", type=int, default=1)
     ap.add_argument("--inflight", type=int, default=2, help="CPIs in flight per cell (contexts)")
+    ap.add_argument("--no-fuse", action="store_true", help="do not fuse the fft2D range stage into monoStaticSensing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -215,7 +218,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     pkg = importlib.import_module(PKG)
-    cells = [Cell(pkg, local_rank, rank * args.cells_per_gpu + c, args.ants, args.slots, args.targets, args.inflight)
+    cells = [Cell(pkg, local_rank, rank * args.cells_per_gpu + c, args.ants, args.slots, args.targets, args.inflight, not args.no_fuse)
              for c in range(args.cells_per_gpu)]
 
     def barrier():

@@ -161,6 +161,17 @@ int isac_mono_static_sensing(isac_ctx* ctx, const isac_c64* tx_wave, int64_t T, 
                              const isac_carrier* carrier, const isac_radar_channel_params* rp,
                              const uint8_t* los, int noise_mode, const isac_c64* noise_unit,
                              uint64_t seed, isac_c64* echo_grid, int32_t* l_out);
+/* monoStaticSensing + the range stage of the fft2D call that follows it (fft2D.m:37-45), fused per
+ * echo column while the column is still on chip.  Results are identical to the two separate calls;
+ * the next isac_fft2d[_submit]_dev on this context with the same d_echo_grid / d_tx_grid / parameters
+ * consumes the cached range rows instead of re-reading rxGrid (single use; any other echo or range
+ * call on the context drops the cache).  Falls back to the plain path when Nfft != nIFFT. */
+int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64* d_tx_wave, int64_t T, int32_t tx_dim_l,
+                                       const isac_carrier* carrier, const isac_radar_channel_params* rp,
+                                       const uint8_t* los, int noise_mode, const isac_c64* d_noise_unit,
+                                       uint64_t seed, isac_c64* d_echo_grid, int32_t* l_out,
+                                       const isac_est_params* ep, const isac_cfar_config* cfar,
+                                       const isac_c64* d_tx_grid);
 /* number of whole OFDM symbols in T samples (size query for the call above) */
 int isac_ofdm_symbol_count(const isac_carrier* carrier, int64_t T, int32_t* n_symbols);
 

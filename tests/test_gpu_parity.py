@@ -175,6 +175,35 @@ def test_fft2d_small(pkg, ctx):
     assert np.array_equal(got2.rngEst, got.rngEst) and np.array_equal(got2.aziEst, got.aziEst)
 
 
+def test_fused_range_stage_is_identical(pkg, ctx):
+    """monoStaticSensing(fuse_fft2d=...) + fft2D must give bit-identical echo grid, |rdm|^2 window and
+    detections to the unfused call sequence (full-size numerology: the fused kernel needs Nfft == nIFFT == 4096)."""
+    sc = make_scene(n_ants=3, n_slots=4, nrb=273, targets=((100.0, 20.0, 1.5),), velocity=(7.0,), seed=9)
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    cf = pkg.sensing.detection.cfar2D(rp)
+    d_wave, d_noise, d_txg = ctx.to_device(sc.tx_wave), ctx.to_device(sc.noise), ctx.to_device(sc.tx_grid)
+    e0 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, noise=d_noise, nfft=4096)
+    est0, dbg0 = pkg.sensing.estimation.fft2D(rp, cf, e0, d_txg, return_debug=True)
+    e1 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, noise=d_noise, nfft=4096,
+                                       fuse_fft2d=(rp, cf, d_txg))
+    est1, dbg1 = pkg.sensing.estimation.fft2D(rp, cf, e1, d_txg, return_debug=True)
+    assert np.array_equal(e0.numpy(), e1.numpy())
+    assert np.array_equal(dbg0.power_window, dbg1.power_window)
+    assert all(np.array_equal(a, b) for a, b in zip(dbg0.detections, dbg1.detections))
+    assert np.array_equal(est0.rngEst, est1.rngEst) and np.array_equal(est0.aziEst, est1.aziEst)
+    # the cache is single-use and keyed on the grids: a different rxGrid must not consume it
+    e2 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, noise=d_noise, nfft=4096,
+                                       fuse_fft2d=(rp, cf, d_txg))
+    other = ctx.to_device(np.asfortranarray(2.0 * e0.numpy()))
+    _, dbg2 = pkg.sensing.estimation.fft2D(rp, cf, other, d_txg, return_debug=True)
+    assert np.allclose(dbg2.power_window, 4.0 * dbg0.power_window, rtol=1e-12)
+    # padded symbol dimension (txDimension(2) > whole symbols) through the fused path
+    e3 = pkg.sensing.monoStaticSensing(ctx.to_device(sc.tx_wave[:-9]), sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096,
+                                       fuse_fft2d=(rp, cf, d_txg))
+    e4 = pkg.sensing.monoStaticSensing(ctx.to_device(sc.tx_wave[:-9]), sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096)
+    assert np.array_equal(e3.numpy(), e4.numpy()) and np.all(e3.numpy()[:, -1, :] == 0)
+
+
 def test_fft2d_multi_target_odd_antennas(pkg, ctx):
     sc = make_scene(n_ants=6, n_slots=8, nrb=51, targets=((120.0, 60.0, 1.5), (-250.0, 80.0, 1.5)), velocity=(10.0, -6.0),
                     num_slots_param=12, seed=5)
