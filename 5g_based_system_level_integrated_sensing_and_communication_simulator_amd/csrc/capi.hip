@@ -221,7 +221,7 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   for (auto& kv : ctx->sind) hipFree(kv.second.p);
   DevBuf* bufs[] = {&ctx->beam, &ctx->coef, &ctx->phase_rx, &ctx->steer,
                     &ctx->ymid, &ctx->pwin, &ctx->flags, &ctx->det_cut, &ctx->det_pow, &ctx->det_cnt, &ctx->cov_part,
-                    &ctx->cov, &ctx->eig_w, &ctx->eig_v, &ctx->spec, &ctx->misc, &ctx->stage_a, &ctx->stage_b,
+                    &ctx->cov, &ctx->eig_w, &ctx->eig_v, &ctx->eig_scratch, &ctx->spec, &ctx->misc, &ctx->stage_a, &ctx->stage_b,
                     &ctx->stage_c, &ctx->sind_tab};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);

@@ -174,11 +174,12 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
   FFT fft;
   fft.init(lds, tw, tid);
   {
-    // one (symbol, antenna) column per workgroup; antenna fastest so that the workgroups resident at the
-    // same time share one symbol's 64 KB window of coef/phase_rx in their XCD's L2 (reuse distance 64 KB
-    // instead of the whole 31 MB coefficient set -- rocprof FETCH_SIZE 1.45 GB -> see profiles/)
+    // one (symbol, antenna) column per workgroup, symbol fastest: consecutive workgroups write consecutive
+    // 52 KB columns of one antenna plane.  (Antenna-fastest order would re-use a symbol's coef window in L2
+    // -- rocprof shows 1.4 GB of coef/phase re-fetch from the Infinity Cache here -- but it scatters the
+    // grid writes over 64 planes 11.7 MB apart and measured 15-20 % slower.)
     const int col = blockIdx.x;
-    const int r = col % A, l = col / A;
+    const int l = col % L_whole, r = col / L_whole;
     const int cp = cp_of_symbol(l, g.cp_base, g.cp_long, g.sym_per_half);
     const int off = cp / 2;  // fix(cp * CyclicPrefixFraction), fraction 0.5
     const long long w0 = symbol_start(l, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) + off;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void demod_range_kernel(OfdmGeom g, long lo
   FFT fft;
   fft.init(lds, tw, tid);
   const int col = blockIdx.x;
-  const int r = col % A, l = col / A;              // antenna fastest: L2 reuse of the symbol's coef window
+  const int l = col % L_whole, r = col / L_whole;  // symbol fastest (see demod_kernel)
   const int cp = cp_of_symbol(l, g.cp_base, g.cp_long, g.sym_per_half);
   const int off = cp / 2;
   const long long w0 = symbol_start(l, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) + off;

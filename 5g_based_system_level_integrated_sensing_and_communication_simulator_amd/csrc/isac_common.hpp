@@ -88,7 +88,7 @@ struct isac_ctx {
   std::map<std::pair<long long, long long>, isac::DevBuf> sind;     // (scale, granularity) -> sind(scan angles)
   // scratch
   isac::DevBuf beam, coef, phase_rx, steer, ymid, pwin, flags, det_cut, det_pow, det_cnt, cov_part, cov,
-      eig_w, eig_v, spec, misc, stage_a, stage_b, stage_c, sind_tab;
+      eig_w, eig_v, eig_scratch, spec, misc, stage_a, stage_b, stage_c, sind_tab;
   void* pinned = nullptr; size_t pinned_cap = 0;
   isac::Fft2dLast last;
   isac::Fft2dPending pending;

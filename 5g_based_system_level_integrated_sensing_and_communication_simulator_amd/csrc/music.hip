@@ -281,15 +281,17 @@ __device__ __forceinline__ void rr_pair(int round, int k, int n /* even */, int&
 //   U: thread (a, b) owns the 2x2 block (pair a) x (pair b) of H and applies  J_a^H B J_b  in place
 //      (a one-phase two-sided update -- nobody else touches that block this round); the same
 //      threads rotate two (row, pair) column pairs of V.
+// A <= 64: H and V live in LDS (gscratch == nullptr).  Larger arrays (config 4: 256-element ULA) keep H and V
+// in a global scratch that stays L2-resident (2 MB at A = 256); same algorithm, still one workgroup.
 __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict__ Hin, int A, int max_sweeps,
                                                            double* __restrict__ w_out, c64* __restrict__ V_out,
-                                                           int* __restrict__ info /* [0]=sweeps used */) {
+                                                           int* __restrict__ info /* [0]=sweeps used */, c64* gscratch) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int n = (A + 1) & ~1;                      // pad to even with an isolated zero row/col
   const int h = n / 2;
-  c64* H = reinterpret_cast<c64*>(smem_raw);       // [n x n] column-major
+  c64* H = gscratch ? gscratch : reinterpret_cast<c64*>(smem_raw);       // [n x n] column-major
   c64* V = H + n * n;                              // [n x n]
-  c64* rg = V + n * n;                             // [h] g_k
+  c64* rg = gscratch ? reinterpret_cast<c64*>(smem_raw) : V + n * n;     // [h] g_k
   double* rc = reinterpret_cast<double*>(rg + h);  // [h] c_k
   int* rp = reinterpret_cast<int*>(rc + h);        // [h] p_k
   int* rq = rp + h;                                // [h] q_k
@@ -311,10 +313,10 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
     __syncthreads();
     for (int round = 0; round < n - 1; ++round) {
       // ---- P: rotation parameters of the h disjoint pairs
-      if (tid < h) {
+      for (int kk = tid; kk < h; kk += nt) {
         int p, q;
-        rr_pair(round, tid, n, p, q);
-        rp[tid] = p; rq[tid] = q;
+        rr_pair(round, kk, n, p, q);
+        rp[kk] = p; rq[kk] = q;
         const c64 beta = H[p + n * q];
         const double d = H[q + n * q].re - H[p + n * p].re;
         const double m2 = beta.re * beta.re + beta.im * beta.im;
@@ -328,13 +330,13 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
           const double cu = c * u;
           g = mk(cu * beta.re, cu * beta.im);
         }
-        rc[tid] = c;
-        rg[tid] = g;
+        rc[kk] = c;
+        rg[kk] = g;
       }
       __syncthreads();
       // ---- U: two-sided 2x2 block updates of H, column rotations of V
-      if (tid < h * h) {
-        const int a = tid % h, b = tid / h;
+      for (int blk = tid; blk < h * h; blk += nt) {
+        const int a = blk % h, b = blk / h;
         const int pa = rp[a], qa = rq[a], pb = rp[b], qb = rq[b];
         const double ca = rc[a], cb = rc[b];
         const c64 ga = rg[a], gb = rg[b];
@@ -477,15 +479,21 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
 // device eig: H [A x A] (device) -> ctx->eig_w [A], ctx->eig_v [A x A] (unsorted)
 int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
   if (!st) st = ctx->stream;
-  if (A > kJacobiMaxA) return fail(ctx, ISAC_ERR_UNSUPPORTED, "device eigensolver supports up to 64 antennas in this build");
+  if (A > 1024) return fail(ctx, ISAC_ERR_UNSUPPORTED, "device eigensolver supports up to 1024 antennas");
   const int n = (A + 1) & ~1;
+  const bool big = A > kJacobiMaxA;
+  c64* gs = nullptr;
+  if (big) {
+    ISAC_TRY(ensure(ctx, ctx->eig_scratch, sizeof(c64) * (size_t)2 * n * n));
+    gs = (c64*)ctx->eig_scratch.p;
+  }
   ISAC_TRY(ensure(ctx, ctx->eig_w, sizeof(double) * (size_t)A + 64));
   ISAC_TRY(ensure(ctx, ctx->eig_v, sizeof(c64) * (size_t)A * A));
-  size_t lds = sizeof(c64) * ((size_t)2 * n * n + n / 2) + sizeof(double) * (n / 2) + sizeof(int) * (n + 1) + 64;
+  size_t lds = sizeof(c64) * ((big ? 0 : (size_t)2 * n * n) + n / 2) + sizeof(double) * (n / 2) + sizeof(int) * (n + 1) + 64;
   { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
   int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
   hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(1024), lds, st, d_H, A, 40, (double*)ctx->eig_w.p,
-                     (c64*)ctx->eig_v.p, info);
+                     (c64*)ctx->eig_v.p, info, gs);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }

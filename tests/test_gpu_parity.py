@@ -218,6 +218,13 @@ def test_fft2d_full_size_grid(pkg, ctx):
     assert gd.power_window.shape[:2] == (376, 29) and gd.first_row == 39 and gd.first_col == 115
 
 
+def test_fft2d_256_element_array(pkg, ctx):
+    """Config 4 shape on the array side: 256-element ULA (generic MFMA covariance, global-memory Jacobi)."""
+    sc = make_scene(n_ants=256, n_slots=2, nrb=24, targets=((150.0, 40.0, 1.5),), velocity=(0.0,), num_slots_param=3,
+                    zero_s_slots=False, seed=13)
+    _run_fft2d_case(pkg, sc)
+
+
 def test_fft2d_zero_detections_is_an_error(pkg, ctx):
     sc = make_scene(n_ants=2, n_slots=4, nrb=24, num_slots_param=6, with_noise=False)
     rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
@@ -228,7 +235,7 @@ def test_fft2d_zero_detections_is_an_error(pkg, ctx):
 
 
 # ------------------------------------------------------------------ covariance / eig / MUSIC
-@pytest.mark.parametrize("n,a", [(8064, 4), (4096 + 37, 19), (733824, 16), (65536, 64)])
+@pytest.mark.parametrize("n,a", [(8064, 4), (4096 + 37, 19), (733824, 16), (65536, 64), (20000, 100), (8192, 256)])
 def test_covariance_mfma(pkg, ctx, n, a):
     rng = np.random.default_rng(a)
     g = np.asfortranarray(rng.standard_normal((n, a)) + 1j * rng.standard_normal((n, a)))
@@ -241,7 +248,7 @@ def test_covariance_mfma(pkg, ctx, n, a):
     assert rel(ra, want) < 1e-12 and np.array_equal(ra, ra.conj().T)
 
 
-@pytest.mark.parametrize("a", [2, 5, 16, 33, 64])
+@pytest.mark.parametrize("a", [2, 5, 16, 33, 64, 96, 256])
 def test_eigh_jacobi(pkg, ctx, a):
     rng = np.random.default_rng(a)
     m = rng.standard_normal((a, a)) + 1j * rng.standard_normal((a, a))
