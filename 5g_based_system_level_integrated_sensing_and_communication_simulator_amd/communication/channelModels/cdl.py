@@ -1,0 +1,185 @@
+"""CDL MIMO channel apply -- the seam the reference fills with the toolbox object ``nrCDLChannel``
+(+parameters/+channelModels/+communication/cdl.m:57-64,78-85; stepped at uePhy.m:729-731, gNBPhy.m:838-840).
+
+Host side (this file): TR 38.901 7.7.1 parameter preparation -- CDL-A / CDL-D cluster tables, 20-ray clusters,
+38.901 element pattern, polarisation model-2, seeded ray phases/couplings, sample-and-hold path gains, fractional-delay
+filter taps.  Scalar/array prep of a few 10^4 values per call, like ``sensing.radarParams``.
+Device side (csrc/cdl.hip): the antenna contraction as one complex GEMM on fp64 MFMA + the per-path delay FIR.
+
+The toolbox source is not in the reference and its random stream is MATLAB's; this follows the published 3GPP model
+with the toolbox's documented defaults, so agreement with MATLAB is statistical only."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from types import SimpleNamespace
+
+import numpy as np
+
+from ... import _lib as L
+from ..._philox import uniform
+
+RAY_OFFSETS = np.array([0.0447, -0.0447, 0.1413, -0.1413, 0.2492, -0.2492, 0.3715, -0.3715, 0.5129, -0.5129,
+                        0.6797, -0.6797, 0.8844, -0.8844, 1.1481, -1.1481, 1.5195, -1.5195, 2.1551, -2.1551])   # TR 38.901 Table 7.5-3
+# TR 38.901 Table 7.7.1-1 (CDL-A) and 7.7.1-4 (CDL-D): normalised delay, power [dB], AOD, AOA, ZOD, ZOA [deg]
+_TABLES = {
+    "CDL-A": (np.array([
+        [0.0000, -13.4, -178.1, 51.3, 50.2, 125.4], [0.3819, 0.0, -4.2, -152.7, 93.2, 91.3], [0.4025, -2.2, -4.2, -152.7, 93.2, 91.3],
+        [0.5868, -4.0, -4.2, -152.7, 93.2, 91.3], [0.4610, -6.0, 90.2, 76.6, 122.0, 94.0], [0.5375, -8.2, 90.2, 76.6, 122.0, 94.0],
+        [0.6708, -9.9, 90.2, 76.6, 122.0, 94.0], [0.5750, -10.5, 121.5, -1.8, 150.2, 47.1], [0.7618, -7.5, -81.7, -41.9, 55.2, 56.0],
+        [1.5375, -15.9, 158.4, 94.2, 26.4, 30.1], [1.8978, -6.6, -83.0, 51.9, 126.4, 58.8], [2.2242, -16.7, 134.8, -115.9, 171.6, 26.0],
+        [2.1718, -12.4, -153.0, 26.6, 151.4, 49.2], [2.4942, -15.2, -172.0, 76.6, 157.2, 143.1], [2.5119, -10.8, -129.9, -7.0, 47.2, 117.4],
+        [3.0582, -11.3, -136.0, -23.0, 40.4, 122.7], [4.0810, -12.7, 165.4, -47.2, 43.3, 123.2], [4.4579, -16.2, 148.4, 110.4, 161.8, 32.6],
+        [4.5695, -18.3, 132.7, 144.5, 10.8, 27.2], [4.7966, -18.9, -118.6, 155.3, 16.7, 15.2], [5.0066, -16.6, -154.1, 102.0, 171.7, 146.0],
+        [5.3043, -19.9, 126.5, -151.8, 22.7, 150.7], [9.6586, -29.7, -56.2, 55.2, 144.9, 156.1]]),
+        dict(cASD=5.0, cASA=11.0, cZSD=3.0, cZSA=3.0, XPR=10.0), False),
+    "CDL-D": (np.array([
+        [0.0000, -0.2, 0.0, -180.0, 98.5, 81.5], [0.0000, -13.5, 0.0, -180.0, 98.5, 81.5],
+        [0.0350, -18.8, 89.2, 89.2, 85.5, 86.9], [0.6120, -21.0, 89.2, 89.2, 85.5, 86.9], [1.3630, -22.8, 89.2, 89.2, 85.5, 86.9],
+        [1.4050, -17.9, 13.0, 163.0, 97.5, 79.4], [1.8040, -20.1, 13.0, 163.0, 97.5, 79.4], [2.5960, -21.9, 13.0, 163.0, 97.5, 79.4],
+        [1.7750, -22.9, 34.6, -137.0, 98.5, 78.2], [4.0420, -27.8, -64.5, 74.5, 88.4, 73.6], [7.9370, -23.6, -32.9, 127.7, 91.3, 78.3],
+        [9.4240, -24.8, 52.6, -119.6, 103.8, 87.0], [9.7080, -30.0, -132.1, -9.1, 80.3, 70.6], [12.5250, -27.7, 77.2, -83.8, 86.5, 72.9]]),
+        dict(cASD=5.0, cASA=8.0, cZSD=3.0, cZSA=3.0, XPR=11.0), True),
+}
+FILTER_TAPS, FILTER_DELAY = 16, 7
+
+
+def _unit(theta_deg, phi_deg):
+    t, p = np.radians(theta_deg), np.radians(phi_deg)
+    return np.stack([np.sin(t) * np.cos(p), np.sin(t) * np.sin(p), np.cos(t)], axis=-1)
+
+
+def _positions(size):
+    m_, n_, p_, mg_, ng_ = (int(v) for v in size)
+    idx = np.indices((ng_, mg_, p_, n_, m_)).reshape(5, -1)           # m fastest
+    ng, mg, p, n, m = idx
+    pos = np.stack([np.zeros(m.size), 0.5 * n + ng * 0.5 * n_, 0.5 * m + mg * 0.5 * m_], axis=1)
+    return pos, p
+
+
+def _pattern(theta, phi, element):
+    if element == "38.901":                                            # TR 38.901 Table 7.3-1
+        ph = (phi + 180.0) % 360.0 - 180.0
+        a_v = -np.minimum(12.0 * ((theta - 90.0) / 65.0) ** 2, 30.0)
+        a_h = -np.minimum(12.0 * (ph / 65.0) ** 2, 30.0)
+        return 10.0 ** ((-np.minimum(-(a_v + a_h), 30.0) + 8.0) / 20.0)
+    return np.ones_like(theta)
+
+
+class CDLChannel:
+    """The subset of ``nrCDLChannel`` the reference configures (cdl.m:57-64) with the toolbox defaults it leaves
+    alone.  Stateful like the System object: channel time advances by the waveform duration on every call."""
+
+    def __init__(self, DelayProfile="CDL-D", DelaySpread=300e-9, CarrierFrequency=3.5e9, TransmitAntennaArraySize=(1, 8, 2, 1, 1),
+                 ReceiveAntennaArraySize=(1, 1, 2, 1, 1), SampleRate=122.88e6, MaximumDopplerShift=5.0, Seed=73, SampleDensity=64):
+        if DelayProfile not in _TABLES:
+            raise ValueError("DelayProfile must be 'CDL-A' or 'CDL-D' (updateCDLModels.m:9-14)")
+        self.DelayProfile, self.DelaySpread, self.CarrierFrequency = DelayProfile, float(DelaySpread), float(CarrierFrequency)
+        self.TransmitAntennaArraySize = tuple(int(v) for v in TransmitAntennaArraySize)
+        self.ReceiveAntennaArraySize = tuple(int(v) for v in ReceiveAntennaArraySize)
+        self.SampleRate, self.MaximumDopplerShift = float(SampleRate), float(MaximumDopplerShift)
+        self.Seed, self.SampleDensity = int(Seed), int(SampleDensity)
+        self.UTDirectionOfTravel = (0.0, 90.0)
+        self.TxPolAngles, self.RxPolAngles = (45.0, -45.0), (0.0, 90.0)
+        self.TxElement, self.RxElement = "38.901", "isotropic"
+        self.NormalizePathGains = self.NormalizeChannelOutputs = True
+        self.time = 0.0                                                 # InitialTime
+        self._rays = None
+
+    # ---- info(channel): uePhy.m:288-289
+    def info(self):
+        d = self.path_delays()
+        return SimpleNamespace(PathDelays=d, ChannelFilterDelay=FILTER_DELAY,
+                               MaxChannelDelay=int(math.ceil(np.max(d * self.SampleRate))) + FILTER_DELAY)
+
+    def path_delays(self):
+        tab, _, los = _TABLES[self.DelayProfile]
+        d = tab[:, 0] * self.DelaySpread
+        return d[1:] if los else d
+
+    def _draw(self):
+        if self._rays is not None:
+            return self._rays
+        tab, spr, los = _TABLES[self.DelayProfile]
+        nl = tab[1:] if los else tab
+        n_cl, m = nl.shape[0], RAY_OFFSETS.size
+        phases = (2.0 * uniform(self.Seed, 1, n_cl * m * 4).reshape(n_cl, m, 4) - 1.0) * np.pi
+        perms = np.argsort(uniform(self.Seed, 2, n_cl * m * 3).reshape(n_cl, 3, m), axis=2, kind="stable")
+        p_lin = 10.0 ** (tab[:, 1] / 10.0)
+        if self.NormalizePathGains:
+            p_lin = p_lin / p_lin.sum()
+        self._rays = SimpleNamespace(
+            aod=nl[:, 2:3] + spr["cASD"] * RAY_OFFSETS[None, :], aoa=nl[:, 3:4] + spr["cASA"] * RAY_OFFSETS[perms[:, 0, :]],
+            zod=nl[:, 4:5] + spr["cZSD"] * RAY_OFFSETS[perms[:, 1, :]], zoa=nl[:, 5:6] + spr["cZSA"] * RAY_OFFSETS[perms[:, 2, :]],
+            phases=phases, power=p_lin, los=los, table=tab, kappa=10.0 ** (spr["XPR"] / 10.0))
+        return self._rays
+
+    def path_gains(self, t_snap: float) -> np.ndarray:
+        """H[n, s, u] at channel time t_snap (TR 38.901 eq. 7.5-22; LOS term 7.5-29 folded into path 0)."""
+        r = self._draw()
+        txp, txpol = _positions(self.TransmitAntennaArraySize)
+        rxp, rxpol = _positions(self.ReceiveAntennaArraySize)
+        vhat = _unit(self.UTDirectionOfTravel[1], self.UTDirectionOfTravel[0])
+        r_tx, r_rx = _unit(r.zod, r.aod), _unit(r.zoa, r.aoa)            # [n, m, 3]
+        amp_t, amp_r = _pattern(r.zod, r.aod, self.TxElement), _pattern(r.zoa, r.aoa, self.RxElement)
+        zt, zr = np.radians(np.asarray(self.TxPolAngles)[txpol]), np.radians(np.asarray(self.RxPolAngles)[rxpol])
+        ft = np.stack([amp_t[..., None] * np.cos(zt), amp_t[..., None] * np.sin(zt)], axis=-1)     # [n, m, s, 2]
+        fr = np.stack([amp_r[..., None] * np.cos(zr), amp_r[..., None] * np.sin(zr)], axis=-1)     # [n, m, u, 2]
+        sk = math.sqrt(1.0 / r.kappa)
+        e = np.exp(1j * r.phases)
+        xp = np.stack([np.stack([e[..., 0], sk * e[..., 1]], -1), np.stack([sk * e[..., 2], e[..., 3]], -1)], -2)   # [n, m, 2, 2]
+        a_tx = np.exp(2j * np.pi * np.einsum("sd,nmd->nms", txp, r_tx))
+        a_rx = np.exp(2j * np.pi * np.einsum("ud,nmd->nmu", rxp, r_rx))
+        dop = np.exp(2j * np.pi * self.MaximumDopplerShift * (r_rx @ vhat) * t_snap)                 # [n, m]
+        core = np.einsum("nmui,nmij,nmsj->nmsu", fr, xp, ft)
+        p_nl = r.power[1:] if r.los else r.power
+        h = np.einsum("nmsu,nms,nmu,nm->nsu", core, a_tx, a_rx, dop) * np.sqrt(p_nl / RAY_OFFSETS.size)[:, None, None]
+        if r.los:
+            row = r.table[0]
+            rt, rr = _unit(row[4], row[2]), _unit(row[5], row[3])
+            at_, ar_ = _pattern(np.array(row[4]), np.array(row[2]), self.TxElement), _pattern(np.array(row[5]), np.array(row[3]), self.RxElement)
+            ft0 = np.stack([at_ * np.cos(zt), at_ * np.sin(zt)], -1)    # [s, 2]
+            fr0 = np.stack([ar_ * np.cos(zr), ar_ * np.sin(zr)], -1)    # [u, 2]
+            los_core = fr0[None, :, 0] * ft0[:, None, 0] - fr0[None, :, 1] * ft0[:, None, 1]          # [s, u]
+            d0 = np.exp(2j * np.pi * self.MaximumDopplerShift * float(rr @ vhat) * t_snap)
+            h[0] += math.sqrt(r.power[0]) * los_core * np.exp(2j * np.pi * (txp @ rt))[:, None] * np.exp(2j * np.pi * (rxp @ rr))[None, :] * d0
+        return h
+
+    def filter_taps(self):
+        d = self.path_delays() * self.SampleRate
+        shift = np.floor(d).astype(np.int32)
+        x = np.arange(FILTER_TAPS, dtype=np.float64)[None, :] - FILTER_DELAY - (d - shift)[:, None]
+        g = np.sinc(x) * np.where(np.abs(x) < FILTER_TAPS / 2, 0.5 + 0.5 * np.cos(np.pi * x / (FILTER_TAPS / 2)), 0.0)
+        return np.ascontiguousarray(g), shift
+
+    def __call__(self, waveform, *, ctx=None):
+        return applyCDL(self, waveform, ctx=ctx)
+
+
+def applyCDL(channel: CDLChannel, waveform, *, ctx=None):
+    """rxWaveform = channel(waveform)   (uePhy.m:731 / gNBPhy.m:840).  waveform [T x Nt] -> [T x Nr]; numpy in ->
+    numpy out, DeviceArray in -> DeviceArray out.  Advances the channel time by T / SampleRate."""
+    dev = isinstance(waveform, L.DeviceArray)
+    ctx = ctx or (waveform.ctx if dev else L.default_context())
+    T, nt = (waveform.shape if dev else np.shape(waveform))
+    if nt != int(np.prod(channel.TransmitAntennaArraySize)):
+        raise ValueError("waveform columns differ from the transmit array size")
+    nr = int(np.prod(channel.ReceiveAntennaArraySize))
+    rate = 2.0 * channel.SampleDensity * channel.MaximumDopplerShift
+    tt = channel.time + np.array([0, T - 1]) / channel.SampleRate
+    b0, b1 = (np.floor(tt * rate + 1e-9)).astype(np.int64)
+    blocks = np.arange(b0, b1 + 1)
+    # first output sample of each block: smallest t with floor((time + t/fs) rate + 1e-9) >= b
+    starts = np.maximum(0, np.ceil(((blocks - 1e-9) / rate - channel.time) * channel.SampleRate - 1e-6)).astype(np.int64)
+    starts[0] = 0
+    h = np.ascontiguousarray(np.stack([channel.path_gains(b / rate) for b in blocks]))        # [b, n, s, u]
+    g, shift = channel.filter_taps()
+    scale = 1.0 / math.sqrt(nr) if channel.NormalizeChannelOutputs else 1.0
+    d_x = waveform if dev else ctx.to_device(L.as_c128_f(waveform))
+    d_y = ctx.empty((T, nr))
+    ctx.check(ctx.lib.isac_cdl_apply_dev(ctx.handle, C.c_void_p(d_x.ptr), C.c_int64(T), C.c_int32(nt), C.c_int32(nr), C.c_int32(h.shape[1]),
+                                         h.ctypes.data_as(C.c_void_p), C.c_int32(len(blocks)), starts.ctypes.data_as(C.c_void_p),
+                                         g.ctypes.data_as(C.c_void_p), C.c_int32(FILTER_TAPS), shift.ctypes.data_as(C.c_void_p),
+                                         C.c_double(scale), C.c_void_p(d_y.ptr)))
+    channel.time += T / channel.SampleRate
+    return d_y if dev else d_y.numpy()

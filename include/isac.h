@@ -246,6 +246,19 @@ int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_params* ep, c
  * cyclic Jacobi on the device. */
 int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w, isac_c64* V);
 
+/* ------------------------------------------------------------------ CDL MIMO channel apply
+ * The seam is the toolbox object call  rxWaveform = obj.ChannelModel(rxWaveform)  (uePhy.m:729-731,
+ * gNBPhy.m:838-840; nrCDLChannel configured in +parameters/+channelModels/+communication/cdl.m:57-64).
+ * TR 38.901 7.7.1 with sample-and-hold path gains:
+ *   y[t,u] = out_scale * sum_n sum_k taps[n][k] * sum_s H_b(t)[n][s][u] * x[t - shift[n] - k, s]
+ * x [T x Nt], y [T x Nr] column-major device arrays; H [n_blocks][n_paths][Nt][Nr] (host, u fastest),
+ * block_start[b] = first OUTPUT sample that uses gain block b (block_start[0] = 0); taps [n_paths x n_taps].
+ * The antenna contraction runs as one complex GEMM on fp64 MFMA, the delay filter on the reduced signals.
+ * Path gains, delays and filter taps are host-side scalar prep (Python mirror: communication.channelModels). */
+int isac_cdl_apply_dev(isac_ctx* ctx, const isac_c64* d_x, int64_t T, int32_t Nt, int32_t Nr, int32_t n_paths,
+                       const isac_c64* H, int32_t n_blocks, const int64_t* block_start,
+                       const double* taps, int32_t n_taps, const int32_t* shift, double out_scale, isac_c64* d_y);
+
 /* ------------------------------------------------------------------ synthetic inputs (bench/tests) */
 /* QPSK txGrid [K x L x A] (unit modulus, zero planes for 'S' slots: every 4th grid slot when
  * zero_s_slots != 0) generated on the device from a Philox stream. */

@@ -306,3 +306,28 @@ def test_chain_against_golden_fixture(pkg, ctx):
     assert np.array_equal(est.rngEst, g["rngEst"]) and np.array_equal(est.velEst, g["velEst"])
     assert np.array_equal(est.aziEst, g["aziEst"])
     assert np.array_equal(np.concatenate(dbg.detections, axis=1), g["det_idx"])
+
+
+# ------------------------------------------------------------------ CDL MIMO channel apply
+@pytest.mark.parametrize("profile,tx_size,t_len,t0", [
+    ("CDL-D", (1, 4, 2, 1, 1), 7680 + 65, 0.0),
+    ("CDL-A", (1, 8, 2, 1, 1), 3000, 0.0),
+    ("CDL-A", (1, 3, 2, 1, 1), 4097, 1.0 / 640 - 1000 / 15.36e6),       # crosses a path-gain refresh inside the block
+    ("CDL-D", (1, 32, 2, 1, 1), 7680 + 65, 0.25),                        # 64 transmit elements (the benchmark array)
+])
+def test_cdl_apply_matches_oracle(pkg, ctx, profile, tx_size, t_len, t0):
+    import oracle.cdl as OC
+    fs = 15.36e6
+    cfg = OC.cdl_config(profile, 3.5e9, tx_size, (1, 1, 2, 1, 1), fs)
+    ch = pkg.communication.channelModels.CDLChannel(profile, 300e-9, 3.5e9, tx_size, (1, 1, 2, 1, 1), fs)
+    ch.time = t0
+    nt = int(np.prod(tx_size))
+    rng = np.random.default_rng(nt)
+    x = np.asfortranarray(rng.standard_normal((t_len, nt)) + 1j * rng.standard_normal((t_len, nt)))
+    want = OC.apply_cdl(cfg, x, t0)
+    got = pkg.communication.channelModels.applyCDL(ch, x)
+    assert got.shape == (t_len, 2) and rel(got, want) < RTOL
+    assert ch.time == pytest.approx(t0 + t_len / fs)
+    # device-resident call continues from the advanced channel time
+    got2 = pkg.communication.channelModels.applyCDL(ch, ctx.to_device(x)).numpy()
+    assert rel(got2, OC.apply_cdl(cfg, x, t0 + t_len / fs)) < RTOL
