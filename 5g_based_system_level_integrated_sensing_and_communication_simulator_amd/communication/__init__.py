@@ -1,2 +1,2 @@
 """Mirror of the reference's ``+communication`` package (hot-path seams only)."""
-from . import channelModels  # noqa: F401
+from . import channelModels, phyLayer  # noqa: F401

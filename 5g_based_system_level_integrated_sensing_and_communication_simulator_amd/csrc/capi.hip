@@ -658,6 +658,98 @@ extern "C" int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_pa
   return ISAC_OK;
 }
 
+// ------------------------------------------------------------------ music2D (music2D.m:1-123)
+int isac_music2d_plane(isac_ctx* ctx, const c64* d_rx, const c64* d_tx, long long n, c64* d_h);
+int isac_music2d_signal_vectors(isac_ctx* ctx, const c64* d_h, int K, int Ls, const int* d_top, int Lsig, c64* d_U);
+int isac_music2d_scan(isac_ctx* ctx, const c64* d_U, int N, int ldU, const int* d_cols, int Lsig, int conj_u, double coef, double den,
+                      double x0, double dx, int n_steps, double* d_p);
+
+extern "C" int isac_music2d_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_music2d_params* mp, const isac_c64* d_rx_grid,
+                                const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A, isac_est_result* out) {
+  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  if (!ep || !mp || !d_rx_grid || !d_tx_grid || !out || K <= 0 || L <= 0 || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  std::memset(out, 0, sizeof(*out));
+  const double c0 = 299792458.0;                                        // physconst('LightSpeed')  music2D.m:35
+  const double lambda = c0 / mp->fc;                                    // :37
+  const double r_gran = 0.5, v_gran = 0.5;                              // :43-44
+  const int r_steps = (int)std::floor((mp->r_max + 1.0) / r_gran);      // :45
+  const int v_steps = (int)std::floor((mp->v_max + 1.0) / v_gran);      // :46
+  // ---- DoA: Ra -> eig -> determineNumTargets -> ULA scan                                   :57-63
+  ISAC_TRY(ensure(ctx, ctx->cov, sizeof(c64) * (size_t)std::max(A * A, L * L)));
+  ISAC_TRY(isac_covariance_on(ctx, ctx->stream, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));
+  ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, nullptr));
+  std::vector<double> wa((size_t)A);
+  ISAC_HIP(hipMemcpyAsync(wa.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  std::sort(wa.begin(), wa.end());
+  const int Lsig = determine_num_targets(wa);                           // music.m:22 on ascending eigenvalues
+  out->num_dets = Lsig;
+  if (ep->array_is_upa) return fail(ctx, ISAC_ERR_UNSUPPORTED, "UPA DoA: music.m:69 calls tools.find2DPeaks, which the reference does not define");
+  int n_steps = 0;
+  const double* d_sind = nullptr;
+  ISAC_TRY(get_sind_table(ctx, ep, &d_sind, &n_steps));
+  ISAC_TRY(ensure(ctx, ctx->spec, sizeof(double) * (size_t)std::max(n_steps, std::max(r_steps, v_steps))));
+  ISAC_TRY(isac_music_scan_dev(ctx, A, nullptr, Lsig, d_sind, n_steps, 0.5, (double*)ctx->spec.p, nullptr));
+  std::vector<double> spec((size_t)n_steps);
+  ISAC_HIP(hipMemcpyAsync(spec.data(), ctx->spec.p, sizeof(double) * (size_t)n_steps, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  auto to_db = [](std::vector<double>& v) {
+    double mx = 0.0;
+    for (double x : v) mx = std::max(mx, std::fabs(x));
+    for (double& x : v) x = 20.0 * std::log10(std::fabs(x) / mx);
+  };
+  to_db(spec);
+  if (Lsig <= 0) return fail(ctx, ISAC_ERR_NO_DETECTION, "findpeaks 'NPeaks' must be a positive integer");
+  {
+    const std::vector<int> locs = findpeaks_desc(spec, Lsig);
+    out->n_azi = (int)std::min<size_t>(locs.size(), ISAC_MAX_EST);
+    for (int i = 0; i < out->n_azi; ++i) {
+      out->azi_est[i] = locs[(size_t)i] * ep->azimuth_scan_granularity - ep->azimuth_scan_scale / 2.0;
+      out->ele_est[i] = NAN;
+    }
+  }
+  // ---- range / velocity: H = channelInfo(:,:,1); Gram matrix G/K = H^H H / K (= conj(Rv));  Rr's signal vectors u = H v / sqrt(K mu)
+  ISAC_TRY(ensure(ctx, ctx->stage_a, sizeof(c64) * (size_t)K * L));
+  c64* d_h = (c64*)ctx->stage_a.p;
+  ISAC_TRY(isac_music2d_plane(ctx, (const c64*)d_rx_grid, (const c64*)d_tx_grid, (long long)K * L, d_h));      // :67-68
+  ISAC_TRY(isac_covariance_on(ctx, ctx->stream, (const isac_c64*)d_h, (int64_t)K, L, (isac_c64*)ctx->cov.p));  // G/K        :71-72
+  ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, L, nullptr));                                            // :77-89
+  std::vector<double> wg((size_t)L);
+  ISAC_HIP(hipMemcpyAsync(wg.data(), ctx->eig_w.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<int> order((size_t)L);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return wg[(size_t)p] > wg[(size_t)q]; });    // sort(.,'descend')
+  const int Lu = std::min(Lsig, L);
+  std::vector<int> top(order.begin(), order.begin() + Lu);
+  ISAC_TRY(ensure(ctx, ctx->stage_b, sizeof(c64) * (size_t)K * Lu + sizeof(int) * (size_t)Lu + 64));
+  c64* d_U = (c64*)ctx->stage_b.p;
+  int* d_top = (int*)((char*)ctx->stage_b.p + sizeof(c64) * (size_t)K * Lu);
+  ISAC_HIP(hipMemcpyAsync(d_top, top.data(), sizeof(int) * (size_t)Lu, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_TRY(isac_music2d_signal_vectors(ctx, d_h, K, L, d_top, Lu, d_U));
+  // range scan  ar = exp(-2j*pi*scs*2*r*n/c)                                                :92,:98-102
+  const double coef_r = ((-2.0 * M_PI) * mp->scs_hz) * 2.0;
+  ISAC_TRY(isac_music2d_scan(ctx, d_U, K, K, nullptr, Lu, 0, coef_r, c0, 0.0, r_gran, r_steps, (double*)ctx->spec.p));
+  std::vector<double> pr((size_t)r_steps), pv((size_t)v_steps);
+  ISAC_HIP(hipMemcpyAsync(pr.data(), ctx->spec.p, sizeof(double) * (size_t)r_steps, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  // velocity scan  av = exp(2j*pi*T*2*v*m/lambda), Uvs = conj(V(:,top))                       :93,:104-108
+  const double coef_v = ((2.0 * M_PI) * mp->t_sri) * 2.0;
+  ISAC_TRY(isac_music2d_scan(ctx, (const c64*)ctx->eig_v.p, L, L, d_top, Lu, 1, coef_v, lambda, -mp->v_max / 2.0, v_gran, v_steps,
+                             (double*)ctx->spec.p));
+  ISAC_HIP(hipMemcpyAsync(pv.data(), ctx->spec.p, sizeof(double) * (size_t)v_steps, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  to_db(pr);                                                            // :111-117
+  to_db(pv);
+  const std::vector<int> rl = findpeaks_desc(pr, Lsig), vl = findpeaks_desc(pv, Lsig);                          // :120-121
+  out->n_rng = (int)std::min<size_t>(rl.size(), ISAC_MAX_EST);
+  out->n_vel = (int)std::min<size_t>(vl.size(), ISAC_MAX_EST);
+  for (int i = 0; i < out->n_rng; ++i) out->rng_est[i] = rl[(size_t)i] * r_gran;                               // :122
+  for (int i = 0; i < out->n_vel; ++i) out->vel_est[i] = vl[(size_t)i] * v_gran - mp->v_max / 2.0;             // :123
+  ctx->last.spectrum_db = pr;
+  return ISAC_OK;
+}
+
 // ------------------------------------------------------------------ host-pointer wrappers of the echo path
 extern "C" int isac_basic_radar_channel(isac_ctx* ctx, const isac_c64* tx_wave, int64_t T,
                                         const isac_radar_channel_params* rp, const uint8_t* los, int noise_mode,

@@ -418,6 +418,64 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const double* __restric
   }
 }
 
+// ---------------------------------------------------------------- music2D (music2D.m:67-108) building blocks
+// H = rx(:,:,1) .* conj(tx(:,:,1))   [K x Ls]                                               music2D.m:67-68
+__global__ __launch_bounds__(256) void chan_plane_kernel(const c64* __restrict__ rx, const c64* __restrict__ tx, long long n,
+                                                         c64* __restrict__ h) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) h[i] = mul_conj(rx[i], tx[i]);
+}
+
+// Signal-subspace vectors of Rr = H H^H / Ls obtained from the small Gram problem (G/K) v = mu v:
+//   u_i = H v_i / sqrt(K mu_i)        (unit norm; the K - Ls dimensional null space never has to be formed)
+__global__ __launch_bounds__(256) void signal_vectors_kernel(const c64* __restrict__ Hc /* [K x Ls] */, int K, int Ls,
+                                                             const double* __restrict__ w, const c64* __restrict__ V /* [Ls x Ls] */,
+                                                             const int* __restrict__ top /* [Lsig] eigen indices */, int Lsig,
+                                                             c64* __restrict__ U /* [K x Lsig] */) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (n >= K || i >= Lsig) return;
+  const int e = top[i];
+  const c64* v = V + (long long)Ls * e;
+  c64 acc = mk(0.0, 0.0);
+  for (int m = 0; m < Ls; ++m) acc = fma(Hc[n + (long long)K * m], v[m], acc);
+  const double nrm = sqrt((double)K * w[e]);
+  U[n + (long long)K * i] = mk(acc.re / nrm, acc.im / nrm);
+}
+
+// P(x) = 1 / (N - sum_i |u_i^H a(x)|^2),  a(x)[n] = exp(j * ((coef * x) * n) / den)   (music2D.m:92-93,98-108)
+// conj_u = 0: y_i = sum_n conj(U[n,i]) a[n] (range, U = Urs);  conj_u = 1: y_i = sum_n U[n,i] a[n] (velocity, Uvs = conj(V))
+__global__ __launch_bounds__(256) void music2d_scan_kernel(const c64* __restrict__ U, int N, int ldU, const int* __restrict__ cols,
+                                                           int Lsig, int conj_u, double coef, double den, double x0, double dx,
+                                                           double* __restrict__ p_out) {
+  __shared__ double s_red[4];
+  const double x = x0 + dx * (double)blockIdx.x;
+  const double a = coef * x;
+  double tot = 0.0;
+  for (int i = 0; i < Lsig; ++i) {
+    const c64* u = U + (long long)ldU * (cols ? cols[i] : i);
+    c64 y = mk(0.0, 0.0);
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+      double s, c;
+      sincos((a * (double)n) / den, &s, &c);
+      const c64 un = conj_u ? u[n] : conj(u[n]);
+      y = fma(un, mk(c, s), y);
+    }
+    double yr = y.re, yi = y.im;
+    for (int o = 32; o > 0; o >>= 1) { yr += __shfl_down(yr, o); yi += __shfl_down(yi, o); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = yr;
+    __syncthreads();
+    yr = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = yi;
+    __syncthreads();
+    yi = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    tot += yr * yr + yi * yi;
+  }
+  if (threadIdx.x == 0) p_out[blockIdx.x] = 1.0 / ((double)N - tot);
+}
+
 }  // namespace isac
 
 // ================================================================= host side
@@ -505,6 +563,26 @@ int isac_music_scan_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num_det
   hipLaunchKernelGGL(music_scan_kernel, dim3(n_steps), dim3(256), sizeof(c64) * (size_t)A, st,
                      (const double*)ctx->eig_w.p, (const c64*)ctx->eig_v.p, A, d_num_dets, num_dets_host, d_sind, d_ratio,
                      2.220446049250313e-16, d_spec);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+// ---- music2D stages (host side lives in capi.hip)
+int isac_music2d_plane(isac_ctx* ctx, const c64* d_rx, const c64* d_tx, long long n, c64* d_h) {
+  hipLaunchKernelGGL(chan_plane_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, d_rx, d_tx, n, d_h);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+int isac_music2d_signal_vectors(isac_ctx* ctx, const c64* d_h, int K, int Ls, const int* d_top, int Lsig, c64* d_U) {
+  hipLaunchKernelGGL(signal_vectors_kernel, dim3(cdiv(K, 256), Lsig), dim3(256), 0, ctx->stream, d_h, K, Ls, (const double*)ctx->eig_w.p,
+                     (const c64*)ctx->eig_v.p, d_top, Lsig, d_U);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+int isac_music2d_scan(isac_ctx* ctx, const c64* d_U, int N, int ldU, const int* d_cols, int Lsig, int conj_u, double coef, double den,
+                      double x0, double dx, int n_steps, double* d_p) {
+  hipLaunchKernelGGL(music2d_scan_kernel, dim3(n_steps), dim3(256), 0, ctx->stream, d_U, N, ldU, d_cols, Lsig, conj_u, coef, den, x0, dx,
+                     d_p);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }

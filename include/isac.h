@@ -241,6 +241,22 @@ int isac_covariance_dev(isac_ctx* ctx, const isac_c64* d_grid, int64_t N, int32_
 int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_params* ep, const isac_c64* Ra,
                    int32_t A, int32_t* L_out, double* azi_est, double* ele_est, int32_t cap, int32_t* n_est);
 
+/* sensing.estimation.music2D(rdrEstParams, bsParams, rxGrid, txGrid) (+sensing/+estimation/music2D.m:1-123):
+ * MUSIC DoA with the model order from determineNumTargets, then MUSIC range and velocity spectra from
+ * H = rxGrid(:,:,1).*conj(txGrid(:,:,1)).  The K x K eigenproblem of Rr = H H'/nSym (music2D.m:71,77) is solved
+ * through the nSym x nSym Gram matrix H'H (same non-zero spectrum; the signal vectors are H v / sqrt(K mu)), so a
+ * 3276^2 eig never has to be formed.  out: aziEst/eleEst, rngEst, velEst, num_dets = L. */
+typedef struct {
+  double fc;       /* rdrEstParams.fc                                  */
+  double t_sri;    /* rdrEstParams.Tsri                                */
+  double scs_hz;   /* bsParams.scs * 1e3                   music2D.m:34 */
+  double r_max;    /* rdrEstParams.cfarEstZone(1,2)        music2D.m:41 */
+  double v_max;    /* rdrEstParams.cfarEstZone(2,2) * 2    music2D.m:42 */
+} isac_music2d_params;
+int isac_music2d_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_music2d_params* mp,
+                     const isac_c64* d_rx_grid, const isac_c64* d_tx_grid,
+                     int32_t K, int32_t L, int32_t A, isac_est_result* out);
+
 /* Hermitian eigendecomposition used by MUSIC (eig(Ra), music.m:19): ascending real
  * eigenvalues w [A], orthonormal eigenvectors V [A x A] column-major.  One-workgroup
  * cyclic Jacobi on the device. */
@@ -258,6 +274,15 @@ int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w, isac_c64* 
 int isac_cdl_apply_dev(isac_ctx* ctx, const isac_c64* d_x, int64_t T, int32_t Nt, int32_t Nr, int32_t n_paths,
                        const isac_c64* H, int32_t n_blocks, const int64_t* block_start,
                        const double* taps, int32_t n_taps, const int32_t* shift, double out_scale, isac_c64* d_y);
+
+/* ------------------------------------------------------------------ SINR -> CQI (config 5)
+ * precodedSINR(H, sigma, W) (+communication/+phyLayer/precodedSINR.m:11-17) for every resource element of a
+ * channel estimate, its mean, and getCQI (+communication/+phyLayer/cqiSelect.m:697-722) against a SINR table
+ * (+communication/setupSINRtoCQIMappingTable.m:7-11).  d_H [n_re x Nr x P] device (RE fastest), W [P x n_layers]
+ * host column-major.  d_sinr_per_re (device, optional) receives the per-RE values; *cqi = 0..n_table, -1 for NaN. */
+int isac_precoded_sinr_cqi_dev(isac_ctx* ctx, const isac_c64* d_H, int64_t n_re, int32_t Nr, int32_t P,
+                               const isac_c64* W, int32_t n_layers, double sigma, const double* sinr_table_db,
+                               int32_t n_table, double* d_sinr_per_re, double* mean_sinr, int32_t* cqi);
 
 /* ------------------------------------------------------------------ synthetic inputs (bench/tests) */
 /* QPSK txGrid [K x L x A] (unit modulus, zero planes for 'S' slots: every 4th grid slot when

@@ -331,3 +331,38 @@ def test_cdl_apply_matches_oracle(pkg, ctx, profile, tx_size, t_len, t0):
     # device-resident call continues from the advanced channel time
     got2 = pkg.communication.channelModels.applyCDL(ch, ctx.to_device(x)).numpy()
     assert rel(got2, OC.apply_cdl(cfg, x, t0 + t_len / fs)) < RTOL
+
+
+# ------------------------------------------------------------------ SINR -> CQI
+@pytest.mark.parametrize("nr,p,nl", [(2, 4, 1), (2, 4, 2), (4, 8, 4), (8, 32, 8)])
+def test_precoded_sinr_and_cqi(pkg, ctx, nr, p, nl):
+    import oracle.cqi as OQ
+    rng = np.random.default_rng(nr * 100 + p + nl)
+    n_re = 52 * 12
+    h = np.asfortranarray((rng.standard_normal((n_re, nr, p)) + 1j * rng.standard_normal((n_re, nr, p))) * 3.0)
+    w, _ = np.linalg.qr(rng.standard_normal((p, nl)) + 1j * rng.standard_normal((p, nl)))
+    w = w / np.sqrt(nl)
+    sigma = 0.7
+    want = OQ.precoded_sinr_batch(h, sigma, w)
+    got = pkg.communication.phyLayer.precodedSINR(h, sigma, w)
+    assert got.shape == (n_re,) and np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+    assert pkg.communication.phyLayer.precodedSINR(h[0], sigma, w) == pytest.approx(OQ.precoded_sinr(h[0], sigma, w), rel=1e-10)
+    for table in (OQ.DOWNLINK_SINR90PC, OQ.UPLINK_SINR90PC):
+        cqi, mean = pkg.communication.phyLayer.cqiFromChannel(h, sigma, w, table)
+        assert mean == pytest.approx(want.mean(), rel=1e-12) and cqi == OQ.get_cqi(want.mean(), table)
+    assert pkg.communication.phyLayer.getCQI(1e-3, OQ.DOWNLINK_SINR90PC) == 0 == OQ.get_cqi(1e-3, OQ.DOWNLINK_SINR90PC)
+    assert pkg.communication.phyLayer.getCQI(10 ** 3.6, OQ.DOWNLINK_SINR90PC) == 15
+
+
+# ------------------------------------------------------------------ music2D
+@pytest.mark.parametrize("n_ants,targets,vel", [(8, ((150.0, 40.0, 1.5),), (0.0,)), (16, ((120.0, 60.0, 1.5), (-250.0, 80.0, 1.5)), (10.0, -6.0))])
+def test_music2d_matches_oracle(pkg, ctx, n_ants, targets, vel):
+    from types import SimpleNamespace
+    sc = make_scene(n_ants=n_ants, n_slots=2, nrb=24, targets=targets, velocity=vel, num_slots_param=3, zero_s_slots=False, seed=4)
+    rx = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, sc.noise, nfft=sc.wave.Nfft)
+    want, dbg = O.music2d(sc.rp, 30, rx, sc.tx_grid, return_debug=True)
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    got = pkg.sensing.estimation.music2D(rp, SimpleNamespace(scs=30), rx, sc.tx_grid)
+    assert got.L == dbg.L
+    assert np.array_equal(got.aziEst, want.aziEst)
+    assert np.array_equal(got.rngEst, want.rngEst) and np.array_equal(got.velEst, want.velEst)
