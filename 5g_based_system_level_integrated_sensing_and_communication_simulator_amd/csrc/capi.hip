@@ -328,16 +328,20 @@ __global__ void pack_kernel(const int* __restrict__ det_cnt, const int* __restri
   __syncthreads();
   for (int a = tid; a <= A; a += blockDim.x) hdr[3 + a] = s_off[a];
   for (int i = tid; i < n_steps; i += blockDim.x) spec_out[i] = spec[i];
-  for (int a = 0; a < A; ++a) {
-    const int n = s_off[a + 1] - s_off[a];
-    for (int i = tid; i < n; i += blockDim.x) {
-      const int o = s_off[a] + i;
-      const int c = det_cut[(long long)a * cap + i];
-      const double p = det_pow[(long long)a * cap + i];
-      full_cut[o] = c;
-      full_pow[o] = p;
-      if (o < pack_first) { first_cut[o] = c; first_pow[o] = p; }
+  // flat copy: every thread finds its antenna by binary search, so all loads are issued at once
+  const int total = s_off[A];
+  for (int o = tid; o < total; o += blockDim.x) {
+    int lo = 0, hi = A;                       // largest a with s_off[a] <= o
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_off[mid] <= o) lo = mid; else hi = mid;
     }
+    const int i = o - s_off[lo];
+    const int c = det_cut[(long long)lo * cap + i];
+    const double p = det_pow[(long long)lo * cap + i];
+    full_cut[o] = c;
+    full_pow[o] = p;
+    if (o < pack_first) { first_cut[o] = c; first_pow[o] = p; }
   }
 }
 

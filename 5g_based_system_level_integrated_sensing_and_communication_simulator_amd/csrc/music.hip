@@ -283,15 +283,18 @@ __device__ __forceinline__ void rr_pair(int round, int k, int n /* even */, int&
 //      threads rotate two (row, pair) column pairs of V.
 // A <= 64: H and V live in LDS (gscratch == nullptr).  Larger arrays (config 4: 256-element ULA) keep H and V
 // in a global scratch that stays L2-resident (2 MB at A = 256); same algorithm, still one workgroup.
+template <bool BIG>   // compile-time so that H/V accesses are plain ds_* (LDS) or global_* instructions, never flat
 __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict__ Hin, int A, int max_sweeps,
                                                            double* __restrict__ w_out, c64* __restrict__ V_out,
                                                            int* __restrict__ info /* [0]=sweeps used */, c64* gscratch) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int n = (A + 1) & ~1;                      // pad to even with an isolated zero row/col
   const int h = n / 2;
-  c64* H = gscratch ? gscratch : reinterpret_cast<c64*>(smem_raw);       // [n x n] column-major
+  c64* lds0 = reinterpret_cast<c64*>(smem_raw);
+  c64* H;                                          // [n x n] column-major
+  c64* rg;                                         // [h] g_k
+  if constexpr (BIG) { H = gscratch; rg = lds0; } else { H = lds0; rg = lds0 + 2 * n * n; }
   c64* V = H + n * n;                              // [n x n]
-  c64* rg = gscratch ? reinterpret_cast<c64*>(smem_raw) : V + n * n;     // [h] g_k
   double* rc = reinterpret_cast<double*>(rg + h);  // [h] c_k
   int* rp = reinterpret_cast<int*>(rc + h);        // [h] p_k
   int* rq = rp + h;                                // [h] q_k
@@ -548,10 +551,12 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
   ISAC_TRY(ensure(ctx, ctx->eig_w, sizeof(double) * (size_t)A + 64));
   ISAC_TRY(ensure(ctx, ctx->eig_v, sizeof(c64) * (size_t)A * A));
   size_t lds = sizeof(c64) * ((big ? 0 : (size_t)2 * n * n) + n / 2) + sizeof(double) * (n / 2) + sizeof(int) * (n + 1) + 64;
-  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+  if (!big) { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
   int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
-  hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(1024), lds, st, d_H, A, 40, (double*)ctx->eig_w.p,
-                     (c64*)ctx->eig_v.p, info, gs);
+  if (big)
+    hipLaunchKernelGGL(jacobi_eigh_kernel<true>, dim3(1), dim3(1024), lds, st, d_H, A, 40, (double*)ctx->eig_w.p, (c64*)ctx->eig_v.p, info, gs);
+  else
+    hipLaunchKernelGGL(jacobi_eigh_kernel<false>, dim3(1), dim3(1024), lds, st, d_H, A, 40, (double*)ctx->eig_w.p, (c64*)ctx->eig_v.p, info, gs);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }

@@ -104,6 +104,75 @@ __global__ __launch_bounds__(512) void doppler_pow_kernel(const c64* __restrict_
   }
 }
 
+// ---------------------------------------------------------------- Doppler, nFFT = 256: two radix-16 passes per row
+// Same staging as doppler_pow_kernel, but each row's zero-padded slow-time sequence goes through a 256-point
+// FFT held by 16 threads (16 points each) instead of a 224-term direct sum per needed bin: ~10x fewer LDS
+// operations.  16 rows x 16 threads = 256 threads per workgroup; the exchange image overlays the staging slab.
+__global__ __launch_bounds__(256, 2) void doppler_fft256_kernel(const c64* __restrict__ ymid, int n_rows, int L, int A,
+                                                                const c64* __restrict__ tw_d /* e^{-2 pi j m / 256} */,
+                                                                double sqrt_nfft, int col_lo, int n_cols,
+                                                                double* __restrict__ pwin) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int NF = 256, RT = kDopRows;
+  c64* s_tw = reinterpret_cast<c64*>(smem_raw);                 // [256]
+  c64* s_y = s_tw + NF;                                         // staging [Lu][RT+1]   /   exchange [RT][16][17]
+  const int Lu = L < NF ? L : NF;
+  const int a = blockIdx.y;
+  const int r0 = blockIdx.x * RT;
+  const int tid = threadIdx.x;
+  s_tw[tid] = tw_d[tid];
+  const int half = L / 2;
+  for (int i0 = tid; i0 < Lu * RT; i0 += 4 * blockDim.x) {     // 4 independent loads in flight per thread
+    c64 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * blockDim.x;
+      const int ii = i < Lu * RT ? i : 0;
+      const int rr = ii % RT, li = ii / RT;
+      int lsrc = li + half;
+      if (lsrc >= L) lsrc -= L;
+      const int row = min(r0 + rr, n_rows - 1);
+      v[u] = ymid[(long long)row + (long long)n_rows * ((long long)lsrc + (long long)L * a)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * blockDim.x;
+      if (i < Lu * RT) s_y[(i / RT) * (RT + 1) + (i % RT)] = v[u];
+    }
+  }
+  __syncthreads();
+  const int rr = tid >> 4, j = tid & 15;
+  c64 x[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = j + 16 * q;
+    x[q] = i < Lu ? s_y[i * (RT + 1) + rr] : mk(0.0, 0.0);      // zero-pad L -> 256
+  }
+  dft16<-1>(x);
+  __syncthreads();                                              // staging fully consumed: overlay the exchange image
+  c64* s_z = s_y + rr * (16 * 17);
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) s_z[k1 * 17 + j] = k1 ? x[k1] * s_tw[j * k1] : x[0];
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 16; ++d) x[d] = s_z[j * 17 + d];          // thread (rr, k1 = j)
+  dft16<-1>(x);                                                  // x[k2] = X[k1 + 16 k2]
+  const int row = r0 + rr;
+  if (row < n_rows) {
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+      const int kbin = j + 16 * k2;
+      const int c = (kbin + NF / 2) & (NF - 1);                  // fftshift: column c <-> bin (c + 128) mod 256
+      const int cc = c - col_lo;
+      if (cc >= 0 && cc < n_cols) {
+        const double re = x[k2].re / sqrt_nfft, im = x[k2].im / sqrt_nfft;
+        const double h = hypot(re, im);
+        pwin[(long long)row + (long long)n_rows * ((long long)cc + (long long)n_cols * a)] = h * h;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- 2D CA-CFAR on the power window
 // One workgroup per antenna.  The window (CUT rectangle +- guard+training) is staged in LDS in
 // column panels; each thread sums its CUT's training cells in the ORACLE-DEFINED order
@@ -127,23 +196,38 @@ __global__ __launch_bounds__(1024) void cfar_window_kernel(const double* __restr
                                                            unsigned* __restrict__ row_seen /* [n_cut_rows] flags */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* s_p = reinterpret_cast<double*>(smem_raw);            // [nr x (panel_cols + 2 hc)]
-  __shared__ int s_wave_cnt[32];   // [0..15] per-wave counts, [16] running base (one object: keeps the dynamic LDS base 16-B aligned)
-  int& s_base = s_wave_cnt[16];
+  int* s_cnt2 = reinterpret_cast<int*>(s_p + (size_t)g.nr * (panel_cols + 2 * g.hc));   // [32 x 16] per-(iteration, wave) counts
+  int& s_base = s_cnt2[32 * 16];                                // running base
+  unsigned char* s_rank = reinterpret_cast<unsigned char*>(s_cnt2 + 32 * 16 + 4);        // [n_cut of a panel] rank inside the wave
   const int a = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, n_waves = blockDim.x >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const double* p = pwin + (long long)g.nr * g.nc * a;
+  for (int q = tid; q < 32 * 16; q += blockDim.x) s_cnt2[q] = 0;
   if (tid == 0) s_base = 0;
   __syncthreads();
   for (int pc0 = 0; pc0 < g.n_cut_cols; pc0 += panel_cols) {
     const int pcs = min(panel_cols, g.n_cut_cols - pc0);
     const int wc = pcs + 2 * g.hc;                              // staged columns
-    for (int i = tid; i < g.nr * wc; i += blockDim.x) s_p[i] = p[(long long)pc0 * g.nr + i];   // contiguous run
+    {   // contiguous run; 8 independent loads in flight per thread (a plain loop waits for each round trip)
+      const double* src = p + (long long)pc0 * g.nr;
+      const int n_el = g.nr * wc;
+      for (int i0 = tid; i0 < n_el; i0 += 8 * blockDim.x) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * blockDim.x; v[u] = src[i < n_el ? i : n_el - 1]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * blockDim.x; if (i < n_el) s_p[i] = v[u]; }
+      }
+    }
     __syncthreads();
     const int n_cut = g.n_cut_rows * pcs;
-    for (int base = 0; base < n_cut; base += blockDim.x) {
-      const int i = base + tid;
+    const int n_iter = (n_cut + (int)blockDim.x - 1) / (int)blockDim.x;       // <= 32 (panel sizing bounds n_cut by the LDS budget)
+    // pass 1: every thread evaluates all of its CUTs (i = k * blockDim + tid) with no barrier in between;
+    // the per-(iteration, wave) detection counts go to LDS
+    unsigned det_bits = 0u;
+    for (int k = 0; k < n_iter; ++k) {
+      const int i = k * blockDim.x + tid;
       bool det = false;
-      double pv = 0.0;
       if (i < n_cut) {
         const int cr = i % g.n_cut_rows, cc = i / g.n_cut_rows;   // CUT order: rows fastest (cfar2D.m:23-24)
         const int r = cr + g.hr, c = cc + g.hc;                    // position inside the staged panel
@@ -158,32 +242,41 @@ __global__ __launch_bounds__(1024) void cfar_window_kernel(const double* __restr
         }
         const double noise = __ddiv_rn(acc, g.n_train);
         const double thr = __dmul_rn(g.alpha, noise);
-        pv = s_p[c * g.nr + r];
-        det = pv > thr;                                            // strict
+        det = s_p[c * g.nr + r] > thr;                             // strict
       }
-      // ordered compaction: lane order == CUT order inside a wave, waves in order
       const unsigned long long mask = __ballot(det);
-      if (lane == 0) s_wave_cnt[wid] = __popcll(mask);
-      __syncthreads();
-      int off = s_base;
-      for (int w = 0; w < wid; ++w) off += s_wave_cnt[w];
-      if (det) {
-        int pos = off + __popcll(mask & ((1ull << lane) - 1ull));
+      if (det) det_bits |= 1u << k;
+      if (lane == 0) s_cnt2[k * 16 + wid] = __popcll(mask);
+      // lane-local rank inside the wave for this iteration, kept in a packed byte array
+      const unsigned rank = (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+      if (det) s_rank[i] = (unsigned char)rank;
+    }
+    __syncthreads();
+    // pass 2: ordered positions = base + (detections in earlier iterations / earlier waves) + rank in wave
+    if (det_bits) {
+      for (int k = 0; k < n_iter; ++k) {
+        if (!(det_bits & (1u << k))) continue;
+        int off = s_base;
+        for (int q = 0; q < k * 16 + wid; ++q) off += s_cnt2[q];      // (iteration, wave) pairs in CUT order; waves beyond n_waves hold 0
+        const int i = k * blockDim.x + tid;
+        const int pos = off + s_rank[i];
         if (pos < g.cap) {
-          const int cr = i % g.n_cut_rows, cc = i / g.n_cut_rows + pc0;
-          det_cut[(long long)a * g.cap + pos] = cr + g.n_cut_rows * cc;
-          det_pow[(long long)a * g.cap + pos] = pv;
+          const int cr = i % g.n_cut_rows, cc = i / g.n_cut_rows;
+          det_cut[(long long)a * g.cap + pos] = cr + g.n_cut_rows * (cc + pc0);
+          det_pow[(long long)a * g.cap + pos] = s_p[(cc + g.hc) * g.nr + cr + g.hr];
           row_seen[cr] = 1u;
         }
       }
-      __syncthreads();
-      if (tid == 0) {
-        int tot = 0;
-        for (int w = 0; w < n_waves; ++w) tot += s_wave_cnt[w];
-        s_base += tot;
-      }
-      __syncthreads();
     }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int q = 0; q < n_iter * 16; ++q) tot += s_cnt2[q];
+      s_base += tot;
+    }
+    __syncthreads();
+    for (int q = tid; q < 32 * 16; q += blockDim.x) s_cnt2[q] = 0;     // next panel starts from clean counters
+    __syncthreads();
   }
   if (tid == 0) det_cnt[a] = s_base;   // may exceed cap: host reports ISAC_ERR_CAPACITY
 }
@@ -295,11 +388,19 @@ int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_c
                                                             (c64*)ctx->ymid.p))));
   }
   const int Lu = L < n_fft ? L : n_fft;
-  size_t lds = sizeof(c64) * ((size_t)n_fft + (size_t)Lu * (kDopRows + 1));
-  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(doppler_pow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
-  hipLaunchKernelGGL(doppler_pow_kernel, dim3(cdiv(nr, kDopRows), A), dim3(512), lds, ctx->stream, (const c64*)ctx->ymid.p, nr,
-                     L, A, n_fft, twd, std::sqrt((double)n_fft), col_lo, nc, (double*)ctx->pwin.p, (c64*)nullptr);
-  ISAC_HIP(hipGetLastError());
+  if (n_fft == 256 && !std::getenv("ISAC_DOPPLER_DIRECT")) {
+    size_t lds = sizeof(c64) * (256 + std::max((size_t)Lu * (kDopRows + 1), (size_t)kDopRows * 16 * 17));
+    { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(doppler_fft256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+    hipLaunchKernelGGL(doppler_fft256_kernel, dim3(cdiv(nr, kDopRows), A), dim3(256), lds, ctx->stream, (const c64*)ctx->ymid.p, nr, L,
+                       A, twd, std::sqrt((double)n_fft), col_lo, nc, (double*)ctx->pwin.p);
+    ISAC_HIP(hipGetLastError());
+  } else {
+    size_t lds = sizeof(c64) * ((size_t)n_fft + (size_t)Lu * (kDopRows + 1));
+    { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(doppler_pow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+    hipLaunchKernelGGL(doppler_pow_kernel, dim3(cdiv(nr, kDopRows), A), dim3(512), lds, ctx->stream, (const c64*)ctx->ymid.p, nr,
+                       L, A, n_fft, twd, std::sqrt((double)n_fft), col_lo, nc, (double*)ctx->pwin.p, (c64*)nullptr);
+    ISAC_HIP(hipGetLastError());
+  }
   *nr_out = nr;
   *nc_out = nc;
   return ISAC_OK;
@@ -323,7 +424,9 @@ int isac_cfar_window(isac_ctx* ctx, const isac_cfar_config* cf, int nr, int nc, 
   int panel = (int)(budget / (sizeof(double) * (size_t)nr)) - 2 * g.hc;
   if (panel < 1) return fail(ctx, ISAC_ERR_UNSUPPORTED, "CUT zone has too many rows for the LDS-staged detector");
   if (panel > g.n_cut_cols) panel = g.n_cut_cols;
-  size_t lds = sizeof(double) * (size_t)nr * (panel + 2 * g.hc);
+  if ((long long)g.n_cut_rows * panel > 32 * 1024) panel = (32 * 1024) / g.n_cut_rows;   // <= 32 iterations of 1024 threads
+  if (panel < 1) return fail(ctx, ISAC_ERR_UNSUPPORTED, "CUT zone has too many rows for the LDS-staged detector");
+  size_t lds = sizeof(double) * (size_t)nr * (panel + 2 * g.hc) + sizeof(int) * (32 * 16 + 4) + (size_t)g.n_cut_rows * panel + 16;
   ISAC_TRY(ensure(ctx, ctx->det_cut, sizeof(int) * (size_t)A * cap));
   ISAC_TRY(ensure(ctx, ctx->det_pow, sizeof(double) * (size_t)A * cap));
   ISAC_TRY(ensure(ctx, ctx->det_cnt, sizeof(int) * (size_t)A));
