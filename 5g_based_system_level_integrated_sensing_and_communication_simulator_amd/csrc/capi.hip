@@ -15,7 +15,7 @@ int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_c
 int isac_cfar_window(isac_ctx* ctx, const isac_cfar_config* cf, int nr, int nc, int A, int cap);
 int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st);
 int isac_music_scan_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num_dets_host, const double* d_sind, int n_steps,
-                        double d_ratio, double* d_spec, hipStream_t st);
+                        double d_ratio, double* d_spec, hipStream_t st, int mode = 0);
 int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra);
 
 namespace {
@@ -620,8 +620,8 @@ extern "C" int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w,
   return ISAC_OK;
 }
 
-extern "C" int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_params* ep, const isac_c64* Ra, int32_t A,
-                              int32_t* L_out, double* azi_est, double* ele_est, int32_t cap, int32_t* n_est) {
+static int doa_scan(isac_ctx* ctx, int mode, int32_t num_dets, const isac_est_params* ep, const isac_c64* Ra, int32_t A,
+                    int32_t* L_out, double* azi_est, double* ele_est, int32_t cap, int32_t* n_est) {
   if (!ctx) return ISAC_ERR_INVALID_ARG;
   if (!ep || !Ra || A <= 0 || !n_est) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   *n_est = 0;
@@ -642,7 +642,7 @@ extern "C" int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_pa
   const double* d_sind = nullptr;
   ISAC_TRY(get_sind_table(ctx, ep, &d_sind, &n_steps));
   ISAC_TRY(ensure(ctx, ctx->spec, sizeof(double) * (size_t)n_steps));
-  ISAC_TRY(isac_music_scan_dev(ctx, A, nullptr, L, d_sind, n_steps, 0.5, (double*)ctx->spec.p, nullptr));
+  ISAC_TRY(isac_music_scan_dev(ctx, A, nullptr, L, d_sind, n_steps, 0.5, (double*)ctx->spec.p, nullptr, mode));
   std::vector<double> spec((size_t)n_steps);
   ISAC_HIP(hipMemcpyAsync(spec.data(), ctx->spec.p, sizeof(double) * (size_t)n_steps, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
@@ -660,6 +660,17 @@ extern "C" int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_pa
     if (ele_est) ele_est[i] = NAN;
   }
   return ISAC_OK;
+}
+
+extern "C" int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_params* ep, const isac_c64* Ra, int32_t A,
+                              int32_t* L_out, double* azi_est, double* ele_est, int32_t cap, int32_t* n_est) {
+  return doa_scan(ctx, 0, num_dets, ep, Ra, A, L_out, azi_est, ele_est, cap, n_est);
+}
+extern "C" int isac_beamscan_doa(isac_ctx* ctx, int32_t method, int32_t num_dets, const isac_est_params* ep, const isac_c64* Ra,
+                                 int32_t A, double* azi_est, double* ele_est, int32_t cap, int32_t* n_est) {
+  if (method != 1 && method != 2) return fail(ctx, ISAC_ERR_INVALID_ARG, "method: 1 = digitalBF, 2 = mvdrBF");
+  if (num_dets < 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "digitalBF / mvdrBF need numDets (digitalBF.m:84, mvdrBF.m:84)");
+  return doa_scan(ctx, method, num_dets, ep, Ra, A, nullptr, azi_est, ele_est, cap, n_est);
 }
 
 // ------------------------------------------------------------------ music2D (music2D.m:1-123)

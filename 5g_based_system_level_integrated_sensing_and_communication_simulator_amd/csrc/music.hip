@@ -213,6 +213,25 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_small_kernel(const c64* __res
   }
 }
 
+// first reduction level: slice s of S sums a contiguous run of workgroup partials (fixed order) into part2[s];
+// spreads the 60 MB of partial tiles over S x n_tiles workgroups instead of n_tiles (per-CU bandwidth bound)
+__global__ __launch_bounds__(256) void cov_reduce_slice_kernel(const double* __restrict__ part, int n_wg, int n_tiles, int S,
+                                                               double* __restrict__ part2 /* [S][n_tiles][3][256] */) {
+  const int t = blockIdx.x, sl = blockIdx.y, e = threadIdx.x;
+  const int per = (n_wg + S - 1) / S;
+  const int w0 = sl * per, w1 = min(n_wg, w0 + per);
+  double sr = 0.0, sp = 0.0, sm = 0.0;
+#pragma unroll 8
+  for (int w = w0; w < w1; ++w) {
+    const double* o = part + (((long long)w * n_tiles + t) * 3) * 256;
+    sr += o[e];
+    sp += o[256 + e];
+    sm += o[512 + e];
+  }
+  double* d = part2 + (((long long)sl * n_tiles + t) * 3) * 256;
+  d[e] = sr; d[256 + e] = sp; d[512 + e] = sm;
+}
+
 // fixed-order reduction over workgroup partials + Hermitian fill + 1/N.
 __global__ __launch_bounds__(1024) void cov_reduce_kernel(const double* __restrict__ part, int n_wg, int n_tiles, int A,
                                                           double inv_n, c64* __restrict__ Ra /* [A x A] column-major */) {
@@ -380,10 +399,12 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
 
 // ---------------------------------------------------------------- MUSIC pseudo-spectrum (ULA), music.m:82-91
 // One workgroup per scan angle.  Noise subspace = eigenvectors whose descending rank >= L.
+// mode 0: MUSIC  1/(a' Uan Uan' a + eps);  mode 1: digital beamforming |a' Ra a| (digitalBF.m:72);
+// mode 2: MVDR 1/(a' Ra^-1 a + eps) (mvdrBF.m:72) -- all three are weighted sums of |v_i' a|^2 over the eigenpairs.
 __global__ __launch_bounds__(256) void music_scan_kernel(const double* __restrict__ w, const c64* __restrict__ V, int A,
                                                          const int* __restrict__ num_dets_dev, int num_dets_host,
                                                          const double* __restrict__ sind_tab, double d_ratio, double eps1,
-                                                         double* __restrict__ p_out) {
+                                                         double* __restrict__ p_out, int mode) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* s_a = reinterpret_cast<c64*>(smem_raw);     // steering vector [A]
   __shared__ double s_red[4];
@@ -402,14 +423,19 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const double* __restric
   double acc = 0.0;
   for (int v = tid; v < A; v += blockDim.x) {
     // descending rank of eigenvalue v (stable: ties keep index order)
-    int rank = 0;
     const double wv = w[v];
-    for (int j = 0; j < A; ++j) rank += (w[j] > wv || (w[j] == wv && j < v)) ? 1 : 0;
-    if (rank < Lsig) continue;                      // signal subspace
+    double weight = 1.0;
+    if (mode == 0) {
+      int rank = 0;
+      for (int j = 0; j < A; ++j) rank += (w[j] > wv || (w[j] == wv && j < v)) ? 1 : 0;
+      if (rank < Lsig) continue;                    // signal subspace
+    } else {
+      weight = (mode == 1) ? wv : 1.0 / wv;
+    }
     c64 y = mk(0.0, 0.0);
     const c64* col = V + (long long)A * v;
     for (int m = 0; m < A; ++m) y = fma(conj(col[m]), s_a[m], y);
-    acc += y.re * y.re + y.im * y.im;
+    acc += weight * (y.re * y.re + y.im * y.im);
   }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
@@ -417,7 +443,7 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const double* __restric
   if (tid == 0) {
     double t = 0.0;
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += s_red[i];
-    p_out[blockIdx.x] = fabs(1.0 / (t + eps1));    // music.m:90,94
+    p_out[blockIdx.x] = (mode == 1) ? fabs(t) : fabs(1.0 / (t + eps1));    // music.m:90,94 / digitalBF.m:72,76 / mvdrBF.m:72,76
   }
 }
 
@@ -498,10 +524,15 @@ static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long lo
   const long long per = (total + gx - 1) / gx;
   gx = (total + per - 1) / per;
   const int n_part = (int)gx * P::kPhases;
-  ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * (size_t)n_part * P::kTiles * 3 * 256));
+  ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * ((size_t)n_part + 32) * P::kTiles * 3 * 256));
   hipLaunchKernelGGL(cov_mfma_small_kernel<NB>, dim3((unsigned)gx), dim3(256), 0, st, G, N, A, per, (double*)ctx->cov_part.p);
   ISAC_HIP(hipGetLastError());
-  hipLaunchKernelGGL(cov_reduce_kernel, dim3(P::kTiles), dim3(256, 4), 0, st, (const double*)ctx->cov_part.p, n_part, P::kTiles, A,
+  const int S = 32;
+  double* part2 = (double*)ctx->cov_part.p + (size_t)n_part * P::kTiles * 3 * 256;
+  hipLaunchKernelGGL(cov_reduce_slice_kernel, dim3(P::kTiles, S), dim3(256), 0, st, (const double*)ctx->cov_part.p, n_part, P::kTiles, S,
+                     part2);
+  ISAC_HIP(hipGetLastError());
+  hipLaunchKernelGGL(cov_reduce_kernel, dim3(P::kTiles), dim3(256, 4), 0, st, (const double*)part2, S, P::kTiles, A,
                      1.0 / (double)N, Ra);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
@@ -563,11 +594,11 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
 
 // scan: uses ctx->eig_w / eig_v; L from device pointer (fused pipeline) or host value
 int isac_music_scan_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num_dets_host, const double* d_sind, int n_steps,
-                        double d_ratio, double* d_spec, hipStream_t st) {
+                        double d_ratio, double* d_spec, hipStream_t st, int mode) {
   if (!st) st = ctx->stream;
   hipLaunchKernelGGL(music_scan_kernel, dim3(n_steps), dim3(256), sizeof(c64) * (size_t)A, st,
                      (const double*)ctx->eig_w.p, (const c64*)ctx->eig_v.p, A, d_num_dets, num_dets_host, d_sind, d_ratio,
-                     2.220446049250313e-16, d_spec);
+                     2.220446049250313e-16, d_spec, mode);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }

@@ -67,7 +67,7 @@ class Cell:
     branch of CPI i (covariance -> eig -> scan, latency-bound on one CU) runs under the echo / range
     kernels of CPI i+1.  Results are collected in submission order."""
 
-    def __init__(self, pkg, device, cell_id, n_ants, n_slots, n_targets, inflight=1, fuse=True):
+    def __init__(self, pkg, device, cell_id, n_ants, n_slots, n_targets, inflight=1, fuse=False):
         L = pkg._lib
         self.fuse = fuse
         self.pkg, self.L = pkg, L

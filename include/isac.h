@@ -241,6 +241,11 @@ int isac_covariance_dev(isac_ctx* ctx, const isac_c64* d_grid, int64_t N, int32_
 int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_params* ep, const isac_c64* Ra,
                    int32_t A, int32_t* L_out, double* azi_est, double* ele_est, int32_t cap, int32_t* n_est);
 
+/* sensing.estimation.doaEstimation.digitalBF (method 1, digitalBF.m:55-86: |a' Ra a|) and .mvdrBF (method 2,
+ * mvdrBF.m:55-86: 1/(a' Ra^-1 a + eps)), ULA branch; same scan/findpeaks tail as music. */
+int isac_beamscan_doa(isac_ctx* ctx, int32_t method, int32_t num_dets, const isac_est_params* ep, const isac_c64* Ra,
+                      int32_t A, double* azi_est, double* ele_est, int32_t cap, int32_t* n_est);
+
 /* sensing.estimation.music2D(rdrEstParams, bsParams, rxGrid, txGrid) (+sensing/+estimation/music2D.m:1-123):
  * MUSIC DoA with the model order from determineNumTargets, then MUSIC range and velocity spectra from
  * H = rxGrid(:,:,1).*conj(txGrid(:,:,1)).  The K x K eigenproblem of Rr = H H'/nSym (music2D.m:71,77) is solved

@@ -366,3 +366,19 @@ def test_music2d_matches_oracle(pkg, ctx, n_ants, targets, vel):
     assert got.L == dbg.L
     assert np.array_equal(got.aziEst, want.aziEst)
     assert np.array_equal(got.rngEst, want.rngEst) and np.array_equal(got.velEst, want.velEst)
+
+
+def test_digital_and_mvdr_beamforming(pkg, ctx):
+    sc = make_scene(n_ants=16, n_slots=1, nrb=24, with_noise=False)
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    m = np.arange(16)
+    a1 = np.exp(-2j * np.pi * m * 0.5 * float(O.sind(15)))
+    a2 = np.exp(-2j * np.pi * m * 0.5 * float(O.sind(-40)))
+    ra = 4 * np.outer(a1, a1.conj()) + np.outer(a2, a2.conj()) + np.diag(np.random.default_rng(3).uniform(0.01, 0.03, 16))
+    for l in (1, 2, 4):
+        wa, _ = O.digital_bf(l, sc.rp, ra)
+        ga, ge = pkg.sensing.estimation.doaEstimation.digitalBF(l, rp, ra)
+        assert np.array_equal(ga, wa) and np.isnan(ge).all()
+        wa, _ = O.mvdr_bf(l, sc.rp, ra)
+        ga, _ = pkg.sensing.estimation.doaEstimation.mvdrBF(l, rp, ra)
+        assert np.array_equal(ga, wa)
