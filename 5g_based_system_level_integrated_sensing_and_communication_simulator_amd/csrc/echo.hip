@@ -202,7 +202,6 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
   const int tid = threadIdx.x;
   const int n_cols = L_whole * A;
   FFT fft;
-  fft.init(lds, tw, tid);
   {
     // one (symbol, antenna) column per workgroup, symbol fastest: consecutive workgroups write consecutive
     // 52 KB columns of one antenna plane.  (Antenna-fastest order would re-use a symbol's coef window in L2
@@ -224,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
       const c64* src = wave + w0 + T * (long long)r;
       fft.fill([&](int n) { return src[n]; }, tid);
     }
+    fft.init(lds, tw, tid);   // after the fill: the twiddle-table loads fly together with the column's loads
     fft.template transform<-1>(lds, tw, tid);
     c64* dst = grid + (long long)g.n_sc * ((long long)l + (long long)L_out * r);
     const int half = g.n_sc / 2;
@@ -257,7 +257,6 @@ __global__ __launch_bounds__(256, 2) void demod_range_kernel(OfdmGeom g, long lo
   c64* lds = reinterpret_cast<c64*>(smem_raw);
   const int tid = threadIdx.x;
   FFT fft;
-  fft.init(lds, tw, tid);
   const int col = blockIdx.x;
   const int l = col % L_whole, r = col / L_whole;  // symbol fastest (see demod_kernel)
   const int cp = cp_of_symbol(l, g.cp_base, g.cp_long, g.sym_per_half);
@@ -269,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void demod_range_kernel(OfdmGeom g, long lo
     fft.template fill<4>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, ISAC_NOISE_PHILOX, noise, n0s, seed); }, tid);
   else
     fft.template fill<8>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, noise_mode, noise, n0s, seed); }, tid);
+  fft.init(lds, tw, tid);
   fft.template transform<-1>(lds, tw, tid);
   const long long colg = (long long)l + (long long)L_out * r;
   c64* dst = grid + (long long)g.n_sc * colg;
@@ -318,7 +318,6 @@ __global__ __launch_bounds__(256, 2) void mod_kernel(OfdmGeom g, long long T, in
   const int tid = threadIdx.x;
   const int n_cols = L * A;
   FFT fft;
-  fft.init(lds, tw, tid);
   {
     const int col = blockIdx.x;                    // one (symbol, antenna) column per workgroup
     const int l = col % L, a = col / L;
@@ -335,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void mod_kernel(OfdmGeom g, long long T, in
           return ok ? v : mk(0.0, 0.0);
         },
         tid);
+    fft.init(lds, tw, tid);
     fft.template transform<+1>(lds, tw, tid);
     c64* dst = wave + s0 + T * (long long)a;
     fft.drain(

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, 2) void range_kernel(const c64* __restrict__ r
   const int tid = threadIdx.x;
   const int n_cols = L * A;
   FFT fft;
-  fft.init(lds, tw, tid);
+  fft.init(lds, tw, tid);   // (issuing the table loads after the column's loads measured 8 % slower here)
   {
     const int col = blockIdx.x;                    // one (symbol, antenna) column per workgroup
     const c64* prx = rx + (long long)K * col;
