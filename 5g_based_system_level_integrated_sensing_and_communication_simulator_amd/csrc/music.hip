@@ -136,9 +136,10 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
   constexpr int NT = (T0 + P::kPerGroup <= P::kTiles) ? P::kPerGroup : (P::kTiles - T0);
   constexpr int SPL = P::kSamplesPerLane;
   const int li = lane & 15, kq = lane >> 4;
-  v4f64 re[NT], imp[NT], imm[NT];
+  // Re += Gr_I Gr_J + Gi_I Gi_J ;  Im += Gr_I Gi_J + (-Gi_I) Gr_J   (one accumulator each: 16 VGPRs per tile)
+  v4f64 re[NT], im[NT];
 #pragma unroll
-  for (int u = 0; u < NT; ++u) re[u] = imp[u] = imm[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+  for (int u = 0; u < NT; ++u) re[u] = im[u] = v4f64{0.0, 0.0, 0.0, 0.0};
   // column pointers of this lane's antenna in each block (clamped: loads stay unconditional)
   const c64* colp[NB];
   bool colok[NB];
@@ -149,8 +150,11 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
     colp[b] = G + N * (long long)(colok[b] ? a : 0);
   }
   const long long lane_off = 4 * kq + SPL * phase;              // first sample of this lane inside a slab
-  c64 cur[NB][SPL], nxt[NB][SPL];
-  auto load = [&](c64 (&dst)[NB][SPL], long long slab) {
+  // No register double-buffering: the kernel stays under 160 VGPRs so that (a) three of its waves fit a SIMD and
+  // hide the load latency by themselves, and (b) one of its waves fits NEXT TO the two resident waves of the
+  // HBM-bound range_kernel (2 x 176 + 160 = 512 VGPRs), letting the MFMA work run under that kernel's memory time.
+  for (long long slab = s_begin; slab < s_end; ++slab) {
+    c64 cur[NB][SPL];
     const long long n0 = slab * 16 + lane_off;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -160,12 +164,8 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
         const bool ok = (n < N) && colok[b];
         if (n >= N) n = N - 1;
         c64 v = colp[b][n];
-        dst[b][e] = ok ? v : mk(0.0, 0.0);
+        cur[b][e] = ok ? v : mk(0.0, 0.0);
       }
-  };
-  if (s_begin < s_end) load(cur, s_begin);
-  for (long long slab = s_begin; slab < s_end; ++slab) {
-    if (slab + 1 < s_end) load(nxt, slab + 1);
     static_for<0, NT>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);   // row-major upper-triangular tile order
@@ -173,14 +173,10 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
       for (int e = 0; e < SPL; ++e) {
         re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].re, re[u], 0, 0, 0);
         re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].im, re[u], 0, 0, 0);
-        imp[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].im, imp[u], 0, 0, 0);
-        imm[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].re, imm[u], 0, 0, 0);
+        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].im, im[u], 0, 0, 0);
+        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cur[I][e].im, cur[J][e].re, im[u], 0, 0, 0);
       }
     });
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-#pragma unroll
-      for (int e = 0; e < SPL; ++e) cur[b][e] = nxt[b][e];
   }
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
@@ -188,14 +184,14 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       o[0 * 256 + r * 64 + lane] = re[u][r];
-      o[1 * 256 + r * 64 + lane] = imp[u][r];
-      o[2 * 256 + r * 64 + lane] = imm[u][r];
+      o[1 * 256 + r * 64 + lane] = im[u][r];
+      o[2 * 256 + r * 64 + lane] = 0.0;                        // (imm plane kept for the generic kernel's layout)
     }
   }
 }
 
 template <int NB>
-__global__ __launch_bounds__(256, 2) void cov_mfma_small_kernel(const c64* __restrict__ G, long long N, int A,
+__global__ __launch_bounds__(256, 3) void cov_mfma_small_kernel(const c64* __restrict__ G, long long N, int A,
                                                                 long long slabs_per_wg,
                                                                 double* __restrict__ part /* [gridX*kPhases][kTiles][3][256] */) {
   using P = CovPlan<NB>;
@@ -519,7 +515,7 @@ template <int NB>
 static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long long N, int A, c64* Ra) {
   using P = CovPlan<NB>;
   const long long total = (N + 15) / 16;
-  long long gx = 512;
+  long long gx = 768;                       // 3 workgroups per CU (register-limited occupancy of the kernel)
   if (gx > total) gx = total;
   const long long per = (total + gx - 1) / gx;
   gx = (total + per - 1) / per;

@@ -202,8 +202,8 @@ def cpu_baseline(n_ants, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--ants", type=int, default=64)
     ap.add_argument("--slots", type=int, default=16)
     ap.add_argument("--targets", type=int, default=1)
@@ -220,8 +220,14 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        n_dev = torch.cuda.device_count()
+        backend = os.environ.get("ISAC_DIST_BACKEND", "nccl")          # "gloo": test hook (several ranks on one GPU)
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(n_dev, 1)
+            dist.init_process_group(backend)
     pkg = importlib.import_module(PKG)
     cells = [Cell(pkg, local_rank, rank * args.cells_per_gpu + c, args.ants, args.slots, args.targets, args.inflight, args.fuse)
              for c in range(args.cells_per_gpu)]
@@ -256,7 +262,8 @@ def main():
     # per-cell result record gather -- the only collective (KB-scale, RCCL over xGMI); max over ranks of the timed region
     d = importlib.import_module(PKG + "._dist")
     recs = np.array([d.make_record(rank * args.cells_per_gpu + i, cell.last, dt) for i, cell in enumerate(cells)])
-    allr = d.gather_records(recs, dist, torch.device("cuda", local_rank) if dist is not None else None)
+    on_gpu = dist is not None and dist.get_backend() == "nccl"
+    allr = d.gather_records(recs, dist, torch.device("cuda", local_rank) if on_gpu else None)
     dt = float(np.nanmax(allr[:, 6])) if allr.size else dt
     n_cpi = args.steps * args.cells_per_gpu * world
     slots = n_cpi * args.slots

@@ -18,7 +18,31 @@ def summarise(path):
     return [(r[0], r[1], r[2] / 1e3, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, 100.0 * r[3] / tot) for r in rows]
 
 
+def summarise_pmc(path):
+    """Per-kernel average of every collected counter (rocprofv3 --pmc ...)."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    pm = [t for t in tabs if t.startswith("rocpd_pmc_event")][0]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    ip = [t for t in tabs if t.startswith("rocpd_info_pmc")][0]
+    q = (f"select s.kernel_name, i.name, count(*), avg(p.value), avg(d.end-d.start)/1e3 from {pm} p join {kd} d on p.event_id=d.event_id "
+         f"join {ks} s on d.kernel_id=s.id join {ip} i on p.pmc_id=i.id group by s.kernel_name, i.name order by 4 desc")
+    return list(cur.execute(q))
+
+
 if __name__ == "__main__":
+    if "--pmc" in sys.argv:
+        rows = summarise_pmc(sys.argv[1])
+        lines = ["kernel,counter,dispatches,avg_value,avg_duration_us"]
+        for r in rows:
+            lines.append(f"\"{r[0]}\",{r[1]},{r[2]},{r[3]:.1f},{r[4]:.2f}")
+        if "--csv" in sys.argv:
+            open(sys.argv[sys.argv.index("--csv") + 1], "w").write("\n".join(lines) + "\n")
+        for r in rows[:16]:
+            print(f"{r[0][:70]:70s} {r[1]:12s} n={r[2]:4d} avg={r[3]:14.1f} dur={r[4]:9.1f}us")
+        sys.exit(0)
     rows = summarise(sys.argv[1])
     lines = ["kernel,calls,avg_us,total_us,min_us,max_us,pct"]
     for r in rows:
