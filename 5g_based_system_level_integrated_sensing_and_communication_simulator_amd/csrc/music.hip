@@ -154,6 +154,9 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
   // hide the load latency by themselves, and (b) one of its waves fits NEXT TO the two resident waves of the
   // HBM-bound range_kernel (2 x 176 + 160 = 512 VGPRs), letting the MFMA work run under that kernel's memory time.
   for (long long slab = s_begin; slab < s_end; ++slab) {
+    // keep the four waves of the workgroup on the same 16-sample slab so that it is fetched from HBM once and
+    // shared through L1/L2 (without this the waves drift apart and rocprof FETCH_SIZE doubles)
+    __builtin_amdgcn_s_barrier();
     c64 cur[NB][SPL];
     const long long n0 = slab * 16 + lane_off;
 #pragma unroll

@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "5g_based_system_level_integrated_sensing_and_communication_simulator_amd"
 
+RANGE_KERNEL_HBM_BYTES_A64 = int((2 * 735380 + 84226) * 1024)   # 1.592e9 B vs 1.503e9 B algorithmic: no wasted re-reads
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
 
 
@@ -280,7 +281,11 @@ def main():
                        "parallelism": f"cells sharded over {world} GPU(s)"},
             "roofline": {"bound": "hbm", "kernel": "range_kernel<Fft4096> (fft2D range stage: rx.*conj(tx), Kaiser, 4096-pt IFFT)",
                          "achieved": round(rdm_b / 1e9 / (range_ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(rdm_b / 1e9 / (range_ms / 1e3) / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(rdm_b / 1e9 / (range_ms / 1e3) / HBM_PEAK_GBS, 4),
+                         # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_*.csv): 2 x FETCH_SIZE (gfx950 counts
+                         # wide coalesced reads at half, MI355X_MICROARCH.md) + WRITE_SIZE, KB -> B; measured at the A=64 shape only
+                         "traffic": RANGE_KERNEL_HBM_BYTES_A64 if (args.ants == 64 and args.slots == 16) else None,
+                         "traffic_source": "profiles/r01_pmc_fetch_size.csv + r01_pmc_write_size.csv (separate --pmc passes)",
                          "avg_launch_ms": round(range_ms, 4), "algorithmic_bytes_per_launch": rdm_b,
                          "whole_cpi": {"algorithmic_bytes": echo_b + rdm_b, "ms": round(per_cpi_ms, 4),
                                        "achieved_GBps": round((echo_b + rdm_b) / 1e9 / (per_cpi_ms / 1e3), 1),
