@@ -382,3 +382,61 @@ def test_digital_and_mvdr_beamforming(pkg, ctx):
         wa, _ = O.mvdr_bf(l, sc.rp, ra)
         ga, _ = pkg.sensing.estimation.doaEstimation.mvdrBF(l, rp, ra)
         assert np.array_equal(ga, wa)
+
+
+# ------------------------------------------------------------------ edge cases the reference's parameter space allows
+def test_many_targets_and_single_antenna(pkg, ctx):
+    """11 LoS targets exercise the 8 + 2 + 1 beam-sum tiling; a 1-antenna array exercises the NB = 1 MFMA plan."""
+    rng = np.random.default_rng(17)
+    tg = tuple((float(r * np.cos(a)), float(r * np.sin(a)), 1.5) for r, a in zip(rng.uniform(60, 400, 11), rng.uniform(-1, 1, 11)))
+    vel = tuple(float(v) for v in rng.integers(-10, 11, 11))
+    los = np.ones(11, dtype=int); los[4] = 0
+    sc = make_scene(n_ants=3, n_slots=1, nrb=24, targets=tg, velocity=vel, seed=8)
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    want = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, los, sc.noise, nfft=sc.wave.Nfft)
+    got = pkg.sensing.monoStaticSensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, rp, los, noise=sc.noise, nfft=sc.wave.Nfft)
+    assert rel(got, want) < RTOL
+    sc1 = make_scene(n_ants=1, n_slots=4, nrb=24, targets=((150.0, 40.0, 1.5),), velocity=(0.0,), num_slots_param=6, zero_s_slots=False)
+    _run_fft2d_case(pkg, sc1)
+
+
+def test_doppler_truncation_when_more_symbols_than_nfft(pkg, ctx):
+    """fft(., nFFT, 2) truncates when L > nFFT (fft2D.m:46): 56 symbols against nFFT = 32."""
+    sc = make_scene(n_ants=2, n_slots=4, nrb=24, targets=((150.0, 40.0, 1.5),), velocity=(0.0,), num_slots_param=3, zero_s_slots=False)
+    assert sc.rp.nFFT == 32 and sc.L == 56
+    _run_fft2d_case(pkg, sc)
+
+
+@pytest.mark.parametrize("nrb,nfft", [(133, 2048), (51, 1024)])
+def test_other_numerologies_stockham_path(pkg, ctx, nrb, nfft):
+    sc = make_scene(n_ants=2, n_slots=2, nrb=nrb, targets=((120.0, 30.0, 1.5),), velocity=(3.0,), num_slots_param=3, zero_s_slots=False)
+    assert sc.wave.Nfft == nfft
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    want = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, sc.noise, nfft=nfft)
+    got = pkg.sensing.monoStaticSensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, noise=sc.noise, nfft=nfft)
+    assert rel(got, want) < RTOL
+    _run_fft2d_case(pkg, sc)
+
+
+def test_full_size_round_trip_properties(pkg, ctx):
+    """Size-independent properties at the benchmark's full shape (K=3276, L=224, A=8 here to bound host memory):
+    modulate -> demodulate is the identity; the device generator's grid is unit-modulus QPSK with zeroed S slots;
+    covariance is Hermitian PSD with trace = mean power."""
+    K, L, A = 3276, 224, 8
+    car = pkg._lib.Carrier(K, 4096, 30, 0)
+    d_grid, d_wave, d_back = ctx.empty((K, L, A)), ctx.empty((983040, A)), ctx.empty((K, L, A))
+    ctx.check(ctx.lib.isac_synth_qpsk_grid_dev(ctx.handle, C.c_void_p(d_grid.ptr), K, L, A, C.c_uint64(5), 1))
+    ctx.check(ctx.lib.isac_ofdm_modulate_dev(ctx.handle, C.c_void_p(d_grid.ptr), L, A, C.byref(car), C.c_double(2.5), C.c_void_p(d_wave.ptr), C.c_int64(983040)))
+    ctx.check(ctx.lib.isac_ofdm_demodulate_dev(ctx.handle, C.c_void_p(d_wave.ptr), C.c_int64(983040), A, C.byref(car), C.c_void_p(d_back.ptr), L))
+    g, b = d_grid.numpy(), d_back.numpy()
+    assert rel(b / 2.5, g) < 1e-11
+    mod = np.abs(g)
+    s_slots = np.zeros(L, bool)
+    for s in range(3, 16, 4):
+        s_slots[14 * s:14 * (s + 1)] = True
+    assert np.all(mod[:, s_slots, :] == 0) and np.allclose(mod[:, ~s_slots, :], 1.0, atol=1e-15)
+    d_ra = ctx.empty((A, A))
+    ctx.check(ctx.lib.isac_covariance_dev(ctx.handle, C.c_void_p(d_back.ptr), C.c_int64(K * L), C.c_int32(A), C.c_void_p(d_ra.ptr)))
+    ra = d_ra.numpy()
+    assert np.array_equal(ra, ra.conj().T) and np.linalg.eigvalsh(ra).min() > -1e-9
+    assert np.trace(ra).real == pytest.approx((np.abs(b) ** 2).sum() / (K * L), rel=1e-12)
