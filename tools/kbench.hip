@@ -6,7 +6,7 @@
 using namespace isac;
 
 // FLAGS bit0: global loads in fill, bit1: transform, bit2: drain stores, bit3: init twiddle loads
-template <int FLAGS>
+template <int FLAGS, int GROUP = 8>
 __global__ __launch_bounds__(256, 2) void range_variant(const c64* __restrict__ rx, const c64* __restrict__ tx, int K,
                                                         const c64* __restrict__ tw, const double* __restrict__ win_k,
                                                         const double* __restrict__ win_r, int row_lo, int n_rows,
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256, 2) void range_variant(const c64* __restrict__ 
   const c64* prx = rx + (long long)K * col;
   const c64* ptx = tx + (long long)K * col;
   if (FLAGS & 1)
-    fft.fill([&](int n) { const int nc = n < K ? n : K - 1; c64 v = mul_conj(prx[nc], ptx[nc]) * win_k[nc]; return n < K ? v : mk(0.0, 0.0); }, tid);
+    fft.template fill<GROUP>([&](int n) { const int nc = n < K ? n : K - 1; c64 v = mul_conj(prx[nc], ptx[nc]) * win_k[nc]; return n < K ? v : mk(0.0, 0.0); }, tid);
   else
     fft.fill([&](int n) { return mk((double)(n ^ col), 1.0); }, tid);
   if (FLAGS & 2) fft.template transform<+1>(lds, tw, tid);
@@ -37,16 +37,16 @@ __global__ __launch_bounds__(256, 2) void range_variant(const c64* __restrict__ 
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-template <int FLAGS>
+template <int FLAGS, int GROUP = 8>
 int run(const char* name, const c64* rx, const c64* tx, int K, int ncols, const c64* tw, const double* wk, const double* wr, c64* y) {
   size_t lds = sizeof(c64) * Fft4096::LDS_ELEMS;
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(range_variant<FLAGS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(range_variant<FLAGS, GROUP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e9f;
   for (int it = 0; it < 6; ++it) {
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(range_variant<FLAGS>, dim3(ncols), dim3(256), lds, 0, rx, tx, K, tw, wk, wr, 38, 376, y);
+    hipLaunchKernelGGL((range_variant<FLAGS, GROUP>), dim3(ncols), dim3(256), lds, 0, rx, tx, K, tw, wk, wr, 38, 376, y);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (it && ms < best) best = ms;
@@ -67,6 +67,9 @@ int main() {
   CK(hipMemset(rx, 0x3c, sizeof(c64) * (size_t)K * ncols)); CK(hipMemset(tx, 0x3c, sizeof(c64) * (size_t)K * ncols));
   CK(hipMemset(wk, 0x3c, 8 * 4096)); CK(hipMemset(wr, 0x3c, 8 * 4096));
   run<15>("full (loads+init+fft+stores)", rx, tx, K, ncols, tw, wk, wr, y);
+  run<15, 4>("full, fill group 4", rx, tx, K, ncols, tw, wk, wr, y);
+  run<15, 16>("full, fill group 16", rx, tx, K, ncols, tw, wk, wr, y);
+  run<15, 2>("full, fill group 2", rx, tx, K, ncols, tw, wk, wr, y);
   run<7>("no init twiddle loads", rx, tx, K, ncols, tw, wk, wr, y);
   run<14>("no fill loads", rx, tx, K, ncols, tw, wk, wr, y);
   run<13>("no transform", rx, tx, K, ncols, tw, wk, wr, y);
