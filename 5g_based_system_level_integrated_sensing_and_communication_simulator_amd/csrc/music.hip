@@ -396,6 +396,203 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
   if (tid == 0 && info) info[0] = sweep;
 }
 
+// ---------------------------------------------------------------- Hermitian eigensolver II: Householder tridiagonalisation + implicit QL
+// eig(Ra) of music.m:19 the LAPACK way (zhetd2 -> zungtr -> tql2), one workgroup:
+//   1. n-1 Householder reflectors reduce H to a REAL symmetric tridiagonal (d, e)   [parallel matvec + rank-2 update]
+//   2. Q = H_0 ... H_{n-2} is formed explicitly in Z                                  [parallel]
+//   3. implicit-shift QL on (d, e); every plane rotation is applied to two columns of Z.  Thread r owns ROW r of
+//      Z, and every wave recomputes the (cheap, strictly sequential) scalar recurrence itself on its own copy of
+//      (d, e), so this phase needs no barrier at all.
+// ~n^2 sequential rotations instead of Jacobi's ~10 sweeps x (n-1) barrier-separated rounds: 3-10x lower latency.
+template <bool BIG>
+__global__ __launch_bounds__(1024) void eigh_ql_kernel(const c64* __restrict__ Hin, int A, double* __restrict__ w_out,
+                                                       c64* __restrict__ V_out, int* __restrict__ info, c64* gscratch) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int n = A;
+  c64* lds0 = reinterpret_cast<c64*>(smem_raw);
+  c64* M;                                           // [n x n] column-major working matrix (reflectors end up below the subdiagonal)
+  c64* sv;                                          // [n] current reflector / scratch vector
+  if constexpr (BIG) { M = gscratch; sv = lds0; } else { M = lds0; sv = lds0 + 2 * n * n; }
+  c64* Z = M + n * n;                               // [n x n]
+  c64* sp = sv + n;                                 // [n] p / w vector
+  c64* stau = sp + n;                               // [n] tau_k
+  double* sd = reinterpret_cast<double*>(stau + n); // [n]
+  double* se = sd + n;                              // [n]
+  double* swd = se + n;                             // per-wave copies for the QL phase: [4][n] d, [4][n] e
+  double* swe = swd + 4 * n;
+  double* sred = swe + 4 * n;                       // [2 x 16] block-reduction scratch
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
+
+  auto block_sum2 = [&](double a, double b, double& oa, double& ob) {   // sum over the workgroup of two values
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+    __syncthreads();
+    if (lane == 0) { sred[wid] = a; sred[16 + wid] = b; }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < nw; ++w) { ta += sred[w]; tb += sred[16 + w]; }
+    oa = ta; ob = tb;
+  };
+
+  const long long t_start = clock64();
+  for (int i = tid; i < n * n; i += nt) M[i] = Hin[i];
+  __syncthreads();
+  // ---- 1. tridiagonalisation (zhetd2, lower)
+  for (int k = 0; k < n - 1; ++k) {
+    const int m = n - k - 1;                        // trailing size, rows/cols k+1 .. n-1
+    double xn2 = 0.0, dummy = 0.0;
+    for (int i = k + 2 + tid; i < n; i += nt) { const c64 x = M[i + n * k]; xn2 += x.re * x.re + x.im * x.im; }
+    double xnorm2, unused;
+    block_sum2(xn2, dummy, xnorm2, unused);
+    const c64 alpha = M[k + 1 + n * k];
+    c64 tau = mk(0.0, 0.0), scale = mk(0.0, 0.0);
+    double beta = alpha.re;
+    if (xnorm2 != 0.0 || alpha.im != 0.0) {         // zlarfg
+      beta = -copysign(sqrt(alpha.re * alpha.re + alpha.im * alpha.im + xnorm2), alpha.re);
+      tau = mk((beta - alpha.re) / beta, -alpha.im / beta);
+      const c64 dlt = mk(alpha.re - beta, alpha.im);
+      const double dn = dlt.re * dlt.re + dlt.im * dlt.im;
+      scale = mk(dlt.re / dn, -dlt.im / dn);        // 1 / (alpha - beta)
+    }
+    for (int i = k + 1 + tid; i < n; i += nt) {
+      const c64 vi = (i == k + 1) ? mk(1.0, 0.0) : M[i + n * k] * scale;
+      sv[i] = vi;
+      if (i > k + 1) M[i + n * k] = vi;             // keep the reflector for step 2
+    }
+    if (tid == 0) { sd[k] = M[k + n * k].re; se[k] = beta; stau[k] = tau; }
+    __syncthreads();
+    if (tau.re != 0.0 || tau.im != 0.0) {
+      // p = tau * A22 * v   (thread per row, coalesced across lanes)
+      for (int i = k + 1 + tid; i < n; i += nt) {
+        c64 acc = mk(0.0, 0.0);
+        for (int j = k + 1; j < n; ++j) acc = fma(M[i + n * j], sv[j], acc);
+        sp[i] = tau * acc;
+      }
+      __syncthreads();
+      // alpha2 = -1/2 tau (p^H v);  w = p + alpha2 v
+      double pr = 0.0, pi = 0.0;
+      for (int i = k + 1 + tid; i < n; i += nt) { const c64 t = mul_conj(sv[i], sp[i]); pr += t.re; pi += t.im; }
+      double sr, si;
+      block_sum2(pr, pi, sr, si);
+      const c64 a2 = mk(-0.5, 0.0) * (tau * mk(sr, si));
+      __syncthreads();
+      for (int i = k + 1 + tid; i < n; i += nt) sp[i] = sp[i] + a2 * sv[i];
+      __syncthreads();
+      // A22 -= v w^H + w v^H
+      for (int e = tid; e < m * m; e += nt) {
+        const int i = k + 1 + e % m, j = k + 1 + e / m;
+        M[i + n * j] = M[i + n * j] - mul_conj(sv[i], sp[j]) - mul_conj(sp[i], sv[j]);
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { sd[n - 1] = M[n - 1 + n * (n - 1)].re; se[n - 1] = 0.0; }
+  const long long t_tri = clock64();
+  // ---- 2. Q (zungtr): Z = H_0 H_1 ... H_{n-2}, accumulated backwards
+  for (int i = tid; i < n * n; i += nt) Z[i] = mk((i % n) == (i / n) ? 1.0 : 0.0, 0.0);
+  __syncthreads();
+  for (int k = n - 2; k >= 0; --k) {
+    const c64 tau = stau[k];
+    if (tau.re == 0.0 && tau.im == 0.0) continue;   // (uniform)
+    const int m = n - k - 1;
+    for (int i = k + 1 + tid; i < n; i += nt) sv[i] = (i == k + 1) ? mk(1.0, 0.0) : M[i + n * k];
+    __syncthreads();
+    // u[j] = v^H Z[k+1:, j]
+    for (int j = k + 1 + tid; j < n; j += nt) {
+      c64 acc = mk(0.0, 0.0);
+      for (int i = k + 1; i < n; ++i) acc = fma(conj(sv[i]), Z[i + n * j], acc);
+      sp[j] = tau * acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < m * m; e += nt) {
+      const int i = k + 1 + e % m, j = k + 1 + e / m;
+      Z[i + n * j] = Z[i + n * j] - sv[i] * sp[j];
+    }
+    __syncthreads();
+  }
+  const long long t_q = clock64();
+  // ---- 3. implicit QL (tql2); wave-private (d, e), thread-private rows of Z, no barriers
+  int sweeps = 0;
+  const int row_waves = (n + 63) >> 6;
+  if (wid < row_waves && wid < 4) {
+    double* d = swd + wid * n;
+    double* e = swe + wid * n;
+    for (int i = lane; i < n; i += 64) { d[i] = sd[i]; e[i] = se[i]; }
+    const bool own = tid < n;
+    const int r = own ? tid : n - 1;                // my row of Z; surplus lanes shadow row n-1 (loads stay unconditional) and never store
+    for (int l = 0; l < n; ++l) {
+      int iter = 0;
+      while (true) {
+        // every lane computes the same scalars; readfirstlane tells the compiler so (scalar branches instead of
+        // exec-mask juggling around each break)
+        int mm = l;
+        for (; mm < n - 1; ++mm) {
+          const double dd = fabs(d[mm]) + fabs(d[mm + 1]);
+          if (__builtin_amdgcn_readfirstlane((int)(fabs(e[mm]) <= 2.220446049250313e-16 * dd))) break;
+        }
+        if (mm == l) break;
+        if (++iter > 60) break;                     // (never reached for Hermitian input; keeps the loop bounded)
+        ++sweeps;
+        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+        double rr = sqrt(g * g + 1.0);
+        g = d[mm] - d[l] + e[l] / (g + copysign(rr, g));
+        double sn = 1.0, cs = 1.0, p = 0.0;
+        c64 zhi = Z[r + n * mm];   // column i+1 of my row, carried between rotations
+        int i = mm - 1;
+        bool underflow = false;
+        // software pipeline: operands of rotation i-1 are fetched while rotation i computes; d[i+1] of rotation i
+        // is the d[i] rotation i+1 already holds, so each rotation issues one d load, one e load and one Z load
+        double d_hi = d[mm];
+        double e_i = e[i], d_i = d[i];
+        c64 zlo = Z[r + n * i];
+        for (; i >= l; --i) {
+          const int ip = i > l ? i - 1 : l;
+          const double e_nx = e[ip], d_nx = d[ip];
+          const c64 z_nx = Z[r + n * ip];
+          const double f = sn * e_i;
+          const double b = cs * e_i;
+          const double rr2 = ::fma(f, f, g * g);
+          if (__builtin_amdgcn_readfirstlane((int)(rr2 == 0.0))) {
+            e[i + 1] = 0.0; d[i + 1] = d_hi - p; e[mm] = 0.0;     // every lane stores the same value (no branch)
+            underflow = true;
+            break;
+          }
+          // 1/sqrt(rr2): hardware estimate + two Newton steps (relative error ~1e-16), instead of sqrt + two divides
+          double inv = __builtin_amdgcn_rsq(rr2);
+          double hh = 0.5 * rr2 * inv;
+          inv = ::fma(::fma(-hh, inv, 0.5), inv, inv);
+          hh = 0.5 * rr2 * inv;
+          inv = ::fma(::fma(-hh, inv, 0.5), inv, inv);
+          rr = rr2 * inv;
+          e[i + 1] = rr;
+          sn = f * inv;
+          cs = g * inv;
+          g = d_hi - p;
+          rr = ::fma(d_i - g, sn, 2.0 * cs * b);
+          p = sn * rr;
+          d[i + 1] = g + p;
+          g = ::fma(cs, rr, -b);
+          // z[r][i+1] = s z[r][i] + c z[r][i+1];  z[r][i] = c z[r][i] - s z[r][i+1]
+          const c64 nhi = mk(::fma(sn, zlo.re, cs * zhi.re), ::fma(sn, zlo.im, cs * zhi.im));
+          const c64 nlo = mk(::fma(cs, zlo.re, -sn * zhi.re), ::fma(cs, zlo.im, -sn * zhi.im));
+          if (own) Z[r + n * (i + 1)] = nhi;
+          zhi = nlo;
+          d_hi = d_i; d_i = d_nx; e_i = e_nx; zlo = z_nx;
+        }
+        if (own) Z[r + n * (i + 1)] = zhi;          // the last carried column
+        if (underflow) continue;
+        { const double dl = d[l] - p; d[l] = dl; e[l] = g; e[mm] = 0.0; }
+      }
+    }
+    if (wid == 0) for (int i = lane; i < n; i += 64) w_out[i] = d[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < n * n; i += nt) V_out[i] = Z[i];
+  if (tid == 0 && info) {
+    info[0] = sweeps;
+    info[1] = (int)((t_tri - t_start) >> 6); info[2] = (int)((t_q - t_tri) >> 6); info[3] = (int)((clock64() - t_q) >> 6);   // x64 cycles
+  }
+}
+
 // ---------------------------------------------------------------- MUSIC pseudo-spectrum (ULA), music.m:82-91
 // One workgroup per scan angle.  Noise subspace = eigenvectors whose descending rank >= L.
 // mode 0: MUSIC  1/(a' Uan Uan' a + eps);  mode 1: digital beamforming |a' Ra a| (digitalBF.m:72);
@@ -571,18 +768,38 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
 int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
   if (!st) st = ctx->stream;
   if (A > 1024) return fail(ctx, ISAC_ERR_UNSUPPORTED, "device eigensolver supports up to 1024 antennas");
-  const int n = (A + 1) & ~1;
+  static const bool use_jacobi = std::getenv("ISAC_EIG_JACOBI") != nullptr;
   const bool big = A > kJacobiMaxA;
+  ISAC_TRY(ensure(ctx, ctx->eig_w, sizeof(double) * (size_t)A + 64));
+  ISAC_TRY(ensure(ctx, ctx->eig_v, sizeof(c64) * (size_t)A * A));
+  int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
+  // measured: Jacobi wins while H and V fit LDS (A = 64: 1.4 ms vs 2.3 ms), tridiagonal QL wins beyond (A = 256: 48 ms vs 99 ms)
+  static const bool force_ql = std::getenv("ISAC_EIG_QL") != nullptr;
+  if (!use_jacobi && A <= 256 && (big || force_ql)) {
+    const int n = A;
+    c64* gs = nullptr;
+    if (big) {
+      ISAC_TRY(ensure(ctx, ctx->eig_scratch, sizeof(c64) * (size_t)2 * n * n));
+      gs = (c64*)ctx->eig_scratch.p;
+    }
+    size_t lds = sizeof(c64) * ((big ? 0 : (size_t)2 * n * n) + 3 * (size_t)n) + sizeof(double) * (10 * (size_t)n + 32) + 64;
+    if (big) {
+      hipLaunchKernelGGL(eigh_ql_kernel<true>, dim3(1), dim3(1024), lds, st, d_H, A, (double*)ctx->eig_w.p, (c64*)ctx->eig_v.p, info, gs);
+    } else {
+      { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_ql_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+      hipLaunchKernelGGL(eigh_ql_kernel<false>, dim3(1), dim3(1024), lds, st, d_H, A, (double*)ctx->eig_w.p, (c64*)ctx->eig_v.p, info, gs);
+    }
+    ISAC_HIP(hipGetLastError());
+    return ISAC_OK;
+  }
+  const int n = (A + 1) & ~1;
   c64* gs = nullptr;
   if (big) {
     ISAC_TRY(ensure(ctx, ctx->eig_scratch, sizeof(c64) * (size_t)2 * n * n));
     gs = (c64*)ctx->eig_scratch.p;
   }
-  ISAC_TRY(ensure(ctx, ctx->eig_w, sizeof(double) * (size_t)A + 64));
-  ISAC_TRY(ensure(ctx, ctx->eig_v, sizeof(c64) * (size_t)A * A));
   size_t lds = sizeof(c64) * ((big ? 0 : (size_t)2 * n * n) + n / 2) + sizeof(double) * (n / 2) + sizeof(int) * (n + 1) + 64;
   if (!big) { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
-  int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
   if (big)
     hipLaunchKernelGGL(jacobi_eigh_kernel<true>, dim3(1), dim3(1024), lds, st, d_H, A, 40, (double*)ctx->eig_w.p, (c64*)ctx->eig_v.p, info, gs);
   else

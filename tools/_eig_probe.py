@@ -3,9 +3,9 @@ import numpy as np
 sys.path.insert(0, os.getcwd())
 import bench
 pkg = importlib.import_module(bench.PKG)
-ctx = pkg.Context(0)
+cell = bench.Cell(pkg, 0, 0, 64, 16, 1)
+ctx = cell.ctx
 lib = ctx.lib
-cell = bench.Cell(pkg, ctx, 0, 64, 16, 1)
 cell.step()
 A = 64
 ra = np.zeros((A, A), dtype=np.complex128, order="F")
