@@ -524,10 +524,15 @@ __global__ __launch_bounds__(1024) void eigh_ql_kernel(const c64* __restrict__ H
       while (true) {
         // every lane computes the same scalars; readfirstlane tells the compiler so (scalar branches instead of
         // exec-mask juggling around each break)
-        int mm = l;
-        for (; mm < n - 1; ++mm) {
-          const double dd = fabs(d[mm]) + fabs(d[mm + 1]);
-          if (__builtin_amdgcn_readfirstlane((int)(fabs(e[mm]) <= 2.220446049250313e-16 * dd))) break;
+        // first mm >= l with a negligible e[mm] (or n-1): 64 candidates per ballot instead of a serial scan
+        // (a VALU -> SALU hand-off costs ~110 cycles on this chip, tools/latbench.hip)
+        int mm = n - 1;
+        for (int base = l; base < n - 1; base += 64) {
+          const int j = base + lane;
+          bool small = false;
+          if (j < n - 1) small = fabs(e[j]) <= 2.220446049250313e-16 * (fabs(d[j]) + fabs(d[j + 1]));
+          const unsigned long long mask = __ballot(small);
+          if (mask) { mm = base + __builtin_ctzll(mask); break; }
         }
         if (mm == l) break;
         if (++iter > 60) break;                     // (never reached for Hermitian input; keeps the loop bounded)
@@ -536,14 +541,16 @@ __global__ __launch_bounds__(1024) void eigh_ql_kernel(const c64* __restrict__ H
         double rr = sqrt(g * g + 1.0);
         g = d[mm] - d[l] + e[l] / (g + copysign(rr, g));
         double sn = 1.0, cs = 1.0, p = 0.0;
-        c64 zhi = Z[r + n * mm];   // column i+1 of my row, carried between rotations
+        c64 zhi = Z[r + n * mm];                       // column i+1 of my row, carried between rotations
         int i = mm - 1;
-        bool underflow = false;
         // software pipeline: operands of rotation i-1 are fetched while rotation i computes; d[i+1] of rotation i
-        // is the d[i] rotation i+1 already holds, so each rotation issues one d load, one e load and one Z load
+        // is the d[i] rotation i+1 already holds, so each rotation issues one d load, one e load and one Z load.
+        // The rr == 0 recovery of tql2 (rare) is handled without a branch in the chase: once it triggers, `live`
+        // turns the remaining rotations of this sweep into identities; one scalar test after the loop.
         double d_hi = d[mm];
         double e_i = e[i], d_i = d[i];
         c64 zlo = Z[r + n * i];
+        bool live = true, underflow = false;
         for (; i >= l; --i) {
           const int ip = i > l ? i - 1 : l;
           const double e_nx = e[ip], d_nx = d[ip];
@@ -551,35 +558,36 @@ __global__ __launch_bounds__(1024) void eigh_ql_kernel(const c64* __restrict__ H
           const double f = sn * e_i;
           const double b = cs * e_i;
           const double rr2 = ::fma(f, f, g * g);
-          if (__builtin_amdgcn_readfirstlane((int)(rr2 == 0.0))) {
-            e[i + 1] = 0.0; d[i + 1] = d_hi - p; e[mm] = 0.0;     // every lane stores the same value (no branch)
-            underflow = true;
-            break;
-          }
+          const bool zero = live && (rr2 == 0.0);
           // 1/sqrt(rr2): hardware estimate + two Newton steps (relative error ~1e-16), instead of sqrt + two divides
-          double inv = __builtin_amdgcn_rsq(rr2);
-          double hh = 0.5 * rr2 * inv;
+          const double rs = zero ? 1.0 : rr2;
+          double inv = __builtin_amdgcn_rsq(rs);
+          double hh = 0.5 * rs * inv;
           inv = ::fma(::fma(-hh, inv, 0.5), inv, inv);
-          hh = 0.5 * rr2 * inv;
+          hh = 0.5 * rs * inv;
           inv = ::fma(::fma(-hh, inv, 0.5), inv, inv);
-          rr = rr2 * inv;
-          e[i + 1] = rr;
-          sn = f * inv;
-          cs = g * inv;
-          g = d_hi - p;
-          rr = ::fma(d_i - g, sn, 2.0 * cs * b);
-          p = sn * rr;
-          d[i + 1] = g + p;
-          g = ::fma(cs, rr, -b);
+          rr = rs * inv;
+          const double e_out = zero ? 0.0 : rr;                  // e[i+1]
+          const double sn_n = f * inv, cs_n = g * inv;
+          const double g1 = d_hi - p;
+          const double rr1 = ::fma(d_i - g1, sn_n, 2.0 * cs_n * b);
+          const double p_n = sn_n * rr1;
+          const double d_out = zero ? g1 : g1 + p_n;             // d[i+1]  (tql2: d[i+1] -= p on underflow)
+          const double g_n = ::fma(cs_n, rr1, -b);
+          if (live) { e[i + 1] = e_out; d[i + 1] = d_out; }
           // z[r][i+1] = s z[r][i] + c z[r][i+1];  z[r][i] = c z[r][i] - s z[r][i+1]
-          const c64 nhi = mk(::fma(sn, zlo.re, cs * zhi.re), ::fma(sn, zlo.im, cs * zhi.im));
-          const c64 nlo = mk(::fma(cs, zlo.re, -sn * zhi.re), ::fma(cs, zlo.im, -sn * zhi.im));
+          const bool rot = live && !zero;
+          const c64 nhi = rot ? mk(::fma(sn_n, zlo.re, cs_n * zhi.re), ::fma(sn_n, zlo.im, cs_n * zhi.im)) : zhi;
+          const c64 nlo = rot ? mk(::fma(cs_n, zlo.re, -sn_n * zhi.re), ::fma(cs_n, zlo.im, -sn_n * zhi.im)) : zlo;
           if (own) Z[r + n * (i + 1)] = nhi;
           zhi = nlo;
+          if (rot) { sn = sn_n; cs = cs_n; p = p_n; g = g_n; }
+          underflow = underflow || zero;
+          live = live && !zero;
           d_hi = d_i; d_i = d_nx; e_i = e_nx; zlo = z_nx;
         }
         if (own) Z[r + n * (i + 1)] = zhi;          // the last carried column
-        if (underflow) continue;
+        if (__builtin_amdgcn_readfirstlane((int)underflow)) { e[mm] = 0.0; continue; }
         { const double dl = d[l] - p; d[l] = dl; e[l] = g; e[mm] = 0.0; }
       }
     }
