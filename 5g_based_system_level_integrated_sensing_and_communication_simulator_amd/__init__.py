@@ -17,6 +17,6 @@ The package name starts with a digit, so import it by string::
 """
 from . import _lib  # noqa: F401
 from ._lib import Context, DeviceArray, IsacError, default_context, library_path  # noqa: F401
-from . import sensing, communication  # noqa: F401
+from . import sensing, communication, networkTopology  # noqa: F401
 
-__all__ = ["sensing", "communication", "Context", "DeviceArray", "IsacError", "default_context", "library_path"]
+__all__ = ["sensing", "communication", "networkTopology", "Context", "DeviceArray", "IsacError", "default_context", "library_path"]

@@ -518,7 +518,7 @@ __global__ __launch_bounds__(1024) void eigh_ql_kernel(const c64* __restrict__ H
     double* e = swe + wid * n;
     for (int i = lane; i < n; i += 64) { d[i] = sd[i]; e[i] = se[i]; }
     const bool own = tid < n;
-    const int r = own ? tid : n - 1;                // my row of Z; surplus lanes shadow row n-1 (loads stay unconditional) and never store
+    const int r = own ? tid : n - 1;                // my row of Z; surplus lanes shadow row n-1 (same loads, same stores)
     for (int l = 0; l < n; ++l) {
       int iter = 0;
       while (true) {
@@ -545,12 +545,15 @@ __global__ __launch_bounds__(1024) void eigh_ql_kernel(const c64* __restrict__ H
         int i = mm - 1;
         // software pipeline: operands of rotation i-1 are fetched while rotation i computes; d[i+1] of rotation i
         // is the d[i] rotation i+1 already holds, so each rotation issues one d load, one e load and one Z load.
-        // The rr == 0 recovery of tql2 (rare) is handled without a branch in the chase: once it triggers, `live`
-        // turns the remaining rotations of this sweep into identities; one scalar test after the loop.
-        double d_hi = d[mm];
+        // The chase is one dependent fp64 chain (~20 ops x 11 cycles).  Anything that routes a VALU result through
+        // the scalar unit (a branch on it, or boolean algebra on compare masks) adds ~100 cycles per hop, so the
+        // rr == 0 recovery of tql2 (rare) is carried as a 0/1 double: once it triggers, `lv` = 0 turns the remaining
+        // rotations of this sweep into identities and every store writes back the value it found; all stores are
+        // unconditional (surplus lanes shadow row n-1 and write the same values as its owner).
+        double d_hi = d[mm], e_hi = e[mm];
         double e_i = e[i], d_i = d[i];
         c64 zlo = Z[r + n * i];
-        bool live = true, underflow = false;
+        double lv = 1.0, uf = 0.0;
         for (; i >= l; --i) {
           const int ip = i > l ? i - 1 : l;
           const double e_nx = e[ip], d_nx = d[ip];
@@ -558,36 +561,37 @@ __global__ __launch_bounds__(1024) void eigh_ql_kernel(const c64* __restrict__ H
           const double f = sn * e_i;
           const double b = cs * e_i;
           const double rr2 = ::fma(f, f, g * g);
-          const bool zero = live && (rr2 == 0.0);
           // 1/sqrt(rr2): hardware estimate + two Newton steps (relative error ~1e-16), instead of sqrt + two divides
-          const double rs = zero ? 1.0 : rr2;
+          const double rs = (rr2 == 0.0) ? 1.0 : rr2;
           double inv = __builtin_amdgcn_rsq(rs);
-          double hh = 0.5 * rs * inv;
-          inv = ::fma(::fma(-hh, inv, 0.5), inv, inv);
-          hh = 0.5 * rs * inv;
-          inv = ::fma(::fma(-hh, inv, 0.5), inv, inv);
-          rr = rs * inv;
-          const double e_out = zero ? 0.0 : rr;                  // e[i+1]
+          const double hrs = 0.5 * rs;
+          inv = ::fma(::fma(-hrs * inv, inv, 0.5), inv, inv);
+          inv = ::fma(::fma(-hrs * inv, inv, 0.5), inv, inv);
+          const double e_cand = (rr2 == 0.0) ? 0.0 : rs * inv;   // e[i+1] = r
           const double sn_n = f * inv, cs_n = g * inv;
           const double g1 = d_hi - p;
           const double rr1 = ::fma(d_i - g1, sn_n, 2.0 * cs_n * b);
           const double p_n = sn_n * rr1;
-          const double d_out = zero ? g1 : g1 + p_n;             // d[i+1]  (tql2: d[i+1] -= p on underflow)
+          const double d_cand = (rr2 == 0.0) ? g1 : g1 + p_n;    // d[i+1]  (tql2: d[i+1] -= p when r == 0)
           const double g_n = ::fma(cs_n, rr1, -b);
-          if (live) { e[i + 1] = e_out; d[i + 1] = d_out; }
+          const double rotf = (rr2 == 0.0) ? 0.0 : lv;           // 1: apply this rotation
+          e[i + 1] = (lv != 0.0) ? e_cand : e_hi;
+          d[i + 1] = (lv != 0.0) ? d_cand : d_hi;
           // z[r][i+1] = s z[r][i] + c z[r][i+1];  z[r][i] = c z[r][i] - s z[r][i+1]
-          const bool rot = live && !zero;
-          const c64 nhi = rot ? mk(::fma(sn_n, zlo.re, cs_n * zhi.re), ::fma(sn_n, zlo.im, cs_n * zhi.im)) : zhi;
-          const c64 nlo = rot ? mk(::fma(cs_n, zlo.re, -sn_n * zhi.re), ::fma(cs_n, zlo.im, -sn_n * zhi.im)) : zlo;
-          if (own) Z[r + n * (i + 1)] = nhi;
+          const bool rot = rotf != 0.0;
+          c64 nhi = mk(::fma(sn_n, zlo.re, cs_n * zhi.re), ::fma(sn_n, zlo.im, cs_n * zhi.im));
+          c64 nlo = mk(::fma(cs_n, zlo.re, -sn_n * zhi.re), ::fma(cs_n, zlo.im, -sn_n * zhi.im));
+          nhi.re = rot ? nhi.re : zhi.re; nhi.im = rot ? nhi.im : zhi.im;
+          nlo.re = rot ? nlo.re : zlo.re; nlo.im = rot ? nlo.im : zlo.im;
+          Z[r + n * (i + 1)] = nhi;
           zhi = nlo;
-          if (rot) { sn = sn_n; cs = cs_n; p = p_n; g = g_n; }
-          underflow = underflow || zero;
-          live = live && !zero;
-          d_hi = d_i; d_i = d_nx; e_i = e_nx; zlo = z_nx;
+          sn = rot ? sn_n : sn; cs = rot ? cs_n : cs; p = rot ? p_n : p; g = rot ? g_n : g;
+          uf += lv - rotf;
+          lv = rotf;
+          d_hi = d_i; e_hi = e_i; d_i = d_nx; e_i = e_nx; zlo = z_nx;
         }
-        if (own) Z[r + n * (i + 1)] = zhi;          // the last carried column
-        if (__builtin_amdgcn_readfirstlane((int)underflow)) { e[mm] = 0.0; continue; }
+        Z[r + n * (i + 1)] = zhi;                   // the last carried column
+        if (__builtin_amdgcn_readfirstlane((int)(uf != 0.0))) { e[mm] = 0.0; continue; }
         { const double dl = d[l] - p; d[l] = dl; e[l] = g; e[mm] = 0.0; }
       }
     }

@@ -289,6 +289,26 @@ int isac_precoded_sinr_cqi_dev(isac_ctx* ctx, const isac_c64* d_H, int64_t n_re,
                                const isac_c64* W, int32_t n_layers, double sigma, const double* sinr_table_db,
                                int32_t n_table, double* d_sinr_per_re, double* mean_sinr, int32_t* cqi);
 
+/* ------------------------------------------------------------------ line-of-sight blockage
+ * Batched openStreetMapCity.checkLoS (+networkTopology/+blockages/openStreetMapCity.m:67-93): for every link
+ * (ue, ant) and every wall, wallBlockage.checkBlockage (+networkTopology/+blockages/wallBlockage.m:88-121, winding
+ * number :170-216); a link is NLoS if any wall blocks it (building.m:113-137).  The reference evaluates one link at a
+ * time from networkSimulation.m:138,154; its result is the targetLoSConditions / ueLoSConditions vector consumed by
+ * isac_mono_static_sensing.  d_ue, d_ant [3 x n_links] (x;y;z per column); walls are packed: d_corners [3 x total
+ * corners], d_wall_offsets [n_walls+1] (0-based first corner of each wall), d_normals [3 x n_walls] and d_norm_dist
+ * [n_walls] are wallBlockage.normVec / normDist (host prep, wallBlockage.m:57-65).  d_los [n_links] receives 1 = LoS,
+ * 0 = blocked; d_n_blocking (optional, [n_links]) the number of blocking walls.  Asynchronous on the context stream.
+ * Quirk kept: the intersection is with the infinite UE-antenna line (no segment test), as in the reference. */
+int isac_los_check_dev(isac_ctx* ctx, const double* d_ue, const double* d_ant, int64_t n_links,
+                       const double* d_corners, const int32_t* d_wall_offsets, const double* d_normals,
+                       const double* d_norm_dist, int32_t n_walls, uint8_t* d_los, int32_t* d_n_blocking);
+/* getWindingNumber (wallBlockage.m:170-216) of n_points points against n_walls polygons; d_winding [n_points x
+ * n_walls] (point fastest).  wallBlockage.checkIsInside / building.checkIsInside (building.m:139-174) is
+ * `winding > 0.1` against the ceiling polygon. */
+int isac_winding_number_dev(isac_ctx* ctx, const double* d_points, int64_t n_points, const double* d_corners,
+                            const int32_t* d_wall_offsets, const double* d_normals, int32_t n_walls,
+                            double* d_winding);
+
 /* ------------------------------------------------------------------ synthetic inputs (bench/tests) */
 /* QPSK txGrid [K x L x A] (unit modulus, zero planes for 'S' slots: every 4th grid slot when
  * zero_s_slots != 0) generated on the device from a Philox stream. */
