@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libisac_hip.so")
 SOURCES = ["capi.hip", "echo.hip", "rdm.hip", "music.hip", "cdl.hip", "cqi.hip", "los.hip"]
-HEADERS = ["isac_common.hpp", "fft_lds.hpp", os.path.join("..", "..", "include", "isac.h")]
+HEADERS = ["isac_common.hpp", "fft_lds.hpp", "echo_dev.hpp", os.path.join("..", "..", "include", "isac.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result", "-ffp-contract=on"]

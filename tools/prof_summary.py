@@ -32,7 +32,50 @@ def summarise_pmc(path):
     return list(cur.execute(q))
 
 
+def overlap(path):
+    """Concurrency analysis of a kernel trace: union busy time vs sum of durations, and for every kernel which other
+    kernels were resident while it ran (time-weighted).  Uses the middle 60 % of the trace (steady state)."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    rows = list(cur.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    lo, hi = t0 + 0.2 * (t1 - t0), t0 + 0.8 * (t1 - t0)
+    rows = [(n.split("(")[0][:60], max(a, lo), min(b, hi)) for n, a, b in rows if b > lo and a < hi]
+    ev = sorted([(a, 1, n) for n, a, b in rows] + [(b, -1, n) for n, a, b in rows])
+    active, last, busy, hist, co = {}, lo, 0.0, {}, {}
+    for t, d, n in ev:
+        dt = t - last
+        if dt > 0:
+            k = sum(active.values())
+            hist[k] = hist.get(k, 0.0) + dt
+            if k:
+                busy += dt
+                for a in active:
+                    if active[a]:
+                        c = co.setdefault(a, {})
+                        for b in active:
+                            if active[b] and b != a:
+                                c[b] = c.get(b, 0.0) + dt
+                        c["__self__"] = c.get("__self__", 0.0) + dt
+        active[n] = active.get(n, 0) + d
+        last = t
+    total = sum(b - a for _, a, b in rows)
+    print(f"window {1e-6 * (hi - lo):.2f} ms: busy (union) {1e-6 * busy:.2f} ms, sum of kernel durations {1e-6 * total:.2f} ms, "
+          f"mean concurrency while busy {total / max(busy, 1):.2f}")
+    print("resident-kernel histogram: " + "  ".join(f"{k}:{100 * v / (hi - lo):.0f}%" for k, v in sorted(hist.items())))
+    for a, c in sorted(co.items(), key=lambda kv: -kv[1]["__self__"])[:8]:
+        self_t = c.pop("__self__")
+        tops = sorted(c.items(), key=lambda kv: -kv[1])[:4]
+        print(f"  {a[:44]:44s} resident {1e-6 * self_t:8.2f} ms; with: " + ", ".join(f"{b[:28]} {100 * v / self_t:.0f}%" for b, v in tops))
+
+
 if __name__ == "__main__":
+    if "--overlap" in sys.argv:
+        overlap(sys.argv[1])
+        sys.exit(0)
     if "--pmc" in sys.argv:
         rows = summarise_pmc(sys.argv[1])
         lines = ["kernel,counter,dispatches,avg_value,avg_duration_us"]
