@@ -153,6 +153,28 @@ int isac_get_twiddles(isac_ctx* ctx, int n, const c64** out) {
 }
 int isac_get_twiddles2(isac_ctx* ctx, int n, const c64** out) { return isac_get_twiddles(ctx, n, out); }
 
+// (1 / c_i, ln c_i) for the kLogTabSize mantissa buckets of the table-driven Box-Muller radius (echo_dev.hpp); c_i is
+// the bucket centre in [0.5, 1); ln is taken of the reciprocal actually stored so that ln m = ln c_i + log1p(m / c_i - 1)
+// holds to rounding.  Kept in the twiddle map under a negative key (freed with the context).
+int isac_get_logtab(isac_ctx* ctx, const c64** out) {
+  isac_ctx& t = *ctx;
+  const int key = -128;
+  auto it = t.twiddles.find(key);
+  if (it == t.twiddles.end()) {
+    std::vector<c64> lt(128);
+    for (int i = 0; i < 128; ++i) {
+      const long double c = 0.5L * (1.0L + ((long double)i + 0.5L) / 128.0L);
+      const double inv = (double)(1.0L / c);
+      lt[(size_t)i] = mk(inv, (double)(-logl((long double)inv)));
+    }
+    DevBuf b;
+    ISAC_TRY(upload(ctx, b, lt.data(), sizeof(c64) * lt.size()));
+    it = t.twiddles.emplace(key, b).first;
+  }
+  *out = (const c64*)it->second.p;
+  return ISAC_OK;
+}
+
 int isac_get_windows(isac_ctx* ctx, int K, int n_ifft, const double** win_k, const double** win_r) {
   isac_ctx& t = *ctx;
   auto get = [&](int n, int shifted, const double** out) -> int {

@@ -17,6 +17,7 @@
 // ((2*pi*fc) * (n*Ts), all in fp64) so the ~1e-8 rad rounding of those huge arguments
 // is reproduced rather than "improved".
 #include <cstring>
+#include <type_traits>
 
 #include "fft_lds.hpp"
 #include "echo_dev.hpp"
@@ -111,22 +112,26 @@ struct OfdmGeom {
   int nfft, n_sc, cp_base, cp_long, sym_per_half;
 };
 
-template <class FFT, bool SYNTH>
+// QT > 0: the number of LoS targets as a compile-time constant (a run-time target loop inside the 16 unrolled sample
+// producers sends the register allocator to 256 VGPRs + scratch); QT = 0: any count.
+template <class FFT, bool SYNTH, int QT = 0>
 __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, int A, int L_whole, int L_out,
                                                        const c64* __restrict__ tw,
                                                        // SYNTH = true: synthesise rx samples
-                                                       int Q, const c64* __restrict__ coef,
+                                                       int Q_rt, const c64* __restrict__ coef,
                                                        const c64* __restrict__ steer_rq, const c64* __restrict__ phase_rx,
                                                        int noise_mode, const c64* __restrict__ noise, double n0s,
                                                        uint64_t seed,
                                                        // SYNTH = false: read them
                                                        const c64* __restrict__ wave,
-                                                       c64* __restrict__ grid) {
+                                                       c64* __restrict__ grid, const c64* __restrict__ logtab_g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);
   const int tid = threadIdx.x;
   const int n_cols = L_whole * A;
   FFT fft;
+  constexpr bool kTables = SYNTH && QT > 0 && std::is_same<FFT, Fft4096>::value;   // LDS tables for the Philox Box-Muller
+  const int Q = QT ? QT : Q_rt;
   {
     // one (symbol, antenna) column per workgroup, symbol fastest: consecutive workgroups write consecutive
     // 52 KB columns of one antenna plane.  (Antenna-fastest order would re-use a symbol's coef window in L2
@@ -140,15 +145,30 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
     const int dshift = cp - off;  // window leads the useful part by dshift samples
     if constexpr (SYNTH) {
       const c64* sr = steer_rq + (long long)r * Q;
-      if (noise_mode == ISAC_NOISE_PHILOX)   // Box-Muller per sample is register hungry: interleave at most 4 producers
-        fft.template fill<4>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, ISAC_NOISE_PHILOX, noise, n0s, seed); }, tid);
-      else
-        fft.template fill<8>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, noise_mode, noise, n0s, seed); }, tid);
+      if (noise_mode == ISAC_NOISE_PHILOX) {
+        // Box-Muller per sample is register hungry: interleave at most 4 producers.  At Nfft = 4096 the transform's own
+        // W256 table (angle) and a 2 KB log table (radius) in LDS replace libm's sincospi / log (tools/dbench.hip:
+        // 272 -> 222 us of VALU time per launch), so the tables go in first.
+        if constexpr (kTables) {
+          c64* lt = lds + FFT::LDS_ELEMS;
+          if (tid < kLogTabSize) lt[tid] = logtab_g[tid];
+          fft.init_table(lds, tw, tid);
+          const c64* w256 = lds + FFT::IMG;
+          fft.template fill<4>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, ISAC_NOISE_PHILOX, noise, n0s, seed, w256, lt); }, tid);
+          fft.init_twiddles(tw, tid);
+        } else {
+          fft.template fill<4>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, ISAC_NOISE_PHILOX, noise, n0s, seed); }, tid);
+        }
+      } else {
+        const int nm = (noise_mode == ISAC_NOISE_INJECTED) ? ISAC_NOISE_INJECTED : ISAC_NOISE_NONE;   // no generator code on this path
+        fft.template fill<8>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, nm, noise, n0s, seed); }, tid);
+      }
     } else {
       const c64* src = wave + w0 + T * (long long)r;
       fft.fill([&](int n) { return src[n]; }, tid);
     }
-    fft.init(lds, tw, tid);   // after the fill: the twiddle-table loads fly together with the column's loads
+    // after the fill: the twiddle-table loads fly together with the column's loads
+    if (!(kTables && noise_mode == ISAC_NOISE_PHILOX)) fft.init(lds, tw, tid);
     fft.template transform<-1>(lds, tw, tid);
     c64* dst = grid + (long long)g.n_sc * ((long long)l + (long long)L_out * r);
     const int half = g.n_sc / 2;
@@ -175,19 +195,21 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
 // keep the CUT rows.  echoGrid is still written (covariance + API output) but never re-read by the
 // range kernel: saves K*L*A*16 B of HBM reads per CPI and lets the VALU-bound noise synthesis of one
 // workgroup overlap the HBM-bound loads of another inside the same launch.  Requires Nfft == nIFFT.
-template <class FFT>
+template <class FFT, int QT = 0>
 __global__ __launch_bounds__(256, 2) void demod_range_kernel(OfdmGeom g, long long T, int A, int L_whole, int L_out,
-                                                             const c64* __restrict__ tw, int Q, const c64* __restrict__ coef,
+                                                             const c64* __restrict__ tw, int Q_rt, const c64* __restrict__ coef,
                                                              const c64* __restrict__ steer_rq, const c64* __restrict__ phase_rx,
                                                              int noise_mode, const c64* __restrict__ noise, double n0s,
                                                              uint64_t seed, c64* __restrict__ grid,
                                                              const c64* __restrict__ txg, const double* __restrict__ win_k,
                                                              const double* __restrict__ win_r, double inv_n, double sqrt_n,
-                                                             int row_lo, int n_rows, c64* __restrict__ ymid) {
+                                                             int row_lo, int n_rows, c64* __restrict__ ymid,
+                                                             const c64* __restrict__ logtab_g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);
   const int tid = threadIdx.x;
   FFT fft;
+  const int Q = QT ? QT : Q_rt;
   const int col = blockIdx.x;
   const int l = col % L_whole, r = col / L_whole;  // symbol fastest (see demod_kernel)
   const int cp = cp_of_symbol(l, g.cp_base, g.cp_long, g.sym_per_half);
@@ -195,11 +217,21 @@ __global__ __launch_bounds__(256, 2) void demod_range_kernel(OfdmGeom g, long lo
   const long long w0 = symbol_start(l, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) + off;
   const int dshift = cp - off;
   const c64* sr = steer_rq + (long long)r * Q;
-  if (noise_mode == ISAC_NOISE_PHILOX)
+  if (noise_mode == ISAC_NOISE_PHILOX && QT == 0) {  // any target count: libm generator (the table path spills here)
     fft.template fill<4>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, ISAC_NOISE_PHILOX, noise, n0s, seed); }, tid);
-  else
-    fft.template fill<8>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, noise_mode, noise, n0s, seed); }, tid);
-  fft.init(lds, tw, tid);
+    fft.init(lds, tw, tid);
+  } else if (noise_mode == ISAC_NOISE_PHILOX) {      // table-driven Box-Muller (see demod_kernel)
+    c64* lt = lds + FFT::LDS_ELEMS;
+    if (tid < kLogTabSize) lt[tid] = logtab_g[tid];
+    fft.init_table(lds, tw, tid);
+    const c64* w256 = lds + FFT::IMG;
+    fft.template fill<4>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, ISAC_NOISE_PHILOX, noise, n0s, seed, w256, lt); }, tid);
+    fft.init_twiddles(tw, tid);
+  } else {
+    const int nm = (noise_mode == ISAC_NOISE_INJECTED) ? ISAC_NOISE_INJECTED : ISAC_NOISE_NONE;
+    fft.template fill<8>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, nm, noise, n0s, seed); }, tid);
+    fft.init(lds, tw, tid);
+  }
   fft.template transform<-1>(lds, tw, tid);
   const long long colg = (long long)l + (long long)L_out * r;
   c64* dst = grid + (long long)g.n_sc * colg;
@@ -301,6 +333,7 @@ __global__ __launch_bounds__(256) void synth_qpsk_kernel(c64* __restrict__ grid,
 using namespace isac;
 
 int isac_get_twiddles(isac_ctx* ctx, int n, const c64** out);  // capi.hip
+int isac_get_logtab(isac_ctx* ctx, const c64** out);           // capi.hip
 
 static int check_carrier(isac_ctx* ctx, const isac_carrier* c) {
   if (!c) return fail(ctx, ISAC_ERR_INVALID_ARG, "carrier is NULL");
@@ -440,15 +473,17 @@ extern "C" int isac_basic_radar_channel_dev(isac_ctx* ctx, const isac_c64* d_tx_
   return ISAC_OK;
 }
 
-template <class FFT, bool SYNTH>
+template <class FFT, bool SYNTH, int QT = 0>
 static int launch_demod(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, int L_whole, int L_out, const c64* tw, int Q,
                         int noise_mode, const c64* noise, double n0s, uint64_t seed, const c64* wave, c64* grid) {
-  size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
-  auto kern = demod_kernel<FFT, SYNTH>;
+  size_t lds = sizeof(c64) * (FFT::LDS_ELEMS + kLogTabSize);
+  const c64* logtab = nullptr;
+  ISAC_TRY(isac_get_logtab(ctx, &logtab));
+  auto kern = demod_kernel<FFT, SYNTH, QT>;
   { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
   hipLaunchKernelGGL(kern, dim3(fft_grid(L_whole * A)), dim3(256), lds, ctx->stream, g, T, A, L_whole, L_out, tw, Q,
                      (const c64*)ctx->coef.p, SYNTH ? (const c64*)ctx->steer.p + (size_t)A * Q : nullptr,
-                     (const c64*)ctx->phase_rx.p, noise_mode, noise, n0s, seed, wave, grid);
+                     (const c64*)ctx->phase_rx.p, noise_mode, noise, n0s, seed, wave, grid, logtab);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }
@@ -475,24 +510,33 @@ extern "C" int isac_mono_static_sensing_dev(isac_ctx* ctx, const isac_c64* d_tx_
   const c64* tw = nullptr;
   ISAC_TRY(isac_get_twiddles(ctx, g.nfft, &tw));
   const double n0s = std::sqrt(rp->n0 / 2.0);
-  ISAC_FFT_DISPATCH(g.nfft, ISAC_TRY((launch_demod<FFT, true>(ctx, g, T, A, L_whole, L_out, tw, Q, noise_mode,
-                                                              (const c64*)d_noise_unit, n0s, seed, nullptr,
-                                                              (c64*)d_echo_grid))));
+#define ISAC_DEMOD_Q(QT) ISAC_TRY((launch_demod<Fft4096, true, QT>(ctx, g, T, A, L_whole, L_out, tw, Q, noise_mode, \
+                                                                   (const c64*)d_noise_unit, n0s, seed, nullptr, (c64*)d_echo_grid)))
+  if (g.nfft == 4096 && Q >= 1 && Q <= 4) {
+    switch (Q) { case 1: ISAC_DEMOD_Q(1); break; case 2: ISAC_DEMOD_Q(2); break; case 3: ISAC_DEMOD_Q(3); break; default: ISAC_DEMOD_Q(4); break; }
+  } else {
+    ISAC_FFT_DISPATCH(g.nfft, ISAC_TRY((launch_demod<FFT, true>(ctx, g, T, A, L_whole, L_out, tw, Q, noise_mode,
+                                                                (const c64*)d_noise_unit, n0s, seed, nullptr,
+                                                                (c64*)d_echo_grid))));
+  }
+#undef ISAC_DEMOD_Q
   return ISAC_OK;
 }
 
 int isac_get_windows(isac_ctx* ctx, int K, int n_ifft, const double** win_k, const double** win_r);   // capi.hip
 
-template <class FFT>
+template <class FFT, int QT = 0>
 static int launch_demod_range(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, int L_whole, int L_out, const c64* tw, int Q,
                               int noise_mode, const c64* noise, double n0s, uint64_t seed, c64* grid, const c64* txg,
                               const double* wk, const double* wr, int n_ifft, int row_lo, int nr, c64* ymid) {
-  size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
-  auto kern = demod_range_kernel<FFT>;
+  size_t lds = sizeof(c64) * (FFT::LDS_ELEMS + kLogTabSize);
+  const c64* logtab = nullptr;
+  ISAC_TRY(isac_get_logtab(ctx, &logtab));
+  auto kern = demod_range_kernel<FFT, QT>;
   { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
   hipLaunchKernelGGL(kern, dim3((unsigned)(L_whole * A)), dim3(256), lds, ctx->stream, g, T, A, L_whole, L_out, tw, Q,
                      (const c64*)ctx->coef.p, (const c64*)ctx->steer.p + (size_t)A * Q, (const c64*)ctx->phase_rx.p, noise_mode,
-                     noise, n0s, seed, grid, txg, wk, wr, 1.0 / n_ifft, std::sqrt((double)n_ifft), row_lo, nr, ymid);
+                     noise, n0s, seed, grid, txg, wk, wr, 1.0 / n_ifft, std::sqrt((double)n_ifft), row_lo, nr, ymid, logtab);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }
@@ -532,8 +576,11 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
   ISAC_TRY(isac_get_twiddles(ctx, g.nfft, &tw));
   ISAC_TRY(isac_get_windows(ctx, g.n_sc, ep->n_ifft, &wk, &wr));
   const double n0s = std::sqrt(rp->n0 / 2.0);
-  ISAC_TRY((launch_demod_range<Fft4096>(ctx, g, T, A, L_whole, L_out, tw, Q, noise_mode, (const c64*)d_noise_unit, n0s, seed,
-                                        (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, ep->n_ifft, row_lo, nr, (c64*)ctx->ymid.p)));
+#define ISAC_FUSED_Q(QT) ISAC_TRY((launch_demod_range<Fft4096, QT>(ctx, g, T, A, L_whole, L_out, tw, Q, noise_mode, (const c64*)d_noise_unit, \
+                                                                   n0s, seed, (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, ep->n_ifft, \
+                                                                   row_lo, nr, (c64*)ctx->ymid.p)))
+  switch (Q) { case 1: ISAC_FUSED_Q(1); break; case 2: ISAC_FUSED_Q(2); break; case 3: ISAC_FUSED_Q(3); break; case 4: ISAC_FUSED_Q(4); break; default: ISAC_FUSED_Q(0); break; }
+#undef ISAC_FUSED_Q
   RangeCache& rc = ctx->range_cache;
   rc.rx = d_echo_grid; rc.tx = d_tx_grid; rc.K = g.n_sc; rc.L = L_out; rc.A = A; rc.n_ifft = ep->n_ifft; rc.row_lo = row_lo; rc.nr = nr;
   rc.valid = true;

@@ -66,16 +66,70 @@ __device__ __forceinline__ c64 philox_normal_pair(uint64_t e, uint64_t seed, uin
   return c64{r * c, r * s};
 }
 
+// Table-driven evaluation of the same Box-Muller pair for kernels that have LDS to spare (the 4096-point demodulator):
+//   * angle: theta = 2 pi k2 / 2^53 = 2 pi i / 256 + phi, i = top 8 bits of k2; (cos, sin)(2 pi i / 256) comes from the
+//     FFT's own W256 table, (cos, sin)(phi), phi < 0.0246, from 3-term series (truncation < 4e-18), one complex product.
+//   * radius: ln u = e ln2 + ln c_i + log1p(r), c_i the centre of the mantissa's 1/128-wide bucket, r = m / c_i - 1,
+//     |r| <= 2^-8, log1p to r^7 (truncation < 2^-59 relative); table entry i = (1 / c_i, ln c_i).
+// ~55 fp64 instructions instead of ~95; agrees with philox_normal_pair to ~4e-16 relative (both are a few ulp from the
+// exact transform of the same two uniforms).  kLogTabSize entries of c64 = 2 KB.
+constexpr int kLogTabSize = 128;
+
+__device__ __forceinline__ c64 philox_normal_pair_tab(uint64_t e, uint64_t seed, uint32_t stream,
+                                                      const c64* __restrict__ w256 /* LDS: exp(-2 pi j i / 256) */,
+                                                      const c64* __restrict__ logtab /* LDS: (1/c_i, ln c_i) */) {
+  uint32_t o[4];
+  philox4x32_10((uint32_t)e, (uint32_t)(e >> 32), stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+  // ---- radius from (o[0], o[1]): u1 = (k1 + 1) 2^-53 in (0, 1]
+  const uint64_t w0 = (uint64_t)o[0] | ((uint64_t)o[1] << 32);
+  const double u1 = ((double)(w0 >> 11) + 1.0) * 0x1.0p-53;
+  int ex;
+  const double m = frexp(u1, &ex);                                   // m in [0.5, 1)
+  const int idx = (int)((__double2hiint(m) >> 13) & (kLogTabSize - 1));   // top 7 mantissa bits
+  const c64 lt = logtab[idx];
+  const double r = ::fma(m, lt.re, -1.0);
+  double q = 1.0 / 7.0;
+  q = ::fma(q, r, -1.0 / 6.0); q = ::fma(q, r, 1.0 / 5.0); q = ::fma(q, r, -1.0 / 4.0); q = ::fma(q, r, 1.0 / 3.0); q = ::fma(q, r, -0.5);
+  const double l1p = ::fma(r * r, q, r);
+  const double ln_u = ::fma((double)ex, 0.69314718055994530942, lt.im + l1p);
+  const double y = -2.0 * ln_u;
+  double rad = 0.0;
+  if (y > 0.0) {
+    const double rs = __builtin_amdgcn_rsq(y);
+    double sq = y * rs;
+    const double h = 0.5 * rs;
+    sq = ::fma(::fma(-sq, sq, y), h, sq);
+    sq = ::fma(::fma(-sq, sq, y), h, sq);
+    rad = sq;
+  }
+  // ---- angle from (o[2], o[3]): k2 = 53 bits
+  const uint32_t hi = o[3];                                          // k2 = (o[3] : o[2]) >> 11
+  const int i = (int)(hi >> 24);                                     // top 8 bits of k2
+  // rem = k2 mod 2^45 = ((hi & 0xFFFFFF) << 21) | (o[2] >> 11); phi = rem * 2 pi 2^-53
+  const double rem = ::fma((double)(hi & 0x00FFFFFFu), 2097152.0, (double)(o[2] >> 11));
+  const double phi = rem * (6.28318530717958647692 * 0x1.0p-53);
+  const double p2 = phi * phi;
+  const double sphi = phi * ::fma(p2, ::fma(p2, ::fma(p2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+  const double cphi = ::fma(p2, ::fma(p2, ::fma(p2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
+  const c64 w = w256[i];                                             // (cos a, -sin a)
+  const double c = ::fma(w.re, cphi, w.im * sphi);                   // cos(a + phi) = ca cphi - sa sphi, sa = -w.im
+  const double sn = ::fma(w.re, sphi, -w.im * cphi);                 // sin(a + phi) = sa cphi + ca sphi
+  return c64{rad * c, rad * sn};
+}
+
 // rx[t,r] for one sample (shared by the fused demodulator and the waveform materialiser)
 __device__ __forceinline__ c64 rx_sample(long long t, int r, long long T, int Q, const c64* __restrict__ coef,
                                          const c64* __restrict__ s_steer_r /* [Q] a_q[r] */,
                                          const c64* __restrict__ phase_rx, int noise_mode,
-                                         const c64* __restrict__ noise, double n0s, uint64_t seed) {
+                                         const c64* __restrict__ noise, double n0s, uint64_t seed,
+                                         const c64* __restrict__ w256 = nullptr /* LDS tables: table-driven Box-Muller */,
+                                         const c64* __restrict__ logtab = nullptr) {
   c64 v = mk(0.0, 0.0);
   for (int q = 0; q < Q; ++q) v = fma(coef[(long long)q * T + t], s_steer_r[q], v);
   if (noise_mode != ISAC_NOISE_NONE) {
     uint64_t e = (uint64_t)t + (uint64_t)T * (uint64_t)r;
-    c64 nz = (noise_mode == ISAC_NOISE_INJECTED) ? noise[e] : philox_normal_pair(e, seed, 0u);
+    c64 nz = (noise_mode == ISAC_NOISE_INJECTED) ? noise[e]
+             : (w256 ? philox_normal_pair_tab(e, seed, 0u, w256, logtab) : philox_normal_pair(e, seed, 0u));
     v = v + (nz * n0s) * phase_rx[t];
   }
   return v;

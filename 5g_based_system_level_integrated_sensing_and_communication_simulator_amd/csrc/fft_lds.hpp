@@ -96,12 +96,19 @@ struct Fft4096 {
 
   // once per workgroup
   __device__ __forceinline__ void init(c64* __restrict__ lds, const c64* __restrict__ tw, int tid) {
+    init_twiddles(tw, tid);
+    init_table(lds, tw, tid);
+  }
+  // the two halves of init(), for kernels that need the LDS table before their fill but not the 16 twiddle registers
+  __device__ __forceinline__ void init_table(c64* __restrict__ lds, const c64* __restrict__ tw, int tid) {
+    lds[IMG + tid] = tw[16 * tid];  // W256^tid
+    __syncthreads();
+  }
+  __device__ __forceinline__ void init_twiddles(const c64* __restrict__ tw, int tid) {
     wb[0] = tw[tid];
     wb[1] = tw[2 * tid];
     wb[2] = tw[4 * tid];
     wb[3] = tw[8 * tid];
-    lds[IMG + tid] = tw[16 * tid];  // W256^tid
-    __syncthreads();
   }
   // exp(+2 pi j kb dshift / 4096) for the OFDM window offset; dshift is a multiple of 16 at Nfft = 4096
   __device__ __forceinline__ c64 phase_ramp(const c64* __restrict__ lds, const c64* __restrict__, int kb, int dshift) const {

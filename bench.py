@@ -36,6 +36,7 @@ PKG = "5g_based_system_level_integrated_sensing_and_communication_simulator_amd"
 
 RANGE_KERNEL_HBM_BYTES_A64 = int((2 * 735380 + 84226) * 1024)   # 1.592e9 B vs 1.503e9 B algorithmic: no wasted re-reads
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix (= vector) dense peak
 
 
 def cell_params(n_ants, targets, velocity):
@@ -171,6 +172,43 @@ class Cell:
         return c.timer_stop_ms() / reps
 
 
+def stage_table(cell, reps=5):
+    """Isolated per-stage durations (HIP events on the context stream, one CPI resident, nothing else running) with each
+    stage's own roofline -- so that the JSON line shows every large kernel, not only the one quoted in `roofline`."""
+    c = cell.ctx
+    b = 16
+    K, L, A, T = cell.K, cell.Lsym, cell.A, cell.T
+
+    def timed(fn):
+        fn(); c.sync()
+        c.timer_start()
+        for _ in range(reps):
+            fn()
+        return c.timer_stop_ms() / reps
+
+    def mono(noise):
+        kw = dict(seed=cell.seed if noise else None, nfft=4096, out=cell.echo[0], ctx=c)
+        return lambda: cell.pkg.sensing.monoStaticSensing(cell.tx_wave, (K, L, A), cell.carrier, cell.rp, cell.los, **kw)
+
+    ra = c.empty((A, A))
+    cov = lambda: c.check(c.lib.isac_covariance_dev(c.handle, C.c_void_p(cell.echo[0].ptr), C.c_int64(K * L), C.c_int32(A), C.c_void_p(ra.ptr)))
+    out = []
+    echo_b = T * A * b + K * L * A * b
+    for name, fn, note in (("monoStaticSensing = beamsum + coef + demod, Philox AWGN", mono(True),
+                            "fp64-VALU-bound: Philox4x32-10 + Box-Muller for 4096*L*A complex samples, then the OFDM FFT"),
+                           ("monoStaticSensing, noise off", mono(False), "HBM: read txWaveform once, write echoGrid once")):
+        ms = timed(fn)
+        out.append({"stage": name, "ms": round(ms, 4), "bound": "hbm", "algorithmic_bytes": echo_b,
+                    "achieved_GBps": round(echo_b / 1e9 / (ms / 1e3), 1), "frac": round(echo_b / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4), "note": note})
+    ms = timed(cov)
+    fl = 8.0 * A * A * K * L
+    out.append({"stage": "covariance Ra = X X^H / N (fp64 MFMA, Hermitian half issued)", "ms": round(ms, 4), "bound": "mfma",
+                "algorithmic_flops": fl, "achieved_TFLOPs": round(fl / 1e12 / (ms / 1e3), 2), "peak_TFLOPs": FP64_MFMA_PEAK_TFLOPS,
+                "frac": round(fl / 1e12 / (ms / 1e3) / FP64_MFMA_PEAK_TFLOPS, 4),
+                "note": "nominal 8 A^2 K L flop; the kernel issues the upper-triangular 10 of 16 tiles"})
+    return out
+
+
 def cpu_baseline(n_ants, budget_s=25.0):
     """The NumPy/SciPy oracle ("port": the MATLAB reference cannot run here) timed on the host cores on a
     bounded sample of the same workload: the full 273-PRB / 224-symbol CPI with a reduced antenna count,
@@ -260,6 +298,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     range_ms = cells[0].time_range_kernel() if rank == 0 else 0.0
+    stages = stage_table(cells[0]) if rank == 0 else []
     # per-cell result record gather -- the only collective (KB-scale, RCCL over xGMI); max over ranks of the timed region
     d = importlib.import_module(PKG + "._dist")
     recs = np.array([d.make_record(rank * args.cells_per_gpu + i, cell.last, dt) for i, cell in enumerate(cells)])
@@ -287,6 +326,7 @@ def main():
                          "traffic": RANGE_KERNEL_HBM_BYTES_A64 if (args.ants == 64 and args.slots == 16) else None,
                          "traffic_source": "profiles/r01_pmc_fetch_size.csv + r01_pmc_write_size.csv (separate --pmc passes)",
                          "avg_launch_ms": round(range_ms, 4), "algorithmic_bytes_per_launch": rdm_b,
+                         "other_stages": stages,
                          "whole_cpi": {"algorithmic_bytes": echo_b + rdm_b, "ms": round(per_cpi_ms, 4),
                                        "achieved_GBps": round((echo_b + rdm_b) / 1e9 / (per_cpi_ms / 1e3), 1),
                                        "frac": round((echo_b + rdm_b) / 1e9 / (per_cpi_ms / 1e3) / HBM_PEAK_GBS, 4)}},
