@@ -212,6 +212,164 @@ __global__ __launch_bounds__(256, 3) void cov_mfma_small_kernel(const c64* __res
   }
 }
 
+// ---- arrays wider than 64 elements (config 4: 256-element ULA): Ra is cut into 64 x 64 blocks and every workgroup owns
+// one block pair (BI <= BJ) over a chunk of samples -- a classical LDS-staged GEMM step:
+//   * the 16-sample x (64 + 64)-antenna slab is fetched once per workgroup with line-friendly loads (16 consecutive lanes
+//     read the 256 contiguous bytes of one antenna) into a double-buffered LDS image (row pitch 17 complex: the
+//     transposing writes and the MFMA operand reads are both conflict-free); the loads of slab s+1 fly under the MFMAs
+//     of slab s; one barrier per slab;
+//   * wave w computes up to four 16 x 16 tiles per slab from LDS operands: tile row w on off-diagonal blocks, a balanced
+//     3/3/2/2 split of the 10 upper-triangular tiles on diagonal blocks.
+// Workgroups of the same sample chunk are adjacent in the grid so that block pairs sharing an antenna block stream it
+// together (Infinity Cache).  (The generic kernel above re-reads its operands once per tile triple: 8.8 ms at A = 256;
+// a register-operand version of this kernel, 20 strided global loads per wave and slab: 6.4 ms.)
+constexpr int kCovPitch = 17;                                   // complex elements per (block, sample) row
+constexpr int kCovBufElems = 8 * 16 * kCovPitch;                // one slab image: 8 antenna blocks x 16 samples
+__constant__ unsigned char kCovDiagTiles[4][4] = {              // 16*I + J per (wave, slot); 255 = idle
+    {0x00, 0x01, 0x02, 255}, {0x03, 0x11, 0x12, 255}, {0x13, 0x22, 255, 255}, {0x23, 0x33, 255, 255}};
+
+__global__ __launch_bounds__(256, 2) void cov_mfma_block_kernel(const c64* __restrict__ G, long long N, int A, int n_blk,
+                                                                int n_pairs, long long slabs_per_wg,
+                                                                double* __restrict__ part /* [chunk][pair][16][2][256] */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* lds = reinterpret_cast<c64*>(smem_raw);      // [2][kCovBufElems]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int pair = blockIdx.x % n_pairs, chunk = blockIdx.x / n_pairs;
+  int BI = 0, BJ = 0;
+  {
+    int rem = pair;                                 // pair-th (BI <= BJ) in row-major order
+    while (rem >= n_blk - BI) { rem -= n_blk - BI; ++BI; }
+    BJ = BI + rem;
+  }
+  const bool diag = BI == BJ;
+  // tiles of this wave: (I, J) inside the 64 x 64 block
+  int tI[4], tJ[4];
+  bool tv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int code = diag ? (int)kCovDiagTiles[wid][u] : (16 * wid + u);
+    tv[u] = code != 255;
+    tI[u] = tv[u] ? (code >> 4) : 0;
+    tJ[u] = tv[u] ? (code & 15) : 0;
+  }
+  const int jbase = diag ? 0 : 4;                   // LDS blocks 0..3 = antenna block BI, 4..7 = BJ (absent on diagonal pairs)
+  // staging ownership: flat = j*256 + tid -> antenna slot flat/16 (0..127), sample flat%16
+  const int n_stage = diag ? 4 : 8;                 // loads per thread and slab
+  const int s_smp = tid & 15;
+  const c64* s_col[8];
+  bool s_ok[8];
+  int s_lds[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int slot = j * 16 + (tid >> 4);           // 0..127
+    const int blk = slot >> 4, l16 = slot & 15;
+    const int ant = 64 * (blk < 4 ? BI : BJ) + 16 * (blk & 3) + l16;
+    s_ok[j] = ant < A;
+    s_col[j] = G + N * (long long)(s_ok[j] ? ant : 0);
+    s_lds[j] = (blk * 16 + s_smp) * kCovPitch + l16;
+  }
+  v4f64 re[4], im[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) re[u] = im[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+  const long long total = (N + 15) / 16;
+  const long long s_begin = (long long)chunk * slabs_per_wg;
+  long long s_end = s_begin + slabs_per_wg;
+  if (s_end > total) s_end = total;
+  c64 g[8];
+  auto fetch = [&](long long slab) {
+    long long n = slab * 16 + s_smp;
+    const bool in = n < N;
+    if (!in) n = N - 1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < n_stage) {                            // (uniform)
+        const c64 v = s_col[j][n];
+        g[j] = (in && s_ok[j]) ? v : mk(0.0, 0.0);
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    c64* d = lds + buf * kCovBufElems;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < n_stage) d[s_lds[j]] = g[j];
+  };
+  if (s_begin < s_end) { fetch(s_begin); stash(0); }
+  __syncthreads();
+  for (long long slab = s_begin; slab < s_end; ++slab) {
+    const int buf = (int)((slab - s_begin) & 1);
+    const bool more = slab + 1 < s_end;
+    if (more) fetch(slab + 1);                      // in flight under the MFMAs below
+    const c64* cur = lds + buf * kCovBufElems;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!tv[u]) continue;                         // (wave-uniform)
+      const c64* pa = cur + ((tI[u] * 16 + 4 * kq) * kCovPitch + li);
+      const c64* pb = cur + (((jbase + tJ[u]) * 16 + 4 * kq) * kCovPitch + li);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const c64 xa = pa[e * kCovPitch], xb = pb[e * kCovPitch];
+        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xb.re, re[u], 0, 0, 0);
+        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.im, xb.im, re[u], 0, 0, 0);
+        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xb.im, im[u], 0, 0, 0);
+        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa.im, xb.re, im[u], 0, 0, 0);
+      }
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (!tv[u]) continue;
+    double* o = part + ((((long long)chunk * n_pairs + pair) * 16 + (tI[u] * 4 + tJ[u])) * 2) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[r * 64 + lane] = re[u][r];
+      o[256 + r * 64 + lane] = im[u][r];
+    }
+  }
+}
+
+// fixed-order sum over the sample chunks of one tile + Hermitian fill + 1/N (block layout of cov_mfma_block_kernel)
+__global__ __launch_bounds__(1024) void cov_block_reduce_kernel(const double* __restrict__ part, int n_chunks, int n_blk, int n_pairs,
+                                                                int A, double inv_n, c64* __restrict__ Ra) {
+  __shared__ double s_sum[2][4][256];
+  const int tile = blockIdx.x, pair = blockIdx.y;
+  int BI = 0, BJ = 0;
+  {
+    int rem = pair;
+    while (rem >= n_blk - BI) { rem -= n_blk - BI; ++BI; }
+    BJ = BI + rem;
+  }
+  const int I = tile >> 2, J = tile & 3;
+  if (BI == BJ && J < I) return;                    // never computed
+  const int e = threadIdx.x, g = threadIdx.y;
+  const int per = (n_chunks + 3) / 4;
+  const int c0 = g * per, c1 = min(n_chunks, c0 + per);
+  double sr = 0.0, si = 0.0;
+  for (int c = c0; c < c1; ++c) {
+    const double* o = part + ((((long long)c * n_pairs + pair) * 16 + tile) * 2) * 256;
+    sr += o[e];
+    si += o[256 + e];
+  }
+  s_sum[0][g][e] = sr; s_sum[1][g][e] = si;
+  __syncthreads();
+  if (g != 0) return;
+  sr = ((s_sum[0][0][e] + s_sum[0][1][e]) + s_sum[0][2][e]) + s_sum[0][3][e];
+  si = ((s_sum[1][0][e] + s_sum[1][1][e]) + s_sum[1][2][e]) + s_sum[1][3][e];
+  const int r = e >> 6, lane = e & 63;
+  const int a = 64 * BI + 16 * I + (lane >> 4) + 4 * r;   // f64 MFMA C/D layout: row = (lane>>4) + 4*reg, col = lane&15
+  const int b = 64 * BJ + 16 * J + (lane & 15);
+  if (a >= A || b >= A) return;
+  c64 v = mk(sr * inv_n, si * inv_n);
+  if (a == b) v.im = 0.0;
+  if (BI == BJ && I == J && a > b) return;          // diagonal tile: keep the upper triangle, mirror it (exactly Hermitian)
+  Ra[a + (long long)A * b] = v;
+  if (a != b) Ra[b + (long long)A * a] = conj(v);
+}
+
 // first reduction level: slice s of S sums a contiguous run of workgroup partials (fixed order) into part2[s];
 // spreads the 60 MB of partial tiles over S x n_tiles workgroups instead of n_tiles (per-CU bandwidth bound)
 __global__ __launch_bounds__(256) void cov_reduce_slice_kernel(const double* __restrict__ part, int n_wg, int n_tiles, int S,
@@ -329,10 +487,12 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
   const double tol2 = 1e-28;
   int& s_dirty = rq[h];                            // lives in the dynamic LDS carve (keeps its base 16-B aligned)
   int sweep = 0;
+  long long cyc_p = 0, cyc_u = 0;                  // phase instrumentation (ISAC_DEBUG): cycles of thread 0
   for (; sweep < max_sweeps; ++sweep) {
     if (tid == 0) s_dirty = 0;
     __syncthreads();
     for (int round = 0; round < n - 1; ++round) {
+      const long long t_p0 = clock64();
       // ---- P: rotation parameters of the h disjoint pairs
       for (int kk = tid; kk < h; kk += nt) {
         int p, q;
@@ -355,6 +515,8 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
         rg[kk] = g;
       }
       __syncthreads();
+      const long long t_u0 = clock64();
+      cyc_p += t_u0 - t_p0;
       // ---- U: two-sided 2x2 block updates of H, column rotations of V
       for (int blk = tid; blk < h * h; blk += nt) {
         const int a = blk % h, b = blk / h;
@@ -383,6 +545,7 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
         V[row + n * q] = vp * g + vq * c;
       }
       __syncthreads();
+      cyc_u += clock64() - t_u0;
     }
     const int dirty = s_dirty;
     __syncthreads();                      // everyone has read the flag before thread 0 clears it again
@@ -393,7 +556,7 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
     int r = i % A, c = i / A;
     V_out[i] = V[r + n * c];
   }
-  if (tid == 0 && info) info[0] = sweep;
+  if (tid == 0 && info) { info[0] = sweep; info[1] = (int)(cyc_p >> 6); info[2] = (int)(cyc_u >> 6); info[3] = 0; }
 }
 
 // ---------------------------------------------------------------- Hermitian eigensolver II: Householder tridiagonalisation + implicit QL
@@ -756,6 +919,26 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
       case 3: return launch_cov_small<3>(ctx, st, (const c64*)d_grid, N, A, (c64*)d_Ra);
       default: return launch_cov_small<4>(ctx, st, (const c64*)d_grid, N, A, (c64*)d_Ra);
     }
+  }
+  if (!std::getenv("ISAC_COV_GENERIC")) {            // 64 x 64 block pairs (any A > 64)
+    const int n_blk = (A + 63) / 64;
+    const int n_pairs = n_blk * (n_blk + 1) / 2;
+    const long long total = (N + 15) / 16;
+    long long n_chunks = 1024 / n_pairs;              // ~4 workgroups per CU over the launch, 2 resident
+    if (n_chunks < 1) n_chunks = 1;
+    if (n_chunks > total) n_chunks = total;
+    const long long per = (total + n_chunks - 1) / n_chunks;
+    n_chunks = (total + per - 1) / per;
+    ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * (size_t)n_chunks * n_pairs * 16 * 2 * 256));
+    const size_t lds = sizeof(c64) * 2 * kCovBufElems;
+    { static bool set = false; if (!set) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cov_mfma_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; } }
+    hipLaunchKernelGGL(cov_mfma_block_kernel, dim3((unsigned)(n_chunks * n_pairs)), dim3(256), lds, st, (const c64*)d_grid, (long long)N, A,
+                       n_blk, n_pairs, per, (double*)ctx->cov_part.p);
+    ISAC_HIP(hipGetLastError());
+    hipLaunchKernelGGL(cov_block_reduce_kernel, dim3(16, n_pairs), dim3(256, 4), 0, st, (const double*)ctx->cov_part.p, (int)n_chunks,
+                       n_blk, n_pairs, A, 1.0 / (double)N, (c64*)d_Ra);
+    ISAC_HIP(hipGetLastError());
+    return ISAC_OK;
   }
   const int n_tiles = nb * (nb + 1) / 2;
   const int tiles_per_wg = kCovWaves * kCovTPW;
