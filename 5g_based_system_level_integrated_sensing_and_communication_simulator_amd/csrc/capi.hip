@@ -628,9 +628,10 @@ extern "C" int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w,
   ISAC_HIP(hipMemcpyAsync(vv.data(), ctx->eig_v.p, sizeof(c64) * (size_t)A * A, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   if (std::getenv("ISAC_DEBUG")) {
-    int inf[4] = {-1, 0, 0, 0};
+    int inf[6] = {-1, 0, 0, 0, 0, 0};
     ISAC_HIP(hipMemcpy(inf, (char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(inf), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "[isac] eigh A=%d sweeps=%d phases(x64 clk): tridiag=%d formQ=%d ql=%d\n", A, inf[0], inf[1], inf[2], inf[3]);
+    std::fprintf(stderr, "[isac] eigh A=%d sweeps=%d rotations=%d phases(x64 clk): tridiag=%d formQ=%d ql-recurrence=%d replay=%d\n", A, inf[0],
+                 inf[5], inf[1], inf[2], inf[3], inf[4]);
   }
   std::vector<int> order((size_t)A);
   std::iota(order.begin(), order.end(), 0);

@@ -560,30 +560,48 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
 }
 
 // ---------------------------------------------------------------- Hermitian eigensolver II: Householder tridiagonalisation + implicit QL
-// eig(Ra) of music.m:19 the LAPACK way (zhetd2 -> zungtr -> tql2), one workgroup:
-//   1. n-1 Householder reflectors reduce H to a REAL symmetric tridiagonal (d, e)   [parallel matvec + rank-2 update]
-//   2. Q = H_0 ... H_{n-2} is formed explicitly in Z                                  [parallel]
-//   3. implicit-shift QL on (d, e); every plane rotation is applied to two columns of Z.  Thread r owns ROW r of
-//      Z, and every wave recomputes the (cheap, strictly sequential) scalar recurrence itself on its own copy of
-//      (d, e), so this phase needs no barrier at all.
-// ~n^2 sequential rotations instead of Jacobi's ~10 sweeps x (n-1) barrier-separated rounds: 3-10x lower latency.
-template <bool BIG>
-__global__ __launch_bounds__(1024) void eigh_ql_kernel(const c64* __restrict__ Hin, int A, double* __restrict__ w_out,
-                                                       c64* __restrict__ V_out, int* __restrict__ info, c64* gscratch) {
+// eig(Ra) of music.m:19 the LAPACK way (zhetd2 -> zungtr -> tql2) for arrays that do not fit the LDS Jacobi solver
+// (A > 64; config 4: 256-element ULA), as three launches on one stream, all state in an L2-resident global scratch:
+//   K1  eigh_tridiag_kernel   one workgroup: n-1 Householder reflectors reduce H to a REAL symmetric tridiagonal (d, e)
+//   K2  eigh_formq_ql_kernel  two independent workgroups side by side:
+//         block 0: Q = H_0 ... H_{n-2} formed explicitly in Z (zungtr)
+//         block 1: one wavefront runs the strictly sequential implicit-shift QL recurrence on (d, e) ALONE -- one
+//                  dependent fp64 chain per plane rotation, no matrix traffic -- and records every rotation (c, s)
+//   K3  eigh_replay_kernel    the recorded rotations are replayed on the rows of Z; rows are independent, so this
+//         part spreads over several CUs (one CU streams a 1 MB Z once per sweep at ~29 B/clk -- that bandwidth, not
+//         the arithmetic, bounded the single-workgroup version).
+// A = 256: 99 ms (Jacobi in global memory) -> 27 ms (one workgroup doing everything) -> see DESIGN.md section 6.
+struct EighScratch {   // carve of ctx->eig_scratch for order n
+  c64 *M, *Z, *tau, *rot;
+  double *d, *e;
+  int *desc, *cnt;     // desc: (mm, l) per sweep; cnt: {n_sweeps, n_rot, overflow, -}
+  long long rot_cap;
+  int desc_cap;
+  __host__ __device__ static size_t bytes(int n) {
+    return sizeof(c64) * ((size_t)2 * n * n + n + (size_t)16 * n * n) + sizeof(double) * 2 * n + sizeof(int) * (2 * (size_t)(30 * n + 2) + 8) + 256;
+  }
+  __host__ __device__ EighScratch(void* base, int n) {
+    c64* p = reinterpret_cast<c64*>(base);
+    M = p; p += (size_t)n * n;
+    Z = p; p += (size_t)n * n;
+    tau = p; p += n;
+    rot = p; rot_cap = (long long)16 * n * n; p += rot_cap;
+    d = reinterpret_cast<double*>(p);
+    e = d + n;
+    desc_cap = 30 * n + 2;
+    desc = reinterpret_cast<int*>(e + n + (n & 1));
+    cnt = desc + 2 * (size_t)desc_cap;
+  }
+};
+
+__global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restrict__ Hin, int n, void* scratch, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int n = A;
-  c64* lds0 = reinterpret_cast<c64*>(smem_raw);
-  c64* M;                                           // [n x n] column-major working matrix (reflectors end up below the subdiagonal)
-  c64* sv;                                          // [n] current reflector / scratch vector
-  if constexpr (BIG) { M = gscratch; sv = lds0; } else { M = lds0; sv = lds0 + 2 * n * n; }
-  c64* Z = M + n * n;                               // [n x n]
+  EighScratch S(scratch, n);
+  c64* M = S.M;                                     // [n x n] column-major working matrix (reflectors end up below the subdiagonal)
+  c64* sv = reinterpret_cast<c64*>(smem_raw);       // [n] current reflector
   c64* sp = sv + n;                                 // [n] p / w vector
-  c64* stau = sp + n;                               // [n] tau_k
-  double* sd = reinterpret_cast<double*>(stau + n); // [n]
-  double* se = sd + n;                              // [n]
-  double* swd = se + n;                             // per-wave copies for the QL phase: [4][n] d, [4][n] e
-  double* swe = swd + 4 * n;
-  double* sred = swe + 4 * n;                       // [2 x 16] block-reduction scratch
+  c64* spart = sp + n;                              // [4][n] partial matrix-vector products
+  double* sred = reinterpret_cast<double*>(spart + 4 * n);   // [2 x 16] block-reduction scratch
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
 
   auto block_sum2 = [&](double a, double b, double& oa, double& ob) {   // sum over the workgroup of two values
@@ -599,8 +617,7 @@ __global__ __launch_bounds__(1024) void eigh_ql_kernel(const c64* __restrict__ H
   const long long t_start = clock64();
   for (int i = tid; i < n * n; i += nt) M[i] = Hin[i];
   __syncthreads();
-  // ---- 1. tridiagonalisation (zhetd2, lower)
-  for (int k = 0; k < n - 1; ++k) {
+  for (int k = 0; k < n - 1; ++k) {                 // zhetd2, lower
     const int m = n - k - 1;                        // trailing size, rows/cols k+1 .. n-1
     double xn2 = 0.0, dummy = 0.0;
     for (int i = k + 2 + tid; i < n; i += nt) { const c64 x = M[i + n * k]; xn2 += x.re * x.re + x.im * x.im; }
@@ -619,16 +636,34 @@ __global__ __launch_bounds__(1024) void eigh_ql_kernel(const c64* __restrict__ H
     for (int i = k + 1 + tid; i < n; i += nt) {
       const c64 vi = (i == k + 1) ? mk(1.0, 0.0) : M[i + n * k] * scale;
       sv[i] = vi;
-      if (i > k + 1) M[i + n * k] = vi;             // keep the reflector for step 2
+      if (i > k + 1) M[i + n * k] = vi;             // keep the reflector for zungtr
     }
-    if (tid == 0) { sd[k] = M[k + n * k].re; se[k] = beta; stau[k] = tau; }
+    if (tid == 0) { S.d[k] = M[k + n * k].re; S.e[k] = beta; S.tau[k] = tau; }
     __syncthreads();
     if (tau.re != 0.0 || tau.im != 0.0) {
-      // p = tau * A22 * v   (thread per row, coalesced across lanes)
-      for (int i = k + 1 + tid; i < n; i += nt) {
-        c64 acc = mk(0.0, 0.0);
-        for (int j = k + 1; j < n; ++j) acc = fma(M[i + n * j], sv[j], acc);
-        sp[i] = tau * acc;
+      // p = tau * A22 * v: thread (row i, column quarter jq); rows are coalesced across lanes, the four quarters of a
+      // row are summed through LDS.  (One thread per row left 3/4 of the workgroup idle and walked the m columns as one
+      // dependent chain of L2 round trips.)
+      {
+        const int rows_pt = (m + 255) >> 8;
+        const int jq = tid >> 8, il = tid & 255;
+        const int jlen = (m + 3) >> 2;
+        const int j0 = k + 1 + jq * jlen, j1 = min(n, j0 + jlen);
+        for (int rr = 0; rr < rows_pt; ++rr) {
+          const int i = k + 1 + il + 256 * rr;
+          c64 a0 = mk(0.0, 0.0), a1 = a0, a2 = a0, a3 = a0;
+          if (i < n && jq < 4) {
+            int j = j0;
+            for (; j + 4 <= j1; j += 4) {
+              const c64 m0 = M[i + n * j], m1 = M[i + n * (j + 1)], m2 = M[i + n * (j + 2)], m3 = M[i + n * (j + 3)];
+              a0 = fma(m0, sv[j], a0); a1 = fma(m1, sv[j + 1], a1); a2 = fma(m2, sv[j + 2], a2); a3 = fma(m3, sv[j + 3], a3);
+            }
+            for (; j < j1; ++j) a0 = fma(M[i + n * j], sv[j], a0);
+            spart[jq * n + i] = (a0 + a1) + (a2 + a3);
+          }
+        }
+        __syncthreads();
+        for (int i = k + 1 + tid; i < n; i += nt) sp[i] = tau * ((spart[i] + spart[n + i]) + (spart[2 * n + i] + spart[3 * n + i]));
       }
       __syncthreads();
       // alpha2 = -1/2 tau (p^H v);  w = p + alpha2 v
@@ -640,91 +675,137 @@ __global__ __launch_bounds__(1024) void eigh_ql_kernel(const c64* __restrict__ H
       __syncthreads();
       for (int i = k + 1 + tid; i < n; i += nt) sp[i] = sp[i] + a2 * sv[i];
       __syncthreads();
-      // A22 -= v w^H + w v^H
-      for (int e = tid; e < m * m; e += nt) {
-        const int i = k + 1 + e % m, j = k + 1 + e / m;
-        M[i + n * j] = M[i + n * j] - mul_conj(sv[i], sp[j]) - mul_conj(sp[i], sv[j]);
+      // A22 -= v w^H + w v^H   (thread = row slot x column phase: rows coalesced, no per-element division)
+      for (int i = k + 1 + (tid & 255); i < n; i += 256) {
+        const c64 vi = sv[i], wi = sp[i];
+        for (int j = k + 1 + (tid >> 8); j < n; j += (nt >> 8))
+          M[i + n * j] = M[i + n * j] - mul_conj(vi, sp[j]) - mul_conj(wi, sv[j]);
       }
     }
     __syncthreads();
   }
-  if (tid == 0) { sd[n - 1] = M[n - 1 + n * (n - 1)].re; se[n - 1] = 0.0; }
-  const long long t_tri = clock64();
-  // ---- 2. Q (zungtr): Z = H_0 H_1 ... H_{n-2}, accumulated backwards
-  for (int i = tid; i < n * n; i += nt) Z[i] = mk((i % n) == (i / n) ? 1.0 : 0.0, 0.0);
-  __syncthreads();
-  for (int k = n - 2; k >= 0; --k) {
-    const c64 tau = stau[k];
-    if (tau.re == 0.0 && tau.im == 0.0) continue;   // (uniform)
-    const int m = n - k - 1;
-    for (int i = k + 1 + tid; i < n; i += nt) sv[i] = (i == k + 1) ? mk(1.0, 0.0) : M[i + n * k];
-    __syncthreads();
-    // u[j] = v^H Z[k+1:, j]
-    for (int j = k + 1 + tid; j < n; j += nt) {
-      c64 acc = mk(0.0, 0.0);
-      for (int i = k + 1; i < n; ++i) acc = fma(conj(sv[i]), Z[i + n * j], acc);
-      sp[j] = tau * acc;
-    }
-    __syncthreads();
-    for (int e = tid; e < m * m; e += nt) {
-      const int i = k + 1 + e % m, j = k + 1 + e / m;
-      Z[i + n * j] = Z[i + n * j] - sv[i] * sp[j];
-    }
-    __syncthreads();
+  if (tid == 0) {
+    S.d[n - 1] = M[n - 1 + n * (n - 1)].re; S.e[n - 1] = 0.0;
+    if (info) info[1] = (int)((clock64() - t_start) >> 6);
   }
-  const long long t_q = clock64();
-  // ---- 3. implicit QL (tql2); wave-private (d, e), thread-private rows of Z, no barriers
+}
+
+// block 0: zungtr; block 1 (first wavefront): tql2 recurrence, rotations recorded
+__global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratch, double* __restrict__ w_out, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  EighScratch S(scratch, n);
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
+  const long long t0 = clock64();
+  if (blockIdx.x == 0) {
+    // ---- Q (zungtr): Z = H_0 H_1 ... H_{n-2}, accumulated backwards
+    const c64* M = S.M;
+    c64* Z = S.Z;
+    c64* sv = reinterpret_cast<c64*>(smem_raw);     // [n]
+    c64* sp = sv + n;                               // [n]
+    for (int i = tid; i < n * n; i += nt) Z[i] = mk((i % n) == (i / n) ? 1.0 : 0.0, 0.0);
+    __syncthreads();
+    for (int k = n - 2; k >= 0; --k) {
+      const c64 tau = S.tau[k];
+      if (tau.re == 0.0 && tau.im == 0.0) continue; // (uniform)
+      for (int i = k + 1 + tid; i < n; i += nt) sv[i] = (i == k + 1) ? mk(1.0, 0.0) : M[i + n * k];
+      __syncthreads();
+      // u[j] = v^H Z[k+1:, j]: one wave per column (lanes along the column: coalesced), shuffle reduction
+      for (int j = k + 1 + wid; j < n; j += nw) {
+        c64 acc = mk(0.0, 0.0);
+        for (int i = k + 1 + lane; i < n; i += 64) acc = fma(conj(sv[i]), Z[i + n * j], acc);
+        for (int o = 32; o > 0; o >>= 1) { acc.re += __shfl_down(acc.re, o); acc.im += __shfl_down(acc.im, o); }
+        if (lane == 0) sp[j] = tau * acc;
+      }
+      __syncthreads();
+      for (int i = k + 1 + (tid & 255); i < n; i += 256) {
+        const c64 vi = sv[i];
+        for (int j = k + 1 + (tid >> 8); j < n; j += (nt >> 8)) Z[i + n * j] = Z[i + n * j] - vi * sp[j];
+      }
+      __syncthreads();
+    }
+    if (tid == 0 && info) info[2] = (int)((clock64() - t0) >> 6);
+    return;
+  }
+  if (wid != 0) return;
+  // ---- implicit QL (tql2) on (d, e) only.  All 64 lanes compute the same scalars (no divergence, no broadcasts);
+  // lanes only split the work in the split search, the backup copy and the flush of the recorded rotations.
+  // A lone wavefront issues one instruction every ~5-8 cycles whatever the dependences (tools/latbench.hip: the whole
+  // recurrence from registers = 160 cycles per rotation), so the loop is written for instruction count: (d, e) are
+  // interleaved in one LDS array (one 16-byte read and one 16-byte write per rotation), no per-rotation underflow test
+  // (a zero r^2 turns the carried values into NaNs, tested once after the sweep).
+  c64* de = reinterpret_cast<c64*>(smem_raw);       // [n] (.re = d, .im = e)
+  c64* bde = de + n;                                // [n] backup of the sweep window (r == 0 recovery)
+  c64* rec = bde + n;                               // [n] rotations of the current sweep
+  for (int i = lane; i < n; i += 64) de[i] = mk(S.d[i], S.e[i]);
   int sweeps = 0;
-  const int row_waves = (n + 63) >> 6;
-  if (wid < row_waves && wid < 4) {
-    double* d = swd + wid * n;
-    double* e = swe + wid * n;
-    for (int i = lane; i < n; i += 64) { d[i] = sd[i]; e[i] = se[i]; }
-    const bool own = tid < n;
-    const int r = own ? tid : n - 1;                // my row of Z; surplus lanes shadow row n-1 (same loads, same stores)
-    for (int l = 0; l < n; ++l) {
-      int iter = 0;
-      while (true) {
-        // every lane computes the same scalars; readfirstlane tells the compiler so (scalar branches instead of
-        // exec-mask juggling around each break)
-        // first mm >= l with a negligible e[mm] (or n-1): 64 candidates per ballot instead of a serial scan
-        // (a VALU -> SALU hand-off costs ~110 cycles on this chip, tools/latbench.hip)
-        int mm = n - 1;
-        for (int base = l; base < n - 1; base += 64) {
-          const int j = base + lane;
-          bool small = false;
-          if (j < n - 1) small = fabs(e[j]) <= 2.220446049250313e-16 * (fabs(d[j]) + fabs(d[j + 1]));
-          const unsigned long long mask = __ballot(small);
-          if (mask) { mm = base + __builtin_ctzll(mask); break; }
-        }
-        if (mm == l) break;
-        if (++iter > 60) break;                     // (never reached for Hermitian input; keeps the loop bounded)
-        ++sweeps;
-        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-        double rr = sqrt(g * g + 1.0);
-        g = d[mm] - d[l] + e[l] / (g + copysign(rr, g));
-        double sn = 1.0, cs = 1.0, p = 0.0;
-        c64 zhi = Z[r + n * mm];                       // column i+1 of my row, carried between rotations
+  long long nrot = 0;
+  int overflow = 0;
+  for (int l = 0; l < n && !overflow; ++l) {
+    int iter = 0;
+    while (true) {
+      // first mm >= l with a negligible e[mm] (or n-1): 64 candidates per ballot instead of a serial scan
+      // (a VALU -> SALU hand-off costs ~110 cycles on this chip, tools/latbench.hip)
+      int mm = n - 1;
+      for (int base = l; base < n - 1; base += 64) {
+        const int j = base + lane;
+        bool small = false;
+        if (j < n - 1) small = fabs(de[j].im) <= 2.220446049250313e-16 * (fabs(de[j].re) + fabs(de[j + 1].re));
+        const unsigned long long mask = __ballot(small);
+        if (mask) { mm = base + __builtin_ctzll(mask); break; }
+      }
+      if (mm == l) break;
+      if (++iter > 60) break;                       // (never reached for Hermitian input; keeps the loop bounded)
+      if (sweeps >= S.desc_cap || nrot + (mm - l) > S.rot_cap) { overflow = 1; break; }
+      for (int i = l + lane; i <= mm; i += 64) bde[i] = de[i];
+      const c64 de_l = de[l];
+      double g0 = (de[l + 1].re - de_l.re) / (2.0 * de_l.im);
+      const double r0 = sqrt(g0 * g0 + 1.0);
+      g0 = de[mm].re - de_l.re + de_l.im / (g0 + copysign(r0, g0));
+      // ---- fast chase
+      double g = g0, sn = 1.0, cs = 1.0, p = 0.0;
+      {
         int i = mm - 1;
-        // software pipeline: operands of rotation i-1 are fetched while rotation i computes; d[i+1] of rotation i
-        // is the d[i] rotation i+1 already holds, so each rotation issues one d load, one e load and one Z load.
-        // The chase is one dependent fp64 chain (~20 ops x 11 cycles).  Anything that routes a VALU result through
-        // the scalar unit (a branch on it, or boolean algebra on compare masks) adds ~100 cycles per hop, so the
-        // rr == 0 recovery of tql2 (rare) is carried as a 0/1 double: once it triggers, `lv` = 0 turns the remaining
-        // rotations of this sweep into identities and every store writes back the value it found; all stores are
-        // unconditional (surplus lanes shadow row n-1 and write the same values as its owner).
-        double d_hi = d[mm], e_hi = e[mm];
-        double e_i = e[i], d_i = d[i];
-        c64 zlo = Z[r + n * i];
+        double d_hi = de[mm].re;
+        c64 x = de[i];                               // (d_i, e_i)
+        for (; i >= l; --i) {
+          const c64 nx = de[i > l ? i - 1 : l];      // operands of the next rotation, fetched one ahead
+          const double f = sn * x.im;
+          const double b = cs * x.im;
+          const double rr2 = ::fma(f, f, g * g);
+          // 1/sqrt(rr2): hardware estimate + two Newton steps (relative error ~1e-16), instead of sqrt + two divides
+          double inv = __builtin_amdgcn_rsq(rr2);
+          const double hrs = 0.5 * rr2;
+          inv = ::fma(::fma(-hrs * inv, inv, 0.5), inv, inv);
+          inv = ::fma(::fma(-hrs * inv, inv, 0.5), inv, inv);
+          sn = f * inv;
+          cs = g * inv;
+          const double g1 = d_hi - p;
+          const double rr1 = ::fma(x.re - g1, sn, 2.0 * cs * b);
+          p = sn * rr1;
+          de[i + 1] = mk(g1 + p, rr2 * inv);         // d[i+1], e[i+1] = r
+          g = ::fma(cs, rr1, -b);
+          rec[mm - 1 - i] = mk(cs, sn);
+          d_hi = x.re;
+          x = nx;
+        }
+      }
+      bool underflow = false;
+      if (__builtin_amdgcn_readfirstlane((int)!(g == g && p == p))) {
+        // ---- tql2's r == 0 exit happened somewhere in this sweep (or the input holds a NaN): restore and redo it
+        // carefully.  The recovery is carried as a 0/1 double (`lv`): once r == 0, the remaining rotations become
+        // identities and every store writes back the value it found -- no branch on a VALU result inside the chain.
+        for (int i = l + lane; i <= mm; i += 64) de[i] = bde[i];
+        g = g0; sn = 1.0; cs = 1.0; p = 0.0;
+        int i = mm - 1;
+        double d_hi = de[mm].re, e_hi = de[mm].im;
+        double e_i = de[i].im, d_i = de[i].re;
         double lv = 1.0, uf = 0.0;
         for (; i >= l; --i) {
           const int ip = i > l ? i - 1 : l;
-          const double e_nx = e[ip], d_nx = d[ip];
-          const c64 z_nx = Z[r + n * ip];
+          const double e_nx = de[ip].im, d_nx = de[ip].re;
           const double f = sn * e_i;
           const double b = cs * e_i;
           const double rr2 = ::fma(f, f, g * g);
-          // 1/sqrt(rr2): hardware estimate + two Newton steps (relative error ~1e-16), instead of sqrt + two divides
           const double rs = (rr2 == 0.0) ? 1.0 : rr2;
           double inv = __builtin_amdgcn_rsq(rs);
           const double hrs = 0.5 * rs;
@@ -738,34 +819,135 @@ __global__ __launch_bounds__(1024) void eigh_ql_kernel(const c64* __restrict__ H
           const double d_cand = (rr2 == 0.0) ? g1 : g1 + p_n;    // d[i+1]  (tql2: d[i+1] -= p when r == 0)
           const double g_n = ::fma(cs_n, rr1, -b);
           const double rotf = (rr2 == 0.0) ? 0.0 : lv;           // 1: apply this rotation
-          e[i + 1] = (lv != 0.0) ? e_cand : e_hi;
-          d[i + 1] = (lv != 0.0) ? d_cand : d_hi;
-          // z[r][i+1] = s z[r][i] + c z[r][i+1];  z[r][i] = c z[r][i] - s z[r][i+1]
-          const bool rot = rotf != 0.0;
-          c64 nhi = mk(::fma(sn_n, zlo.re, cs_n * zhi.re), ::fma(sn_n, zlo.im, cs_n * zhi.im));
-          c64 nlo = mk(::fma(cs_n, zlo.re, -sn_n * zhi.re), ::fma(cs_n, zlo.im, -sn_n * zhi.im));
-          nhi.re = rot ? nhi.re : zhi.re; nhi.im = rot ? nhi.im : zhi.im;
-          nlo.re = rot ? nlo.re : zlo.re; nlo.im = rot ? nlo.im : zlo.im;
-          Z[r + n * (i + 1)] = nhi;
-          zhi = nlo;
-          sn = rot ? sn_n : sn; cs = rot ? cs_n : cs; p = rot ? p_n : p; g = rot ? g_n : g;
+          de[i + 1] = mk((lv != 0.0) ? d_cand : d_hi, (lv != 0.0) ? e_cand : e_hi);
+          const bool on = rotf != 0.0;
+          rec[mm - 1 - i] = mk(on ? cs_n : 1.0, on ? sn_n : 0.0);
+          sn = on ? sn_n : sn; cs = on ? cs_n : cs; p = on ? p_n : p; g = on ? g_n : g;
           uf += lv - rotf;
           lv = rotf;
-          d_hi = d_i; e_hi = e_i; d_i = d_nx; e_i = e_nx; zlo = z_nx;
+          d_hi = d_i; e_hi = e_i; d_i = d_nx; e_i = e_nx;
         }
-        Z[r + n * (i + 1)] = zhi;                   // the last carried column
-        if (__builtin_amdgcn_readfirstlane((int)(uf != 0.0))) { e[mm] = 0.0; continue; }
-        { const double dl = d[l] - p; d[l] = dl; e[l] = g; e[mm] = 0.0; }
+        underflow = __builtin_amdgcn_readfirstlane((int)(uf != 0.0)) != 0;
       }
+      // hand the sweep to the replay kernel
+      for (int k = lane; k < mm - l; k += 64) S.rot[nrot + k] = rec[k];
+      if (lane == 0) { S.desc[2 * sweeps] = mm; S.desc[2 * sweeps + 1] = l; }
+      nrot += mm - l;
+      ++sweeps;
+      if (underflow) { de[mm].im = 0.0; continue; }
+      { const double dl = de[l].re - p; de[l] = mk(dl, g); de[mm].im = 0.0; }
     }
-    if (wid == 0) for (int i = lane; i < n; i += 64) w_out[i] = d[i];
   }
+  for (int i = lane; i < n; i += 64) w_out[i] = de[i].re;
+  if (lane == 0) {
+    S.cnt[0] = sweeps; S.cnt[1] = (int)nrot; S.cnt[2] = overflow;
+    if (info) { info[0] = overflow ? -1 : sweeps; info[3] = (int)((clock64() - t0) >> 6); info[5] = (int)nrot; }
+  }
+}
+
+// Replay of the recorded plane rotations on Z.  One thread per (row, real/imaginary part): the rotations are real, so
+// the two parts of a row never mix, and rows are independent.  LDS = true: the workgroup keeps its rows in LDS for the
+// whole replay (blockDim x n doubles, column-major over the threads: conflict-free), Z is read once and V written once.
+// (Streaming the rows through global memory instead stalls on the store acknowledgements -- loads and stores share
+// vmcnt on this chip -- ~480 cycles per rotation; it remains as the fallback for n too large for LDS.)
+// (c, s) and the sweep table have wave-uniform addresses (scalar loads).
+template <bool LDS>
+__global__ __launch_bounds__(256) void eigh_replay_kernel(int n, void* scratch, c64* __restrict__ V_out, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  EighScratch S(scratch, n);
+  const long long t0 = clock64();
+  const int bt = blockDim.x;
+  const int gid = blockIdx.x * bt + threadIdx.x;
+  const int n_items = 2 * n;
+  const int item = gid < n_items ? gid : n_items - 1;           // surplus lanes shadow the last item (same values, same stores)
+  double* Zg = reinterpret_cast<double*>(S.Z) + item;            // element (row, col, part) at Zg[2 n col], item = 2 row + part
+  const long long gs = 2 * (long long)n;                         // global column stride in doubles
+  double* Zd;
+  long long cs;
+  if constexpr (LDS) {
+    Zd = reinterpret_cast<double*>(smem_raw) + threadIdx.x;
+    cs = bt;
+    for (int c = 0; c < n; ++c) Zd[cs * c] = Zg[gs * c];
+  } else {
+    Zd = Zg;
+    cs = gs;
+  }
+  const int n_sweeps = S.cnt[0];
+  const c64* __restrict__ rot = S.rot;
+  const int* __restrict__ desc = S.desc;
+  // The (c, s) of one sweep are staged in LDS (double buffered; the global loads of sweep q+1 are issued before sweep q
+  // is replayed): a direct read per rotation is a dependent L2 round trip -- ~330 cycles per rotation measured.
+  c64* stage = reinterpret_cast<c64*>(smem_raw + (LDS ? (size_t)bt * n * sizeof(double) : 0));   // [2][n]
+  const int per_thread = (n + bt - 1) / bt;         // rotations each thread stages per sweep (<= 8 for bt >= n / 8)
+  c64 pre[8];
+  auto fetch = [&](long long o, int cnt) {          // unconditional loads (clamped): all eight fly together
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = threadIdx.x + u * bt;
+      pre[u] = rot[o + ((u < per_thread && k < cnt) ? k : 0)];
+    }
+  };
+  auto stash = [&](int buf, int cnt) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = threadIdx.x + u * bt;
+      if (u < per_thread && k < cnt) stage[buf * n + k] = pre[u];
+    }
+  };
+  long long off = 0;
+  if (n_sweeps > 0) { fetch(0, desc[0] - desc[1]); stash(0, desc[0] - desc[1]); }
   __syncthreads();
-  for (int i = tid; i < n * n; i += nt) V_out[i] = Z[i];
-  if (tid == 0 && info) {
-    info[0] = sweeps;
-    info[1] = (int)((t_tri - t_start) >> 6); info[2] = (int)((t_q - t_tri) >> 6); info[3] = (int)((clock64() - t_q) >> 6);   // x64 cycles
+  for (int q = 0; q < n_sweeps; ++q) {
+    const int mm = desc[2 * q], lo = desc[2 * q + 1];
+    const int cnt = mm - lo;
+    const bool more = q + 1 < n_sweeps;
+    const int cnt_nx = more ? desc[2 * q + 2] - desc[2 * q + 3] : 0;
+    if (more) fetch(off + cnt, cnt_nx);              // in flight during the replay below
+    const c64* rec = stage + (q & 1) * n;
+    double zhi = Zd[cs * mm];                        // column i+1 of my row, carried between rotations
+    int i = mm - 1;
+    // full groups of eight rotations: operands of group g+1 are read before group g is computed, nothing conditional
+    // inside, and the only loop-carried dependence is one FMA per rotation (zhi)
+    double zl[8];
+    c64 cg[8];
+    if (i - 7 >= lo) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { zl[u] = Zd[cs * (i - u)]; cg[u] = rec[mm - 1 - (i - u)]; }
+    }
+    while (i - 7 >= lo) {
+      double zn[8];
+      c64 cn[8];
+      const bool next_full = i - 15 >= lo;
+      const int ib = next_full ? i - 8 : i;          // (uniform) re-read the same group when no full group follows
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { zn[u] = Zd[cs * (ib - u)]; cn[u] = rec[mm - 1 - (ib - u)]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        // z[r][i+1] = s z[r][i] + c z[r][i+1];  z[r][i] = c z[r][i] - s z[r][i+1]
+        const double czl = cg[u].re * zl[u];
+        Zd[cs * (i - u + 1)] = ::fma(cg[u].im, zl[u], cg[u].re * zhi);
+        zhi = ::fma(-cg[u].im, zhi, czl);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { zl[u] = zn[u]; cg[u] = cn[u]; }
+      i -= 8;
+    }
+    for (; i >= lo; --i) {                           // tail (< 8 rotations)
+      const c64 c1 = rec[mm - 1 - i];
+      const double z1 = Zd[cs * i];
+      Zd[cs * (i + 1)] = ::fma(c1.im, z1, c1.re * zhi);
+      zhi = ::fma(-c1.im, zhi, c1.re * z1);
+    }
+    Zd[cs * lo] = zhi;                               // the last carried column
+    off += cnt;
+    if (more) stash((q + 1) & 1, cnt_nx);
+    __syncthreads();
   }
+  if (gid < n_items) {
+    double* Vd = reinterpret_cast<double*>(V_out) + item;
+    for (int c = 0; c < n; ++c) Vd[gs * c] = Zd[cs * c];
+  }
+  if (gid == 0 && info) info[4] = (int)((clock64() - t0) >> 6);
 }
 
 // ---------------------------------------------------------------- MUSIC pseudo-spectrum (ULA), music.m:82-91
@@ -968,21 +1150,31 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
   ISAC_TRY(ensure(ctx, ctx->eig_w, sizeof(double) * (size_t)A + 64));
   ISAC_TRY(ensure(ctx, ctx->eig_v, sizeof(c64) * (size_t)A * A));
   int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
-  // measured: Jacobi wins while H and V fit LDS (A = 64: 1.4 ms vs 2.3 ms), tridiagonal QL wins beyond (A = 256: 48 ms vs 99 ms)
+  // measured: Jacobi wins while H and V fit LDS (A = 64: 1.4 ms vs 1.8 ms), the tridiagonal route wins beyond (A = 256: 99 ms Jacobi)
   static const bool force_ql = std::getenv("ISAC_EIG_QL") != nullptr;
-  if (!use_jacobi && A <= 256 && (big || force_ql)) {
+  if (!use_jacobi && A >= 3 && (big || force_ql)) {
     const int n = A;
-    c64* gs = nullptr;
-    if (big) {
-      ISAC_TRY(ensure(ctx, ctx->eig_scratch, sizeof(c64) * (size_t)2 * n * n));
-      gs = (c64*)ctx->eig_scratch.p;
-    }
-    size_t lds = sizeof(c64) * ((big ? 0 : (size_t)2 * n * n) + 3 * (size_t)n) + sizeof(double) * (10 * (size_t)n + 32) + 64;
-    if (big) {
-      hipLaunchKernelGGL(eigh_ql_kernel<true>, dim3(1), dim3(1024), lds, st, d_H, A, (double*)ctx->eig_w.p, (c64*)ctx->eig_v.p, info, gs);
+    ISAC_TRY(ensure(ctx, ctx->eig_scratch, EighScratch::bytes(n)));
+    void* gs = ctx->eig_scratch.p;
+    const size_t lds1 = sizeof(c64) * 6 * (size_t)n + sizeof(double) * 32 + 64;
+    hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
+    ISAC_HIP(hipGetLastError());
+    // > half of a CU's LDS, so that the two workgroups cannot share a CU: next to the 16 waves of the zungtr block the
+    // single recurrence wavefront only got every other issue slot (345 instead of 160 cycles per rotation)
+    size_t lds2 = sizeof(c64) * 3 * (size_t)n + sizeof(double) * 4 * (size_t)n + 64;
+    if (lds2 < 96 * 1024) lds2 = 96 * 1024;
+    { static bool set = false; if (!set) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_formq_ql_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } }
+    hipLaunchKernelGGL(eigh_formq_ql_kernel, dim3(2), dim3(1024), lds2, st, n, gs, (double*)ctx->eig_w.p, info);
+    ISAC_HIP(hipGetLastError());
+    int bt = 64;                                       // threads per replay workgroup: its rows must fit LDS
+    if ((size_t)bt * n * sizeof(double) > 150 * 1024) bt = 32;
+    const size_t rows3 = (size_t)bt * n * sizeof(double), stage3 = sizeof(c64) * 2 * (size_t)n;
+    const size_t lds3 = rows3 + stage3;
+    if (rows3 <= 150 * 1024 && n <= 8 * bt) {
+      { static size_t set_for = 0; if (set_for < lds3) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_replay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); set_for = lds3; } }
+      hipLaunchKernelGGL(eigh_replay_kernel<true>, dim3((unsigned)((2 * n + bt - 1) / bt)), dim3(bt), lds3, st, n, gs, (c64*)ctx->eig_v.p, info);
     } else {
-      { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_ql_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
-      hipLaunchKernelGGL(eigh_ql_kernel<false>, dim3(1), dim3(1024), lds, st, d_H, A, (double*)ctx->eig_w.p, (c64*)ctx->eig_v.p, info, gs);
+      hipLaunchKernelGGL(eigh_replay_kernel<false>, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), stage3, st, n, gs, (c64*)ctx->eig_v.p, info);
     }
     ISAC_HIP(hipGetLastError());
     return ISAC_OK;
