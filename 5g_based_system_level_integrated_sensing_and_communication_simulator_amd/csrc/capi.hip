@@ -630,8 +630,11 @@ extern "C" int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w,
   if (std::getenv("ISAC_DEBUG")) {
     int inf[6] = {-1, 0, 0, 0, 0, 0};
     ISAC_HIP(hipMemcpy(inf, (char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(inf), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "[isac] eigh A=%d sweeps=%d rotations=%d phases(x64 clk): tridiag=%d formQ=%d ql-recurrence=%d replay=%d\n", A, inf[0],
-                 inf[5], inf[1], inf[2], inf[3], inf[4]);
+    if (inf[5] < 0)
+      std::fprintf(stderr, "[isac] eigh A=%d Jacobi sweeps=%d phases(x64 clk): rotation parameters=%d two-sided updates=%d\n", A, inf[0], inf[1], inf[2]);
+    else
+      std::fprintf(stderr, "[isac] eigh A=%d QL sweeps=%d rotations=%d phases(x64 clk): tridiag=%d formQ=%d ql-recurrence=%d replay=%d\n", A, inf[0],
+                   inf[5], inf[1], inf[2], inf[3], inf[4]);
   }
   std::vector<int> order((size_t)A);
   std::iota(order.begin(), order.end(), 0);

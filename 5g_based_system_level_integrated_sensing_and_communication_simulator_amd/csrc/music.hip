@@ -556,7 +556,7 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
     int r = i % A, c = i / A;
     V_out[i] = V[r + n * c];
   }
-  if (tid == 0 && info) { info[0] = sweep; info[1] = (int)(cyc_p >> 6); info[2] = (int)(cyc_u >> 6); info[3] = 0; }
+  if (tid == 0 && info) { info[0] = sweep; info[1] = (int)(cyc_p >> 6); info[2] = (int)(cyc_u >> 6); info[3] = 0; info[4] = 0; info[5] = -1; }
 }
 
 // ---------------------------------------------------------------- Hermitian eigensolver II: Householder tridiagonalisation + implicit QL
