@@ -436,6 +436,25 @@ __global__ __launch_bounds__(1024) void cov_reduce_kernel(const double* __restri
   }
 }
 
+// zheev-style safe scaling: when the largest |entry| lies outside [2^-400, 2^400] (squares would under/overflow), the
+// matrix is multiplied by an exact power of two on load and the eigenvalues by its inverse on output.  Returns the factor
+// (1.0 in the normal range, so ordinary inputs are untouched bit for bit).  s_red: >= 16 doubles of LDS.
+__device__ __forceinline__ double eigh_safe_scale(const c64* __restrict__ Hin, int count, double* s_red) {
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
+  double mx = 0.0;
+  for (int i = tid; i < count; i += nt) { const c64 v = Hin[i]; mx = fmax(mx, fmax(fabs(v.re), fabs(v.im))); }
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o));
+  __syncthreads();
+  if (lane == 0) s_red[wid] = mx;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < nw; ++w) t = fmax(t, s_red[w]);
+  __syncthreads();
+  if (!(t > 0.0) || !(t < 1.7976931348623157e308)) return 1.0;      // zero matrix, Inf or NaN: leave as is
+  const int ex = ilogb(t);
+  return (ex < -400 || ex > 400) ? ldexp(1.0, -ex) : 1.0;
+}
+
 // ---------------------------------------------------------------- Hermitian eigensolver: one-workgroup cyclic Jacobi in LDS
 // Round-robin (tournament) ordering: A/2 disjoint rotations per round, A-1 rounds per sweep.
 constexpr int kJacobiMaxA = 64;
@@ -475,9 +494,10 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
   int* rp = reinterpret_cast<int*>(rc + h);        // [h] p_k
   int* rq = rp + h;                                // [h] q_k
   const int tid = threadIdx.x, nt = blockDim.x;
+  const double scl = eigh_safe_scale(Hin, A * A, reinterpret_cast<double*>(smem_raw));   // (LDS not in use yet; >= 128 B for n >= 2)
   for (int i = tid; i < n * n; i += nt) {
     int r = i % n, c = i / n;
-    H[i] = (r < A && c < A) ? Hin[r + (long long)A * c] : mk(0.0, 0.0);
+    H[i] = (r < A && c < A) ? Hin[r + (long long)A * c] * scl : mk(0.0, 0.0);
     V[i] = mk(r == c ? 1.0 : 0.0, 0.0);
   }
   __syncthreads();
@@ -551,7 +571,7 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
     __syncthreads();                      // everyone has read the flag before thread 0 clears it again
     if (!dirty) { ++sweep; break; }
   }
-  for (int i = tid; i < A; i += nt) w_out[i] = H[i + n * i].re;
+  for (int i = tid; i < A; i += nt) w_out[i] = H[i + n * i].re / scl;     // (power of two: exact)
   for (int i = tid; i < A * A; i += nt) {
     int r = i % A, c = i / A;
     V_out[i] = V[r + n * c];
@@ -573,12 +593,12 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
 // A = 256: 99 ms (Jacobi in global memory) -> 27 ms (one workgroup doing everything) -> see DESIGN.md section 6.
 struct EighScratch {   // carve of ctx->eig_scratch for order n
   c64 *M, *Z, *tau, *rot;
-  double *d, *e;
+  double *d, *e, *scale;
   int *desc, *cnt;     // desc: (mm, l) per sweep; cnt: {n_sweeps, n_rot, overflow, -}
   long long rot_cap;
   int desc_cap;
   __host__ __device__ static size_t bytes(int n) {
-    return sizeof(c64) * ((size_t)2 * n * n + n + (size_t)16 * n * n) + sizeof(double) * 2 * n + sizeof(int) * (2 * (size_t)(30 * n + 2) + 8) + 256;
+    return sizeof(c64) * ((size_t)2 * n * n + n + (size_t)16 * n * n) + sizeof(double) * (2 * n + 4) + sizeof(int) * (2 * (size_t)(30 * n + 2) + 8) + 256;
   }
   __host__ __device__ EighScratch(void* base, int n) {
     c64* p = reinterpret_cast<c64*>(base);
@@ -588,8 +608,9 @@ struct EighScratch {   // carve of ctx->eig_scratch for order n
     rot = p; rot_cap = (long long)16 * n * n; p += rot_cap;
     d = reinterpret_cast<double*>(p);
     e = d + n;
+    scale = e + n + (n & 1);
     desc_cap = 30 * n + 2;
-    desc = reinterpret_cast<int*>(e + n + (n & 1));
+    desc = reinterpret_cast<int*>(scale + 2);
     cnt = desc + 2 * (size_t)desc_cap;
   }
 };
@@ -615,7 +636,9 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
   };
 
   const long long t_start = clock64();
-  for (int i = tid; i < n * n; i += nt) M[i] = Hin[i];
+  const double scl = eigh_safe_scale(Hin, n * n, sred);
+  for (int i = tid; i < n * n; i += nt) M[i] = Hin[i] * scl;
+  if (tid == 0) *S.scale = scl;
   __syncthreads();
   for (int k = 0; k < n - 1; ++k) {                 // zhetd2, lower
     const int m = n - k - 1;                        // trailing size, rows/cols k+1 .. n-1
@@ -838,7 +861,10 @@ __global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratc
       { const double dl = de[l].re - p; de[l] = mk(dl, g); de[mm].im = 0.0; }
     }
   }
-  for (int i = lane; i < n; i += 64) w_out[i] = de[i].re;
+  {
+    const double scl = *S.scale;                    // undo the safe scaling (power of two: exact)
+    for (int i = lane; i < n; i += 64) w_out[i] = de[i].re / scl;
+  }
   if (lane == 0) {
     S.cnt[0] = sweeps; S.cnt[1] = (int)nrot; S.cnt[2] = overflow;
     if (info) { info[0] = overflow ? -1 : sweeps; info[3] = (int)((clock64() - t0) >> 6); info[5] = (int)nrot; }

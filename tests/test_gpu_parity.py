@@ -263,6 +263,53 @@ def test_eigh_jacobi(pkg, ctx, a):
     assert np.abs(h @ v - v * w).max() < 1e-11 * np.abs(wr).max()
 
 
+@pytest.mark.parametrize("kind,a", [("identity", 100), ("rank2", 130), ("diag_repeated", 96), ("tiny", 72), ("huge", 65),
+                                    ("clustered", 200), ("tridiag_zero_blocks", 128),
+                                    ("identity", 12), ("rank2", 40), ("tiny", 33), ("huge", 64), ("clustered", 48), ("zero", 20), ("zero", 80)])
+def test_eigh_degenerate_spectra(pkg, ctx, kind, a):
+    """Edge cases of both eigensolvers (Jacobi A <= 64, tridiagonal/QL pipeline beyond): exact splits, zero and repeated
+    eigenvalues, scales near the fp64 range limits (zheev-style safe scaling), tight clusters, the zero matrix."""
+    rng = np.random.default_rng(a)
+    def rand_unitary(n):
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+        return q
+    if kind == "identity":
+        h = np.eye(a, dtype=np.complex128)
+    elif kind == "rank2":
+        x = rng.standard_normal((a, 2)) + 1j * rng.standard_normal((a, 2))
+        h = x @ x.conj().T
+    elif kind == "zero":
+        h = np.zeros((a, a), dtype=np.complex128)
+    elif kind == "diag_repeated":
+        h = np.diag(np.repeat([3.0, -1.0, 0.0, 7.5], a // 4)).astype(np.complex128)
+    elif kind == "tiny":
+        q = rand_unitary(a)
+        h = (q * rng.uniform(0.5, 2.0, a)) @ q.conj().T * 1e-170
+    elif kind == "huge":
+        q = rand_unitary(a)
+        h = (q * rng.uniform(0.5, 2.0, a)) @ q.conj().T * 1e150
+    elif kind == "clustered":
+        q = rand_unitary(a)
+        w0 = np.concatenate([[100.0, 37.0, 5.0], 1.0 + 1e-13 * rng.standard_normal(a - 3)])
+        h = (q * w0) @ q.conj().T
+    else:
+        h = np.zeros((a, a), dtype=np.complex128)
+        for b0 in range(0, a, 16):                   # decoupled 16 x 16 Hermitian blocks
+            m = rng.standard_normal((16, 16)) + 1j * rng.standard_normal((16, 16))
+            h[b0:b0 + 16, b0:b0 + 16] = m + m.conj().T
+    h = np.asfortranarray((h + h.conj().T) / 2)
+    w = np.zeros(a)
+    v = np.zeros((a, a), dtype=np.complex128, order="F")
+    ctx.check(ctx.lib.isac_eigh(ctx.handle, h.ctypes.data_as(C.c_void_p), C.c_int32(a), w.ctypes.data_as(C.c_void_p),
+                                v.ctypes.data_as(C.c_void_p)))
+    wr = linalg.eigvalsh(h)
+    scale = max(np.abs(wr).max(), 1e-300)
+    assert np.all(np.isfinite(w)) and np.all(np.isfinite(v))
+    assert np.abs(w - wr).max() < 1e-12 * scale
+    assert np.abs(v.conj().T @ v - np.eye(a)).max() < 1e-12
+    assert np.abs(h @ v - v * w).max() < 1e-11 * scale
+
+
 def test_music_doa_kat_and_mirror_ties(pkg, ctx):
     sc = make_scene(n_ants=16, n_slots=1, nrb=24, with_noise=False)
     rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
