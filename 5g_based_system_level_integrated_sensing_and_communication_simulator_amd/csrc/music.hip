@@ -930,6 +930,9 @@ __global__ __launch_bounds__(256) void eigh_replay_kernel(int n, void* scratch, 
     const int cnt_nx = more ? desc[2 * q + 2] - desc[2 * q + 3] : 0;
     if (more) fetch(off + cnt, cnt_nx);              // in flight during the replay below
     const c64* rec = stage + (q & 1) * n;
+    // LDS rows are private, so surplus lanes may replay their shadow copy; in global memory they would race with the
+    // owner of the row (a different wavefront) and must sit the sweep out
+    if (LDS || gid < n_items) {
     double zhi = Zd[cs * mm];                        // column i+1 of my row, carried between rotations
     int i = mm - 1;
     // full groups of eight rotations: operands of group g+1 are read before group g is computed, nothing conditional
@@ -965,6 +968,7 @@ __global__ __launch_bounds__(256) void eigh_replay_kernel(int n, void* scratch, 
       zhi = ::fma(-c1.im, zhi, c1.re * z1);
     }
     Zd[cs * lo] = zhi;                               // the last carried column
+    }
     off += cnt;
     if (more) stash((q + 1) & 1, cnt_nx);
     __syncthreads();

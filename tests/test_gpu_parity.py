@@ -248,7 +248,7 @@ def test_covariance_mfma(pkg, ctx, n, a):
     assert rel(ra, want) < 1e-12 and np.array_equal(ra, ra.conj().T)
 
 
-@pytest.mark.parametrize("a", [2, 5, 16, 33, 64, 96, 256])
+@pytest.mark.parametrize("a", [1, 2, 5, 16, 33, 64, 65, 96, 256, 320, 640])
 def test_eigh_jacobi(pkg, ctx, a):
     rng = np.random.default_rng(a)
     m = rng.standard_normal((a, a)) + 1j * rng.standard_normal((a, a))
