@@ -20,8 +20,6 @@ namespace isac {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-constexpr int kCovTPW = 3;   // tiles per wave
-constexpr int kCovWaves = 4;
 
 __device__ __forceinline__ void tile_ij(int t, int nb, int& I, int& J) {
   // t-th upper-triangular tile in row-major order
@@ -30,68 +28,6 @@ __device__ __forceinline__ void tile_ij(int t, int nb, int& I, int& J) {
   while (rem >= nb - i) { rem -= nb - i; ++i; }
   I = i;
   J = i + rem;
-}
-
-__global__ __launch_bounds__(256, 2) void cov_mfma_kernel(const c64* __restrict__ G, long long N, int A, int n_tiles,
-                                                          long long steps_per_wg /* macro-steps of 16 samples */,
-                                                          double* __restrict__ part /* [gridX][n_tiles][3][256] */) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int li = lane & 15, kq = lane >> 4;
-  const int nb = (A + 15) / 16;
-  const int t0 = (blockIdx.y * kCovWaves + wid) * kCovTPW;
-  int bi[kCovTPW], bj[kCovTPW];
-  bool live[kCovTPW];
-#pragma unroll
-  for (int u = 0; u < kCovTPW; ++u) {
-    live[u] = (t0 + u) < n_tiles;
-    bi[u] = bj[u] = 0;
-    if (live[u]) tile_ij(t0 + u, nb, bi[u], bj[u]);
-  }
-  v4f64 re[kCovTPW], imp[kCovTPW], imm[kCovTPW];
-#pragma unroll
-  for (int u = 0; u < kCovTPW; ++u) re[u] = imp[u] = imm[u] = v4f64{0.0, 0.0, 0.0, 0.0};
-
-  const long long s_begin = (long long)blockIdx.x * steps_per_wg;
-  long long s_end = s_begin + steps_per_wg;
-  const long long total_steps = (N + 15) / 16;
-  if (s_end > total_steps) s_end = total_steps;
-
-  for (long long s = s_begin; s < s_end; ++s) {
-    const long long n0 = s * 16 + 4 * kq;
-#pragma unroll
-    for (int u = 0; u < kCovTPW; ++u) {
-      if (!live[u]) continue;   // wave-uniform
-      const int ca = bi[u] * 16 + li, cb = bj[u] * 16 + li;
-      c64 xa[4], xb[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        long long n = n0 + e;
-        const bool ok = n < N;
-        if (!ok) n = N - 1;
-        const c64 va = G[n + N * (long long)(ca < A ? ca : 0)], vb = G[n + N * (long long)(cb < A ? cb : 0)];   // unconditional loads
-        xa[e] = (ok && ca < A) ? va : mk(0.0, 0.0);
-        xb[e] = (ok && cb < A) ? vb : mk(0.0, 0.0);
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[e].re, xb[e].re, re[u], 0, 0, 0);
-        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[e].im, xb[e].im, re[u], 0, 0, 0);
-        imp[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[e].re, xb[e].im, imp[u], 0, 0, 0);
-        imm[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[e].im, xb[e].re, imm[u], 0, 0, 0);
-      }
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < kCovTPW; ++u) {
-    if (!live[u]) continue;
-    double* o = part + (((long long)blockIdx.x * n_tiles + (t0 + u)) * 3) * 256;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      o[0 * 256 + r * 64 + lane] = re[u][r];
-      o[1 * 256 + r * 64 + lane] = imp[u][r];
-      o[2 * 256 + r * 64 + lane] = imm[u][r];
-    }
-  }
 }
 
 // ---- specialised schedule for A <= 64 (NB = ceil(A/16) <= 4 antenna blocks): every wave keeps ALL blocks'
@@ -476,19 +412,17 @@ __device__ __forceinline__ void rr_pair(int round, int k, int n /* even */, int&
 //   U: thread (a, b) owns the 2x2 block (pair a) x (pair b) of H and applies  J_a^H B J_b  in place
 //      (a one-phase two-sided update -- nobody else touches that block this round); the same
 //      threads rotate two (row, pair) column pairs of V.
-// A <= 64: H and V live in LDS (gscratch == nullptr).  Larger arrays (config 4: 256-element ULA) keep H and V
-// in a global scratch that stays L2-resident (2 MB at A = 256); same algorithm, still one workgroup.
-template <bool BIG>   // compile-time so that H/V accesses are plain ds_* (LDS) or global_* instructions, never flat
+// A <= 64: H and V live in LDS.  Larger arrays take the tridiagonal route below (the same algorithm on a global scratch
+// was 99 ms at A = 256).
 __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict__ Hin, int A, int max_sweeps,
                                                            double* __restrict__ w_out, c64* __restrict__ V_out,
-                                                           int* __restrict__ info /* [0]=sweeps used */, c64* gscratch) {
+                                                           int* __restrict__ info /* [0]=sweeps used */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int n = (A + 1) & ~1;                      // pad to even with an isolated zero row/col
   const int h = n / 2;
   c64* lds0 = reinterpret_cast<c64*>(smem_raw);
-  c64* H;                                          // [n x n] column-major
-  c64* rg;                                         // [h] g_k
-  if constexpr (BIG) { H = gscratch; rg = lds0; } else { H = lds0; rg = lds0 + 2 * n * n; }
+  c64* H = lds0;                                   // [n x n] column-major
+  c64* rg = lds0 + 2 * n * n;                      // [h] g_k
   c64* V = H + n * n;                              // [n x n]
   double* rc = reinterpret_cast<double*>(rg + h);  // [h] c_k
   int* rp = reinterpret_cast<int*>(rc + h);        // [h] p_k
@@ -1124,7 +1058,7 @@ static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long lo
 int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra) {
   if (!d_grid || !d_Ra || N <= 0 || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   const int nb = (A + 15) / 16;
-  if (nb <= 4 && !std::getenv("ISAC_COV_GENERIC")) {
+  if (nb <= 4) {
     switch (nb) {
       case 1: return launch_cov_small<1>(ctx, st, (const c64*)d_grid, N, A, (c64*)d_Ra);
       case 2: return launch_cov_small<2>(ctx, st, (const c64*)d_grid, N, A, (c64*)d_Ra);
@@ -1132,7 +1066,7 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
       default: return launch_cov_small<4>(ctx, st, (const c64*)d_grid, N, A, (c64*)d_Ra);
     }
   }
-  if (!std::getenv("ISAC_COV_GENERIC")) {            // 64 x 64 block pairs (any A > 64)
+  {                                                  // 64 x 64 block pairs (any A > 64)
     const int n_blk = (A + 63) / 64;
     const int n_pairs = n_blk * (n_blk + 1) / 2;
     const long long total = (N + 15) / 16;
@@ -1152,37 +1086,19 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
     ISAC_HIP(hipGetLastError());
     return ISAC_OK;
   }
-  const int n_tiles = nb * (nb + 1) / 2;
-  const int tiles_per_wg = kCovWaves * kCovTPW;
-  const int gy = (n_tiles + tiles_per_wg - 1) / tiles_per_wg;
-  const long long total_steps = (N + 15) / 16;
-  long long gx = 512 / gy;
-  if (gx < 1) gx = 1;
-  if (gx > total_steps) gx = total_steps;
-  const long long steps_per_wg = (total_steps + gx - 1) / gx;
-  gx = (total_steps + steps_per_wg - 1) / steps_per_wg;
-  ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * (size_t)gx * n_tiles * 3 * 256));
-  hipLaunchKernelGGL(cov_mfma_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, (const c64*)d_grid, (long long)N, A,
-                     n_tiles, steps_per_wg, (double*)ctx->cov_part.p);
-  ISAC_HIP(hipGetLastError());
-  hipLaunchKernelGGL(cov_reduce_kernel, dim3(n_tiles), dim3(256, 4), 0, st, (const double*)ctx->cov_part.p, (int)gx,
-                     n_tiles, A, 1.0 / (double)N, (c64*)d_Ra);
-  ISAC_HIP(hipGetLastError());
-  return ISAC_OK;
 }
 
 // device eig: H [A x A] (device) -> ctx->eig_w [A], ctx->eig_v [A x A] (unsorted)
 int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
   if (!st) st = ctx->stream;
   if (A > 1024) return fail(ctx, ISAC_ERR_UNSUPPORTED, "device eigensolver supports up to 1024 antennas");
-  static const bool use_jacobi = std::getenv("ISAC_EIG_JACOBI") != nullptr;
   const bool big = A > kJacobiMaxA;
   ISAC_TRY(ensure(ctx, ctx->eig_w, sizeof(double) * (size_t)A + 64));
   ISAC_TRY(ensure(ctx, ctx->eig_v, sizeof(c64) * (size_t)A * A));
   int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
-  // measured: Jacobi wins while H and V fit LDS (A = 64: 1.4 ms vs 1.8 ms), the tridiagonal route wins beyond (A = 256: 99 ms Jacobi)
-  static const bool force_ql = std::getenv("ISAC_EIG_QL") != nullptr;
-  if (!use_jacobi && A >= 3 && (big || force_ql)) {
+  // measured: Jacobi wins while H and V fit LDS (A = 64: 1.5 ms vs 1.6 ms); beyond, the tridiagonal route is the only one
+  static const bool force_ql = std::getenv("ISAC_EIG_QL") != nullptr;             // development switch: A <= 64 through the pipeline
+  if (A >= 3 && (big || force_ql)) {
     const int n = A;
     ISAC_TRY(ensure(ctx, ctx->eig_scratch, EighScratch::bytes(n)));
     void* gs = ctx->eig_scratch.p;
@@ -1210,17 +1126,9 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
     return ISAC_OK;
   }
   const int n = (A + 1) & ~1;
-  c64* gs = nullptr;
-  if (big) {
-    ISAC_TRY(ensure(ctx, ctx->eig_scratch, sizeof(c64) * (size_t)2 * n * n));
-    gs = (c64*)ctx->eig_scratch.p;
-  }
-  size_t lds = sizeof(c64) * ((big ? 0 : (size_t)2 * n * n) + n / 2) + sizeof(double) * (n / 2) + sizeof(int) * (n + 1) + 64;
-  if (!big) { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
-  if (big)
-    hipLaunchKernelGGL(jacobi_eigh_kernel<true>, dim3(1), dim3(1024), lds, st, d_H, A, 40, (double*)ctx->eig_w.p, (c64*)ctx->eig_v.p, info, gs);
-  else
-    hipLaunchKernelGGL(jacobi_eigh_kernel<false>, dim3(1), dim3(1024), lds, st, d_H, A, 40, (double*)ctx->eig_w.p, (c64*)ctx->eig_v.p, info, gs);
+  size_t lds = sizeof(c64) * ((size_t)2 * n * n + n / 2) + sizeof(double) * (n / 2) + sizeof(int) * (n + 1) + 64;
+  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+  hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(1024), lds, st, d_H, A, 40, (double*)ctx->eig_w.p, (c64*)ctx->eig_v.p, info);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }

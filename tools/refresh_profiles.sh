@@ -32,7 +32,7 @@ rm -rf /tmp/p4 && ISAC_SINGLE_STREAM=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MF
 $PS $(db /tmp/p4) --pmc --csv $OUT/${TAG}_pmc_mfma_busy.csv > /dev/null
 
 python $ROOT/tools/stage_times.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_stage_times_hip_events.txt
-for t in kbench dbench nbench latbench; do
+for t in kbench dbench nbench latbench mbench; do
   [ -x $ROOT/tools/$t ] && $ROOT/tools/$t > $OUT/${TAG}_${t}.txt 2>&1
 done
 python $ROOT/tools/_overlap_probe.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_stage_pair_overlap.txt
