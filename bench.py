@@ -63,17 +63,51 @@ def cell_params(n_ants, targets, velocity):
     return p
 
 
-class Cell:
-    """One cell's device-resident inputs + the per-CPI call chain.  `inflight` contexts (each with its own
-    HIP streams, scratch and echo buffer) let consecutive CPIs of the cell overlap on the GPU: the MUSIC
-    branch of CPI i (covariance -> eig -> scan, latency-bound on one CU) runs under the echo / range
-    kernels of CPI i+1.  Results are collected in submission order."""
+class SlotPool:
+    """`n` execution slots of one GPU (context = HIP streams + scratch) shared by all the cells it hosts: at most `n`
+    CPIs are in flight on the GPU however many cells there are (more than 4 contexts = 8 streams oversubscribe the
+    hardware queues and lose 10-25 %).  Results are collected in submission order."""
 
-    def __init__(self, pkg, device, cell_id, n_ants, n_slots, n_targets, inflight=1, fuse=False):
+    def __init__(self, pkg, device, n):
+        self.ctxs = [pkg.Context(device) for _ in range(max(1, n))]
+        self.owner = [None] * len(self.ctxs)
+        self.k = 0
+
+    def collect(self, slot):
+        cell, self.owner[slot] = self.owner[slot], None
+        return cell.finish(self.ctxs[slot]) if cell is not None else None
+
+    def submit(self, cell):
+        slot = self.k % len(self.ctxs)
+        self.collect(slot)
+        cell.enqueue(self.ctxs[slot])
+        self.owner[slot] = cell
+        self.k += 1
+
+    def drain(self):
+        for s in range(len(self.ctxs)):
+            self.collect((self.k + s) % len(self.ctxs))
+
+    def sync(self):
+        for c in self.ctxs:
+            c.sync()
+
+
+class Cell:
+    """One cell's device-resident inputs + the per-CPI call chain.  CPIs run on the slots of a SlotPool (its own
+    `inflight` slots unless a shared pool is given): consecutive CPIs overlap on the GPU -- the MUSIC branch of
+    CPI i (covariance -> eig -> scan, latency-bound on one CU) runs under the echo / range kernels of CPI i+1.
+    `n_buf` buffer sets (transmit grid + waveform + echo grid) = the number of CPIs of THIS cell that can be in
+    flight at once."""
+
+    def __init__(self, pkg, device, cell_id, n_ants, n_slots, n_targets, inflight=1, fuse=False, pool=None, n_buf=None):
         L = pkg._lib
         self.fuse = fuse
         self.pkg, self.L = pkg, L
-        self.ctxs = [pkg.Context(device) for _ in range(max(1, inflight))]
+        # device arrays are device-global, so a cell's inputs can be consumed on any context of the same device
+        self.pool = pool or SlotPool(pkg, device, inflight)
+        self.ctxs = self.pool.ctxs
+        n_buf = n_buf or len(self.ctxs)
         ctx = self.ctx = self.ctxs[0]
         rng = np.random.default_rng(0x5EED0003 + cell_id)
         r = rng.uniform(50.0, 350.0, n_targets)
@@ -95,7 +129,7 @@ class Cell:
         # overstate the rate by ~13 % (measured)
         amp = 10.0 ** ((46.0 - 30.0) / 20.0) * np.sqrt(4096.0 ** 2 / (self.K * self.A))      # gNBPhy.m:592
         self.tx_grids, self.tx_waves = [], []
-        for s in range(len(self.ctxs)):
+        for s in range(n_buf):
             g = ctx.empty((self.K, self.Lsym, self.A))
             w = ctx.empty((self.T, self.A))
             ctx.check(ctx.lib.isac_synth_qpsk_grid_dev(ctx.handle, C.c_void_p(g.ptr), self.K, self.Lsym, self.A,
@@ -106,42 +140,38 @@ class Cell:
             self.tx_waves.append(w)
         self.tx_grid, self.tx_wave = self.tx_grids[0], self.tx_waves[0]
         self.los = np.ones(n_targets, dtype=np.uint8)
-        self.echo = [c.empty((self.K, self.Lsym, self.A)) for c in self.ctxs]      # one echo grid per in-flight CPI
+        self.echo = [ctx.empty((self.K, self.Lsym, self.A)) for _ in range(n_buf)]  # one echo grid per in-flight CPI
         self.seed = 0x5EED0002 + cell_id
-        self.pending = [False] * len(self.ctxs)
         self.n_sub = 0
         self.last = None
         ctx.sync()
 
-    def _collect(self, slot):
+    def finish(self, ctx):
+        """Collect the CPI this cell enqueued on `ctx`."""
         est = None
-        if self.pending[slot]:
-            try:
-                est = self.pkg.sensing.estimation.fft2D_collect(self.ctxs[slot])
-            except self.pkg.IsacError as e:       # reference: try/catch -> senResults = NaN (cellSimulation.m:196-202)
-                if e.name != "NO_DETECTION":
-                    raise
-            self.pending[slot] = False
-            self.last = est
+        try:
+            est = self.pkg.sensing.estimation.fft2D_collect(ctx)
+        except self.pkg.IsacError as e:           # reference: try/catch -> senResults = NaN (cellSimulation.m:196-202)
+            if e.name != "NO_DETECTION":
+                raise
+        self.last = est
         return est
 
-    def submit(self):
-        """Enqueue one CPI (monoStaticSensing -> fft2D) on the next context; collects that context's
-        previous CPI first."""
-        slot = self.n_sub % len(self.ctxs)
-        self._collect(slot)
-        c = self.ctxs[slot]
-        tx_wave, tx_grid = self.tx_waves[slot], self.tx_grids[slot]
+    def enqueue(self, c):
+        """Enqueue one CPI (monoStaticSensing -> fft2D) on context `c`."""
+        b = self.n_sub % len(self.echo)
+        tx_wave, tx_grid = self.tx_waves[b], self.tx_grids[b]
         echo = self.pkg.sensing.monoStaticSensing(tx_wave, (self.K, self.Lsym, self.A), self.carrier, self.rp, self.los,
-                                                  seed=self.seed + self.n_sub, nfft=4096, out=self.echo[slot], ctx=c,
+                                                  seed=self.seed + self.n_sub, nfft=4096, out=self.echo[b], ctx=c,
                                                   fuse_fft2d=(self.rp, self.cfar, tx_grid) if self.fuse else None)
         self.pkg.sensing.estimation.fft2D_submit(self.rp, self.cfar, echo, tx_grid, ctx=c)
-        self.pending[slot] = True
         self.n_sub += 1
 
+    def submit(self):
+        self.pool.submit(self)
+
     def drain(self):
-        for s in range(len(self.ctxs)):
-            self._collect((self.n_sub + s) % len(self.ctxs))
+        self.pool.drain()
         return self.last
 
     def step(self):
@@ -150,8 +180,7 @@ class Cell:
         return self.drain()
 
     def sync(self):
-        for c in self.ctxs:
-            c.sync()
+        self.pool.sync()
 
     def algorithmic_bytes(self):
         """echo+demod reads txWaveform and writes echoGrid; RDM+CFAR reads rxGrid + txGrid."""
@@ -277,31 +306,28 @@ def main():
             local_rank = local_rank % max(n_dev, 1)
             dist.init_process_group(backend)
     pkg = importlib.import_module(PKG)
-    cells = [Cell(pkg, local_rank, rank * args.cells_per_gpu + c, args.ants, args.slots, args.targets, args.inflight, args.fuse)
+    pool = SlotPool(pkg, local_rank, args.inflight)          # the GPU's execution slots, shared by all its cells
+    n_buf = -(-args.inflight // args.cells_per_gpu)           # CPIs of one cell that can be in flight at once
+    cells = [Cell(pkg, local_rank, rank * args.cells_per_gpu + c, args.ants, args.slots, args.targets, fuse=args.fuse, pool=pool, n_buf=n_buf)
              for c in range(args.cells_per_gpu)]
 
     def barrier():
-        for cell in cells:
-            cell.sync()
+        pool.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
 
-    last = None
     for _ in range(args.warmup):
         for cell in cells:
-            cell.submit()
-    for cell in cells:
-        last = cell.drain()
+            pool.submit(cell)
+    pool.drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for cell in cells:
-            cell.submit()
-    for cell in cells:
-        last = cell.drain()
-    for cell in cells:
-        cell.sync()
+            pool.submit(cell)
+    pool.drain()
+    pool.sync()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
