@@ -235,28 +235,28 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
 
 extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   if (!ctx) return ISAC_ERR_INVALID_ARG;
-  hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
-  hipStreamSynchronize(ctx->stream2);
-  for (auto& kv : ctx->twiddles) hipFree(kv.second.p);
-  for (auto& kv : ctx->kaiser3) hipFree(kv.second.p);
-  for (auto& kv : ctx->sind) hipFree(kv.second.p);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream2);
+  for (auto& kv : ctx->twiddles) (void)hipFree(kv.second.p);
+  for (auto& kv : ctx->kaiser3) (void)hipFree(kv.second.p);
+  for (auto& kv : ctx->sind) (void)hipFree(kv.second.p);
   DevBuf* bufs[] = {&ctx->beam, &ctx->coef, &ctx->phase_rx, &ctx->steer,
                     &ctx->ymid, &ctx->pwin, &ctx->flags, &ctx->det_cut, &ctx->det_pow, &ctx->det_cnt, &ctx->cov_part,
                     &ctx->cov, &ctx->eig_w, &ctx->eig_v, &ctx->eig_scratch, &ctx->spec, &ctx->misc, &ctx->stage_a, &ctx->stage_b,
                     &ctx->stage_c, &ctx->sind_tab};
   for (DevBuf* b : bufs)
-    if (b->p) hipFree(b->p);
-  if (ctx->pinned) hipHostFree(ctx->pinned);
-  hipEventDestroy(ctx->ev_fork);
-  hipEventDestroy(ctx->ev_join);
-  hipEventDestroy(ctx->ev_cfar);
-  hipEventDestroy(ctx->ev_h2d);
-  if (ctx->pinned_in) hipHostFree(ctx->pinned_in);
-  hipEventDestroy(ctx->ev_t0);
-  hipEventDestroy(ctx->ev_t1);
-  hipStreamDestroy(ctx->stream);
-  hipStreamDestroy(ctx->stream2);
+    if (b->p) (void)hipFree(b->p);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  (void)hipEventDestroy(ctx->ev_fork);
+  (void)hipEventDestroy(ctx->ev_join);
+  (void)hipEventDestroy(ctx->ev_cfar);
+  (void)hipEventDestroy(ctx->ev_h2d);
+  if (ctx->pinned_in) (void)hipHostFree(ctx->pinned_in);
+  (void)hipEventDestroy(ctx->ev_t0);
+  (void)hipEventDestroy(ctx->ev_t1);
+  (void)hipStreamDestroy(ctx->stream);
+  (void)hipStreamDestroy(ctx->stream2);
   delete ctx;
   return ISAC_OK;
 }
@@ -557,15 +557,15 @@ extern "C" int isac_fft2d(isac_ctx* ctx, const isac_est_params* ep, const isac_c
   const size_t bytes = sizeof(c64) * (size_t)K * L * A;
   void *d_rx = nullptr, *d_tx = nullptr;
   ISAC_HIP(hipMalloc(&d_rx, bytes));
-  if (hipMalloc(&d_tx, bytes) != hipSuccess) { hipFree(d_rx); return fail(ctx, ISAC_ERR_HIP, "hipMalloc failed"); }
+  if (hipMalloc(&d_tx, bytes) != hipSuccess) { (void)hipFree(d_rx); return fail(ctx, ISAC_ERR_HIP, "hipMalloc failed"); }
   int st = ISAC_OK;
   if (hipMemcpy(d_rx, rx_grid, bytes, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(d_tx, tx_grid, bytes, hipMemcpyHostToDevice) != hipSuccess)
     st = fail(ctx, ISAC_ERR_HIP, "host->device copy failed");
   if (st == ISAC_OK) st = isac_fft2d_dev(ctx, ep, cfar, (const isac_c64*)d_rx, (const isac_c64*)d_tx, K, L, A, out);
-  hipStreamSynchronize(ctx->stream);
-  hipFree(d_rx);
-  hipFree(d_tx);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_rx);
+  (void)hipFree(d_tx);
   return st;
 }
 
@@ -810,7 +810,7 @@ extern "C" int isac_basic_radar_channel(isac_ctx* ctx, const isac_c64* tx_wave, 
     st = isac_basic_radar_channel_dev(ctx, (const isac_c64*)d_tx, T, rp, los, noise_mode, (const isac_c64*)d_nz, seed, (isac_c64*)d_rx);
   if (st == ISAC_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(rx_wave, d_rx, bytes, hipMemcpyDeviceToHost) != hipSuccess))
     st = fail(ctx, ISAC_ERR_HIP, "download failed");
-  hipFree(d_tx); hipFree(d_nz); hipFree(d_rx);
+  (void)hipFree(d_tx); (void)hipFree(d_nz); (void)hipFree(d_rx);
   return st;
 }
 
@@ -838,6 +838,6 @@ extern "C" int isac_mono_static_sensing(isac_ctx* ctx, const isac_c64* tx_wave, 
                                       (const isac_c64*)d_nz, seed, (isac_c64*)d_g, l_out);
   if (st == ISAC_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(echo_grid, d_g, gbytes, hipMemcpyDeviceToHost) != hipSuccess))
     st = fail(ctx, ISAC_ERR_HIP, "download failed");
-  hipFree(d_tx); hipFree(d_nz); hipFree(d_g);
+  (void)hipFree(d_tx); (void)hipFree(d_nz); (void)hipFree(d_g);
   return st;
 }

@@ -128,7 +128,6 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);
   const int tid = threadIdx.x;
-  const int n_cols = L_whole * A;
   FFT fft;
   constexpr bool kTables = SYNTH && QT > 0 && std::is_same<FFT, Fft4096>::value;   // LDS tables for the Philox Box-Muller
   const int Q = QT ? QT : Q_rt;
@@ -279,7 +278,6 @@ __global__ __launch_bounds__(256, 2) void mod_kernel(OfdmGeom g, long long T, in
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);
   const int tid = threadIdx.x;
-  const int n_cols = L * A;
   FFT fft;
   {
     const int col = blockIdx.x;                    // one (symbol, antenna) column per workgroup
@@ -420,7 +418,6 @@ static int prepare_echo(isac_ctx* ctx, const c64* d_tx, long long T, const isac_
   ISAC_TRY(ensure(ctx, ctx->coef, sizeof(c64) * (size_t)Q * T));
   ISAC_TRY(ensure(ctx, ctx->phase_rx, sizeof(c64) * (size_t)T));
   c64* d_steer_aq = (c64*)ctx->steer.p;
-  c64* d_steer_rq = d_steer_aq + (size_t)A * Q;
   {
     // pinned staging so the upload is truly asynchronous; the event guards reuse of the staging buffer
     const size_t bytes = sizeof(c64) * (size_t)A * Q * 2;

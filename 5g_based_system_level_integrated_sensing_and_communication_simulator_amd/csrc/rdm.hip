@@ -28,7 +28,6 @@ __global__ __launch_bounds__(256, 2) void range_kernel(const c64* __restrict__ r
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);
   const int tid = threadIdx.x;
-  const int n_cols = L * A;
   FFT fft;
   fft.init(lds, tw, tid);   // (issuing the table loads after the column's loads measured 8 % slower here)
   {
