@@ -93,3 +93,15 @@ def test_cut_rectangle_recovery():
     assert (r0, r1) == (cf.CUTIdx[0, 0], cf.CUTIdx[0, -1]) and (c0, c1) == (cf.CUTIdx[1, 0], cf.CUTIdx[1, -1])
     with pytest.raises(pkg.IsacError):
         f._cut_rectangle(cf.CUTIdx[:, ::-1])
+
+
+def test_mex_gateway_compiles_against_the_header():
+    """The reference-side binding (mex/isac_mex.cpp) type-checks against include/isac.h."""
+    import shutil
+    import sys
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import __graft_entry__ as g
+    g.check_mex_gateway()
