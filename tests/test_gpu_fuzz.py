@@ -78,3 +78,46 @@ def test_chain_matches_oracle_on_random_scene(pkg, seed):
     if n_sig >= 1 and (w[n_sig - 1] - w[n_sig]) < 1e-9 * w[0]:
         pytest.skip("signal/noise split inside a degenerate eigenvalue cluster: MUSIC peaks undefined")
     assert np.array_equal(got.aziEst, want.aziEst)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fused_and_philox_paths_on_random_scene(pkg, seed):
+    """Full-size numerology (Nfft = nIFFT = 4096): (a) the fused monoStaticSensing+range path is bit-identical to the
+    unfused call sequence for injected, Philox and no noise and 1..6 targets (the compile-time target-count kernels
+    1..4 and the run-time one); (b) Philox-mode echo grids match the oracle fed with the restated generator."""
+    from oracle.philox import philox_normal_pairs
+    rng = np.random.default_rng(7000 + seed)
+    q = int(rng.integers(1, 7))
+    n_ants = int(rng.choice([1, 2, 3, 5]))
+    n_slots = int(rng.choice([2, 3]))
+    r = rng.uniform(60.0, 400.0, q)
+    az = np.deg2rad(rng.uniform(-70.0, 70.0, q))
+    targets = tuple((float(r[i] * np.cos(az[i])), float(r[i] * np.sin(az[i])), 1.5) for i in range(q))
+    sc = make_scene(n_ants=n_ants, n_slots=n_slots, nrb=273, targets=targets, velocity=tuple(float(v) for v in rng.integers(-10, 11, q)),
+                    seed=seed, zero_s_slots=False)
+    ctx = pkg.default_context()
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    cf = pkg.sensing.detection.cfar2D(rp)
+    d_wave, d_txg = ctx.to_device(sc.tx_wave), ctx.to_device(sc.tx_grid)
+    mode = seed % 3
+    kw = [dict(noise=ctx.to_device(sc.noise)), dict(seed=0xABCD + seed), dict()][mode]
+    e0 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, **kw)
+    e1 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, fuse_fft2d=(rp, cf, d_txg), **kw)
+    g0, g1 = e0.numpy(), e1.numpy()
+    assert np.array_equal(g0, g1)
+    if mode == 1:                                         # on-device generator vs its NumPy restatement
+        t, a = sc.tx_wave.shape
+        nz = philox_normal_pairs(np.arange(t * a, dtype=np.uint64), 0xABCD + seed, 0).reshape(a, t).T
+        ref = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, nz, nfft=4096)
+        assert rel(g0, ref) < RTOL
+    try:
+        est0, dbg0 = pkg.sensing.estimation.fft2D(rp, cf, e0, d_txg, return_debug=True)
+    except pkg.IsacError as e:
+        assert e.name == "NO_DETECTION"
+        with pytest.raises(pkg.IsacError):
+            pkg.sensing.estimation.fft2D(rp, cf, e1, d_txg)
+        return
+    est1, dbg1 = pkg.sensing.estimation.fft2D(rp, cf, e1, d_txg, return_debug=True)     # consumes the cached range rows
+    assert np.array_equal(dbg0.power_window, dbg1.power_window)
+    assert all(np.array_equal(x, y) for x, y in zip(dbg0.detections, dbg1.detections))
+    assert np.array_equal(est0.rngEst, est1.rngEst) and np.array_equal(est0.velEst, est1.velEst) and np.array_equal(est0.aziEst, est1.aziEst)
