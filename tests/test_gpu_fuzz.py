@@ -121,3 +121,43 @@ def test_fused_and_philox_paths_on_random_scene(pkg, seed):
     assert np.array_equal(dbg0.power_window, dbg1.power_window)
     assert all(np.array_equal(x, y) for x, y in zip(dbg0.detections, dbg1.detections))
     assert np.array_equal(est0.rngEst, est1.rngEst) and np.array_equal(est0.velEst, est1.velEst) and np.array_equal(est0.aziEst, est1.aziEst)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_cdl_apply_on_random_configuration(pkg, seed):
+    import oracle.cdl as OC
+    rng = np.random.default_rng(9000 + seed)
+    profile = ["CDL-A", "CDL-D"][int(rng.integers(0, 2))]
+    tx_size = (int(rng.choice([1, 2, 4])), int(rng.choice([1, 2, 3, 4, 8])), 2, 1, 1)
+    fs = float(rng.choice([15.36e6, 30.72e6, 122.88e6]))
+    t_len = int(rng.integers(200, 9000))
+    t0 = float(rng.uniform(0.0, 0.05))
+    cfg = OC.cdl_config(profile, 3.5e9, tx_size, (1, 1, 2, 1, 1), fs)
+    ch = pkg.communication.channelModels.CDLChannel(profile, 300e-9, 3.5e9, tx_size, (1, 1, 2, 1, 1), fs)
+    ch.time = t0
+    nt = int(np.prod(tx_size))
+    x = np.asfortranarray(rng.standard_normal((t_len, nt)) + 1j * rng.standard_normal((t_len, nt)))
+    got = pkg.communication.channelModels.applyCDL(ch, x)
+    assert got.shape == (t_len, 2) and rel(got, OC.apply_cdl(cfg, x, t0)) < RTOL
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_sinr_cqi_on_random_configuration(pkg, seed):
+    import oracle.cqi as OQ
+    rng = np.random.default_rng(9500 + seed)
+    nl = int(rng.integers(1, 9))
+    p = int(rng.choice([q for q in (2, 4, 8, 16, 32) if q >= nl]))
+    nr = int(rng.choice([r for r in (1, 2, 4, 8, 16) if r >= 1]))
+    n_re = int(rng.integers(1, 3000))
+    h = np.asfortranarray((rng.standard_normal((n_re, nr, p)) + 1j * rng.standard_normal((n_re, nr, p))) * rng.uniform(0.1, 10.0))
+    w, _ = np.linalg.qr(rng.standard_normal((p, nl)) + 1j * rng.standard_normal((p, nl)))
+    w = w / np.sqrt(nl)
+    sigma = float(rng.uniform(0.05, 3.0))
+    want = OQ.precoded_sinr_batch(h, sigma, w)
+    got = pkg.communication.phyLayer.precodedSINR(h, sigma, w)
+    assert got.shape == (n_re,) and np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+    cqi, mean = pkg.communication.phyLayer.cqiFromChannel(h, sigma, w, OQ.DOWNLINK_SINR90PC)
+    assert mean == pytest.approx(want.mean(), rel=1e-11)
+    edges = 10.0 ** (np.asarray(OQ.DOWNLINK_SINR90PC) / 10.0)
+    if np.min(np.abs(want.mean() / edges - 1.0)) > 1e-9:      # away from a table edge the integer CQI is exact
+        assert cqi == OQ.get_cqi(want.mean(), OQ.DOWNLINK_SINR90PC)
