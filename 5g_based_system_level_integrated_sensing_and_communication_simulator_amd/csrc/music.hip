@@ -14,6 +14,7 @@
 // Per-workgroup partial tiles are reduced in a fixed order (deterministic).
 #include <type_traits>
 
+#include <algorithm>
 #include "isac_common.hpp"
 
 namespace isac {
@@ -544,11 +545,11 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
 struct EighScratch {   // carve of ctx->eig_scratch for order n
   c64 *M, *Z, *tau, *rot;
   double *d, *e, *scale;
-  int *desc, *cnt;     // desc: (mm, l) per sweep; cnt: {n_sweeps, n_rot, overflow, -}
+  int *desc, *cnt;     // desc: (mm, l, first rotation, -) per sweep; cnt: {sweeps published, n_rot, overflow, zungtr done, QL done}
   long long rot_cap;
   int desc_cap;
   __host__ __device__ static size_t bytes(int n) {
-    return sizeof(c64) * ((size_t)2 * n * n + n + (size_t)16 * n * n) + sizeof(double) * (2 * n + 4) + sizeof(int) * (2 * (size_t)(30 * n + 2) + 8) + 256;
+    return sizeof(c64) * ((size_t)2 * n * n + n + (size_t)16 * n * n) + sizeof(double) * (2 * n + 4) + sizeof(int) * (4 * (size_t)(30 * n + 2) + 8) + 256;
   }
   __host__ __device__ EighScratch(void* base, int n) {
     c64* p = reinterpret_cast<c64*>(base);
@@ -560,8 +561,8 @@ struct EighScratch {   // carve of ctx->eig_scratch for order n
     e = d + n;
     scale = e + n + (n & 1);
     desc_cap = 30 * n + 2;
-    desc = reinterpret_cast<int*>(scale + 2);
-    cnt = desc + 2 * (size_t)desc_cap;
+    desc = reinterpret_cast<int*>(scale + 2);       // 16-byte aligned (rot is, and n + (n & 1) + 2 doubles follow)
+    cnt = desc + 4 * (size_t)desc_cap;
   }
 };
 
@@ -589,6 +590,7 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
   const double scl = eigh_safe_scale(Hin, n * n, sred);
   for (int i = tid; i < n * n; i += nt) M[i] = Hin[i] * scl;
   if (tid == 0) *S.scale = scl;
+  if (tid < 8) S.cnt[tid] = 0;                      // publication counters of the next two stages
   __syncthreads();
   for (int k = 0; k < n - 1; ++k) {                 // zhetd2, lower
     const int m = n - k - 1;                        // trailing size, rows/cols k+1 .. n-1
@@ -663,8 +665,13 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
   }
 }
 
-// block 0: zungtr; block 1 (first wavefront): tql2 recurrence, rotations recorded
-__global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratch, double* __restrict__ w_out, int* __restrict__ info) {
+template <bool LDS, bool LIVE>
+__device__ __forceinline__ void eigh_replay_body(int n, const EighScratch& S, c64* __restrict__ V_out, char* smem_raw, int block,
+                                                 int bt, int* __restrict__ info);
+
+// block 0: zungtr; block 1 (first wavefront): tql2 recurrence, rotations recorded; blocks >= 2: live replay
+__global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratch, double* __restrict__ w_out, int* __restrict__ info,
+                                                             c64* __restrict__ V_out, int replay_bt) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   EighScratch S(scratch, n);
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
@@ -696,7 +703,16 @@ __global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratc
       }
       __syncthreads();
     }
-    if (tid == 0 && info) info[2] = (int)((clock64() - t0) >> 6);
+    __threadfence();                                // Z complete and visible before the flag
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_store(&S.cnt[3], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (info) info[2] = (int)((clock64() - t0) >> 6);
+    }
+    return;
+  }
+  if (blockIdx.x >= 2) {                            // live replay blocks (only launched when the rows fit LDS)
+    eigh_replay_body<true, true>(n, S, V_out, smem_raw, (int)blockIdx.x - 2, replay_bt, info);
     return;
   }
   if (wid != 0) return;
@@ -728,7 +744,7 @@ __global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratc
       }
       if (mm == l) break;
       if (++iter > 60) break;                       // (never reached for Hermitian input; keeps the loop bounded)
-      if (sweeps >= S.desc_cap || nrot + (mm - l) > S.rot_cap) { overflow = 1; break; }
+      if (sweeps >= S.desc_cap || nrot + (mm - l) + 8 > S.rot_cap) { overflow = 1; break; }
       for (int i = l + lane; i <= mm; i += 64) bde[i] = de[i];
       const c64 de_l = de[l];
       double g0 = (de[l + 1].re - de_l.re) / (2.0 * de_l.im);
@@ -737,30 +753,37 @@ __global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratc
       // ---- fast chase
       double g = g0, sn = 1.0, cs = 1.0, p = 0.0;
       {
-        int i = mm - 1;
-        double d_hi = de[mm].re;
-        c64 x = de[i];                               // (d_i, e_i)
-        for (; i >= l; --i) {
-          const c64 nx = de[i > l ? i - 1 : l];      // operands of the next rotation, fetched one ahead
-          const double f = sn * x.im;
-          const double b = cs * x.im;
+        // one rotation; (dx, ex) = (d_i, e_i), dh = d_{i+1} before the rotation
+        auto rotate = [&](int i, double dx, double ex, double dh) {
+          const double f = sn * ex;
+          const double b2 = (cs + cs) * ex;            // 2 b
           const double rr2 = ::fma(f, f, g * g);
-          // 1/sqrt(rr2): hardware estimate + two Newton steps (relative error ~1e-16), instead of sqrt + two divides
-          double inv = __builtin_amdgcn_rsq(rr2);
-          const double hrs = 0.5 * rr2;
-          inv = ::fma(::fma(-hrs * inv, inv, 0.5), inv, inv);
-          inv = ::fma(::fma(-hrs * inv, inv, 0.5), inv, inv);
+          // 1/sqrt(rr2) from the hardware estimate y0 (~2^-23 relative) by one third-order step
+          //   y = y0 (1 + h/2 + 3 h^2/8),  h = 1 - rr2 y0^2   (error ~ h^3 = 2^-69), instead of sqrt + two divides
+          const double y0 = __builtin_amdgcn_rsq(rr2);
+          const double h = ::fma(-rr2 * y0, y0, 1.0);
+          const double inv = ::fma(y0 * h, ::fma(h, 0.375, 0.5), y0);
           sn = f * inv;
           cs = g * inv;
-          const double g1 = d_hi - p;
-          const double rr1 = ::fma(x.re - g1, sn, 2.0 * cs * b);
+          const double g1 = dh - p;
+          const double rr1 = ::fma(dx - g1, sn, cs * b2);
           p = sn * rr1;
-          de[i + 1] = mk(g1 + p, rr2 * inv);         // d[i+1], e[i+1] = r
-          g = ::fma(cs, rr1, -b);
+          de[i + 1] = mk(g1 + p, rr2 * inv);           // d[i+1], e[i+1] = r
+          g = ::fma(cs, rr1, -0.5 * b2);
           rec[mm - 1 - i] = mk(cs, sn);
-          d_hi = x.re;
-          x = nx;
+        };
+        // two rotations per trip (no register shuffling between them); operands are fetched one trip ahead
+        int i = mm - 1;
+        double d_hi = de[mm].re;
+        c64 x0 = de[i], x1 = de[i > l ? i - 1 : l];
+        for (; i - 1 >= l; i -= 2) {
+          const c64 n0 = de[i - 2 >= l ? i - 2 : l], n1 = de[i - 3 >= l ? i - 3 : l];
+          rotate(i, x0.re, x0.im, d_hi);
+          rotate(i - 1, x1.re, x1.im, x0.re);
+          d_hi = x1.re;
+          x0 = n0; x1 = n1;
         }
+        if (i >= l) rotate(i, x0.re, x0.im, d_hi);     // odd tail
       }
       bool underflow = false;
       if (__builtin_amdgcn_readfirstlane((int)!(g == g && p == p))) {
@@ -802,11 +825,15 @@ __global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratc
         }
         underflow = __builtin_amdgcn_readfirstlane((int)(uf != 0.0)) != 0;
       }
-      // hand the sweep to the replay kernel
+      // hand the sweep to the replay: rotations at a 128-byte aligned offset (no cache line is shared by two sweeps, so
+      // a replay block that runs concurrently never holds a line that is written later), then the descriptor, then --
+      // after a fence -- the published sweep count
       for (int k = lane; k < mm - l; k += 64) S.rot[nrot + k] = rec[k];
-      if (lane == 0) { S.desc[2 * sweeps] = mm; S.desc[2 * sweeps + 1] = l; }
-      nrot += mm - l;
+      if (lane == 0) { S.desc[4 * sweeps] = mm; S.desc[4 * sweeps + 1] = l; S.desc[4 * sweeps + 2] = (int)nrot; S.desc[4 * sweeps + 3] = 0; }
+      nrot += (mm - l + 7) & ~7;
       ++sweeps;
+      __threadfence();
+      if (lane == 0) __hip_atomic_store(&S.cnt[0], sweeps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (underflow) { de[mm].im = 0.0; continue; }
       { const double dl = de[l].re - p; de[l] = mk(dl, g); de[mm].im = 0.0; }
     }
@@ -816,118 +843,165 @@ __global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratc
     for (int i = lane; i < n; i += 64) w_out[i] = de[i].re / scl;
   }
   if (lane == 0) {
-    S.cnt[0] = sweeps; S.cnt[1] = (int)nrot; S.cnt[2] = overflow;
+    S.cnt[1] = (int)nrot; S.cnt[2] = overflow;
+    __hip_atomic_store(&S.cnt[0], sweeps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&S.cnt[4], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     if (info) { info[0] = overflow ? -1 : sweeps; info[3] = (int)((clock64() - t0) >> 6); info[5] = (int)nrot; }
   }
 }
 
 // Replay of the recorded plane rotations on Z.  One thread per (row, real/imaginary part): the rotations are real, so
 // the two parts of a row never mix, and rows are independent.  LDS = true: the workgroup keeps its rows in LDS for the
-// whole replay (blockDim x n doubles, column-major over the threads: conflict-free), Z is read once and V written once.
+// whole replay (bt x n doubles, column-major over the threads: conflict-free), Z is read once and V written once.
 // (Streaming the rows through global memory instead stalls on the store acknowledgements -- loads and stores share
 // vmcnt on this chip -- ~480 cycles per rotation; it remains as the fallback for n too large for LDS.)
-// (c, s) and the sweep table have wave-uniform addresses (scalar loads).
-template <bool LDS>
-__global__ __launch_bounds__(256) void eigh_replay_kernel(int n, void* scratch, c64* __restrict__ V_out, int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  EighScratch S(scratch, n);
+// LIVE = true: the block runs NEXT TO the zungtr and QL-recurrence blocks of the same launch and consumes the sweeps as
+// they are published (agent-scope acquire loads of the counters and descriptors, bounded spins).
+__device__ __forceinline__ int eigh_spin_until(const int* flag, int want_gt) {   // returns the value read, or INT_MIN on timeout
+  for (long long it = 0; it < (1LL << 21); ++it) {
+    const int v = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (v > want_gt) return v;
+    __builtin_amdgcn_s_sleep(16);
+  }
+  return -2147483647 - 1;
+}
+
+template <bool LDS, bool LIVE>
+__device__ __forceinline__ void eigh_replay_body(int n, const EighScratch& S, c64* __restrict__ V_out, char* smem_raw, int block,
+                                                 int bt, int* __restrict__ info) {
   const long long t0 = clock64();
-  const int bt = blockDim.x;
-  const int gid = blockIdx.x * bt + threadIdx.x;
+  const int tx = threadIdx.x;
+  if (tx >= bt) return;                             // (LIVE launch: 1024-thread blocks, the first bt threads work)
+  const int gid = block * bt + tx;
   const int n_items = 2 * n;
   const int item = gid < n_items ? gid : n_items - 1;           // surplus lanes shadow the last item (same values, same stores)
   double* Zg = reinterpret_cast<double*>(S.Z) + item;            // element (row, col, part) at Zg[2 n col], item = 2 row + part
   const long long gs = 2 * (long long)n;                         // global column stride in doubles
   double* Zd;
   long long cs;
+  bool timeout = false;
+  if (LIVE) timeout = eigh_spin_until(&S.cnt[3], 0) < 0;         // Z = Q complete (zungtr block)
   if constexpr (LDS) {
-    Zd = reinterpret_cast<double*>(smem_raw) + threadIdx.x;
+    Zd = reinterpret_cast<double*>(smem_raw) + tx;
     cs = bt;
     for (int c = 0; c < n; ++c) Zd[cs * c] = Zg[gs * c];
   } else {
     Zd = Zg;
     cs = gs;
   }
-  const int n_sweeps = S.cnt[0];
-  const c64* __restrict__ rot = S.rot;
-  const int* __restrict__ desc = S.desc;
-  // The (c, s) of one sweep are staged in LDS (double buffered; the global loads of sweep q+1 are issued before sweep q
-  // is replayed): a direct read per rotation is a dependent L2 round trip -- ~330 cycles per rotation measured.
+  const c64* rot = S.rot;
+  const int* desc = S.desc;
+  // The (c, s) of one sweep are staged in LDS: a direct read per rotation is a dependent L2 round trip (~330 cycles per
+  // rotation measured).  Offline they are double buffered (loads of sweep q+1 issued before sweep q is replayed); live,
+  // each sweep is fetched when it has been published (the replay is faster than the recurrence that feeds it).
   c64* stage = reinterpret_cast<c64*>(smem_raw + (LDS ? (size_t)bt * n * sizeof(double) : 0));   // [2][n]
   const int per_thread = (n + bt - 1) / bt;         // rotations each thread stages per sweep (<= 8 for bt >= n / 8)
   c64 pre[8];
   auto fetch = [&](long long o, int cnt) {          // unconditional loads (clamped): all eight fly together
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int k = threadIdx.x + u * bt;
+      const int k = tx + u * bt;
       pre[u] = rot[o + ((u < per_thread && k < cnt) ? k : 0)];
     }
   };
   auto stash = [&](int buf, int cnt) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int k = threadIdx.x + u * bt;
+      const int k = tx + u * bt;
       if (u < per_thread && k < cnt) stage[buf * n + k] = pre[u];
     }
   };
-  long long off = 0;
-  if (n_sweeps > 0) { fetch(0, desc[0] - desc[1]); stash(0, desc[0] - desc[1]); }
-  __syncthreads();
-  for (int q = 0; q < n_sweeps; ++q) {
-    const int mm = desc[2 * q], lo = desc[2 * q + 1];
+  auto block_sync = [&]() {                         // the working threads of the block (one wavefront when bt <= 64)
+    if (LIVE) { if (bt > 64) __builtin_amdgcn_s_barrier(); }   // LIVE launches use bt <= 64: a lone wavefront, LDS ops are in order
+    else __syncthreads();
+  };
+  int n_sweeps = LIVE ? 0 : S.cnt[0];
+  if (!LIVE && n_sweeps > 0) { fetch(desc[2], desc[0] - desc[1]); stash(0, desc[0] - desc[1]); }
+  block_sync();
+  for (int q = 0; ; ++q) {
+    int mm, lo;
+    long long off;
+    if (LIVE) {
+      if (timeout) break;
+      if (q >= n_sweeps) {                          // wait for sweep q, or for the end of the recurrence
+        for (long long it = 0; ; ++it) {
+          const int done = __hip_atomic_load(&S.cnt[4], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          n_sweeps = __hip_atomic_load(&S.cnt[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          if (n_sweeps > q || done) break;
+          if (it > (1LL << 21)) { timeout = true; break; }
+          __builtin_amdgcn_s_sleep(16);
+        }
+        if (timeout || q >= n_sweeps) break;
+      }
+      const long long* d8 = reinterpret_cast<const long long*>(desc + 4 * q);
+      const long long w0 = __hip_atomic_load(d8, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long w1 = __hip_atomic_load(d8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mm = (int)(w0 & 0xffffffffLL); lo = (int)(w0 >> 32); off = (int)(w1 & 0xffffffffLL);
+      fetch(off, mm - lo);
+      stash(q & 1, mm - lo);
+      block_sync();
+    } else {
+      if (q >= n_sweeps) break;
+      mm = desc[4 * q]; lo = desc[4 * q + 1]; off = desc[4 * q + 2];
+      if (q + 1 < n_sweeps) fetch(desc[4 * q + 6], desc[4 * q + 4] - desc[4 * q + 5]);   // in flight during the replay below
+    }
     const int cnt = mm - lo;
-    const bool more = q + 1 < n_sweeps;
-    const int cnt_nx = more ? desc[2 * q + 2] - desc[2 * q + 3] : 0;
-    if (more) fetch(off + cnt, cnt_nx);              // in flight during the replay below
     const c64* rec = stage + (q & 1) * n;
     // LDS rows are private, so surplus lanes may replay their shadow copy; in global memory they would race with the
     // owner of the row (a different wavefront) and must sit the sweep out
     if (LDS || gid < n_items) {
-    double zhi = Zd[cs * mm];                        // column i+1 of my row, carried between rotations
-    int i = mm - 1;
-    // full groups of eight rotations: operands of group g+1 are read before group g is computed, nothing conditional
-    // inside, and the only loop-carried dependence is one FMA per rotation (zhi)
-    double zl[8];
-    c64 cg[8];
-    if (i - 7 >= lo) {
+      double zhi = Zd[cs * mm];                      // column i+1 of my row, carried between rotations
+      int i = mm - 1;
+      // full groups of eight rotations: operands of group g+1 are read before group g is computed, nothing conditional
+      // inside, and the only loop-carried dependence is one FMA per rotation (zhi)
+      double zl[8];
+      c64 cg[8];
+      if (i - 7 >= lo) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { zl[u] = Zd[cs * (i - u)]; cg[u] = rec[mm - 1 - (i - u)]; }
-    }
-    while (i - 7 >= lo) {
-      double zn[8];
-      c64 cn[8];
-      const bool next_full = i - 15 >= lo;
-      const int ib = next_full ? i - 8 : i;          // (uniform) re-read the same group when no full group follows
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { zn[u] = Zd[cs * (ib - u)]; cn[u] = rec[mm - 1 - (ib - u)]; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        // z[r][i+1] = s z[r][i] + c z[r][i+1];  z[r][i] = c z[r][i] - s z[r][i+1]
-        const double czl = cg[u].re * zl[u];
-        Zd[cs * (i - u + 1)] = ::fma(cg[u].im, zl[u], cg[u].re * zhi);
-        zhi = ::fma(-cg[u].im, zhi, czl);
+        for (int u = 0; u < 8; ++u) { zl[u] = Zd[cs * (i - u)]; cg[u] = rec[mm - 1 - (i - u)]; }
       }
+      while (i - 7 >= lo) {
+        double zn[8];
+        c64 cn[8];
+        const bool next_full = i - 15 >= lo;
+        const int ib = next_full ? i - 8 : i;        // (uniform) re-read the same group when no full group follows
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { zl[u] = zn[u]; cg[u] = cn[u]; }
-      i -= 8;
+        for (int u = 0; u < 8; ++u) { zn[u] = Zd[cs * (ib - u)]; cn[u] = rec[mm - 1 - (ib - u)]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          // z[r][i+1] = s z[r][i] + c z[r][i+1];  z[r][i] = c z[r][i] - s z[r][i+1]
+          const double czl = cg[u].re * zl[u];
+          Zd[cs * (i - u + 1)] = ::fma(cg[u].im, zl[u], cg[u].re * zhi);
+          zhi = ::fma(-cg[u].im, zhi, czl);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { zl[u] = zn[u]; cg[u] = cn[u]; }
+        i -= 8;
+      }
+      for (; i >= lo; --i) {                         // tail (< 8 rotations)
+        const c64 c1 = rec[mm - 1 - i];
+        const double z1 = Zd[cs * i];
+        Zd[cs * (i + 1)] = ::fma(c1.im, z1, c1.re * zhi);
+        zhi = ::fma(-c1.im, zhi, c1.re * z1);
+      }
+      Zd[cs * lo] = zhi;                             // the last carried column
     }
-    for (; i >= lo; --i) {                           // tail (< 8 rotations)
-      const c64 c1 = rec[mm - 1 - i];
-      const double z1 = Zd[cs * i];
-      Zd[cs * (i + 1)] = ::fma(c1.im, z1, c1.re * zhi);
-      zhi = ::fma(-c1.im, zhi, c1.re * z1);
-    }
-    Zd[cs * lo] = zhi;                               // the last carried column
-    }
-    off += cnt;
-    if (more) stash((q + 1) & 1, cnt_nx);
-    __syncthreads();
+    (void)cnt;
+    if (!LIVE && q + 1 < n_sweeps) stash((q + 1) & 1, desc[4 * q + 4] - desc[4 * q + 5]);
+    block_sync();
   }
   if (gid < n_items) {
     double* Vd = reinterpret_cast<double*>(V_out) + item;
     for (int c = 0; c < n; ++c) Vd[gs * c] = Zd[cs * c];
   }
-  if (gid == 0 && info) info[4] = (int)((clock64() - t0) >> 6);
+  if (gid == 0 && info) { info[4] = (int)((clock64() - t0) >> 6); if (timeout) info[0] = -2; }
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(256) void eigh_replay_kernel(int n, void* scratch, c64* __restrict__ V_out, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  EighScratch S(scratch, n);
+  eigh_replay_body<LDS, false>(n, S, V_out, smem_raw, (int)blockIdx.x, (int)blockDim.x, info);
 }
 
 // ---------------------------------------------------------------- MUSIC pseudo-spectrum (ULA), music.m:82-91
@@ -1108,11 +1182,13 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
 int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
   if (!st) st = ctx->stream;
   if (A > 1024) return fail(ctx, ISAC_ERR_UNSUPPORTED, "device eigensolver supports up to 1024 antennas");
-  const bool big = A > kJacobiMaxA;
+  // measured host-call times (tools/_eig_sizes.py): Jacobi 0.16 / 0.34 / 0.77 / 1.40 ms at A = 16 / 32 / 48 / 64, the
+  // tridiagonal pipeline 0.20 / 0.41 / 0.70 / 1.05 ms: Jacobi up to 40 antennas, the pipeline beyond
+  static const int jacobi_max = std::getenv("ISAC_EIG_JACOBI_MAX") ? std::min(kJacobiMaxA, std::atoi(std::getenv("ISAC_EIG_JACOBI_MAX"))) : 40;
+  const bool big = A > jacobi_max;
   ISAC_TRY(ensure(ctx, ctx->eig_w, sizeof(double) * (size_t)A + 64));
   ISAC_TRY(ensure(ctx, ctx->eig_v, sizeof(c64) * (size_t)A * A));
   int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
-  // measured: Jacobi wins while H and V fit LDS (A = 64: 1.5 ms vs 1.6 ms); beyond, the tridiagonal route is the only one
   static const bool force_ql = std::getenv("ISAC_EIG_QL") != nullptr;             // development switch: A <= 64 through the pipeline
   if (A >= 3 && (big || force_ql)) {
     const int n = A;
@@ -1121,24 +1197,30 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
     const size_t lds1 = sizeof(c64) * 6 * (size_t)n + sizeof(double) * 32 + 64;
     hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
     ISAC_HIP(hipGetLastError());
-    // > half of a CU's LDS, so that the two workgroups cannot share a CU: next to the 16 waves of the zungtr block the
-    // single recurrence wavefront only got every other issue slot (345 instead of 160 cycles per rotation)
-    size_t lds2 = sizeof(c64) * 3 * (size_t)n + sizeof(double) * 4 * (size_t)n + 64;
-    if (lds2 < 96 * 1024) lds2 = 96 * 1024;
-    { static bool set = false; if (!set) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_formq_ql_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } }
-    hipLaunchKernelGGL(eigh_formq_ql_kernel, dim3(2), dim3(1024), lds2, st, n, gs, (double*)ctx->eig_w.p, info);
-    ISAC_HIP(hipGetLastError());
+    // (forcing the zungtr block and the lone recurrence wavefront onto different CUs with an oversized LDS request made no
+    // difference to the recurrence -- 345 vs 350 cycles per rotation at the time -- and cost CU capacity in pipelined runs)
+    const size_t lds2 = sizeof(c64) * 3 * (size_t)n + sizeof(double) * 4 * (size_t)n + 64;
     int bt = 64;                                       // threads per replay workgroup: its rows must fit LDS
     if ((size_t)bt * n * sizeof(double) > 150 * 1024) bt = 32;
     const size_t rows3 = (size_t)bt * n * sizeof(double), stage3 = sizeof(c64) * 2 * (size_t)n;
     const size_t lds3 = rows3 + stage3;
-    if (rows3 <= 150 * 1024 && n <= 8 * bt) {
-      { static size_t set_for = 0; if (set_for < lds3) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_replay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); set_for = lds3; } }
-      hipLaunchKernelGGL(eigh_replay_kernel<true>, dim3((unsigned)((2 * n + bt - 1) / bt)), dim3(bt), lds3, st, n, gs, (c64*)ctx->eig_v.p, info);
-    } else {
-      hipLaunchKernelGGL(eigh_replay_kernel<false>, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), stage3, st, n, gs, (c64*)ctx->eig_v.p, info);
-    }
+    const bool lds_replay = rows3 <= 150 * 1024 && n <= 8 * bt;
+    static const bool no_overlap = std::getenv("ISAC_EIG_NO_OVERLAP") != nullptr;   // development switch
+    const bool live = lds_replay && !no_overlap;       // replay blocks ride along with zungtr and the recurrence
+    const int n_replay = (2 * n + bt - 1) / bt;
+    { static bool set = false; if (!set) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_formq_ql_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } }
+    hipLaunchKernelGGL(eigh_formq_ql_kernel, dim3(live ? 2 + n_replay : 2), dim3(1024), live ? std::max(lds2, lds3) : lds2, st, n, gs,
+                       (double*)ctx->eig_w.p, info, (c64*)ctx->eig_v.p, bt);
     ISAC_HIP(hipGetLastError());
+    if (!live) {
+      if (lds_replay) {
+        { static size_t set_for = 0; if (set_for < lds3) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_replay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); set_for = lds3; } }
+        hipLaunchKernelGGL(eigh_replay_kernel<true>, dim3((unsigned)n_replay), dim3(bt), lds3, st, n, gs, (c64*)ctx->eig_v.p, info);
+      } else {
+        hipLaunchKernelGGL(eigh_replay_kernel<false>, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), stage3, st, n, gs, (c64*)ctx->eig_v.p, info);
+      }
+      ISAC_HIP(hipGetLastError());
+    }
     return ISAC_OK;
   }
   const int n = (A + 1) & ~1;
