@@ -566,10 +566,14 @@ struct EighScratch {   // carve of ctx->eig_scratch for order n
   }
 };
 
+// MLDS: the working matrix lives in LDS (n <= 64: 64 KB) instead of the L2-resident scratch -- every step is a handful of
+// dependent round trips to it (column norm, matrix-vector product, rank-2 update), 100 instead of 700 cycles each.
+template <bool MLDS>
 __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restrict__ Hin, int n, void* scratch, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   EighScratch S(scratch, n);
-  c64* M = S.M;                                     // [n x n] column-major working matrix (reflectors end up below the subdiagonal)
+  // [n x n] column-major working matrix (reflectors end up below the subdiagonal)
+  c64* M = MLDS ? reinterpret_cast<c64*>(smem_raw) + 6 * n + 16 : S.M;  // (LDS copy placed after the vectors and the 32-double reduction scratch)
   c64* sv = reinterpret_cast<c64*>(smem_raw);       // [n] current reflector
   c64* sp = sv + n;                                 // [n] p / w vector
   c64* spart = sp + n;                              // [4][n] partial matrix-vector products
@@ -586,6 +590,7 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
     oa = ta; ob = tb;
   };
 
+  constexpr int RWU = MLDS ? 64 : 256;              // row tile of the rank-2 update
   const long long t_start = clock64();
   const double scl = eigh_safe_scale(Hin, n * n, sred);
   for (int i = tid; i < n * n; i += nt) M[i] = Hin[i] * scl;
@@ -620,14 +625,17 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
       // row are summed through LDS.  (One thread per row left 3/4 of the workgroup idle and walked the m columns as one
       // dependent chain of L2 round trips.)
       {
-        const int rows_pt = (m + 255) >> 8;
-        const int jq = tid >> 8, il = tid & 255;
-        const int jlen = (m + 3) >> 2;
+        // row tile RW (64 rows when the matrix is that small, else 256), G = blockDim / RW column groups
+        const int rw_shift = MLDS ? 6 : 8, RW = 1 << rw_shift;
+        const int rows_pt = (m + RW - 1) >> rw_shift;
+        const int G = nt >> rw_shift;
+        const int jq = tid >> rw_shift, il = tid & (RW - 1);
+        const int jlen = (m + G - 1) / G;
         const int j0 = k + 1 + jq * jlen, j1 = min(n, j0 + jlen);
         for (int rr = 0; rr < rows_pt; ++rr) {
-          const int i = k + 1 + il + 256 * rr;
+          const int i = k + 1 + il + RW * rr;
           c64 a0 = mk(0.0, 0.0), a1 = a0, a2 = a0, a3 = a0;
-          if (i < n && jq < 4) {
+          if (i < n) {
             int j = j0;
             for (; j + 4 <= j1; j += 4) {
               const c64 m0 = M[i + n * j], m1 = M[i + n * (j + 1)], m2 = M[i + n * (j + 2)], m3 = M[i + n * (j + 3)];
@@ -638,7 +646,11 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
           }
         }
         __syncthreads();
-        for (int i = k + 1 + tid; i < n; i += nt) sp[i] = tau * ((spart[i] + spart[n + i]) + (spart[2 * n + i] + spart[3 * n + i]));
+        for (int i = k + 1 + tid; i < n; i += nt) {
+          c64 acc = spart[i];
+          for (int gq = 1; gq < G; ++gq) acc = acc + spart[gq * n + i];
+          sp[i] = tau * acc;
+        }
       }
       __syncthreads();
       // alpha2 = -1/2 tau (p^H v);  w = p + alpha2 v
@@ -651,13 +663,16 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
       for (int i = k + 1 + tid; i < n; i += nt) sp[i] = sp[i] + a2 * sv[i];
       __syncthreads();
       // A22 -= v w^H + w v^H   (thread = row slot x column phase: rows coalesced, no per-element division)
-      for (int i = k + 1 + (tid & 255); i < n; i += 256) {
+      for (int i = k + 1 + (tid & (RWU - 1)); i < n; i += RWU) {
         const c64 vi = sv[i], wi = sp[i];
-        for (int j = k + 1 + (tid >> 8); j < n; j += (nt >> 8))
+        for (int j = k + 1 + tid / RWU; j < n; j += nt / RWU)
           M[i + n * j] = M[i + n * j] - mul_conj(vi, sp[j]) - mul_conj(wi, sv[j]);
       }
     }
     __syncthreads();
+  }
+  if (MLDS) {                                       // the reflectors go where zungtr expects them
+    for (int i = tid; i < n * n; i += nt) S.M[i] = M[i];
   }
   if (tid == 0) {
     S.d[n - 1] = M[n - 1 + n * (n - 1)].re; S.e[n - 1] = 0.0;
@@ -1182,9 +1197,12 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
 int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
   if (!st) st = ctx->stream;
   if (A > 1024) return fail(ctx, ISAC_ERR_UNSUPPORTED, "device eigensolver supports up to 1024 antennas");
-  // measured host-call times (tools/_eig_sizes.py): Jacobi 0.16 / 0.34 / 0.77 / 1.40 ms at A = 16 / 32 / 48 / 64, the
-  // tridiagonal pipeline 0.20 / 0.41 / 0.70 / 1.05 ms: Jacobi up to 40 antennas, the pipeline beyond
-  static const int jacobi_max = std::getenv("ISAC_EIG_JACOBI_MAX") ? std::min(kJacobiMaxA, std::atoi(std::getenv("ISAC_EIG_JACOBI_MAX"))) : 40;
+  // measured host-call times (tools/_eig_sizes.py): Jacobi 0.10 / 0.16 / 0.26 / 0.35 / 0.78 / 1.41 ms at A = 8 / 16 / 24 / 32 / 48 /
+  // 64, the tridiagonal pipeline 0.10 / 0.17 / 0.24 / 0.33 / 0.57 / 0.86 ms: Jacobi up to 16 antennas, the pipeline beyond
+  // ISAC_EIG_JACOBI_MAX=64 selects the throughput trade-off instead: the pipeline occupies up to five CUs (1024-thread zungtr
+  // block, recurrence, spinning replay blocks), Jacobi one -- with several CPIs in flight per GPU its 1.4 ms are hidden and
+  // the sensing rate is ~3-5 % higher (bench.py sets it when --inflight > 1)
+  static const int jacobi_max = std::getenv("ISAC_EIG_JACOBI_MAX") ? std::min(kJacobiMaxA, std::atoi(std::getenv("ISAC_EIG_JACOBI_MAX"))) : 16;
   const bool big = A > jacobi_max;
   ISAC_TRY(ensure(ctx, ctx->eig_w, sizeof(double) * (size_t)A + 64));
   ISAC_TRY(ensure(ctx, ctx->eig_v, sizeof(c64) * (size_t)A * A));
@@ -1195,7 +1213,13 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
     ISAC_TRY(ensure(ctx, ctx->eig_scratch, EighScratch::bytes(n)));
     void* gs = ctx->eig_scratch.p;
     const size_t lds1 = sizeof(c64) * 6 * (size_t)n + sizeof(double) * 32 + 64;
-    hipLaunchKernelGGL(eigh_tridiag_kernel, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
+    if (n <= 64) {
+      const size_t lds1m = lds1 + sizeof(c64) * (size_t)n * n;
+      { static bool set = false; if (!set) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); set = true; } }
+      hipLaunchKernelGGL(eigh_tridiag_kernel<true>, dim3(1), dim3(256), lds1m, st, d_H, n, gs, info);   // small matrix: 4 waves, cheap barriers
+    } else {
+      hipLaunchKernelGGL(eigh_tridiag_kernel<false>, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
+    }
     ISAC_HIP(hipGetLastError());
     // (forcing the zungtr block and the lone recurrence wavefront onto different CUs with an oversized LDS request made no
     // difference to the recurrence -- 345 vs 350 cycles per rotation at the time -- and cost CU capacity in pipelined runs)

@@ -289,6 +289,11 @@ def main():
     ap.add_argument("--fuse", action="store_true", help="fuse the fft2D range stage into monoStaticSensing (measured slower: off by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    # eigensolver trade-off (music.hip isac_eigh_dev): with several CPIs in flight the one-workgroup Jacobi solver (1.4 ms at
+    # A = 64, hidden behind the other CPIs, one CU) gives a 3-5 % higher rate than the latency-optimised tridiagonal pipeline
+    # (0.9 ms, up to five CUs); a blocking caller (--inflight 1, the reference's call order) gets the pipeline
+    if args.inflight > 1:
+        os.environ.setdefault("ISAC_EIG_JACOBI_MAX", "64")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
