@@ -531,17 +531,19 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
 }
 
 // ---------------------------------------------------------------- Hermitian eigensolver II: Householder tridiagonalisation + implicit QL
-// eig(Ra) of music.m:19 the LAPACK way (zhetd2 -> zungtr -> tql2) for arrays that do not fit the LDS Jacobi solver
-// (A > 64; config 4: 256-element ULA), as three launches on one stream, all state in an L2-resident global scratch:
+// eig(Ra) of music.m:19 the LAPACK way (zhetd2 -> zungtr -> tql2), two launches on one stream, state in an L2-resident
+// global scratch (working matrix in LDS while n <= 64):
 //   K1  eigh_tridiag_kernel   one workgroup: n-1 Householder reflectors reduce H to a REAL symmetric tridiagonal (d, e)
-//   K2  eigh_formq_ql_kernel  two independent workgroups side by side:
+//   K2  eigh_formq_ql_kernel  independent workgroups side by side:
 //         block 0: Q = H_0 ... H_{n-2} formed explicitly in Z (zungtr)
 //         block 1: one wavefront runs the strictly sequential implicit-shift QL recurrence on (d, e) ALONE -- one
-//                  dependent fp64 chain per plane rotation, no matrix traffic -- and records every rotation (c, s)
-//   K3  eigh_replay_kernel    the recorded rotations are replayed on the rows of Z; rows are independent, so this
-//         part spreads over several CUs (one CU streams a 1 MB Z once per sweep at ~29 B/clk -- that bandwidth, not
-//         the arithmetic, bounded the single-workgroup version).
-// A = 256: 99 ms (Jacobi in global memory) -> 27 ms (one workgroup doing everything) -> see DESIGN.md section 6.
+//                  dependent fp64 chain per plane rotation, no matrix traffic -- records every rotation (c, s) and
+//                  publishes the sweeps one by one
+//         blocks 2..: replay the published rotations on their rows of Z (rows are independent; held in LDS) as soon as
+//                  zungtr has finished -- one CU streams a 1 MB Z once per sweep at ~29 B/clk, and that bandwidth, not
+//                  the arithmetic, bounded the version in which one workgroup did everything
+//       (eigh_replay_kernel: the same replay as a third launch when the rows do not fit LDS.)
+// A = 256: 99 ms (Jacobi in global memory) -> 27 ms (one workgroup doing everything) -> 11 ms; A = 64: 0.86 ms (Jacobi 1.4).
 struct EighScratch {   // carve of ctx->eig_scratch for order n
   c64 *M, *Z, *tau, *rot;
   double *d, *e, *scale;
