@@ -248,7 +248,8 @@ def stage_table(cell, reps=5):
 
 
 def cpu_baseline(n_ants, budget_s=25.0):
-    """The NumPy/SciPy oracle ("port": the MATLAB reference cannot run here) timed on the host cores on a
+    """The NumPy/SciPy oracle ("port": the MATLAB reference cannot run here; FFTs = multi-threaded pocketfft, the RDM in
+    its shift-free form) timed on the host cores on a
     bounded sample of the same workload: the full 273-PRB / 224-symbol CPI with a reduced antenna count,
     scaled linearly to `n_ants` (every stage of the chain is linear in the antenna count except the
     A x A covariance/eig, which is negligible on the CPU at these sizes)."""
@@ -263,7 +264,7 @@ def cpu_baseline(n_ants, budget_s=25.0):
     while True:
         echo = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, sc.noise)
         try:
-            O.fft2d(sc.rp, cf, echo, sc.tx_grid)
+            O.fft2d(sc.rp, cf, echo, sc.tx_grid, rdm_fn=O.rdm_explicit)   # same bits as the literal form, no shift copies
         except ValueError:
             pass
         reps += 1

@@ -76,13 +76,14 @@ def detect_per_antenna(rdm: np.ndarray, cfar, r_res: float, v_res: float, n_fft:
     return dets, np.concatenate(all_rng), np.concatenate(all_vel)
 
 
-def fft2d(rp, cfar, rx_grid: np.ndarray, tx_grid: np.ndarray, return_debug: bool = False):
+def fft2d(rp, cfar, rx_grid: np.ndarray, tx_grid: np.ndarray, return_debug: bool = False, rdm_fn=None):
     """fft2D.m:1-204 -> estResults{rngEst, velEst, aziEst, eleEst}.
 
     Raises ValueError when no CUT is detected (findpeaks 'NPeaks' = 0 error, music.m:102;
-    cellSimulation.m:196-202 turns it into senResults = NaN)."""
+    cellSimulation.m:196-202 turns it into senResults = NaN).  ``rdm_fn``: ``rdm_literal`` (default, line-by-line) or
+    ``rdm_explicit`` (bit-identical, without the all-dimension shift copies: the timed CPU baseline uses it)."""
     n_ifft, n_fft = int(rp.nIFFT), int(rp.nFFT)
-    rdm = rdm_literal(rx_grid, tx_grid, n_ifft, n_fft)
+    rdm = (rdm_fn or rdm_literal)(rx_grid, tx_grid, n_ifft, n_fft)
     dets, all_rng, all_vel = detect_per_antenna(rdm, cfar, rp.rRes, rp.vRes, n_fft)
     est = SimpleNamespace(rngEst=unique_stable(all_rng), velEst=unique_stable(all_vel))   # :99,:102
     ra = covariance(rx_grid)                                               # :106-107
