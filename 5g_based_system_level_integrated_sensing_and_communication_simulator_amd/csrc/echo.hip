@@ -477,7 +477,7 @@ static int launch_demod(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, in
   const c64* logtab = nullptr;
   ISAC_TRY(isac_get_logtab(ctx, &logtab));
   auto kern = demod_kernel<FFT, SYNTH, QT>;
-  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
   hipLaunchKernelGGL(kern, dim3(fft_grid(L_whole * A)), dim3(256), lds, ctx->stream, g, T, A, L_whole, L_out, tw, Q,
                      (const c64*)ctx->coef.p, SYNTH ? (const c64*)ctx->steer.p + (size_t)A * Q : nullptr,
                      (const c64*)ctx->phase_rx.p, noise_mode, noise, n0s, seed, wave, grid, logtab);
@@ -530,7 +530,7 @@ static int launch_demod_range(isac_ctx* ctx, const OfdmGeom& g, long long T, int
   const c64* logtab = nullptr;
   ISAC_TRY(isac_get_logtab(ctx, &logtab));
   auto kern = demod_range_kernel<FFT, QT>;
-  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
   hipLaunchKernelGGL(kern, dim3((unsigned)(L_whole * A)), dim3(256), lds, ctx->stream, g, T, A, L_whole, L_out, tw, Q,
                      (const c64*)ctx->coef.p, (const c64*)ctx->steer.p + (size_t)A * Q, (const c64*)ctx->phase_rx.p, noise_mode,
                      noise, n0s, seed, grid, txg, wk, wr, 1.0 / n_ifft, std::sqrt((double)n_ifft), row_lo, nr, ymid, logtab);
@@ -606,7 +606,7 @@ static int launch_mod(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, int 
                       double scale, c64* wave) {
   size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
   auto kern = mod_kernel<FFT>;
-  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
   hipLaunchKernelGGL(kern, dim3(fft_grid(L * A)), dim3(256), lds, ctx->stream, g, T, A, L, tw, grid, scale, wave);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;

@@ -83,6 +83,7 @@ struct isac_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cfar = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   std::string err;
   // cached device tables
+  std::map<const void*, size_t> lds_allowed;                        // kernel -> dynamic LDS bytes enabled on this context's device
   std::map<int, isac::DevBuf> twiddles;                             // n -> exp(-2 pi j m / n)
   std::map<std::pair<int, int>, isac::DevBuf> kaiser3;              // (n, shifted) -> kaiser(n,3) / fftshift(kaiser(n,3))
   std::map<std::pair<long long, long long>, isac::DevBuf> sind;     // (scale, granularity) -> sind(scan angles)
@@ -102,6 +103,18 @@ namespace isac {
 inline int fail(isac_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
   return code;
+}
+
+// Dynamic LDS above the 64 KB default has to be enabled per kernel and per device; remembered in the context (a
+// process-wide flag would miss a second device).
+inline int allow_lds(isac_ctx* ctx, const void* kernel, size_t bytes) {
+  size_t& have = ctx->lds_allowed[kernel];
+  if (have < bytes) {
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(ctx, ISAC_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize): ") + hipGetErrorString(e));
+    have = bytes;
+  }
+  return ISAC_OK;
 }
 
 #define ISAC_HIP(call)                                                                     \

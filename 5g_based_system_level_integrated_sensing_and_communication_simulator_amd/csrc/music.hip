@@ -1184,7 +1184,7 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
     n_chunks = (total + per - 1) / per;
     ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * (size_t)n_chunks * n_pairs * 16 * 2 * 256));
     const size_t lds = sizeof(c64) * 2 * kCovBufElems;
-    { static bool set = false; if (!set) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cov_mfma_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set = true; } }
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cov_mfma_block_kernel), (size_t)(lds)));
     hipLaunchKernelGGL(cov_mfma_block_kernel, dim3((unsigned)(n_chunks * n_pairs)), dim3(256), lds, st, (const c64*)d_grid, (long long)N, A,
                        n_blk, n_pairs, per, (double*)ctx->cov_part.p);
     ISAC_HIP(hipGetLastError());
@@ -1217,7 +1217,7 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
     const size_t lds1 = sizeof(c64) * 6 * (size_t)n + sizeof(double) * 32 + 64;
     if (n <= 64) {
       const size_t lds1m = lds1 + sizeof(c64) * (size_t)n * n;
-      { static bool set = false; if (!set) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_tridiag_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); set = true; } }
+      ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_tridiag_kernel<true>), (size_t)(100 * 1024)));
       hipLaunchKernelGGL(eigh_tridiag_kernel<true>, dim3(1), dim3(256), lds1m, st, d_H, n, gs, info);   // small matrix: 4 waves, cheap barriers
     } else {
       hipLaunchKernelGGL(eigh_tridiag_kernel<false>, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
@@ -1234,13 +1234,13 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
     static const bool no_overlap = std::getenv("ISAC_EIG_NO_OVERLAP") != nullptr;   // development switch
     const bool live = lds_replay && !no_overlap;       // replay blocks ride along with zungtr and the recurrence
     const int n_replay = (2 * n + bt - 1) / bt;
-    { static bool set = false; if (!set) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_formq_ql_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; } }
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_formq_ql_kernel), (size_t)(160 * 1024)));
     hipLaunchKernelGGL(eigh_formq_ql_kernel, dim3(live ? 2 + n_replay : 2), dim3(1024), live ? std::max(lds2, lds3) : lds2, st, n, gs,
                        (double*)ctx->eig_w.p, info, (c64*)ctx->eig_v.p, bt);
     ISAC_HIP(hipGetLastError());
     if (!live) {
       if (lds_replay) {
-        { static size_t set_for = 0; if (set_for < lds3) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_replay_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3)); set_for = lds3; } }
+        ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_replay_kernel<true>), lds3));
         hipLaunchKernelGGL(eigh_replay_kernel<true>, dim3((unsigned)n_replay), dim3(bt), lds3, st, n, gs, (c64*)ctx->eig_v.p, info);
       } else {
         hipLaunchKernelGGL(eigh_replay_kernel<false>, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), stage3, st, n, gs, (c64*)ctx->eig_v.p, info);
@@ -1251,7 +1251,7 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
   }
   const int n = (A + 1) & ~1;
   size_t lds = sizeof(c64) * ((size_t)2 * n * n + n / 2) + sizeof(double) * (n / 2) + sizeof(int) * (n + 1) + 64;
-  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_eigh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(jacobi_eigh_kernel), lds));
   hipLaunchKernelGGL(jacobi_eigh_kernel, dim3(1), dim3(1024), lds, st, d_H, A, 40, (double*)ctx->eig_w.p, (c64*)ctx->eig_v.p, info);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;

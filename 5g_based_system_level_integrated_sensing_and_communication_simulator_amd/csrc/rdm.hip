@@ -352,7 +352,7 @@ static int launch_range(isac_ctx* ctx, hipStream_t st, const c64* rx, const c64*
                         const double* wk, const double* wr, int n_ifft, int row_lo, int n_rows, c64* ymid) {
   size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
   auto kern = range_kernel<FFT>;
-  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
   hipLaunchKernelGGL(kern, dim3(fft_grid2(L * A)), dim3(256), lds, st, rx, tx, K, L, A, tw, wk, wr, 1.0 / n_ifft,
                      std::sqrt((double)n_ifft), row_lo, n_rows, ymid);
   ISAC_HIP(hipGetLastError());
@@ -389,13 +389,13 @@ int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_c
   const int Lu = L < n_fft ? L : n_fft;
   if (n_fft == 256 && !std::getenv("ISAC_DOPPLER_DIRECT")) {
     size_t lds = sizeof(c64) * (256 + std::max((size_t)Lu * (kDopRows + 1), (size_t)kDopRows * 16 * 17));
-    { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(doppler_fft256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(doppler_fft256_kernel), lds));
     hipLaunchKernelGGL(doppler_fft256_kernel, dim3(cdiv(nr, kDopRows), A), dim3(256), lds, ctx->stream, (const c64*)ctx->ymid.p, nr, L,
                        A, twd, std::sqrt((double)n_fft), col_lo, nc, (double*)ctx->pwin.p);
     ISAC_HIP(hipGetLastError());
   } else {
     size_t lds = sizeof(c64) * ((size_t)n_fft + (size_t)Lu * (kDopRows + 1));
-    { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(doppler_pow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(doppler_pow_kernel), lds));
     hipLaunchKernelGGL(doppler_pow_kernel, dim3(cdiv(nr, kDopRows), A), dim3(512), lds, ctx->stream, (const c64*)ctx->ymid.p, nr,
                        L, A, n_fft, twd, std::sqrt((double)n_fft), col_lo, nc, (double*)ctx->pwin.p, (c64*)nullptr);
     ISAC_HIP(hipGetLastError());
@@ -431,7 +431,7 @@ int isac_cfar_window(isac_ctx* ctx, const isac_cfar_config* cf, int nr, int nc, 
   ISAC_TRY(ensure(ctx, ctx->det_cnt, sizeof(int) * (size_t)A));
   ISAC_TRY(ensure(ctx, ctx->flags, sizeof(unsigned) * (size_t)g.n_cut_rows));
   ISAC_HIP(hipMemsetAsync(ctx->flags.p, 0, sizeof(unsigned) * (size_t)g.n_cut_rows, ctx->stream));
-  { static size_t set_for = 0; if (set_for < lds) { ISAC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(cfar_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); set_for = lds; } }
+  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cfar_window_kernel), lds));
   hipLaunchKernelGGL(cfar_window_kernel, dim3(A), dim3(1024), lds, ctx->stream, (const double*)ctx->pwin.p, g, panel,
                      (int*)ctx->det_cut.p, (double*)ctx->det_pow.p, (int*)ctx->det_cnt.p, (unsigned*)ctx->flags.p);
   ISAC_HIP(hipGetLastError());
