@@ -214,3 +214,59 @@ def test_music2d_small():
     est, dbg = O.music2d(sc.rp, 30, rx, sc.tx_grid, return_debug=True)
     assert dbg.L >= 1 and est.rngEst.size <= dbg.L
     assert np.array_equal(dbg.Rr, dbg.Rr.conj().T)
+
+
+def test_toolbox_primitives_against_independent_implementations():
+    """The oracle's restatements of toolbox primitives against SciPy / NumPy / pandas implementations of the same
+    published definitions (an independent check of the restatement, not of MATLAB itself)."""
+    import pandas as pd
+    from scipy import linalg, signal
+    from scipy import special
+    rng = np.random.default_rng(11)
+    # kaiser(N, beta): I0(beta sqrt(1 - ((n - (N-1)/2) / ((N-1)/2))^2)) / I0(beta)
+    for n in (2, 3, 8, 33, 256, 3276, 4096):
+        assert np.abs(O.kaiser(n, 3.0) - signal.windows.kaiser(n, 3.0, sym=True)).max() < 2e-15    # a few ulp of I0
+    assert O.kaiser(1, 3.0).tolist() == [1.0]
+    # findpeaks(y, 'SortStr', 'descend'): strict interior local maxima, plateaus report their first sample
+    for _ in range(20):
+        y = np.round(rng.standard_normal(400), 1)            # coarse values: plenty of plateaus and ties
+        pks, locs = O.findpeaks(y)
+        ref, props = signal.find_peaks(y, plateau_size=1)
+        ref_first = props["left_edges"]
+        assert sorted(locs.tolist()) == ref_first.tolist()
+        assert np.all(np.diff(pks) <= 0)
+        for v in np.unique(pks):                             # stable sort: equal peaks keep index order
+            assert np.all(np.diff(locs[pks == v]) > 0)
+    # unique(x, 'stable')
+    x = rng.integers(0, 20, 300).astype(float)
+    assert np.array_equal(O.unique_stable(x), pd.unique(x))
+    # sind / cosd away from the exact points
+    a = rng.uniform(-720, 720, 1000)
+    assert np.abs(O.sind(a) - np.sin(np.deg2rad(a))).max() < 2e-15 and np.abs(O.cosd(a) - np.cos(np.deg2rad(a))).max() < 2e-15
+    # eig-based pieces: covariance is Hermitian PSD, MUSIC noise projector is idempotent
+    g = rng.standard_normal((64, 7, 5)) + 1j * rng.standard_normal((64, 7, 5))
+    ra = O.covariance(g)
+    assert np.array_equal(ra, ra.conj().T) and linalg.eigvalsh(ra).min() > -1e-12
+    # db helpers
+    assert O.db2pow(10.0) == pytest.approx(10.0) and O.db2mag(20.0) == pytest.approx(10.0)
+    assert O.pow2db(100.0) == pytest.approx(20.0) and O.mag2db(100.0) == pytest.approx(40.0)
+    assert special.i0(3.0) == pytest.approx(4.880792585865024)
+
+
+def test_ofdm_demodulate_against_a_plain_fft_model():
+    """nrOFDMDemodulate as restated (CP fraction 0.5 window, phase compensation, fftshift, central K bins) against a
+    direct per-symbol DFT of the CP-stripped samples: they must agree on a CP-OFDM waveform (the half-CP window offset is a
+    pure per-bin phase ramp that the demodulator undoes)."""
+    rng = np.random.default_rng(12)
+    nrb, n_slots, nfft = 24, 2, 512
+    k, l = 12 * nrb, 14 * n_slots
+    grid = (rng.standard_normal((k, l, 2)) + 1j * rng.standard_normal((k, l, 2)))
+    wave = O.ofdm_modulate(grid, nfft, 30)
+    back = O.ofdm_demodulate(wave, k, nfft, 30)
+    assert np.abs(back - grid).max() < 1e-11
+    starts, cps = O.symbol_starts(nfft, 30, l)
+    for sym in (0, 1, 13, 14, 27):
+        seg = wave[starts[sym] + cps[sym]: starts[sym] + cps[sym] + nfft, 0]
+        spec = np.fft.fftshift(np.fft.fft(seg))
+        mid = spec[nfft // 2 - k // 2: nfft // 2 + k // 2]
+        assert np.abs(mid - grid[:, sym, 0]).max() < 1e-10
