@@ -31,6 +31,9 @@ done
 rm -rf /tmp/p4 && ISAC_SINGLE_STREAM=1 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d /tmp/p4 -- python $ROOT/bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline > /dev/null 2>&1
 $PS $(db /tmp/p4) --pmc --csv $OUT/${TAG}_pmc_mfma_busy.csv > /dev/null
 
+rm -rf /tmp/p6 && ISAC_SINGLE_STREAM=1 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d /tmp/p6 -- python $ROOT/bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline > /dev/null 2>&1
+$PS $(db /tmp/p6) --pmc --csv $OUT/${TAG}_pmc_valu_busy.csv > /dev/null
+
 python $ROOT/tools/stage_times.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_stage_times_hip_events.txt
 for t in kbench dbench nbench latbench mbench; do
   [ -x $ROOT/tools/$t ] && $ROOT/tools/$t > $OUT/${TAG}_${t}.txt 2>&1
