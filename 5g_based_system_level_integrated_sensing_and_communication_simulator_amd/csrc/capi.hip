@@ -14,6 +14,15 @@ int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_c
                           int K, int L, int A, int* nr_out, int* nc_out);
 int isac_cfar_window(isac_ctx* ctx, const isac_cfar_config* cf, int nr, int nc, int A, int cap);
 int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st);
+// status word the device eigensolver leaves behind the eigenvalues (ctx->eig_w [A] | info[0..5]): negative = the QL
+// recurrence ran out of rotation storage (-1) or a replay block gave up waiting (-2).  Call after the stream is idle.
+static int eig_status(isac_ctx* ctx, int A) {
+  int sweeps = 0;
+  ISAC_HIP(hipMemcpy(&sweeps, (const char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(int), hipMemcpyDeviceToHost));
+  if (sweeps < 0) return isac::fail(ctx, ISAC_ERR_HIP, sweeps == -1 ? "eigensolver: QL recurrence exceeded its rotation storage (no convergence)"
+                                                                     : "eigensolver: a replay block timed out waiting for the recurrence");
+  return ISAC_OK;
+}
 int isac_music_scan_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num_dets_host, const double* d_sind, int n_steps,
                         double d_ratio, double* d_spec, hipStream_t st, int mode = 0);
 int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra);
@@ -328,7 +337,7 @@ __global__ void pack_kernel(const int* __restrict__ det_cnt, const int* __restri
                             const int* __restrict__ num_dets, int A, int cap, int* __restrict__ hdr /* [3 + A+1] */,
                             int* __restrict__ full_cut, double* __restrict__ full_pow, int pack_first,
                             int* __restrict__ first_cut, double* __restrict__ first_pow, const double* __restrict__ spec,
-                            int n_steps, double* __restrict__ spec_out) {
+                            int n_steps, double* __restrict__ spec_out, const int* __restrict__ eig_info) {
   __shared__ int s_off[1025];
   __shared__ int s_cnt[1024];
   const int tid = threadIdx.x;
@@ -345,7 +354,7 @@ __global__ void pack_kernel(const int* __restrict__ det_cnt, const int* __restri
     s_off[A] = acc;
     hdr[0] = acc;
     hdr[1] = *num_dets;
-    hdr[2] = over;
+    hdr[2] = over | ((eig_info && eig_info[0] < 0) ? 2 : 0);
   }
   __syncthreads();
   for (int a = tid; a <= A; a += blockDim.x) hdr[3 + a] = s_off[a];
@@ -438,7 +447,8 @@ extern "C" int isac_fft2d_submit_dev(isac_ctx* ctx, const isac_est_params* ep, c
   int* d_pcut_full = (int*)((char*)ctx->stage_b.p + sizeof(double) * pack_cap);
   hipLaunchKernelGGL(pack_kernel, dim3(1), dim3(256), 0, ctx->stream, (const int*)ctx->det_cnt.p, (const int*)ctx->det_cut.p,
                      (const double*)ctx->det_pow.p, (const int*)ctx->misc.p, A, cap, (int*)dbase, d_pcut_full, d_ppow_full,
-                     pack_first, d_pcut_first, d_ppow_first, (const double*)ctx->spec.p, n_steps, (double*)(dbase + off_spec));
+                     pack_first, d_pcut_first, d_ppow_first, (const double*)ctx->spec.p, n_steps, (double*)(dbase + off_spec),
+                     upa ? nullptr : (const int*)((const char*)ctx->eig_w.p + sizeof(double) * (size_t)A));
   ISAC_HIP(hipGetLastError());
   char* h = (char*)ctx->pinned;
   ISAC_HIP(hipMemcpyAsync(h, dbase, first_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -472,7 +482,8 @@ extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
   const int* hdr = (const int*)h;
   const int total = hdr[0];
   const int num_dets_dev = hdr[1];
-  if (hdr[2]) return fail(ctx, ISAC_ERR_CAPACITY, "an antenna produced more CFAR detections than the per-antenna capacity (4096)");
+  if (hdr[2] & 2) return fail(ctx, ISAC_ERR_HIP, "eigensolver did not finish (rotation storage exceeded or a replay block timed out)");
+  if (hdr[2] & 1) return fail(ctx, ISAC_ERR_CAPACITY, "an antenna produced more CFAR detections than the per-antenna capacity (4096)");
   std::vector<int> cut((size_t)total);
   std::vector<double> pw((size_t)total);
   if (total <= pack_first) {
@@ -627,6 +638,7 @@ extern "C" int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w,
   ISAC_HIP(hipMemcpyAsync(wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipMemcpyAsync(vv.data(), ctx->eig_v.p, sizeof(c64) * (size_t)A * A, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  ISAC_TRY(eig_status(ctx, A));
   if (std::getenv("ISAC_DEBUG")) {
     int inf[6] = {-1, 0, 0, 0, 0, 0};
     ISAC_HIP(hipMemcpy(inf, (char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(inf), hipMemcpyDeviceToHost));
@@ -672,6 +684,7 @@ static int doa_scan(isac_ctx* ctx, int mode, int32_t num_dets, const isac_est_pa
   std::vector<double> spec((size_t)n_steps);
   ISAC_HIP(hipMemcpyAsync(spec.data(), ctx->spec.p, sizeof(double) * (size_t)n_steps, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  ISAC_TRY(eig_status(ctx, A));
   double mx = 0.0;
   for (double v : spec) mx = std::max(mx, std::fabs(v));
   std::vector<double> db((size_t)n_steps);
@@ -722,6 +735,7 @@ extern "C" int isac_music2d_dev(isac_ctx* ctx, const isac_est_params* ep, const 
   std::vector<double> wa((size_t)A);
   ISAC_HIP(hipMemcpyAsync(wa.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  ISAC_TRY(eig_status(ctx, A));
   std::sort(wa.begin(), wa.end());
   const int Lsig = determine_num_targets(wa);                           // music.m:22 on ascending eigenvalues
   out->num_dets = Lsig;
@@ -758,6 +772,7 @@ extern "C" int isac_music2d_dev(isac_ctx* ctx, const isac_est_params* ep, const 
   std::vector<double> wg((size_t)L);
   ISAC_HIP(hipMemcpyAsync(wg.data(), ctx->eig_w.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  ISAC_TRY(eig_status(ctx, L));
   std::vector<int> order((size_t)L);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return wg[(size_t)p] > wg[(size_t)q]; });    // sort(.,'descend')
