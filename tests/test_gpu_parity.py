@@ -488,3 +488,13 @@ def test_full_size_round_trip_properties(pkg, ctx):
     ra = d_ra.numpy()
     assert np.array_equal(ra, ra.conj().T) and np.linalg.eigvalsh(ra).min() > -1e-9
     assert np.trace(ra).real == pytest.approx((np.abs(b) ** 2).sum() / (K * L), rel=1e-12)
+
+
+def test_eigh_nan_input_is_an_error_not_a_hang(pkg, ctx):
+    """A NaN matrix never converges: the QL recurrence must stop at its sweep budget and the call must fail loudly."""
+    a = 100
+    h = np.full((a, a), np.nan, dtype=np.complex128, order="F")
+    w = np.zeros(a)
+    with pytest.raises(pkg.IsacError) as ei:
+        ctx.check(ctx.lib.isac_eigh(ctx.handle, h.ctypes.data_as(C.c_void_p), C.c_int32(a), w.ctypes.data_as(C.c_void_p), None))
+    assert ei.value.name == "HIP" and "eigensolver" in str(ei.value)
