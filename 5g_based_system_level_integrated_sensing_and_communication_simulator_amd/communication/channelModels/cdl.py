@@ -42,6 +42,7 @@ _TABLES = {
         dict(cASD=5.0, cASA=8.0, cZSD=3.0, cZSA=3.0, XPR=11.0), True),
 }
 FILTER_TAPS, FILTER_DELAY = 16, 7
+_STATIC_CACHE: dict = {}                      # time-independent channel quantities shared by equally configured channels
 
 
 def _unit(theta_deg, phi_deg):
@@ -85,6 +86,7 @@ class CDLChannel:
         self.NormalizePathGains = self.NormalizeChannelOutputs = True
         self.time = 0.0                                                 # InitialTime
         self._rays = None
+        self._st = None
 
     # ---- info(channel): uePhy.m:288-289
     def info(self):
@@ -114,8 +116,18 @@ class CDLChannel:
             phases=phases, power=p_lin, los=los, table=tab, kappa=10.0 ** (spr["XPR"] / 10.0))
         return self._rays
 
-    def path_gains(self, t_snap: float) -> np.ndarray:
-        """H[n, s, u] at channel time t_snap (TR 38.901 eq. 7.5-22; LOS term 7.5-29 folded into path 0)."""
+    def _static(self):
+        """Everything of eq. 7.5-22 / 7.5-29 that does not depend on time: per-ray antenna responses x polarisation
+        coupling x array phases (`base` [n, m, s, u]), the per-ray Doppler rates, and the LOS term.  Computed once per
+        channel object; a snapshot is then one weighted sum over the rays."""
+        if getattr(self, "_st", None) is not None:
+            return self._st
+        key = (self.DelayProfile, self.DelaySpread, self.CarrierFrequency, self.TransmitAntennaArraySize, self.ReceiveAntennaArraySize,
+               self.MaximumDopplerShift, self.Seed, self.UTDirectionOfTravel, self.TxPolAngles, self.RxPolAngles, self.TxElement,
+               self.RxElement, self.NormalizePathGains)
+        if key in _STATIC_CACHE:             # the reference gives every UE the same seed (cdl.m:57-64): identical ray draws
+            self._st = _STATIC_CACHE[key]
+            return self._st
         r = self._draw()
         txp, txpol = _positions(self.TransmitAntennaArraySize)
         rxp, rxpol = _positions(self.ReceiveAntennaArraySize)
@@ -130,10 +142,10 @@ class CDLChannel:
         xp = np.stack([np.stack([e[..., 0], sk * e[..., 1]], -1), np.stack([sk * e[..., 2], e[..., 3]], -1)], -2)   # [n, m, 2, 2]
         a_tx = np.exp(2j * np.pi * np.einsum("sd,nmd->nms", txp, r_tx))
         a_rx = np.exp(2j * np.pi * np.einsum("ud,nmd->nmu", rxp, r_rx))
-        dop = np.exp(2j * np.pi * self.MaximumDopplerShift * (r_rx @ vhat) * t_snap)                 # [n, m]
         core = np.einsum("nmui,nmij,nmsj->nmsu", fr, xp, ft)
         p_nl = r.power[1:] if r.los else r.power
-        h = np.einsum("nmsu,nms,nmu,nm->nsu", core, a_tx, a_rx, dop) * np.sqrt(p_nl / RAY_OFFSETS.size)[:, None, None]
+        base = np.einsum("nmsu,nms,nmu->nmsu", core, a_tx, a_rx) * np.sqrt(p_nl / RAY_OFFSETS.size)[:, None, None, None]
+        st = SimpleNamespace(base=np.ascontiguousarray(base), rate=2.0 * np.pi * self.MaximumDopplerShift * (r_rx @ vhat), los=None)
         if r.los:
             row = r.table[0]
             rt, rr = _unit(row[4], row[2]), _unit(row[5], row[3])
@@ -141,8 +153,18 @@ class CDLChannel:
             ft0 = np.stack([at_ * np.cos(zt), at_ * np.sin(zt)], -1)    # [s, 2]
             fr0 = np.stack([ar_ * np.cos(zr), ar_ * np.sin(zr)], -1)    # [u, 2]
             los_core = fr0[None, :, 0] * ft0[:, None, 0] - fr0[None, :, 1] * ft0[:, None, 1]          # [s, u]
-            d0 = np.exp(2j * np.pi * self.MaximumDopplerShift * float(rr @ vhat) * t_snap)
-            h[0] += math.sqrt(r.power[0]) * los_core * np.exp(2j * np.pi * (txp @ rt))[:, None] * np.exp(2j * np.pi * (rxp @ rr))[None, :] * d0
+            st.los = math.sqrt(r.power[0]) * los_core * np.exp(2j * np.pi * (txp @ rt))[:, None] * np.exp(2j * np.pi * (rxp @ rr))[None, :]
+            st.los_rate = 2.0 * np.pi * self.MaximumDopplerShift * float(rr @ vhat)
+        self._st = _STATIC_CACHE[key] = st
+        return st
+
+    def path_gains(self, t_snap: float) -> np.ndarray:
+        """H[n, s, u] at channel time t_snap (TR 38.901 eq. 7.5-22; LOS term 7.5-29 folded into path 0)."""
+        st = self._static()
+        dop = np.exp(1j * st.rate * t_snap)                               # [n, m]
+        h = np.einsum("nmsu,nm->nsu", st.base, dop)
+        if st.los is not None:
+            h[0] += st.los * np.exp(1j * st.los_rate * t_snap)
         return h
 
     def filter_taps(self):
