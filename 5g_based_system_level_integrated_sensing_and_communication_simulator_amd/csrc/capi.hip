@@ -243,7 +243,7 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
 }
 
 extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream2);
@@ -274,12 +274,13 @@ extern "C" const char* isac_last_error(const isac_ctx* ctx) { return ctx ? ctx->
 
 extern "C" int isac_ctx_get_stream(isac_ctx* ctx, void** hip_stream) {
   if (!ctx || !hip_stream) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   *hip_stream = (void*)ctx->stream;
   return ISAC_OK;
 }
 
 extern "C" int isac_sync(isac_ctx* ctx) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream2));
   return ISAC_OK;
@@ -287,41 +288,48 @@ extern "C" int isac_sync(isac_ctx* ctx) {
 
 extern "C" int isac_dev_alloc(isac_ctx* ctx, size_t bytes, void** dptr) {
   if (!ctx || !dptr) return ISAC_ERR_INVALID_ARG;
-  ISAC_HIP(hipSetDevice(ctx->device));
+  ISAC_ENTER(ctx);
   ISAC_HIP(hipMalloc(dptr, bytes ? bytes : 16));
   return ISAC_OK;
 }
 extern "C" int isac_dev_free(isac_ctx* ctx, void* dptr) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!dptr) return ISAC_OK;
+  ctx->range_cache.valid = false;                  // the freed buffer may be one of the cached grids
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_HIP(hipFree(dptr));
   return ISAC_OK;
 }
 extern "C" int isac_memcpy_h2d(isac_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
   if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
+  ctx->range_cache.valid = false;                  // device contents change: cached range rows may be stale
   ISAC_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   return ISAC_OK;
 }
 extern "C" int isac_memcpy_d2h(isac_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
   if (!ctx || (!dst_host && bytes) || (!src_dev && bytes)) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   ISAC_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   return ISAC_OK;
 }
 extern "C" int isac_memset_dev(isac_ctx* ctx, void* dst_dev, int value, size_t bytes) {
   if (!ctx || (!dst_dev && bytes)) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
+  ctx->range_cache.valid = false;
   ISAC_HIP(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
   return ISAC_OK;
 }
 extern "C" int isac_timer_start(isac_ctx* ctx) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   ISAC_HIP(hipEventRecord(ctx->ev_t0, ctx->stream));
   return ISAC_OK;
 }
 extern "C" int isac_timer_stop_ms(isac_ctx* ctx, double* elapsed_ms) {
   if (!ctx || !elapsed_ms) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   ISAC_HIP(hipEventRecord(ctx->ev_t1, ctx->stream));
   ISAC_HIP(hipEventSynchronize(ctx->ev_t1));
   float ms = 0.f;
@@ -381,7 +389,7 @@ __global__ void pack_kernel(const int* __restrict__ det_cnt, const int* __restri
 extern "C" int isac_fft2d_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
                               const isac_c64* d_rx_grid, const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A,
                               isac_est_result* out) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!out) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
   ISAC_TRY(isac_fft2d_submit_dev(ctx, ep, cfar, d_rx_grid, d_tx_grid, K, L, A));
   return isac_fft2d_collect(ctx, out);
@@ -389,7 +397,7 @@ extern "C" int isac_fft2d_dev(isac_ctx* ctx, const isac_est_params* ep, const is
 
 extern "C" int isac_fft2d_submit_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
                                      const isac_c64* d_rx_grid, const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   ctx->pending.active = false;
   if (!ep || !cfar || !d_rx_grid || !d_tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
   if (K <= 0 || L <= 0 || A <= 0 || A > 1024) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad grid dimensions");
@@ -463,7 +471,7 @@ extern "C" int isac_fft2d_submit_dev(isac_ctx* ctx, const isac_est_params* ep, c
 }
 
 extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!out) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
   Fft2dPending& pd = ctx->pending;
   if (!pd.active) return fail(ctx, ISAC_ERR_INVALID_ARG, "isac_fft2d_collect without a pending isac_fft2d_submit_dev");
@@ -563,7 +571,7 @@ extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
 
 extern "C" int isac_fft2d(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar, const isac_c64* rx_grid,
                           const isac_c64* tx_grid, int32_t K, int32_t L, int32_t A, isac_est_result* out) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!rx_grid || !tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL grid");
   const size_t bytes = sizeof(c64) * (size_t)K * L * A;
   void *d_rx = nullptr, *d_tx = nullptr;
@@ -582,7 +590,7 @@ extern "C" int isac_fft2d(isac_ctx* ctx, const isac_est_params* ep, const isac_c
 
 extern "C" int isac_fft2d_get_detections(isac_ctx* ctx, int32_t* det_idx, double* det_pow, int32_t cap, int32_t* ant_offsets,
                                          int32_t* n_total) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!ctx->last.valid) return fail(ctx, ISAC_ERR_INVALID_ARG, "no completed fft2D call on this context");
   const int total = (int)ctx->last.det_pow.size();
   if (n_total) *n_total = total;
@@ -595,7 +603,7 @@ extern "C" int isac_fft2d_get_detections(isac_ctx* ctx, int32_t* det_idx, double
 
 extern "C" int isac_fft2d_get_power_window(isac_ctx* ctx, double* P, int64_t cap_elems, int32_t dims[3], int32_t* first_row,
                                            int32_t* first_col) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!ctx->last.valid) return fail(ctx, ISAC_ERR_INVALID_ARG, "no completed fft2D call on this context");
   const Fft2dLast& l = ctx->last;
   if (dims) { dims[0] = l.nr; dims[1] = l.nc; dims[2] = l.A; }
@@ -610,13 +618,14 @@ extern "C" int isac_fft2d_get_power_window(isac_ctx* ctx, double* P, int64_t cap
 
 extern "C" int isac_fft2d_get_covariance(isac_ctx* ctx, isac_c64* Ra, int32_t A) {
   if (!ctx || !Ra) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!ctx->last.valid || ctx->last.A != A) return fail(ctx, ISAC_ERR_INVALID_ARG, "no completed fft2D call with this A");
   ISAC_HIP(hipMemcpy(Ra, ctx->cov.p, sizeof(c64) * (size_t)A * A, hipMemcpyDeviceToHost));
   return ISAC_OK;
 }
 
 extern "C" int isac_fft2d_get_music_spectrum(isac_ctx* ctx, double* p_db, int32_t cap, int32_t* n_steps) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!ctx->last.valid) return fail(ctx, ISAC_ERR_INVALID_ARG, "no completed fft2D call on this context");
   const int n = (int)ctx->last.spectrum_db.size();
   if (n_steps) *n_steps = n;
@@ -628,7 +637,7 @@ extern "C" int isac_fft2d_get_music_spectrum(isac_ctx* ctx, double* p_db, int32_
 
 // ------------------------------------------------------------------ stand-alone MUSIC / eig
 extern "C" int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w, isac_c64* V) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!H || !w || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)A * A));
   ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, H, sizeof(c64) * (size_t)A * A, hipMemcpyHostToDevice, ctx->stream));
@@ -660,7 +669,7 @@ extern "C" int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w,
 
 static int doa_scan(isac_ctx* ctx, int mode, int32_t num_dets, const isac_est_params* ep, const isac_c64* Ra, int32_t A,
                     int32_t* L_out, double* azi_est, double* ele_est, int32_t cap, int32_t* n_est) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!ep || !Ra || A <= 0 || !n_est) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   *n_est = 0;
   ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)A * A));
@@ -720,7 +729,7 @@ int isac_music2d_scan(isac_ctx* ctx, const c64* d_U, int N, int ldU, const int* 
 
 extern "C" int isac_music2d_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_music2d_params* mp, const isac_c64* d_rx_grid,
                                 const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A, isac_est_result* out) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!ep || !mp || !d_rx_grid || !d_tx_grid || !out || K <= 0 || L <= 0 || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   std::memset(out, 0, sizeof(*out));
   const double c0 = 299792458.0;                                        // physconst('LightSpeed')  music2D.m:35
@@ -810,7 +819,7 @@ extern "C" int isac_music2d_dev(isac_ctx* ctx, const isac_est_params* ep, const 
 extern "C" int isac_basic_radar_channel(isac_ctx* ctx, const isac_c64* tx_wave, int64_t T,
                                         const isac_radar_channel_params* rp, const uint8_t* los, int noise_mode,
                                         const isac_c64* noise_unit, uint64_t seed, isac_c64* rx_wave) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!tx_wave || !rp || !rx_wave || T <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   const size_t bytes = sizeof(c64) * (size_t)T * rp->n_ants;
   void *d_tx = nullptr, *d_nz = nullptr, *d_rx = nullptr;
@@ -833,7 +842,7 @@ extern "C" int isac_mono_static_sensing(isac_ctx* ctx, const isac_c64* tx_wave, 
                                         const isac_carrier* carrier, const isac_radar_channel_params* rp, const uint8_t* los,
                                         int noise_mode, const isac_c64* noise_unit, uint64_t seed, isac_c64* echo_grid,
                                         int32_t* l_out) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!tx_wave || !rp || !carrier || !echo_grid || T <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   int32_t lw = 0;
   ISAC_TRY(isac_ofdm_symbol_count(carrier, T, &lw));

@@ -97,7 +97,7 @@ using namespace isac;
 extern "C" int isac_cdl_apply_dev(isac_ctx* ctx, const isac_c64* d_x, int64_t T, int32_t Nt, int32_t Nr, int32_t n_paths,
                                   const isac_c64* H, int32_t n_blocks, const int64_t* block_start, const double* taps,
                                   int32_t n_taps, const int32_t* shift, double out_scale, isac_c64* d_y) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!d_x || !d_y || !H || !block_start || !taps || !shift) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
   if (T <= 0 || Nt <= 0 || Nr <= 0 || n_paths <= 0 || n_blocks <= 0 || n_taps <= 0 || n_taps > 64 || n_paths > 64)
     return fail(ctx, ISAC_ERR_INVALID_ARG, "bad dimensions");

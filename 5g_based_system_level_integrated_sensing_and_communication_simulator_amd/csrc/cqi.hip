@@ -96,7 +96,7 @@ static int launch_sinr(isac_ctx* ctx, const c64* H, long long n_re, int Nr, int 
 extern "C" int isac_precoded_sinr_cqi_dev(isac_ctx* ctx, const isac_c64* d_H, int64_t n_re, int32_t Nr, int32_t P,
                                           const isac_c64* W, int32_t n_layers, double sigma, const double* sinr_table_db,
                                           int32_t n_table, double* d_sinr_per_re, double* mean_sinr, int32_t* cqi) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!d_H || !W || n_re <= 0 || Nr <= 0 || Nr > kMaxRx || P <= 0 || n_layers <= 0 || n_layers > kMaxLayers || !(sigma > 0))
     return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments (1 <= layers <= 8, 1 <= Nr <= 16, sigma > 0)");
   ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)P * n_layers + 64));

@@ -456,7 +456,7 @@ static int prepare_echo(isac_ctx* ctx, const c64* d_tx, long long T, const isac_
 extern "C" int isac_basic_radar_channel_dev(isac_ctx* ctx, const isac_c64* d_tx_wave, int64_t T,
                                             const isac_radar_channel_params* rp, const uint8_t* los, int noise_mode,
                                             const isac_c64* d_noise_unit, uint64_t seed, isac_c64* d_rx_wave) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!d_rx_wave) return fail(ctx, ISAC_ERR_INVALID_ARG, "rx_wave is NULL");
   if (noise_mode == ISAC_NOISE_INJECTED && !d_noise_unit) return fail(ctx, ISAC_ERR_INVALID_ARG, "noise buffer missing");
   int Q = 0;
@@ -489,7 +489,7 @@ extern "C" int isac_mono_static_sensing_dev(isac_ctx* ctx, const isac_c64* d_tx_
                                             const isac_carrier* carrier, const isac_radar_channel_params* rp,
                                             const uint8_t* los, int noise_mode, const isac_c64* d_noise_unit,
                                             uint64_t seed, isac_c64* d_echo_grid, int32_t* l_out) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   ctx->range_cache.valid = false;
   ISAC_TRY(check_carrier(ctx, carrier));
   if (!d_echo_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "echo_grid is NULL");
@@ -544,7 +544,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
                                                   uint64_t seed, isac_c64* d_echo_grid, int32_t* l_out,
                                                   const isac_est_params* ep, const isac_cfar_config* cf,
                                                   const isac_c64* d_tx_grid) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   ctx->range_cache.valid = false;
   ISAC_TRY(check_carrier(ctx, carrier));
   if (!d_echo_grid || !ep || !cf || !d_tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
@@ -586,7 +586,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
 
 extern "C" int isac_ofdm_demodulate_dev(isac_ctx* ctx, const isac_c64* d_wave, int64_t T, int32_t A,
                                         const isac_carrier* carrier, isac_c64* d_grid, int32_t L) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   ISAC_TRY(check_carrier(ctx, carrier));
   if (!d_wave || !d_grid || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   OfdmGeom g = geom_of(carrier);
@@ -614,7 +614,7 @@ static int launch_mod(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, int 
 
 extern "C" int isac_ofdm_modulate_dev(isac_ctx* ctx, const isac_c64* d_grid, int32_t L, int32_t A,
                                       const isac_carrier* carrier, double amplitude, isac_c64* d_wave, int64_t T) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   ISAC_TRY(check_carrier(ctx, carrier));
   if (!d_wave || !d_grid || A <= 0 || L <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   OfdmGeom g = geom_of(carrier);
@@ -630,7 +630,7 @@ extern "C" int isac_ofdm_modulate_dev(isac_ctx* ctx, const isac_c64* d_grid, int
 
 extern "C" int isac_synth_qpsk_grid_dev(isac_ctx* ctx, isac_c64* d_grid, int32_t K, int32_t L, int32_t A, uint64_t seed,
                                         int32_t zero_s_slots) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!d_grid || K <= 0 || L <= 0 || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   long long n = (long long)K * L * A;
   hipLaunchKernelGGL(synth_qpsk_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (c64*)d_grid, K, L, A, seed,

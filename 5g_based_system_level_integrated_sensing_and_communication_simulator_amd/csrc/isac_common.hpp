@@ -124,6 +124,16 @@ inline int allow_lds(isac_ctx* ctx, const void* kernel, size_t bytes) {
       return isac::fail(ctx, ISAC_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
   } while (0)
 
+// Top of every extern "C" entry point that takes a context: NULL check + make the context's device current on the
+// calling thread (scratch allocations, table uploads and hipFuncSetAttribute all act on the CURRENT device, so a
+// process that holds contexts on several GPUs, or uses a context from a thread other than its creator, must switch).
+#define ISAC_ENTER(ctx)                                                                            \
+  do {                                                                                             \
+    if (!(ctx)) return ISAC_ERR_INVALID_ARG;                                                       \
+    if (hipSetDevice((ctx)->device) != hipSuccess)                                                 \
+      return isac::fail((ctx), ISAC_ERR_HIP, "hipSetDevice failed for the context's device");     \
+  } while (0)
+
 #define ISAC_TRY(call)              \
   do {                              \
     int s__ = (call);               \

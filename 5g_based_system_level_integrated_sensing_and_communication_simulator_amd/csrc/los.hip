@@ -83,7 +83,7 @@ using namespace isac;
 extern "C" int isac_los_check_dev(isac_ctx* ctx, const double* d_ue, const double* d_ant, int64_t n_links,
                                   const double* d_corners, const int32_t* d_wall_offsets, const double* d_normals,
                                   const double* d_norm_dist, int32_t n_walls, uint8_t* d_los, int32_t* d_n_blocking) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (n_links < 0 || n_walls < 0 || (n_links > 0 && (!d_ue || !d_ant || !d_los)) ||
       (n_walls > 0 && (!d_corners || !d_wall_offsets || !d_normals || !d_norm_dist)))
     return fail(ctx, ISAC_ERR_INVALID_ARG, "los_check: null pointer or negative count");
@@ -96,7 +96,7 @@ extern "C" int isac_los_check_dev(isac_ctx* ctx, const double* d_ue, const doubl
   ISAC_HIP(hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n_links, ctx->stream));
   const long long tasks = (long long)n_links * n_walls;
   if (tasks > 0) {
-    if (cdiv(tasks, 256) > 0x7fffffffLL) return fail(ctx, ISAC_ERR_CAPACITY, "los_check: links x walls exceeds one launch");
+    if ((tasks + 255) / 256 > 0x7fffffffLL) return fail(ctx, ISAC_ERR_CAPACITY, "los_check: links x walls exceeds one launch");
     hipLaunchKernelGGL(los_kernel, dim3((unsigned)cdiv(tasks, 256)), dim3(256), 0, ctx->stream, d_ue, d_ant, (long long)n_links,
                        d_corners, d_wall_offsets, d_normals, d_norm_dist, n_walls, cnt);
     ISAC_HIP(hipGetLastError());
@@ -110,13 +110,13 @@ extern "C" int isac_los_check_dev(isac_ctx* ctx, const double* d_ue, const doubl
 extern "C" int isac_winding_number_dev(isac_ctx* ctx, const double* d_points, int64_t n_points, const double* d_corners,
                                        const int32_t* d_wall_offsets, const double* d_normals, int32_t n_walls,
                                        double* d_winding) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (n_points < 0 || n_walls < 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "winding_number: negative count");
   const long long tasks = (long long)n_points * n_walls;
   if (tasks == 0) return ISAC_OK;
   if (!d_points || !d_corners || !d_wall_offsets || !d_normals || !d_winding)
     return fail(ctx, ISAC_ERR_INVALID_ARG, "winding_number: null pointer");
-  if (cdiv(tasks, 256) > 0x7fffffffLL) return fail(ctx, ISAC_ERR_CAPACITY, "winding_number: points x walls exceeds one launch");
+  if ((tasks + 255) / 256 > 0x7fffffffLL) return fail(ctx, ISAC_ERR_CAPACITY, "winding_number: points x walls exceeds one launch");
   hipLaunchKernelGGL(winding_kernel, dim3((unsigned)cdiv(tasks, 256)), dim3(256), 0, ctx->stream, d_points, (long long)n_points,
                      d_corners, d_wall_offsets, d_normals, n_walls, d_winding);
   ISAC_HIP(hipGetLastError());

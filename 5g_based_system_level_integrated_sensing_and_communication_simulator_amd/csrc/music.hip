@@ -1136,7 +1136,7 @@ using namespace isac;
 
 int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra);
 extern "C" int isac_covariance_dev(isac_ctx* ctx, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   return isac_covariance_on(ctx, ctx->stream, d_grid, N, A, d_Ra);
 }
 template <int NB>

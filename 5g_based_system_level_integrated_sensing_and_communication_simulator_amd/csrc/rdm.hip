@@ -444,7 +444,7 @@ int isac_cfar_window(isac_ctx* ctx, const isac_cfar_config* cf, int nr, int nc, 
 extern "C" int isac_cfar2d_ca(isac_ctx* ctx, const double* P, int32_t n_rows, int32_t n_cols, const int32_t* cut_idx,
                               int32_t n_cut, const int32_t guard[2], const int32_t train[2], double pfa, int32_t* det_idx,
                               int32_t cap, int32_t* n_det) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!P || !cut_idx || !guard || !train || !n_det || n_rows <= 0 || n_cols <= 0 || n_cut < 0)
     return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   const int gr = guard[0], gc = guard[1], hr = guard[0] + train[0], hc = guard[1] + train[1];
@@ -489,7 +489,7 @@ extern "C" int isac_cfar2d_ca(isac_ctx* ctx, const double* P, int32_t n_rows, in
 // exposed so bench.py can time exactly this launch with HIP events for the roofline entry.
 extern "C" int isac_fft2d_range_stage_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf,
                                           const isac_c64* d_rx_grid, const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!ep || !cf || !d_rx_grid || !d_tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
   ctx->range_cache.valid = false;
   const int n_ifft = ep->n_ifft;
@@ -509,7 +509,7 @@ extern "C" int isac_fft2d_range_stage_dev(isac_ctx* ctx, const isac_est_params* 
 
 extern "C" int isac_rdm_plane_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_c64* d_rx_grid,
                                   const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A, int32_t ant, isac_c64* d_rdm) {
-  if (!ctx) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
   if (!ep || !d_rx_grid || !d_tx_grid || !d_rdm || ant < 0 || ant >= A) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   const int n_ifft = ep->n_ifft, n_fft = ep->n_fft;
   const c64 *tw = nullptr, *twd = nullptr;
