@@ -117,6 +117,98 @@ __device__ __forceinline__ c64 philox_normal_pair_tab(uint64_t e, uint64_t seed,
   return c64{rad * c, rad * sn};
 }
 
+// ---------------------------------------------------------------- spectral AWGN (noise drawn on the demodulated grid)
+// OFDM demodulation is linear and (up to sqrt(Nfft)) unitary on every symbol's FFT window, the windows of different
+// symbols are disjoint, and the carrier / window phase factors have unit modulus: i.i.d. CN(0, 2 s^2) time-domain noise
+// (basicRadarChannel.m:67-69) therefore arrives on the kept subcarriers as i.i.d. CN(0, 2 Nfft s^2).  The performance
+// noise modes draw it there directly: K instead of Nfft (+CP) normals per symbol and antenna, and no generator inside the
+// FFT's sample producers.
+// Generator: ONE Philox4x32-10 call per PAIR of grid elements -- (o0, o1) -> element "half 0", (o2, o3) -> "half 1";
+// each Box-Muller transform takes a 32-bit radius uniform u1 = (o + 1) 2^-32 in (0, 1] and a 32-bit angle 2 pi o' 2^-32
+// (the resolution cuRAND's single-precision normals use; |z| <= sqrt(-2 ln 2^-32) = 6.66 sigma), evaluated in fp64.
+// Pairing (defined on the subcarrier index k only, so every kernel shape draws the same field):
+//   slot(k) = (k mod 256) + 256 * ((k div 256) div 2),  half(k) = (k div 256) mod 2,
+//   counter = slot + 2048 * column,  column = l + L * a  (the grid's own column index),  key = seed, stream word = 2.
+constexpr uint32_t kSpectralStream = 2u;
+constexpr int kSpectralSlotsPerColumn = 2048;
+
+__device__ __forceinline__ c64 box_muller32_tab(uint32_t ur, uint32_t ua, const c64* __restrict__ w256 /* LDS: exp(-2 pi j i / 256) */,
+                                                const c64* __restrict__ logtab /* LDS: (1/c_i, ln c_i) */) {
+  // ---- radius
+  const double u1 = ((double)ur + 1.0) * 0x1.0p-32;                 // exact
+  int ex;
+  const double m = frexp(u1, &ex);                                   // m in [0.5, 1)
+  const int idx = (int)((__double2hiint(m) >> 13) & (kLogTabSize - 1));
+  const c64 lt = logtab[idx];
+  const double r = ::fma(m, lt.re, -1.0);
+  double q = 1.0 / 7.0;
+  q = ::fma(q, r, -1.0 / 6.0); q = ::fma(q, r, 1.0 / 5.0); q = ::fma(q, r, -1.0 / 4.0); q = ::fma(q, r, 1.0 / 3.0); q = ::fma(q, r, -0.5);
+  const double l1p = ::fma(r * r, q, r);
+  const double ln_u = ::fma((double)ex, 0.69314718055994530942, lt.im + l1p);
+  const double y = -2.0 * ln_u;
+  double rad = 0.0;
+  if (y > 0.0) {
+    const double rs = __builtin_amdgcn_rsq(y);
+    double sq = y * rs;
+    const double h = 0.5 * rs;
+    sq = ::fma(::fma(-sq, sq, y), h, sq);
+    sq = ::fma(::fma(-sq, sq, y), h, sq);
+    rad = sq;
+  }
+  // ---- angle: theta = 2 pi ua 2^-32 = 2 pi i / 256 + phi
+  const int i = (int)(ua >> 24);
+  const double phi = (double)(ua & 0x00FFFFFFu) * (6.28318530717958647692 * 0x1.0p-32);
+  const double p2 = phi * phi;
+  const double sphi = phi * ::fma(p2, ::fma(p2, ::fma(p2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
+  const double cphi = ::fma(p2, ::fma(p2, ::fma(p2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
+  const c64 w = w256[i];                                             // (cos a, -sin a)
+  const double c = ::fma(w.re, cphi, w.im * sphi);
+  const double sn = ::fma(w.re, sphi, -w.im * cphi);
+  return c64{rad * c, rad * sn};
+}
+
+// One column's synthesis for 256 threads: thread `tid` owns the elements k = tid + 256 j, j = 0..15, and calls
+// emit(j, k, value) for every k < K in ascending j.
+//   value = sum_q D_q[k] * s_q  (+ sig * unit noise)
+// NZ: 0 = noiseless, 1 = Philox spectral (above), 2 = injected unit noise column `nz`.
+template <int QT, int NZ, class E>
+__device__ __forceinline__ void spectral_echo_column(int tid, int K, int Q_rt, const c64* __restrict__ Dl /* D + K*l */,
+                                                     long long d_stride /* K * L_whole */, const c64* __restrict__ sr /* [Q] */,
+                                                     double sig, uint64_t seed, long long column, const c64* __restrict__ nz,
+                                                     const c64* __restrict__ w256, const c64* __restrict__ logtab, E&& emit) {
+  const int Q = QT ? QT : Q_rt;
+#pragma unroll
+  for (int p = 0; p < 8; ++p) {
+    if (512 * p >= K) break;                                         // (uniform)
+    uint32_t o[4] = {0u, 0u, 0u, 0u};
+    if constexpr (NZ == 1) {
+      const uint64_t ctr = (uint64_t)(tid + 256 * p) + (uint64_t)kSpectralSlotsPerColumn * (uint64_t)column;
+      philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), kSpectralStream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = 2 * p + h;
+      const int k = tid + 256 * j;
+      const int kc = k < K ? k : K - 1;                              // unconditional loads, select afterwards
+      c64 v = mk(0.0, 0.0);
+      if constexpr (QT > 0) {
+#pragma unroll
+        for (int q = 0; q < QT; ++q) v = fma(Dl[(long long)q * d_stride + kc], sr[q], v);
+      } else {
+        for (int q = 0; q < Q; ++q) v = fma(Dl[(long long)q * d_stride + kc], sr[q], v);
+      }
+      if constexpr (NZ == 1) {
+        const c64 n1 = box_muller32_tab(o[2 * h], o[2 * h + 1], w256, logtab);
+        v = v + n1 * sig;
+      } else if constexpr (NZ == 2) {
+        v = v + nz[kc] * sig;
+      }
+      if (k < K) emit(j, k, v);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // rx[t,r] for one sample (shared by the fused demodulator and the waveform materialiser)
 __device__ __forceinline__ c64 rx_sample(long long t, int r, long long T, int Q, const c64* __restrict__ coef,
                                          const c64* __restrict__ s_steer_r /* [Q] a_q[r] */,

@@ -1,0 +1,86 @@
+"""Full-size parity: the benchmark shape itself (BASELINE.json configs[1]: K=3276, L=224, A=64, T=983 040, nIFFT 4096,
+nFFT 256), the reference's default 16-element array at the same size (configs[0], ula.m:45) and the 256-element ULA of
+configs[3], run ENTIRELY on the device (beam-sum -> coefficient vectors -> fused synthesis + OFDM demodulation -> range IFFT
+-> Doppler FFT -> CFAR -> covariance -> eig -> MUSIC) with injected AWGN, against
+  (1) the committed golden fixtures tests/golden/config*.npz (oracle outputs: SHA-256 of the per-antenna CFAR index lists,
+      estimates, Ra, |rdm|^2 planes, strided echo sub-sample -- tests/golden/make_golden.py), and
+  (2) the oracle re-run live on the same seeded scene (every element of the echo grid, every antenna's detection list).
+Tolerances: echo grid / Ra / |rdm|^2 <= 1e-10 relative to the field maximum; detection indices, range / velocity / azimuth
+estimates exact (monoStaticSensing.m:1-23, fft2D.m:59-115)."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as O
+from conftest import load_pkg, make_scene
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+from make_golden import FULL, detection_digest, estimate_digest  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-10
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b, scale=None):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / (scale or max(np.abs(np.asarray(b)).max(), 1e-300)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+@pytest.mark.parametrize("name,live_oracle", [("config1_a16", True), ("config2_a64", True), ("config4_a256", True)])
+def test_full_size_chain_on_device(pkg, name, live_oracle):
+    import hashlib
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    sc = make_scene(**FULL[name])
+    assert hashlib.sha256(np.ascontiguousarray(sc.tx_grid[:, :, 0]).tobytes()).hexdigest() == str(g["tx_grid_sha256"])
+    ctx = pkg.Context()
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    cf = pkg.sensing.detection.cfar2D(rp)
+    d_wave, d_noise, d_txg = ctx.to_device(sc.tx_wave), ctx.to_device(sc.noise), ctx.to_device(sc.tx_grid)
+    echo = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, noise=d_noise, nfft=sc.wave.Nfft)
+    est, dbg = pkg.sensing.estimation.fft2D(rp, cf, echo, d_txg, return_debug=True)
+    h_echo = echo.numpy()
+    # ---- (1) committed golden fixture
+    s = tuple(int(v) for v in g["echo_stride"])
+    assert rel(h_echo[::s[0], ::s[1], ::s[2]], g["echo_grid_sub"], float(g["echo_max"])) < RTOL
+    assert detection_digest(dbg.detections) == str(g["det_sha256"]), "per-antenna CFAR detection lists differ from the golden hash"
+    assert np.array_equal([d.shape[1] for d in dbg.detections], g["det_counts"])
+    assert np.array_equal(est.rngEst, g["rngEst"]) and np.array_equal(est.velEst, g["velEst"]) and np.array_equal(est.aziEst, g["aziEst"])
+    assert estimate_digest(est) == str(g["est_sha256"])
+    assert rel(dbg.Ra, g["Ra"]) < RTOL and np.array_equal(dbg.Ra, dbg.Ra.conj().T)
+    r0, c0 = (int(v) for v in g["pw_first"])
+    assert (dbg.first_row, dbg.first_col) == (r0, c0)
+    for i, a in enumerate(g["pw_planes"]):
+        assert rel(dbg.power_window[:, :, int(a)], g["power_window"][:, :, i]) < RTOL
+    assert float(g["cfar_margin"]) > 1e-6            # no CUT of this scene is within rounding distance of its threshold
+    # fused call sequence (range stage inside the demodulator) gives the same bits at this size
+    if sc.wave.Nfft == 4096:
+        e2 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, noise=d_noise, nfft=4096, fuse_fft2d=(rp, cf, d_txg))
+        est2, dbg2 = pkg.sensing.estimation.fft2D(rp, cf, e2, d_txg, return_debug=True)
+        assert np.array_equal(dbg2.power_window, dbg.power_window) and detection_digest(dbg2.detections) == str(g["det_sha256"])
+        assert np.array_equal(est2.aziEst, est.aziEst)
+        del e2
+    if not live_oracle:
+        return
+    # ---- (2) the oracle, live, on every element
+    del d_wave, d_noise
+    want_echo = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, sc.noise, nfft=sc.wave.Nfft)
+    assert h_echo.shape == want_echo.shape and rel(h_echo, want_echo) < RTOL
+    ocf = O.cfar2d_config(sc.rp)
+    want, odbg = O.fft2d(sc.rp, ocf, want_echo, sc.tx_grid, return_debug=True, rdm_fn=O.rdm_explicit)
+    nr, nc, _ = dbg.power_window.shape
+    p_ref = np.abs(odbg.rdm[r0 - 1:r0 - 1 + nr, c0 - 1:c0 - 1 + nc, :]) ** 2
+    assert rel(dbg.power_window, p_ref) < RTOL
+    for a in range(sc.A):
+        assert np.array_equal(dbg.detections[a], odbg.detections[a]), f"antenna {a}"
+    assert np.array_equal(est.rngEst, want.rngEst) and np.array_equal(est.velEst, want.velEst) and np.array_equal(est.aziEst, want.aziEst)
+    assert rel(dbg.Ra, odbg.Ra) < RTOL
+    assert detection_digest(odbg.detections) == str(g["det_sha256"])     # the oracle still reproduces its own fixture
