@@ -15,7 +15,7 @@ _lib = None
 _lock = threading.Lock()
 
 ISAC_MAX_EST = 1024
-NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX = 0, 1, 2
+NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX, NOISE_PHILOX_SPECTRAL, NOISE_INJECTED_SPECTRAL = 0, 1, 2, 3, 4
 
 STATUS_NAMES = {0: "OK", 1: "INVALID_ARG", 2: "HIP", 3: "NO_LOS", 4: "NO_DETECTION", 5: "CFAR_WINDOW",
                 6: "CAPACITY", 7: "UNSUPPORTED", 8: "SHORT_WAVEFORM"}
@@ -75,10 +75,10 @@ class EstResult(C.Structure):
 EXPORTS = [
     "isac_abi_version", "isac_device_count", "isac_ctx_create", "isac_ctx_destroy", "isac_last_error",
     "isac_ctx_get_stream", "isac_sync", "isac_dev_alloc", "isac_dev_free", "isac_memcpy_h2d", "isac_memcpy_d2h",
-    "isac_memset_dev", "isac_timer_start", "isac_timer_stop_ms",
+    "isac_memset_dev", "isac_timer_start", "isac_timer_stop_ms", "isac_profile_enable", "isac_profile_last_kernel_ms",
     "isac_basic_radar_channel_dev", "isac_basic_radar_channel", "isac_mono_static_sensing_dev",
     "isac_mono_static_sensing", "isac_mono_static_sensing_fused_dev", "isac_ofdm_symbol_count", "isac_ofdm_demodulate_dev", "isac_ofdm_modulate_dev",
-    "isac_ofdm_waveform_length", "isac_cfar2d_ca", "isac_fft2d_dev", "isac_fft2d", "isac_fft2d_submit_dev", "isac_fft2d_collect", "isac_fft2d_range_stage_dev", "isac_fft2d_get_detections",
+    "isac_ofdm_waveform_length", "isac_cfar2d_ca", "isac_fft2d_dev", "isac_fft2d", "isac_fft2d_submit_dev", "isac_fft2d_submit_cached_dev", "isac_fft2d_collect", "isac_fft2d_range_stage_dev", "isac_fft2d_get_detections",
     "isac_fft2d_get_power_window", "isac_fft2d_get_covariance", "isac_fft2d_get_music_spectrum",
     "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_beamscan_doa", "isac_music2d_dev", "isac_eigh", "isac_cdl_apply_dev", "isac_precoded_sinr_cqi_dev", "isac_los_check_dev", "isac_winding_number_dev", "isac_synth_qpsk_grid_dev",
 ]

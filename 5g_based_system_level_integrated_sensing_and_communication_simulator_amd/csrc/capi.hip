@@ -11,7 +11,7 @@ using namespace isac;
 
 // kernels / stages implemented in the other translation units
 int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, const c64* d_rx, const c64* d_tx,
-                          int K, int L, int A, int* nr_out, int* nc_out);
+                          int K, int L, int A, int* nr_out, int* nc_out, bool use_cached_range);
 int isac_cfar_window(isac_ctx* ctx, const isac_cfar_config* cf, int nr, int nc, int A, int cap);
 int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st);
 // status word the device eigensolver leaves behind the eigenvalues (ctx->eig_w [A] | info[0..5]): negative = the QL
@@ -234,7 +234,8 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_cfar, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_h2d, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreate(&ctx->ev_t0) != hipSuccess || hipEventCreate(&ctx->ev_t1) != hipSuccess) {
+      hipEventCreate(&ctx->ev_t0) != hipSuccess || hipEventCreate(&ctx->ev_t1) != hipSuccess ||
+      hipEventCreate(&ctx->ev_k0) != hipSuccess || hipEventCreate(&ctx->ev_k1) != hipSuccess) {
     delete ctx;
     return ISAC_ERR_HIP;
   }
@@ -250,7 +251,7 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   for (auto& kv : ctx->twiddles) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->kaiser3) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->sind) (void)hipFree(kv.second.p);
-  DevBuf* bufs[] = {&ctx->beam, &ctx->coef, &ctx->phase_rx, &ctx->steer,
+  DevBuf* bufs[] = {&ctx->beam, &ctx->coef, &ctx->phase_rx, &ctx->steer, &ctx->dgrid,
                     &ctx->ymid, &ctx->pwin, &ctx->flags, &ctx->det_cut, &ctx->det_pow, &ctx->det_cnt, &ctx->cov_part,
                     &ctx->cov, &ctx->eig_w, &ctx->eig_v, &ctx->eig_scratch, &ctx->spec, &ctx->misc, &ctx->stage_a, &ctx->stage_b,
                     &ctx->stage_c, &ctx->sind_tab};
@@ -264,6 +265,8 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   if (ctx->pinned_in) (void)hipHostFree(ctx->pinned_in);
   (void)hipEventDestroy(ctx->ev_t0);
   (void)hipEventDestroy(ctx->ev_t1);
+  (void)hipEventDestroy(ctx->ev_k0);
+  (void)hipEventDestroy(ctx->ev_k1);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->stream2);
   delete ctx;
@@ -295,7 +298,7 @@ extern "C" int isac_dev_alloc(isac_ctx* ctx, size_t bytes, void** dptr) {
 extern "C" int isac_dev_free(isac_ctx* ctx, void* dptr) {
   ISAC_ENTER(ctx);
   if (!dptr) return ISAC_OK;
-  ctx->range_cache.valid = false;                  // the freed buffer may be one of the cached grids
+  ctx->range_cache.touch(dptr, 0);                 // freeing one of the cached grids drops the cached range rows
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_HIP(hipFree(dptr));
   return ISAC_OK;
@@ -303,7 +306,7 @@ extern "C" int isac_dev_free(isac_ctx* ctx, void* dptr) {
 extern "C" int isac_memcpy_h2d(isac_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
   if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return ISAC_ERR_INVALID_ARG;
   ISAC_ENTER(ctx);
-  ctx->range_cache.valid = false;                  // device contents change: cached range rows may be stale
+  ctx->range_cache.touch(dst_dev, bytes);          // overwriting a cached grid drops the cached range rows
   ISAC_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   return ISAC_OK;
@@ -318,7 +321,7 @@ extern "C" int isac_memcpy_d2h(isac_ctx* ctx, void* dst_host, const void* src_de
 extern "C" int isac_memset_dev(isac_ctx* ctx, void* dst_dev, int value, size_t bytes) {
   if (!ctx || (!dst_dev && bytes)) return ISAC_ERR_INVALID_ARG;
   ISAC_ENTER(ctx);
-  ctx->range_cache.valid = false;
+  ctx->range_cache.touch(dst_dev, bytes);
   ISAC_HIP(hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
   return ISAC_OK;
 }
@@ -335,6 +338,23 @@ extern "C" int isac_timer_stop_ms(isac_ctx* ctx, double* elapsed_ms) {
   float ms = 0.f;
   ISAC_HIP(hipEventElapsedTime(&ms, ctx->ev_t0, ctx->ev_t1));
   *elapsed_ms = (double)ms;
+  return ISAC_OK;
+}
+
+extern "C" int isac_profile_enable(isac_ctx* ctx, int on) {
+  ISAC_ENTER(ctx);
+  ctx->profile = on != 0;
+  ctx->profile_recorded = false;
+  return ISAC_OK;
+}
+extern "C" int isac_profile_last_kernel_ms(isac_ctx* ctx, double* ms) {
+  ISAC_ENTER(ctx);
+  if (!ms) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (!ctx->profile || !ctx->profile_recorded) return fail(ctx, ISAC_ERR_INVALID_ARG, "no profiled kernel launch on this context");
+  ISAC_HIP(hipEventSynchronize(ctx->ev_k1));
+  float f = 0.f;
+  ISAC_HIP(hipEventElapsedTime(&f, ctx->ev_k0, ctx->ev_k1));
+  *ms = (double)f;
   return ISAC_OK;
 }
 
@@ -395,8 +415,20 @@ extern "C" int isac_fft2d_dev(isac_ctx* ctx, const isac_est_params* ep, const is
   return isac_fft2d_collect(ctx, out);
 }
 
+static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar, const isac_c64* d_rx_grid,
+                        const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A, bool use_cached_range);
+
 extern "C" int isac_fft2d_submit_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
                                      const isac_c64* d_rx_grid, const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A) {
+  return fft2d_submit(ctx, ep, cfar, d_rx_grid, d_tx_grid, K, L, A, false);
+}
+extern "C" int isac_fft2d_submit_cached_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
+                                            const isac_c64* d_rx_grid, const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A) {
+  return fft2d_submit(ctx, ep, cfar, d_rx_grid, d_tx_grid, K, L, A, true);
+}
+
+static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar, const isac_c64* d_rx_grid,
+                        const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A, bool use_cached_range) {
   ISAC_ENTER(ctx);
   ctx->pending.active = false;
   if (!ep || !cfar || !d_rx_grid || !d_tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
@@ -424,7 +456,7 @@ extern "C" int isac_fft2d_submit_dev(isac_ctx* ctx, const isac_est_params* ep, c
   ISAC_TRY(isac_covariance_on(ctx, s2, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
   if (!upa) ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, s2));                         // music.m:19
   int nr = 0, nc = 0;
-  ISAC_TRY(isac_rdm_power_window(ctx, ep, cfar, rx, tx, K, L, A, &nr, &nc));          // fft2D.m:37-46,61
+  ISAC_TRY(isac_rdm_power_window(ctx, ep, cfar, rx, tx, K, L, A, &nr, &nc, use_cached_range));          // fft2D.m:37-46,61
   const int n_cut_rows = cfar->row1 - cfar->row0 + 1, n_cut_cols = cfar->col1 - cfar->col0 + 1;
   const long long n_cut = (long long)n_cut_rows * n_cut_cols;
   const int cap = (int)std::min<long long>(n_cut, 4096);
@@ -852,8 +884,9 @@ extern "C" int isac_mono_static_sensing(isac_ctx* ctx, const isac_c64* tx_wave, 
   void *d_tx = nullptr, *d_nz = nullptr, *d_g = nullptr;
   int st = ISAC_OK;
   if (hipMalloc(&d_tx, wbytes) != hipSuccess || hipMalloc(&d_g, gbytes) != hipSuccess) st = fail(ctx, ISAC_ERR_HIP, "hipMalloc failed");
-  if (st == ISAC_OK && noise_mode == ISAC_NOISE_INJECTED && noise_unit) {
-    if (hipMalloc(&d_nz, wbytes) != hipSuccess || hipMemcpy(d_nz, noise_unit, wbytes, hipMemcpyHostToDevice) != hipSuccess)
+  if (st == ISAC_OK && (noise_mode == ISAC_NOISE_INJECTED || noise_mode == ISAC_NOISE_INJECTED_SPECTRAL) && noise_unit) {
+    const size_t nbytes = noise_mode == ISAC_NOISE_INJECTED ? wbytes : gbytes;   // [T x A] samples or [n_sc x L_out x A] grid elements
+    if (hipMalloc(&d_nz, nbytes) != hipSuccess || hipMemcpy(d_nz, noise_unit, nbytes, hipMemcpyHostToDevice) != hipSuccess)
       st = fail(ctx, ISAC_ERR_HIP, "noise upload failed");
   }
   if (st == ISAC_OK && hipMemcpy(d_tx, tx_wave, wbytes, hipMemcpyHostToDevice) != hipSuccess) st = fail(ctx, ISAC_ERR_HIP, "upload failed");

@@ -270,6 +270,103 @@ __global__ __launch_bounds__(256, 2) void demod_range_kernel(OfdmGeom g, long lo
       tid);
 }
 
+// ---------------------------------------------------------------- spectral echo synthesis (performance noise modes)
+// By linearity of the OFDM demodulator the echo grid of basicRadarChannel.m:64-74 + nrOFDMDemodulate is
+//     echoGrid[k,l,r] = sum_q a_q[r] * D_q[k,l] + W[k,l,r],   D_q = OFDM-demodulate(coef_q)   (Q columns per symbol, not A)
+// with W the demodulated AWGN -- i.i.d. CN(0, 2 Nfft s^2) on the kept bins (echo_dev.hpp).  With the noise drawn there
+// (ISAC_NOISE_PHILOX_SPECTRAL) or supplied there (ISAC_NOISE_INJECTED_SPECTRAL) the A x L demodulation FFTs shrink to
+// Q x L and the synthesis becomes a streaming rank-Q update: one write of the grid, VALU work = the generator only.
+// One (symbol, antenna) column per workgroup, symbol fastest (as in demod_kernel).
+template <int QT, int NZ>
+__global__ __launch_bounds__(256) void echo_spectral_kernel(int K, int L_whole, int L_out, int A, int Q_rt, const c64* __restrict__ D,
+                                                            const c64* __restrict__ steer_rq, double sig, uint64_t seed,
+                                                            const c64* __restrict__ noise /* [K x L_out x A] unit, NZ == 2 */,
+                                                            const c64* __restrict__ w256_g, const c64* __restrict__ logtab_g,
+                                                            c64* __restrict__ grid) {
+  __shared__ __attribute__((aligned(16))) c64 s_w256[256];
+  __shared__ __attribute__((aligned(16))) c64 s_lt[kLogTabSize];
+  const int tid = threadIdx.x;
+  int l, r;
+  if (!spectral_tile_map(blockIdx.x, L_whole, A, l, r)) return;       // padding workgroup of the tile grid (before any barrier)
+  if constexpr (NZ == 1) {
+    s_w256[tid] = w256_g[tid];
+    if (tid < kLogTabSize) s_lt[tid] = logtab_g[tid];
+    __syncthreads();
+  }
+  const int Q = QT ? QT : Q_rt;
+  const long long colg = (long long)l + (long long)L_out * r;
+  c64* dst = grid + (long long)K * colg;
+  struct None_ {};
+  c64 acc[16];
+  spectral_echo_column<QT, NZ, 4>(tid, K, Q, D + (long long)K * l, (long long)K * L_whole, steer_rq + (long long)r * Q, sig, seed, colg,
+                                  NZ == 2 ? noise + (long long)K * colg : nullptr, s_w256, s_lt, acc, [](int) { return None_{}; },
+                                  [&](int, int k, c64 v, None_) {
+                                    if (k < K) {
+                                      __builtin_nontemporal_store(v.re, &dst[k].re);
+                                      __builtin_nontemporal_store(v.im, &dst[k].im);
+                                    }
+                                    return v;
+                                  });
+}
+
+// Register budget: the LDS image allows two workgroups per CU anyway, so up to 256 VGPRs per lane are free.  (A 154-VGPR
+// variant that leaves a third of the register file to a co-resident covariance / beam-sum wave measured 6 % slower in isolation
+// and 4 % slower pipelined: the kernel is latency-bound at two waves per SIMD and needs the loads in flight.)
+#ifndef ISAC_ECHO_RANGE_WGS
+#define ISAC_ECHO_RANGE_WGS 2
+#endif
+// The same synthesis with the range stage of the following fft2D call (fft2D.m:37-45) applied while the column is still in
+// registers: echoGrid is written once (API output + covariance input) and never re-read by the range stage; txGrid is read
+// once.  HBM traffic of the launch = K L A 16 B written + K L A 16 B read (+ the CUT rows) -- the algorithmic minimum for
+// monoStaticSensing's output + fft2D's range-Doppler input.  Requires nIFFT == 4096 (the FFT the registers are laid out for).
+template <int QT, int NZ, int GROUP = (QT == 1 ? 8 : 4)>   // loads in flight per thread: 2 x GROUP elements (measured: 8 beats 4 by 6 % at Q = 1)
+__global__ __launch_bounds__(256, ISAC_ECHO_RANGE_WGS) void echo_range_kernel(int K, int L_whole, int L_out, int A, int Q_rt, const c64* __restrict__ D,
+                                                            const c64* __restrict__ steer_rq, double sig, uint64_t seed,
+                                                            const c64* __restrict__ noise, const c64* __restrict__ tw,
+                                                            const c64* __restrict__ logtab_g, c64* __restrict__ grid,
+                                                            const c64* __restrict__ txg, const double* __restrict__ win_k,
+                                                            const double* __restrict__ win_r, double inv_n, double sqrt_n,
+                                                            int row_lo, int n_rows, c64* __restrict__ ymid) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* lds = reinterpret_cast<c64*>(smem_raw);
+  using FFT = Fft4096;
+  const int tid = threadIdx.x;
+  FFT fft;
+  const int Q = QT ? QT : Q_rt;
+  int l, r;
+  if (!spectral_tile_map(blockIdx.x, L_whole, A, l, r)) return;       // padding workgroup of the tile grid (before any barrier)
+  const long long colg = (long long)l + (long long)L_out * r;
+  c64* lt = lds + FFT::LDS_ELEMS;
+  if (NZ == 1 && tid < kLogTabSize) lt[tid] = logtab_g[tid];
+  fft.init_table(lds, tw, tid);                      // W256 (generator angle + second-pass twiddles); barrier inside
+  c64* dst = grid + (long long)K * colg;
+  const c64* ptx = txg + (long long)K * colg;
+#pragma unroll
+  for (int j = 0; j < FFT::PER; ++j) fft.x[j] = mk(0.0, 0.0);       // ifft(., nIFFT, 1) zero-pads at the end
+  struct TxWin { c64 tx; double w; };
+  spectral_echo_column<QT, NZ, GROUP>(tid, K, Q, D + (long long)K * l, (long long)K * L_whole, steer_rq + (long long)r * Q, sig, seed, colg,
+                                  NZ == 2 ? noise + (long long)K * colg : nullptr, lds + FFT::IMG, lt, fft.x,
+                                  [&](int kc) { return TxWin{ptx[kc], win_k[kc]}; },   // txGrid sample + range window, loads unconditional
+                                  [&](int, int k, c64 v, TxWin t) {
+                                    if (k < K) {
+                                      __builtin_nontemporal_store(v.re, &dst[k].re);   // echoGrid(k, l, r)
+                                      __builtin_nontemporal_store(v.im, &dst[k].im);
+                                    }
+                                    const c64 y = mul_conj(v, t.tx) * t.w;              // fft2D.m:37,:43 (same order as range_kernel)
+                                    return k < K ? y : mk(0.0, 0.0);                    // ifft(., nIFFT, 1) zero-pads at the end
+                                  });
+  fft.init_twiddles(tw, tid);
+  fft.template transform<+1>(lds, tw, tid);
+  c64* yd = ymid + (long long)n_rows * colg;
+  fft.drain(
+      [&](int n, c64 v) {
+        const int rr = n - row_lo;
+        const double wr = win_r[n];
+        if (rr >= 0 && rr < n_rows) yd[rr] = ((v * inv_n) * sqrt_n) * wr;            // fft2D.m:44-45
+      },
+      tid);
+}
+
 // ---------------------------------------------------------------- plain CP-OFDM modulator (no windowing)
 template <class FFT>
 __global__ __launch_bounds__(256, 2) void mod_kernel(OfdmGeom g, long long T, int A, int L, const c64* __restrict__ tw,
@@ -459,6 +556,8 @@ extern "C" int isac_basic_radar_channel_dev(isac_ctx* ctx, const isac_c64* d_tx_
   ISAC_ENTER(ctx);
   if (!d_rx_wave) return fail(ctx, ISAC_ERR_INVALID_ARG, "rx_wave is NULL");
   if (noise_mode == ISAC_NOISE_INJECTED && !d_noise_unit) return fail(ctx, ISAC_ERR_INVALID_ARG, "noise buffer missing");
+  if (noise_mode < ISAC_NOISE_NONE || noise_mode > ISAC_NOISE_PHILOX)
+    return fail(ctx, ISAC_ERR_INVALID_ARG, "basicRadarChannel returns a time-domain waveform: noise modes NONE / INJECTED / PHILOX only");
   int Q = 0;
   ISAC_TRY(prepare_echo(ctx, (const c64*)d_tx_wave, T, rp, los, &Q));
   const int A = rp->n_ants;
@@ -485,6 +584,64 @@ static int launch_demod(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, in
   return ISAC_OK;
 }
 
+// ---- spectral noise modes: per-target demodulated coefficient grids D [K x L_whole x Q] (the coefficient vectors
+// coef [Q x T] are, byte for byte, a [T x Q] waveform), then one synthesis kernel.
+static int spectral_prepare(isac_ctx* ctx, const c64* d_tx, long long T, const isac_radar_channel_params* rp, const uint8_t* los,
+                            const OfdmGeom& g, int* q_out, int* l_whole_out) {
+  int Q = 0;
+  ISAC_TRY(prepare_echo(ctx, d_tx, T, rp, los, &Q));                                 // monoStaticSensing.m:13
+  const int L_whole = whole_symbols(g, T);
+  if (L_whole <= 0) return fail(ctx, ISAC_ERR_SHORT_WAVEFORM, "waveform shorter than one OFDM symbol");
+  ISAC_TRY(ensure(ctx, ctx->dgrid, sizeof(c64) * (size_t)g.n_sc * L_whole * Q));
+  const c64* tw = nullptr;
+  ISAC_TRY(isac_get_twiddles(ctx, g.nfft, &tw));
+  ISAC_FFT_DISPATCH(g.nfft, ISAC_TRY((launch_demod<FFT, false>(ctx, g, T, Q, L_whole, L_whole, tw, 0, 0, nullptr, 0.0, 0,
+                                                               (const c64*)ctx->coef.p, (c64*)ctx->dgrid.p))));
+  *q_out = Q;
+  *l_whole_out = L_whole;
+  return ISAC_OK;
+}
+
+static bool spectral_mode(int noise_mode) { return noise_mode == ISAC_NOISE_PHILOX_SPECTRAL || noise_mode == ISAC_NOISE_INJECTED_SPECTRAL; }
+
+template <int QT>
+static int launch_echo_spectral(isac_ctx* ctx, const OfdmGeom& g, int A, int L_whole, int L_out, int Q, int noise_mode,
+                                const c64* noise, double sig, uint64_t seed, c64* grid) {
+  const c64 *w256 = nullptr, *logtab = nullptr;
+  ISAC_TRY(isac_get_twiddles(ctx, 256, &w256));
+  ISAC_TRY(isac_get_logtab(ctx, &logtab));
+  const dim3 gr((unsigned)spectral_grid_size(L_whole, A)), bl(256);
+  const c64* D = (const c64*)ctx->dgrid.p;
+  const c64* srq = (const c64*)ctx->steer.p + (size_t)A * Q;
+  if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL)
+    hipLaunchKernelGGL((echo_spectral_kernel<QT, 1>), gr, bl, 0, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, noise, w256, logtab, grid);
+  else if (noise_mode == ISAC_NOISE_INJECTED_SPECTRAL)
+    hipLaunchKernelGGL((echo_spectral_kernel<QT, 2>), gr, bl, 0, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, noise, w256, logtab, grid);
+  else
+    hipLaunchKernelGGL((echo_spectral_kernel<QT, 0>), gr, bl, 0, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, noise, w256, logtab, grid);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+static int mono_static_spectral(isac_ctx* ctx, const c64* d_tx, long long T, int tx_dim_l, const OfdmGeom& g,
+                                const isac_radar_channel_params* rp, const uint8_t* los, int noise_mode, const c64* d_noise,
+                                uint64_t seed, c64* d_grid, int32_t* l_out) {
+  int Q = 0, L_whole = 0;
+  ISAC_TRY(spectral_prepare(ctx, d_tx, T, rp, los, g, &Q, &L_whole));
+  const int A = rp->n_ants;
+  const int L_out = L_whole < tx_dim_l ? tx_dim_l : L_whole;                          // monoStaticSensing.m:19-21
+  if (l_out) *l_out = L_out;
+  if (L_out > L_whole) ISAC_HIP(hipMemsetAsync(d_grid, 0, sizeof(c64) * (size_t)g.n_sc * L_out * A, ctx->stream));
+  const double sig = std::sqrt(rp->n0 / 2.0) * std::sqrt((double)g.nfft);            // basicRadarChannel.m:67 through the unscaled FFT
+  switch (Q) {
+    case 1: return launch_echo_spectral<1>(ctx, g, A, L_whole, L_out, Q, noise_mode, d_noise, sig, seed, d_grid);
+    case 2: return launch_echo_spectral<2>(ctx, g, A, L_whole, L_out, Q, noise_mode, d_noise, sig, seed, d_grid);
+    case 3: return launch_echo_spectral<3>(ctx, g, A, L_whole, L_out, Q, noise_mode, d_noise, sig, seed, d_grid);
+    case 4: return launch_echo_spectral<4>(ctx, g, A, L_whole, L_out, Q, noise_mode, d_noise, sig, seed, d_grid);
+    default: return launch_echo_spectral<0>(ctx, g, A, L_whole, L_out, Q, noise_mode, d_noise, sig, seed, d_grid);
+  }
+}
+
 extern "C" int isac_mono_static_sensing_dev(isac_ctx* ctx, const isac_c64* d_tx_wave, int64_t T, int32_t tx_dim_l,
                                             const isac_carrier* carrier, const isac_radar_channel_params* rp,
                                             const uint8_t* los, int noise_mode, const isac_c64* d_noise_unit,
@@ -493,7 +650,12 @@ extern "C" int isac_mono_static_sensing_dev(isac_ctx* ctx, const isac_c64* d_tx_
   ctx->range_cache.valid = false;
   ISAC_TRY(check_carrier(ctx, carrier));
   if (!d_echo_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "echo_grid is NULL");
-  if (noise_mode == ISAC_NOISE_INJECTED && !d_noise_unit) return fail(ctx, ISAC_ERR_INVALID_ARG, "noise buffer missing");
+  if ((noise_mode == ISAC_NOISE_INJECTED || noise_mode == ISAC_NOISE_INJECTED_SPECTRAL) && !d_noise_unit)
+    return fail(ctx, ISAC_ERR_INVALID_ARG, "noise buffer missing");
+  if (noise_mode < ISAC_NOISE_NONE || noise_mode > ISAC_NOISE_INJECTED_SPECTRAL) return fail(ctx, ISAC_ERR_INVALID_ARG, "unknown noise mode");
+  if (spectral_mode(noise_mode))
+    return mono_static_spectral(ctx, (const c64*)d_tx_wave, T, tx_dim_l, geom_of(carrier), rp, los, noise_mode, (const c64*)d_noise_unit,
+                                seed, (c64*)d_echo_grid, l_out);
   int Q = 0;
   ISAC_TRY(prepare_echo(ctx, (const c64*)d_tx_wave, T, rp, los, &Q));   // monoStaticSensing.m:13
   OfdmGeom g = geom_of(carrier);
@@ -555,10 +717,17 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
   const bool fusable = (g.nfft == 4096 && ep->n_ifft == g.nfft && row_lo >= 0 && row_hi < ep->n_ifft && cf->row1 >= cf->row0);
   if (!fusable)   // other numerologies: plain path, fft2D will run its own range stage
     return isac_mono_static_sensing_dev(ctx, d_tx_wave, T, tx_dim_l, carrier, rp, los, noise_mode, d_noise_unit, seed, d_echo_grid, l_out);
-  int Q = 0;
-  ISAC_TRY(prepare_echo(ctx, (const c64*)d_tx_wave, T, rp, los, &Q));
+  if (noise_mode < ISAC_NOISE_NONE || noise_mode > ISAC_NOISE_INJECTED_SPECTRAL) return fail(ctx, ISAC_ERR_INVALID_ARG, "unknown noise mode");
+  if (noise_mode == ISAC_NOISE_INJECTED_SPECTRAL && !d_noise_unit) return fail(ctx, ISAC_ERR_INVALID_ARG, "noise buffer missing");
+  int Q = 0, L_whole = 0;
+  const bool spectral = spectral_mode(noise_mode);
+  if (spectral) {
+    ISAC_TRY(spectral_prepare(ctx, (const c64*)d_tx_wave, T, rp, los, g, &Q, &L_whole));
+  } else {
+    ISAC_TRY(prepare_echo(ctx, (const c64*)d_tx_wave, T, rp, los, &Q));
+    L_whole = whole_symbols(g, T);
+  }
   const int A = rp->n_ants;
-  const int L_whole = whole_symbols(g, T);
   if (L_whole <= 0) return fail(ctx, ISAC_ERR_SHORT_WAVEFORM, "waveform shorter than one OFDM symbol");
   const int L_out = L_whole < tx_dim_l ? tx_dim_l : L_whole;
   if (l_out) *l_out = L_out;
@@ -576,8 +745,33 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
 #define ISAC_FUSED_Q(QT) ISAC_TRY((launch_demod_range<Fft4096, QT>(ctx, g, T, A, L_whole, L_out, tw, Q, noise_mode, (const c64*)d_noise_unit, \
                                                                    n0s, seed, (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, ep->n_ifft, \
                                                                    row_lo, nr, (c64*)ctx->ymid.p)))
-  switch (Q) { case 1: ISAC_FUSED_Q(1); break; case 2: ISAC_FUSED_Q(2); break; case 3: ISAC_FUSED_Q(3); break; case 4: ISAC_FUSED_Q(4); break; default: ISAC_FUSED_Q(0); break; }
+  if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));   // isac_profile_*: brackets exactly the fused kernel below
+  if (spectral) {
+    const c64* logtab = nullptr;
+    ISAC_TRY(isac_get_logtab(ctx, &logtab));
+    const double sig = n0s * std::sqrt((double)g.nfft);
+    const size_t lds = sizeof(c64) * (Fft4096::LDS_ELEMS + kLogTabSize);
+    const dim3 gr((unsigned)spectral_grid_size(L_whole, A)), bl(256);
+    const c64* D = (const c64*)ctx->dgrid.p;
+    const c64* srq = (const c64*)ctx->steer.p + (size_t)A * Q;
+#define ISAC_SPEC(QT, NZ)                                                                                                            \
+  do {                                                                                                                               \
+    auto kern = echo_range_kernel<QT, NZ>;                                                                                           \
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));                                                              \
+    hipLaunchKernelGGL(kern, gr, bl, lds, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, (const c64*)d_noise_unit, tw,   \
+                       logtab, (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, 1.0 / ep->n_ifft, std::sqrt((double)ep->n_ifft),   \
+                       row_lo, nr, (c64*)ctx->ymid.p);                                                                               \
+  } while (0)
+#define ISAC_SPEC_Q(QT) do { if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL) ISAC_SPEC(QT, 1); else ISAC_SPEC(QT, 2); } while (0)
+    switch (Q) { case 1: ISAC_SPEC_Q(1); break; case 2: ISAC_SPEC_Q(2); break; case 3: ISAC_SPEC_Q(3); break; case 4: ISAC_SPEC_Q(4); break; default: ISAC_SPEC_Q(0); break; }
+#undef ISAC_SPEC_Q
+#undef ISAC_SPEC
+    ISAC_HIP(hipGetLastError());
+  } else {
+    switch (Q) { case 1: ISAC_FUSED_Q(1); break; case 2: ISAC_FUSED_Q(2); break; case 3: ISAC_FUSED_Q(3); break; case 4: ISAC_FUSED_Q(4); break; default: ISAC_FUSED_Q(0); break; }
+  }
 #undef ISAC_FUSED_Q
+  if (ctx->profile) { ISAC_HIP(hipEventRecord(ctx->ev_k1, ctx->stream)); ctx->profile_recorded = true; }
   RangeCache& rc = ctx->range_cache;
   rc.rx = d_echo_grid; rc.tx = d_tx_grid; rc.K = g.n_sc; rc.L = L_out; rc.A = A; rc.n_ifft = ep->n_ifft; rc.row_lo = row_lo; rc.nr = nr;
   rc.valid = true;

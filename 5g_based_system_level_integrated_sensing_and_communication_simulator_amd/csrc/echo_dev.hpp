@@ -167,43 +167,102 @@ __device__ __forceinline__ c64 box_muller32_tab(uint32_t ur, uint32_t ua, const 
   return c64{rad * c, rad * sn};
 }
 
-// One column's synthesis for 256 threads: thread `tid` owns the elements k = tid + 256 j, j = 0..15, and calls
-// emit(j, k, value) for every k < K in ascending j.
-//   value = sum_q D_q[k] * s_q  (+ sig * unit noise)
+// Workgroup -> (symbol l, antenna r) for the spectral synthesis kernels.  Every column (l, r) reads the per-target grids
+// D_q[:, l] (52 KB each at 273 PRB): in plain symbol-fastest order the 64 antennas that share a D column run ~224
+// workgroups apart, D (11.7 MB per target) does not survive in a 4 MB L2, and the kernel re-fetches as many bytes of D as it
+// reads of txGrid.  Tiles of 8 symbols x 8 antennas are therefore pinned to one XCD (the dispatcher places block b on XCD
+// b % 8 -- a speed assumption only, any placement is correct): the 64 workgroups resident on an XCD share 8 D columns in its
+// L2, and each antenna plane is still written in contiguous 8-column (416 KB) runs.
+constexpr int kTileSyms = 8, kTileAnts = 8;
+__host__ __device__ inline int spectral_grid_size(int L_whole, int A) {
+  const int n_tiles = ((L_whole + kTileSyms - 1) / kTileSyms) * ((A + kTileAnts - 1) / kTileAnts);
+  return ((n_tiles + 7) / 8) * 8 * (kTileSyms * kTileAnts);
+}
+__device__ __forceinline__ bool spectral_tile_map(int wg, int L_whole, int A, int& l, int& r) {
+  const int x = wg & 7, s = wg >> 3;
+  const int tile = (s / (kTileSyms * kTileAnts)) * 8 + x, within = s % (kTileSyms * kTileAnts);
+  const int n_ag = (A + kTileAnts - 1) / kTileAnts;
+  const int ag = tile % n_ag, lb = tile / n_ag;
+  r = kTileAnts * ag + within / kTileSyms;
+  l = kTileSyms * lb + within % kTileSyms;
+  return r < A && l < L_whole;
+}
+
+// One column's synthesis for 256 threads: thread `tid` owns the elements k = tid + 256 j, j = 0..15.  `acc[j]` receives
+// the unit noise first and then whatever emit(j, k, value, aux) returns for the element (the fused kernel keeps the
+// range-FFT input there, so the FFT's own register file is the only per-element storage):
+//   value = sum_q D_q[k] * s_q  (+ sig * unit noise);   emit stores it only when k < K.
 // NZ: 0 = noiseless, 1 = Philox spectral (above), 2 = injected unit noise column `nz`.
-template <int QT, int NZ, class E>
+// Memory-level parallelism is laid out by hand (a CU holds only two of the FFT kernel's workgroups, so every round trip
+// that is not overlapped shows up in the launch time): the loads of a GROUP of elements -- the caller's `pre(kc)` (e.g. the
+// txGrid sample and window) and the D values -- are issued one group ahead of their use, the first group before the
+// generator's VALU work.  GROUP bounds the registers held by loads in flight (GROUP x (4 Q + sizeof(pre)/4) VGPRs).
+template <int QT, int NZ, int GROUP, class PRE, class E>
 __device__ __forceinline__ void spectral_echo_column(int tid, int K, int Q_rt, const c64* __restrict__ Dl /* D + K*l */,
                                                      long long d_stride /* K * L_whole */, const c64* __restrict__ sr /* [Q] */,
                                                      double sig, uint64_t seed, long long column, const c64* __restrict__ nz,
-                                                     const c64* __restrict__ w256, const c64* __restrict__ logtab, E&& emit) {
+                                                     const c64* __restrict__ w256, const c64* __restrict__ logtab, c64 (&acc)[16],
+                                                     PRE&& pre, E&& emit) {
+  constexpr int QM = QT ? QT : 1;
+  constexpr int NG = 16 / GROUP;
   const int Q = QT ? QT : Q_rt;
+  const int n_el = 2 * ((K + 511) / 512);                            // elements j < n_el exist for some thread (uniform)
+  using Aux = decltype(pre(0));
+  Aux aux[2][GROUP];
+  c64 dv[2][GROUP][QM];
+  c64 nzv[2][GROUP];
+  auto kc_of = [&](int j) { const int k = tid + 256 * j; return k < K ? k : K - 1; };   // unconditional loads, select afterwards
+  auto load_group = [&](int g, int b) {
 #pragma unroll
-  for (int p = 0; p < 8; ++p) {
-    if (512 * p >= K) break;                                         // (uniform)
-    uint32_t o[4] = {0u, 0u, 0u, 0u};
-    if constexpr (NZ == 1) {
-      const uint64_t ctr = (uint64_t)(tid + 256 * p) + (uint64_t)kSpectralSlotsPerColumn * (uint64_t)column;
-      philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), kSpectralStream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    for (int u = 0; u < GROUP; ++u) {
+      const int j = g * GROUP + u;
+      if (j < n_el) {
+        const int kc = kc_of(j);
+        aux[b][u] = pre(kc);
+        if constexpr (NZ == 2) nzv[b][u] = nz[kc];
+        if constexpr (QT > 0) {
+#pragma unroll
+          for (int q = 0; q < QT; ++q) dv[b][u][q] = Dl[(long long)q * d_stride + kc];
+        }
+      }
     }
+  };
+  load_group(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- generator: VALU only, runs under the loads above
+  if constexpr (NZ == 1) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int j = 2 * p + h;
-      const int k = tid + 256 * j;
-      const int kc = k < K ? k : K - 1;                              // unconditional loads, select afterwards
-      c64 v = mk(0.0, 0.0);
-      if constexpr (QT > 0) {
+    for (int p = 0; p < 8; ++p) {
+      if (2 * p < n_el) {
+        const uint64_t ctr = (uint64_t)(tid + 256 * p) + (uint64_t)kSpectralSlotsPerColumn * (uint64_t)column;
+        uint32_t o[4];
+        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), kSpectralStream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        acc[2 * p] = box_muller32_tab(o[0], o[1], w256, logtab);
+        acc[2 * p + 1] = box_muller32_tab(o[2], o[3], w256, logtab);
+      }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- consume group by group, the next group's loads first
 #pragma unroll
-        for (int q = 0; q < QT; ++q) v = fma(Dl[(long long)q * d_stride + kc], sr[q], v);
-      } else {
-        for (int q = 0; q < Q; ++q) v = fma(Dl[(long long)q * d_stride + kc], sr[q], v);
+  for (int g = 0; g < NG; ++g) {
+    const int b = g & 1;
+    if (g + 1 < NG) load_group(g + 1, b ^ 1);
+#pragma unroll
+    for (int u = 0; u < GROUP; ++u) {
+      const int j = g * GROUP + u;
+      if (j < n_el) {
+        c64 v = mk(0.0, 0.0);
+        if constexpr (QT > 0) {
+#pragma unroll
+          for (int q = 0; q < QT; ++q) v = fma(dv[b][u][q], sr[q], v);
+        } else {
+          for (int q = 0; q < Q; ++q) v = fma(Dl[(long long)q * d_stride + kc_of(j)], sr[q], v);
+        }
+        if constexpr (NZ == 1) v = v + acc[j] * sig;
+        if constexpr (NZ == 2) v = v + nzv[b][u] * sig;
+        acc[j] = emit(j, tid + 256 * j, v, aux[b][u]);
       }
-      if constexpr (NZ == 1) {
-        const c64 n1 = box_muller32_tab(o[2 * h], o[2 * h + 1], w256, logtab);
-        v = v + n1 * sig;
-      } else if constexpr (NZ == 2) {
-        v = v + nz[kc] * sig;
-      }
-      if (k < K) emit(j, k, v);
     }
     __builtin_amdgcn_sched_barrier(0);
   }

@@ -62,6 +62,14 @@ struct RangeCache {  // range rows pre-computed by the fused monoStaticSensing c
   const void* rx = nullptr;
   const void* tx = nullptr;
   int K = 0, L = 0, A = 0, n_ifft = 0, row_lo = 0, nr = 0;
+  // a write of [p, p + bytes) through the library (copy, memset, free) that touches either cached grid drops the cache
+  void touch(const void* p, size_t bytes) {
+    if (!valid) return;
+    const size_t g = sizeof(double) * 2 * (size_t)K * (size_t)L * (size_t)A;
+    const char *b = (const char*)p, *e = b + (bytes ? bytes : 1);
+    auto hits = [&](const void* q) { const char* c = (const char*)q; return c && b < c + g && c < e; };
+    if (hits(rx) || hits(tx)) valid = false;
+  }
 };
 
 struct Fft2dPending {  // state between isac_fft2d_submit_dev and isac_fft2d_collect
@@ -81,6 +89,8 @@ struct isac_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // MUSIC branch (covariance/eig) overlaps the RDM branch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cfar = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // isac_profile_*: around the dominant kernel of the last fused echo call
+  bool profile = false, profile_recorded = false;
   std::string err;
   // cached device tables
   std::map<const void*, size_t> lds_allowed;                        // kernel -> dynamic LDS bytes enabled on this context's device
@@ -88,7 +98,7 @@ struct isac_ctx {
   std::map<std::pair<int, int>, isac::DevBuf> kaiser3;              // (n, shifted) -> kaiser(n,3) / fftshift(kaiser(n,3))
   std::map<std::pair<long long, long long>, isac::DevBuf> sind;     // (scale, granularity) -> sind(scan angles)
   // scratch
-  isac::DevBuf beam, coef, phase_rx, steer, ymid, pwin, flags, det_cut, det_pow, det_cnt, cov_part, cov,
+  isac::DevBuf beam, coef, phase_rx, steer, dgrid, ymid, pwin, flags, det_cut, det_pow, det_cnt, cov_part, cov,
       eig_w, eig_v, eig_scratch, spec, misc, stage_a, stage_b, stage_c, sind_tab;
   void* pinned = nullptr; size_t pinned_cap = 0;
   isac::Fft2dLast last;

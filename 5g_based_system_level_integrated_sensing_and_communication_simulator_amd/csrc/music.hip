@@ -64,7 +64,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int NB, int GRP>
+template <int NB, int GRP, bool DB, bool BAR>
 __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long long N, int A, int n_tiles, int phase, int lane,
                                                long long s_begin, long long s_end, int part_index,
                                                double* __restrict__ part) {
@@ -87,14 +87,7 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
     colp[b] = G + N * (long long)(colok[b] ? a : 0);
   }
   const long long lane_off = 4 * kq + SPL * phase;              // first sample of this lane inside a slab
-  // No register double-buffering: the kernel stays under 160 VGPRs so that (a) three of its waves fit a SIMD and
-  // hide the load latency by themselves, and (b) one of its waves fits NEXT TO the two resident waves of the
-  // HBM-bound range_kernel (2 x 176 + 160 = 512 VGPRs), letting the MFMA work run under that kernel's memory time.
-  for (long long slab = s_begin; slab < s_end; ++slab) {
-    // keep the four waves of the workgroup on the same 16-sample slab so that it is fetched from HBM once and
-    // shared through L1/L2 (without this the waves drift apart and rocprof FETCH_SIZE doubles)
-    __builtin_amdgcn_s_barrier();
-    c64 cur[NB][SPL];
+  auto load = [&](c64 (&dst)[NB][SPL], long long slab) {
     const long long n0 = slab * 16 + lane_off;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -104,8 +97,10 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
         const bool ok = (n < N) && colok[b];
         if (n >= N) n = N - 1;
         c64 v = colp[b][n];
-        cur[b][e] = ok ? v : mk(0.0, 0.0);
+        dst[b][e] = ok ? v : mk(0.0, 0.0);
       }
+  };
+  auto mfmas = [&](const c64 (&cur)[NB][SPL]) {
     static_for<0, NT>([&](auto uc) {
       constexpr int u = decltype(uc)::value;
       constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);   // row-major upper-triangular tile order
@@ -117,23 +112,45 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
         im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cur[I][e].im, cur[J][e].re, im[u], 0, 0, 0);
       }
     });
+  };
+  if constexpr (DB) {
+    // register double buffer: the loads of slab s+1 fly under the MFMAs of slab s
+    c64 cur[NB][SPL], nxt[NB][SPL];
+    if (s_begin < s_end) load(cur, s_begin);
+    for (long long slab = s_begin; slab < s_end; ++slab) {
+      if constexpr (BAR) __builtin_amdgcn_s_barrier();
+      if (slab + 1 < s_end) load(nxt, slab + 1);
+      mfmas(cur);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int e = 0; e < SPL; ++e) cur[b][e] = nxt[b][e];
+    }
+  } else {
+    for (long long slab = s_begin; slab < s_end; ++slab) {
+      // keep the four waves of the workgroup on the same 16-sample slab so that it is fetched from HBM once and
+      // shared through L1/L2 (without this the waves drift apart and rocprof FETCH_SIZE doubles)
+      if constexpr (BAR) __builtin_amdgcn_s_barrier();
+      c64 cur[NB][SPL];
+      load(cur, slab);
+      mfmas(cur);
+    }
   }
 #pragma unroll
   for (int u = 0; u < NT; ++u) {
-    double* o = part + (((long long)part_index * n_tiles + (T0 + u)) * 3) * 256;
+    double* o = part + (((long long)part_index * n_tiles + (T0 + u)) * 2) * 256;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       o[0 * 256 + r * 64 + lane] = re[u][r];
       o[1 * 256 + r * 64 + lane] = im[u][r];
-      o[2 * 256 + r * 64 + lane] = 0.0;                        // (imm plane kept for the generic kernel's layout)
     }
   }
 }
 
-template <int NB>
-__global__ __launch_bounds__(256, 3) void cov_mfma_small_kernel(const c64* __restrict__ G, long long N, int A,
-                                                                long long slabs_per_wg,
-                                                                double* __restrict__ part /* [gridX*kPhases][kTiles][3][256] */) {
+template <int NB, bool DB = true, bool BAR = false, int WGS = 3>
+__global__ __launch_bounds__(256, WGS) void cov_mfma_small_kernel(const c64* __restrict__ G, long long N, int A,
+                                                                  long long slabs_per_wg,
+                                                                  double* __restrict__ part /* [gridX*kPhases][kTiles][2][256] */) {
   using P = CovPlan<NB>;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -143,9 +160,9 @@ __global__ __launch_bounds__(256, 3) void cov_mfma_small_kernel(const c64* __res
   long long s_end = s_begin + slabs_per_wg;
   if (s_end > total) s_end = total;
   const int pidx = blockIdx.x * P::kPhases + phase;
-  if (grp == 0) cov_group_body<NB, 0>(G, N, A, P::kTiles, phase, lane, s_begin, s_end, pidx, part);
+  if (grp == 0) cov_group_body<NB, 0, DB, BAR>(G, N, A, P::kTiles, phase, lane, s_begin, s_end, pidx, part);
   if constexpr (P::kGroups > 1) {
-    if (grp == 1) cov_group_body<NB, 1>(G, N, A, P::kTiles, phase, lane, s_begin, s_end, pidx, part);
+    if (grp == 1) cov_group_body<NB, 1, DB, BAR>(G, N, A, P::kTiles, phase, lane, s_begin, s_end, pidx, part);
   }
 }
 
@@ -310,26 +327,25 @@ __global__ __launch_bounds__(1024) void cov_block_reduce_kernel(const double* __
 // first reduction level: slice s of S sums a contiguous run of workgroup partials (fixed order) into part2[s];
 // spreads the 60 MB of partial tiles over S x n_tiles workgroups instead of n_tiles (per-CU bandwidth bound)
 __global__ __launch_bounds__(256) void cov_reduce_slice_kernel(const double* __restrict__ part, int n_wg, int n_tiles, int S,
-                                                               double* __restrict__ part2 /* [S][n_tiles][3][256] */) {
+                                                               double* __restrict__ part2 /* [S][n_tiles][2][256] */) {
   const int t = blockIdx.x, sl = blockIdx.y, e = threadIdx.x;
   const int per = (n_wg + S - 1) / S;
   const int w0 = sl * per, w1 = min(n_wg, w0 + per);
-  double sr = 0.0, sp = 0.0, sm = 0.0;
+  double sr = 0.0, si = 0.0;
 #pragma unroll 8
   for (int w = w0; w < w1; ++w) {
-    const double* o = part + (((long long)w * n_tiles + t) * 3) * 256;
+    const double* o = part + (((long long)w * n_tiles + t) * 2) * 256;
     sr += o[e];
-    sp += o[256 + e];
-    sm += o[512 + e];
+    si += o[256 + e];
   }
-  double* d = part2 + (((long long)sl * n_tiles + t) * 3) * 256;
-  d[e] = sr; d[256 + e] = sp; d[512 + e] = sm;
+  double* d = part2 + (((long long)sl * n_tiles + t) * 2) * 256;
+  d[e] = sr; d[256 + e] = si;
 }
 
 // fixed-order reduction over workgroup partials + Hermitian fill + 1/N.
 __global__ __launch_bounds__(1024) void cov_reduce_kernel(const double* __restrict__ part, int n_wg, int n_tiles, int A,
                                                           double inv_n, c64* __restrict__ Ra /* [A x A] column-major */) {
-  __shared__ double s_sum[3][4][256];
+  __shared__ double s_sum[2][4][256];
   const int t = blockIdx.x;
   const int nb = (A + 15) / 16;
   int I, J;
@@ -341,23 +357,21 @@ __global__ __launch_bounds__(1024) void cov_reduce_kernel(const double* __restri
   const int col = lane & 15;
   const int per = (n_wg + 3) / 4;
   const int w0 = g * per, w1 = min(n_wg, w0 + per);
-  double sr = 0.0, sp = 0.0, sm = 0.0;
+  double sr = 0.0, si = 0.0;
 #pragma unroll 8
   for (int w = w0; w < w1; ++w) {
-    const double* o = part + (((long long)w * n_tiles + t) * 3) * 256;
+    const double* o = part + (((long long)w * n_tiles + t) * 2) * 256;
     sr += o[e];
-    sp += o[256 + e];
-    sm += o[512 + e];
+    si += o[256 + e];
   }
-  s_sum[0][g][e] = sr; s_sum[1][g][e] = sp; s_sum[2][g][e] = sm;
+  s_sum[0][g][e] = sr; s_sum[1][g][e] = si;
   __syncthreads();
   if (g != 0) return;
   sr = ((s_sum[0][0][e] + s_sum[0][1][e]) + s_sum[0][2][e]) + s_sum[0][3][e];
-  sp = ((s_sum[1][0][e] + s_sum[1][1][e]) + s_sum[1][2][e]) + s_sum[1][3][e];
-  sm = ((s_sum[2][0][e] + s_sum[2][1][e]) + s_sum[2][2][e]) + s_sum[2][3][e];
+  si = ((s_sum[1][0][e] + s_sum[1][1][e]) + s_sum[1][2][e]) + s_sum[1][3][e];
   const int a = I * 16 + row, b = J * 16 + col;
   if (a < A && b < A) {
-    c64 v = mk(sr * inv_n, (sp - sm) * inv_n);
+    c64 v = mk(sr * inv_n, si * inv_n);
     if (I == J) {
       if (a == b) v.im = 0.0;
       // both triangles of a diagonal tile are computed; keep the upper one and mirror it so
@@ -1148,11 +1162,13 @@ static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long lo
   const long long per = (total + gx - 1) / gx;
   gx = (total + per - 1) / per;
   const int n_part = (int)gx * P::kPhases;
-  ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * ((size_t)n_part + 32) * P::kTiles * 3 * 256));
-  hipLaunchKernelGGL(cov_mfma_small_kernel<NB>, dim3((unsigned)gx), dim3(256), 0, st, G, N, A, per, (double*)ctx->cov_part.p);
+  ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * ((size_t)n_part + 32) * P::kTiles * 2 * 256));
+  // register double buffer, no per-slab barrier, three workgroups per CU: 0.303 ms at A = 64 (barrier + single buffer 0.325;
+  // the barrier kept the four waves on one slab so that it was fetched once -- with the prefetch they stay close enough)
+  hipLaunchKernelGGL((cov_mfma_small_kernel<NB, true, false, 3>), dim3((unsigned)gx), dim3(256), 0, st, G, N, A, per, (double*)ctx->cov_part.p);
   ISAC_HIP(hipGetLastError());
   const int S = 32;
-  double* part2 = (double*)ctx->cov_part.p + (size_t)n_part * P::kTiles * 3 * 256;
+  double* part2 = (double*)ctx->cov_part.p + (size_t)n_part * P::kTiles * 2 * 256;
   hipLaunchKernelGGL(cov_reduce_slice_kernel, dim3(P::kTiles, S), dim3(256), 0, st, (const double*)ctx->cov_part.p, n_part, P::kTiles, S,
                      part2);
   ISAC_HIP(hipGetLastError());

@@ -361,7 +361,7 @@ static int launch_range(isac_ctx* ctx, hipStream_t st, const c64* rx, const c64*
 
 // Range + Doppler + power window for the CUT rectangle.  Leaves pwin [nr x nc x A] in ctx->pwin.
 int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, const c64* d_rx,
-                          const c64* d_tx, int K, int L, int A, int* nr_out, int* nc_out) {
+                          const c64* d_tx, int K, int L, int A, int* nr_out, int* nc_out, bool use_cached_range) {
   const int n_ifft = ep->n_ifft, n_fft = ep->n_fft;
   const int hr = cf->guard[0] + cf->train[0], hc = cf->guard[1] + cf->train[1];
   const int row_lo = cf->row0 - 1 - hr, row_hi = cf->row1 - 1 + hr;   // 0-based inclusive
@@ -378,11 +378,17 @@ int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_c
   ISAC_TRY(ensure(ctx, ctx->ymid, sizeof(c64) * (size_t)nr * L * A));
   ISAC_TRY(ensure(ctx, ctx->pwin, sizeof(double) * (size_t)nr * nc * A));
   {
-    RangeCache& rc = ctx->range_cache;   // range rows already produced by isac_mono_static_sensing_fused_dev?
+    // Range rows already produced by isac_mono_static_sensing_fused_dev are consumed only on the caller's explicit request
+    // (isac_fft2d_submit_cached_dev); a plain fft2D call never trusts them, so a grid changed behind the library's back
+    // (the caller's own kernel, another context) cannot produce silently stale estimates.
+    RangeCache& rc = ctx->range_cache;
     const bool hit = rc.valid && rc.rx == (const void*)d_rx && rc.tx == (const void*)d_tx && rc.K == K && rc.L == L && rc.A == A &&
                      rc.n_ifft == n_ifft && rc.row_lo == row_lo && rc.nr == nr;
     rc.valid = false;                    // single use
-    if (!hit)
+    if (use_cached_range && !hit)
+      return fail(ctx, ISAC_ERR_INVALID_ARG, "fft2d_submit_cached: no range rows cached for these grids / parameters on this context "
+                                              "(call isac_mono_static_sensing_fused_dev with the same echoGrid, txGrid, est and cfar blocks first)");
+    if (!use_cached_range)
       ISAC_FFT_DISPATCH(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, d_rx, d_tx, K, L, A, tw, wk, wr, n_ifft, row_lo, nr,
                                                             (c64*)ctx->ymid.p))));
   }

@@ -36,13 +36,15 @@ def _cfar_block(cfar) -> L.CfarConfig:
                         r0, r1, c0, c1)
 
 
-def fft2D(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None, return_debug=False):
+def fft2D(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None, return_debug=False, reuse_range=False):
     """estResults = sensing.estimation.fft2D(radarEstParams, cfar, rxGrid, txGrid).
 
     Returns a namespace with ``rngEst, velEst, aziEst, eleEst`` (fft2D.m:102,114-115).  Raises
     IsacError(NO_DETECTION) where the reference errors inside findpeaks (zero detections); the
     reference's caller turns any error into ``senResults = NaN`` (cellSimulation.m:196-202).
-    Plotting (fft2D.m:119) is not part of the hot path."""
+    Plotting (fft2D.m:119) is not part of the hot path.
+    ``reuse_range=True`` (device grids): consume the range rows the preceding ``monoStaticSensing(..., fuse_fft2d=...)``
+    call cached on this context (isac_fft2d_submit_cached_dev); an error if there are none."""
     dev = isinstance(rxGrid, L.DeviceArray)
     if dev != isinstance(txGrid, L.DeviceArray):
         raise ValueError("rxGrid and txGrid must both be numpy arrays or both DeviceArrays")
@@ -54,7 +56,14 @@ def fft2D(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None, return_debug=False)
     ep = est_block(radarEstParams)
     res = L.EstResult()
     lib = ctx.lib
-    if dev:
+    if dev and reuse_range:
+        st = lib.isac_fft2d_submit_cached_dev(ctx.handle, C.byref(ep), C.byref(cf), C.c_void_p(rxGrid.ptr), C.c_void_p(txGrid.ptr),
+                                              C.c_int32(K), C.c_int32(Lsym), C.c_int32(A))
+        if st == 0:
+            st = lib.isac_fft2d_collect(ctx.handle, C.byref(res))
+    elif reuse_range:
+        raise ValueError("reuse_range needs the DeviceArray grids of a monoStaticSensing(fuse_fft2d=...) call")
+    elif dev:
         st = lib.isac_fft2d_dev(ctx.handle, C.byref(ep), C.byref(cf), C.c_void_p(rxGrid.ptr), C.c_void_p(txGrid.ptr),
                                 C.c_int32(K), C.c_int32(Lsym), C.c_int32(A), C.byref(res))
     else:
@@ -69,7 +78,7 @@ def fft2D(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None, return_debug=False)
     return est
 
 
-def fft2D_submit(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None):
+def fft2D_submit(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None, reuse_range=False):
     """Asynchronous half of fft2D for device-resident grids: enqueues every kernel and the result
     copy on ``ctx`` without waiting (isac_fft2d_submit_dev).  Pair with fft2D_collect(ctx).  Lets a
     host loop keep several cells / CPIs in flight on different contexts."""
@@ -81,8 +90,8 @@ def fft2D_submit(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None):
         raise ValueError("rxGrid and txGrid must have identical [nSc x nSym x nAnts] shape")
     cf = _cfar_block(cfar)
     ep = est_block(radarEstParams)
-    ctx.check(ctx.lib.isac_fft2d_submit_dev(ctx.handle, C.byref(ep), C.byref(cf), C.c_void_p(rxGrid.ptr), C.c_void_p(txGrid.ptr),
-                                            C.c_int32(K), C.c_int32(Lsym), C.c_int32(A)))
+    fn = ctx.lib.isac_fft2d_submit_cached_dev if reuse_range else ctx.lib.isac_fft2d_submit_dev
+    ctx.check(fn(ctx.handle, C.byref(ep), C.byref(cf), C.c_void_p(rxGrid.ptr), C.c_void_p(txGrid.ptr), C.c_int32(K), C.c_int32(Lsym), C.c_int32(A)))
     return ctx
 
 

@@ -10,13 +10,18 @@ from ._marshal import ChannelBlock, carrier_block, los_array
 
 
 def monoStaticSensing(txWaveform, txDimension, carrierInfo, radarParams, targetLoSConditions, *,
-                      noise=None, seed=None, nfft=None, ctx=None, out=None, fuse_fft2d=None):
+                      noise=None, seed=None, nfft=None, ctx=None, out=None, fuse_fft2d=None, spectral_noise=None, noise_domain="time"):
     """echoGrid = monoStaticSensing(txWaveform, txDimension, carrierInfo, radarParams, targetLoSConditions).
 
     Radar channel (:13) + OFDM demodulation (:16) + zero-padding of the symbol dimension up to
     ``txDimension(2)`` (:19-21), fused on the device: the time-domain echo is never written to HBM.
     numpy in -> numpy out; DeviceArray in -> DeviceArray out (``out``: optional pre-allocated
     DeviceArray to reuse between CPIs).  ``noise`` / ``seed`` as in basicRadarChannel.
+
+    ``noise_domain="spectral"`` with ``seed`` (ISAC_NOISE_PHILOX_SPECTRAL) or ``spectral_noise`` = unit complex normals
+    [nSc x nSym x nAnts] (ISAC_NOISE_INJECTED_SPECTRAL): the AWGN is drawn / supplied on the demodulated grid instead of
+    per time sample -- the same distribution (the demodulator is unitary up to sqrt(Nfft) on disjoint windows), and the
+    echo becomes sum_q a_q[r] D_q[k,l] + W with only Q demodulation FFTs per symbol (include/isac.h, isac_noise_mode).
 
     ``fuse_fft2d=(radarEstParams, cfar, txGrid)`` (device path): also run the range stage of the
     ``fft2D(radarEstParams, cfar, echoGrid, txGrid)`` call that follows while each echo column is still
@@ -30,7 +35,18 @@ def monoStaticSensing(txWaveform, txDimension, carrierInfo, radarParams, targetL
         raise ValueError("txWaveform antenna dimension differs from radarParams.nTxAnts")
     los = los_array(targetLoSConditions, cb.block.n_targets)
     car = carrier_block(carrierInfo, nfft)
-    mode = L.NOISE_INJECTED if noise is not None else (L.NOISE_PHILOX if seed is not None else L.NOISE_NONE)
+    if spectral_noise is not None:
+        if noise is not None:
+            raise ValueError("give either time-domain `noise` or `spectral_noise`, not both")
+        mode, noise = L.NOISE_INJECTED_SPECTRAL, spectral_noise
+    elif noise is not None:
+        mode = L.NOISE_INJECTED
+    elif seed is not None:
+        if noise_domain not in ("time", "spectral"):
+            raise ValueError("noise_domain must be 'time' or 'spectral'")
+        mode = L.NOISE_PHILOX_SPECTRAL if noise_domain == "spectral" else L.NOISE_PHILOX
+    else:
+        mode = L.NOISE_NONE
     lib = ctx.lib
     lw = C.c_int32(0)
     st = lib.isac_ofdm_symbol_count(C.byref(car), C.c_int64(T), C.byref(lw))

@@ -11,6 +11,11 @@ GPUs with no data-path collective; one RCCL all-gather of the per-cell result re
 
 Inputs are synthetic and generated ON THE DEVICE before the timed region (QPSK txGrid, CP-OFDM
 txWaveform, Philox AWGN inside the kernels).  Prints one JSON line on rank 0.
+
+`--gpus N` without a torchrun environment launches N ranks itself (one per GPU, RCCL); under torchrun the
+launcher's RANK / LOCAL_RANK / WORLD_SIZE are used.  `roofline` quotes the kernel with the largest share of GPU time
+(the fused echo-synthesis + range-stage kernel) timed with HIP events inside the run; `cpu_baseline` is the C++/OpenMP
+port of the same chain (oracle/cpu_port) on every host core at full size.
 """
 from __future__ import annotations
 
@@ -34,7 +39,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "5g_based_system_level_integrated_sensing_and_communication_simulator_amd"
 
-RANGE_KERNEL_HBM_BYTES_A64 = int((2 * 735413 + 84227) * 1024)   # 1.592e9 B vs 1.503e9 B algorithmic: no wasted re-reads
+# HBM bytes per launch of the dominant kernel (echo_range_kernel<1,1>: fused echo synthesis + fft2D range stage) at the
+# A=64 / 224-symbol shape, from separate rocprofv3 --pmc passes (profiles/r02_pmc_fetch_size.csv, r02_pmc_write_size.csv):
+# 2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half, MI355X_MICROARCH.md) + WRITE_SIZE, KB -> B.  Not measurable from
+# inside this process; quoted "from profile" and only for the shape it was collected at.
+DOMINANT_KERNEL_HBM_BYTES_A64 = int((2 * 414051 + 828878) * 1024)   # 1.70e9 B vs 1.503e9 B algorithmic (+86 MB range rows, +0.1 GB D)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix (= vector) dense peak
 
@@ -100,9 +109,10 @@ class Cell:
     `n_buf` buffer sets (transmit grid + waveform + echo grid) = the number of CPIs of THIS cell that can be in
     flight at once."""
 
-    def __init__(self, pkg, device, cell_id, n_ants, n_slots, n_targets, inflight=1, fuse=False, pool=None, n_buf=None):
+    def __init__(self, pkg, device, cell_id, n_ants, n_slots, n_targets, inflight=1, fuse=True, pool=None, n_buf=None, noise_domain="spectral"):
         L = pkg._lib
         self.fuse = fuse
+        self.noise_domain = noise_domain
         self.pkg, self.L = pkg, L
         # device arrays are device-global, so a cell's inputs can be consumed on any context of the same device
         self.pool = pool or SlotPool(pkg, device, inflight)
@@ -144,11 +154,16 @@ class Cell:
         self.seed = 0x5EED0002 + cell_id
         self.n_sub = 0
         self.last = None
+        self.profile_sink = None      # list: per-launch durations of the fused kernel (HIP events recorded by the library)
         ctx.sync()
 
     def finish(self, ctx):
         """Collect the CPI this cell enqueued on `ctx`."""
         est = None
+        if self.profile_sink is not None and self.fuse:
+            ms = C.c_double(0.0)
+            if ctx.lib.isac_profile_last_kernel_ms(ctx.handle, C.byref(ms)) == 0:
+                self.profile_sink.append(ms.value)
         try:
             est = self.pkg.sensing.estimation.fft2D_collect(ctx)
         except self.pkg.IsacError as e:           # reference: try/catch -> senResults = NaN (cellSimulation.m:196-202)
@@ -162,9 +177,9 @@ class Cell:
         b = self.n_sub % len(self.echo)
         tx_wave, tx_grid = self.tx_waves[b], self.tx_grids[b]
         echo = self.pkg.sensing.monoStaticSensing(tx_wave, (self.K, self.Lsym, self.A), self.carrier, self.rp, self.los,
-                                                  seed=self.seed + self.n_sub, nfft=4096, out=self.echo[b], ctx=c,
+                                                  seed=self.seed + self.n_sub, noise_domain=self.noise_domain, nfft=4096, out=self.echo[b], ctx=c,
                                                   fuse_fft2d=(self.rp, self.cfar, tx_grid) if self.fuse else None)
-        self.pkg.sensing.estimation.fft2D_submit(self.rp, self.cfar, echo, tx_grid, ctx=c)
+        self.pkg.sensing.estimation.fft2D_submit(self.rp, self.cfar, echo, tx_grid, ctx=c, reuse_range=self.fuse)
         self.n_sub += 1
 
     def submit(self):
@@ -189,25 +204,25 @@ class Cell:
         rdm = 2 * self.K * self.Lsym * self.A * b
         return echo, rdm
 
-    def time_range_kernel(self, reps=10):
-        """Average duration of the dominant HBM-bound kernel (range stage of fft2D) measured with HIP events on
-        the stream it is launched on; algorithmic bytes per launch = rxGrid + txGrid = 2 K L A 16 B."""
-        from importlib import import_module
-        m = import_module(self.pkg.__name__ + ".sensing.estimation.fft2D")
-        mm = import_module(self.pkg.__name__ + ".sensing._marshal")
+    def time_dominant_kernel_isolated(self, reps=10):
+        """Average duration of the dominant kernel (fused echo synthesis + range stage) with nothing else on the GPU: HIP events
+        recorded by the library around exactly that launch (isac_profile_*), on the stream it is launched on."""
         c = self.ctx
-        r0, r1, c0, c1 = m._cut_rectangle(self.cfar.CUTIdx)
-        det = self.cfar.cfarDetector2D
-        cf = self.L.CfarConfig(det.ProbabilityFalseAlarm, (C.c_int32 * 2)(*det.GuardBandSize), (C.c_int32 * 2)(*det.TrainingBandSize), r0, r1, c0, c1)
-        ep = mm.est_block(self.rp)
-        def launch():
-            c.check(c.lib.isac_fft2d_range_stage_dev(c.handle, C.byref(ep), C.byref(cf), C.c_void_p(self.echo[0].ptr), C.c_void_p(self.tx_grid.ptr),
-                                                     self.K, self.Lsym, self.A))
-        launch(); c.sync()
-        c.timer_start()
-        for _ in range(reps):
-            launch()
-        return c.timer_stop_ms() / reps
+        c.check(c.lib.isac_profile_enable(c.handle, 1))
+        out = []
+        for i in range(reps + 1):
+            self.pkg.sensing.monoStaticSensing(self.tx_wave, (self.K, self.Lsym, self.A), self.carrier, self.rp, self.los, seed=self.seed + i,
+                                               noise_domain=self.noise_domain, nfft=4096, out=self.echo[0], ctx=c, fuse_fft2d=(self.rp, self.cfar, self.tx_grid))
+            ms = C.c_double(0.0)
+            c.check(c.lib.isac_profile_last_kernel_ms(c.handle, C.byref(ms)))
+            out.append(ms.value)
+        c.sync()
+        return float(np.mean(out[1:]))
+
+    def dominant_kernel_bytes(self):
+        """Algorithmic HBM bytes of one launch of the fused kernel: txGrid read once + echoGrid written once = 2 K L A 16 B
+        (SURVEY 8d's RDM+CFAR read of txGrid + monoStaticSensing's write of echoGrid; rxGrid is never re-read)."""
+        return 2 * self.K * self.Lsym * self.A * 16
 
 
 def stage_table(cell, reps=5):
@@ -224,57 +239,105 @@ def stage_table(cell, reps=5):
             fn()
         return c.timer_stop_ms() / reps
 
-    def mono(noise):
-        kw = dict(seed=cell.seed if noise else None, nfft=4096, out=cell.echo[0], ctx=c)
+    def mono(noise, fuse):
+        kw = dict(seed=cell.seed if noise else None, noise_domain=cell.noise_domain, nfft=4096, out=cell.echo[0], ctx=c,
+                  fuse_fft2d=(cell.rp, cell.cfar, cell.tx_grid) if fuse else None)
         return lambda: cell.pkg.sensing.monoStaticSensing(cell.tx_wave, (K, L, A), cell.carrier, cell.rp, cell.los, **kw)
 
     ra = c.empty((A, A))
     cov = lambda: c.check(c.lib.isac_covariance_dev(c.handle, C.c_void_p(cell.echo[0].ptr), C.c_int64(K * L), C.c_int32(A), C.c_void_p(ra.ptr)))
     out = []
     echo_b = T * A * b + K * L * A * b
-    for name, fn, note in (("monoStaticSensing = beamsum + coef + demod, Philox AWGN", mono(True),
-                            "fp64-VALU-bound: Philox4x32-10 + Box-Muller for 4096*L*A complex samples, then the OFDM FFT"),
-                           ("monoStaticSensing, noise off", mono(False), "HBM: read txWaveform once, write echoGrid once")):
+    fused_b = echo_b + K * L * A * b
+    for name, fn, nb, note in (
+            ("monoStaticSensing + fft2D range stage (beam-sum, coefficient vectors, per-target demodulation, fused synthesis + range kernel), Philox AWGN",
+             mono(True, True), fused_b, "reads txWaveform + txGrid once, writes echoGrid once; the kernel in `roofline` is the last launch of this stage"),
+            ("monoStaticSensing alone (unfused), Philox AWGN", mono(True, False), echo_b, "read txWaveform once, write echoGrid once"),
+            ("monoStaticSensing alone, noise off", mono(False, False), echo_b, "same traffic without the generator")):
         ms = timed(fn)
-        out.append({"stage": name, "ms": round(ms, 4), "bound": "hbm", "algorithmic_bytes": echo_b,
-                    "achieved_GBps": round(echo_b / 1e9 / (ms / 1e3), 1), "frac": round(echo_b / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4), "note": note})
+        out.append({"stage": name, "ms": round(ms, 4), "bound": "hbm", "algorithmic_bytes": nb,
+                    "achieved_GBps": round(nb / 1e9 / (ms / 1e3), 1), "frac": round(nb / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4), "note": note})
     ms = timed(cov)
     fl = 8.0 * A * A * K * L
-    out.append({"stage": "covariance Ra = X X^H / N (fp64 MFMA, Hermitian half issued)", "ms": round(ms, 4), "bound": "mfma",
-                "algorithmic_flops": fl, "achieved_TFLOPs": round(fl / 1e12 / (ms / 1e3), 2), "peak_TFLOPs": FP64_MFMA_PEAK_TFLOPS,
-                "frac": round(fl / 1e12 / (ms / 1e3) / FP64_MFMA_PEAK_TFLOPS, 4),
-                "note": "nominal 8 A^2 K L flop; the kernel issues the upper-triangular 10 of 16 tiles"})
+    nbk = (A + 15) // 16
+    issued = fl * (nbk * (nbk + 1) / 2) / (nbk * nbk)           # Hermitian: upper-triangular 16 x 16 tiles only
+    out.append({"stage": "covariance Ra = X X^H / N (fp64 MFMA)", "ms": round(ms, 4), "bound": "mfma",
+                "issued_flops": issued, "achieved_TFLOPs": round(issued / 1e12 / (ms / 1e3), 2), "peak_TFLOPs": FP64_MFMA_PEAK_TFLOPS,
+                "frac": round(issued / 1e12 / (ms / 1e3) / FP64_MFMA_PEAK_TFLOPS, 4), "nominal_flops": fl,
+                "note": "frac counts ISSUED MFMA flops (upper-triangular tiles: %d of %d); the nominal 8 A^2 K L count would credit the skipped lower triangle" % (nbk * (nbk + 1) // 2, nbk * nbk)})
     return out
 
 
-def cpu_baseline(n_ants, budget_s=25.0):
-    """The NumPy/SciPy oracle ("port": the MATLAB reference cannot run here; FFTs = multi-threaded pocketfft, the RDM in
-    its shift-free form) timed on the host cores on a
-    bounded sample of the same workload: the full 273-PRB / 224-symbol CPI with a reduced antenna count,
-    scaled linearly to `n_ants` (every stage of the chain is linear in the antenna count except the
-    A x A covariance/eig, which is negligible on the CPU at these sizes)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle as O
-    from conftest import make_scene
-    a_s = 16
-    sc = make_scene(n_ants=a_s, n_slots=16, nrb=273, targets=((100.0, 20.0, 1.5),), velocity=(7.0,), seed=3)
-    cf = O.cfar2d_config(sc.rp)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        echo = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, sc.noise)
+def cpu_baseline(cell, budget_s=12.0):
+    """The reference's chain on the host cores: the C++17 / OpenMP port under oracle/cpu_port (kind "port-c++": the MATLAB reference cannot
+    run here -- no MATLAB, no toolboxes).  Same workload as the GPU line at FULL size (all antennas, all 224 symbols): the transmit
+    waveform and grid are copied back from the device, the port draws its own AWGN (inside the timed call, as randn is inside
+    basicRadarChannel), every OpenMP thread the host offers.  Bounded sample: whole CPIs until `budget_s` seconds have elapsed
+    (at least 2, at most 8), median per-CPI time."""
+    from oracle import cpu_port as P
+    tx_wave, tx_grid = cell.tx_wave.numpy(), cell.tx_grid.numpy()
+    cf = SimpleNamespace(CUTIdx=cell.cfar.CUTIdx, Pfa=cell.cfar.cfarDetector2D.ProbabilityFalseAlarm,
+                         GuardBandSize=tuple(cell.cfar.cfarDetector2D.GuardBandSize), TrainingBandSize=tuple(cell.cfar.cfarDetector2D.TrainingBandSize))
+    times, t_start, est = [], time.perf_counter(), None
+    while len(times) < 2 or (time.perf_counter() - t_start < budget_s and len(times) < 8):
+        t0 = time.perf_counter()
+        echo = P.mono_static_sensing(tx_wave, tx_grid.shape, cell.carrier, cell.rp, cell.los, None, nfft=4096, seed=0x5EED0002 + len(times))
         try:
-            O.fft2d(sc.rp, cf, echo, sc.tx_grid, rdm_fn=O.rdm_explicit)   # same bits as the literal form, no shift copies
+            est = P.fft2d(cell.rp, cf, echo, tx_grid)
         except ValueError:
-            pass
-        reps += 1
-        if time.perf_counter() - t0 > budget_s or reps >= 8:
-            break
-    dt = (time.perf_counter() - t0) / reps
-    cpi_s = dt * (n_ants / a_s)
-    return {"value": round(16.0 / cpi_s, 3), "unit": "sensing slots/sec", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"NumPy/SciPy oracle, full 273-PRB x 224-symbol CPI at {a_s} antennas x{reps} reps, scaled x{n_ants // a_s} "
-                      f"to {n_ants} antennas (noise pre-drawn, not timed); scipy.fft workers = all cores"}
+            est = None
+        times.append(time.perf_counter() - t0)
+    cpi_s = float(np.median(times))
+    n_slots = cell.Lsym // 14
+    return {"value": round(n_slots / cpi_s, 3), "unit": "sensing slots/sec", "cores": P.threads(), "kind": "port-c++",
+            "sample": f"{len(times)} whole CPIs of the bench workload ({cell.A} antennas, K={cell.K}, L={cell.Lsym}, T={cell.T}) through oracle/cpu_port "
+                      f"(C++17 + OpenMP, own radix-4 FFT, fp64, AWGN drawn inside the timed call), median {cpi_s:.3f} s per CPI, "
+                      f"{P.threads()} OpenMP threads; first estimates rng {None if est is None else np.round(est.rngEst[:2], 3).tolist()} "
+                      f"azi {None if est is None else est.aziEst[:2].tolist()}",
+            "note": "the MATLAB reference itself cannot be timed (no MATLAB / toolboxes on this host)"}
+
+
+def roofline_entry(cell, args, ms_timed, ms_iso, n_launches, stages, cpi_bytes, per_cpi_ms):
+    """`roofline` for the kernel with the largest share of GPU time (profiles/r02_kernel_stats_*.csv): the fused echo-synthesis +
+    range-stage kernel.  achieved = algorithmic bytes per launch / average launch duration measured with HIP events inside this run."""
+    whole = {"algorithmic_bytes": cpi_bytes, "ms": round(per_cpi_ms, 4), "achieved_GBps": round(cpi_bytes / 1e9 / (per_cpi_ms / 1e3), 1),
+             "frac": round(cpi_bytes / 1e9 / (per_cpi_ms / 1e3) / HBM_PEAK_GBS, 4),
+             "note": "SURVEY 8d bytes per CPI (txWaveform + echoGrid + rxGrid + txGrid) / driver-visible time per CPI"}
+    if not args.fuse or ms_iso is None:
+        return {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "note": "--no-fuse: per-kernel event timing is wired to the fused kernel only", "other_stages": stages, "whole_cpi": whole}
+    nb = cell.dominant_kernel_bytes()
+    # The launch duration that defines the kernel's own roofline fraction is the one with the device to itself: in the timed region up to
+    # `--inflight` CPIs share the GPU, so an event pair around one launch also spans the time the device spends on the other CPIs' kernels
+    # (reported separately below; the end-to-end figure under concurrency is `whole_cpi`).
+    ms = ms_iso
+    at_shape = (args.ants == 64 and args.slots == 16 and args.targets == 1)
+    return {"bound": "hbm", "kernel": "echo_range_kernel<1,1> (fused: per-target rank-1 echo synthesis + Philox AWGN on the demodulated grid -> echoGrid; "
+                                      "rx.*conj(tx), Kaiser, 4096-pt range IFFT, CUT rows)",
+            "achieved": round(nb / 1e9 / (ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
+            "traffic": DOMINANT_KERNEL_HBM_BYTES_A64 if at_shape else None,
+            "traffic_source": "from profile: profiles/r02_pmc_fetch_size.csv (x2, gfx950) + r02_pmc_write_size.csv, separate --pmc passes" if at_shape else None,
+            "avg_launch_ms": round(ms, 4), "launches_averaged": 10,
+            "avg_launch_ms_in_timed_region": None if not ms_timed else round(ms_timed, 4), "launches_in_timed_region": n_launches,
+            "frac_in_timed_region": None if not ms_timed else round(nb / 1e9 / (ms_timed / 1e3) / HBM_PEAK_GBS, 4),
+            "timing": "HIP events recorded by the library around every launch of this kernel, on the stream of the launch: `avg_launch_ms` with the "
+                      "device to itself (10 launches right after the timed region; this is what rocprofv3 reports for the single-stream run, "
+                      "profiles/r02_kernel_stats_single_stream.csv), `..._in_timed_region` with the other in-flight CPIs' kernels sharing the GPU",
+            "algorithmic_bytes_per_launch": nb, "algorithmic_bytes_note": "txGrid read once + echoGrid written once = 2 K L A 16 B; echoGrid is not re-read by the range stage",
+            "other_stages": stages, "whole_cpi": whole}
+
+
+def respawn_under_torchrun(n_gpus):
+    """`python bench.py --gpus N` without a torchrun environment launches its own N ranks (one per GPU, RCCL) on this node."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -286,9 +349,14 @@ def main():
     ap.add_argument("--slots", type=int, default=16)
     ap.add_argument("--targets", type=int, default=1)
     ap.add_argument("--cells-per-gpu", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=0, help="total number of cells, sharded cell c -> rank c mod world (BASELINE configs[2]: 7 cells on "
+                                                         "2/4/8 GPUs, inherently imbalanced); 0 = --cells-per-gpu cells on every rank (weak scaling)")
     ap.add_argument("--inflight", type=int, default=4, help="CPIs in flight per cell (contexts)")
-    ap.add_argument("--fuse", action="store_true", help="fuse the fft2D range stage into monoStaticSensing (measured slower: off by default)")
+    ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="separate monoStaticSensing and fft2D range kernels (the range stage re-reads echoGrid)")
+    ap.add_argument("--noise-domain", choices=("spectral", "time"), default="spectral",
+                    help="Philox AWGN drawn on the demodulated grid (default; same distribution, include/isac.h isac_noise_mode) or per time sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prime-ms", type=float, default=300.0, help="untimed device priming (hot-path steps) before the warm-up steps; 0 = none")
     args = ap.parse_args()
     # eigensolver trade-off (music.hip isac_eigh_dev): with several CPIs in flight the one-workgroup Jacobi solver (1.4 ms at
     # A = 64, hidden behind the other CPIs, one CU) gives a 3-5 % higher rate than the latency-optimised tridiagonal pipeline
@@ -296,8 +364,12 @@ def main():
     if args.inflight > 1:
         os.environ.setdefault("ISAC_EIG_JACOBI_MAX", "64")
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != max(args.gpus, 1) and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; the launcher's world size is used", file=sys.stderr)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
@@ -313,9 +385,12 @@ def main():
             dist.init_process_group(backend)
     pkg = importlib.import_module(PKG)
     pool = SlotPool(pkg, local_rank, args.inflight)          # the GPU's execution slots, shared by all its cells
-    n_buf = -(-args.inflight // args.cells_per_gpu)           # CPIs of one cell that can be in flight at once
-    cells = [Cell(pkg, local_rank, rank * args.cells_per_gpu + c, args.ants, args.slots, args.targets, fuse=args.fuse, pool=pool, n_buf=n_buf)
-             for c in range(args.cells_per_gpu)]
+    d = importlib.import_module(PKG + "._dist")
+    my_cells = d.shard_cells(args.cells, rank, world) if args.cells > 0 else [rank * args.cells_per_gpu + c for c in range(args.cells_per_gpu)]
+    n_total_cells = args.cells if args.cells > 0 else args.cells_per_gpu * world
+    n_buf = -(-args.inflight // max(len(my_cells), 1))        # CPIs of one cell that can be in flight at once
+    cells = [Cell(pkg, local_rank, cid, args.ants, args.slots, args.targets, fuse=args.fuse, pool=pool, n_buf=n_buf, noise_domain=args.noise_domain)
+             for cid in my_cells]
 
     def barrier():
         pool.sync()
@@ -323,10 +398,27 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # Device priming (untimed, before the W warm-up steps): a GPU that has been idle during the host-side set-up runs its first
+    # tens of milliseconds below its sustained clocks -- 20 timed steps behind 5 warm-up steps measured 35 % under the
+    # steady-state rate, behind 100 warm-up steps they measure the steady state (profiles/r02_warmup_sensitivity.txt).  The
+    # timed region below is still exactly K steps of the full hot path between two barriers.
+    prime_steps, t_prime = 0, time.perf_counter()
+    while 1e3 * (time.perf_counter() - t_prime) < args.prime_ms:
+        for cell in cells:
+            pool.submit(cell)
+        prime_steps += 1
+    pool.drain()
+    prime_ms = 1e3 * (time.perf_counter() - t_prime)
     for _ in range(args.warmup):
         for cell in cells:
             pool.submit(cell)
     pool.drain()
+    sink = [] if (rank == 0 and args.fuse) else None
+    if sink is not None:
+        for c_ in pool.ctxs:
+            c_.check(c_.lib.isac_profile_enable(c_.handle, 1))
+        for cell in cells:
+            cell.profile_sink = sink
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -338,45 +430,40 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    range_ms = cells[0].time_range_kernel() if rank == 0 else 0.0
+    for cell in cells:
+        cell.profile_sink = None
+    dom_ms_timed = float(np.mean(sink)) if sink else None                       # fused kernel, launches of the timed region (other CPIs co-running)
+    dom_ms_iso = cells[0].time_dominant_kernel_isolated() if (rank == 0 and args.fuse) else None
     stages = stage_table(cells[0]) if rank == 0 else []
     # per-cell result record gather -- the only collective (KB-scale, RCCL over xGMI); max over ranks of the timed region
-    d = importlib.import_module(PKG + "._dist")
-    recs = np.array([d.make_record(rank * args.cells_per_gpu + i, cell.last, dt) for i, cell in enumerate(cells)])
+    recs = np.array([d.make_record(cid, cell.last, dt) for cid, cell in zip(my_cells, cells)]).reshape(-1, d.RECORD_LEN)
     on_gpu = dist is not None and dist.get_backend() == "nccl"
     allr = d.gather_records(recs, dist, torch.device("cuda", local_rank) if on_gpu else None)
     dt = float(np.nanmax(allr[:, 6])) if allr.size else dt
-    n_cpi = args.steps * args.cells_per_gpu * world
+    n_cpi = args.steps * n_total_cells
     slots = n_cpi * args.slots
     if rank == 0:
         echo_b, rdm_b = cells[0].algorithmic_bytes()
-        per_cpi_ms = 1e3 * dt / (args.steps * args.cells_per_gpu)
+        per_cpi_ms = 1e3 * dt / (args.steps * max(len(my_cells), 1))
         res = {
             "metric": "sensing slots/sec (CDL echo->2D-FFT->2D-CFAR)", "value": round(slots / dt, 2), "unit": "sensing slots/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.cells_per_gpu} cell(s)/GPU, {args.ants}-antenna ULA echo -> 2D-FFT -> 2D-CFAR -> MUSIC, "
+            "higher_is_better": True, "scaling": "strong" if args.cells > 0 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "priming": {"untimed_steps_before_warmup": prime_steps, "ms": round(prime_ms, 1),
+                        "why": "idle GPU ramps to sustained clocks; timed region = exactly `steps` CPIs between barriers"},
+            "config": {"workload": f"{(str(args.cells) + ' cells round-robin over the ranks') if args.cells > 0 else (str(args.cells_per_gpu) + ' cell(s)/GPU')}, {args.ants}-antenna ULA echo -> 2D-FFT -> 2D-CFAR -> MUSIC, "
                                    f"100 MHz / 273 PRB, K=3276 L={14 * args.slots} T={cells[0].T} nIFFT=4096 nFFT=256, "
-                                   f"{args.targets} target(s), Philox AWGN, {args.inflight} CPIs in flight",
+                                   f"{args.targets} target(s), Philox AWGN drawn on the {'demodulated grid' if args.noise_domain == 'spectral' else 'time samples'}, "
+                                   f"{'fused synthesis + range kernel' if args.fuse else 'separate echo / range kernels'}, {args.inflight} CPIs in flight",
                        "parallelism": f"cells sharded over {world} GPU(s)"},
-            "roofline": {"bound": "hbm", "kernel": "range_kernel<Fft4096> (fft2D range stage: rx.*conj(tx), Kaiser, 4096-pt IFFT)",
-                         "achieved": round(rdm_b / 1e9 / (range_ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(rdm_b / 1e9 / (range_ms / 1e3) / HBM_PEAK_GBS, 4),
-                         # HBM bytes per launch from rocprofv3 PMC passes (profiles/r01_pmc_*.csv): 2 x FETCH_SIZE (gfx950 counts
-                         # wide coalesced reads at half, MI355X_MICROARCH.md) + WRITE_SIZE, KB -> B; measured at the A=64 shape only
-                         "traffic": RANGE_KERNEL_HBM_BYTES_A64 if (args.ants == 64 and args.slots == 16) else None,
-                         "traffic_source": "profiles/r01_pmc_fetch_size.csv + r01_pmc_write_size.csv (separate --pmc passes)",
-                         "avg_launch_ms": round(range_ms, 4), "algorithmic_bytes_per_launch": rdm_b,
-                         "other_stages": stages,
-                         "whole_cpi": {"algorithmic_bytes": echo_b + rdm_b, "ms": round(per_cpi_ms, 4),
-                                       "achieved_GBps": round((echo_b + rdm_b) / 1e9 / (per_cpi_ms / 1e3), 1),
-                                       "frac": round((echo_b + rdm_b) / 1e9 / (per_cpi_ms / 1e3) / HBM_PEAK_GBS, 4)}},
+            "roofline": roofline_entry(cells[0], args, dom_ms_timed, dom_ms_iso, len(sink or []), stages, echo_b + rdm_b, per_cpi_ms),
         }
         res["cells"] = [{"cell": int(r[0]), "nRng": None if np.isnan(r[1]) else int(r[1]), "rngEst0": None if np.isnan(r[2]) else round(float(r[2]), 6),
                          "velEst0": None if np.isnan(r[3]) else round(float(r[3]), 6), "aziEst0": None if np.isnan(r[4]) else float(r[4])}
-                        for r in allr[:8]]
+                        for r in allr[:64]]
         if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(args.ants)
+            res["cpu_baseline"] = cpu_baseline(cells[0])
+            res["gpu_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
         print(json.dumps(res))
     if dist is not None:
         dist.destroy_process_group()

@@ -72,6 +72,12 @@ int isac_memset_dev(isac_ctx* ctx, void* dst_dev, int value, size_t bytes);
 int isac_timer_start(isac_ctx* ctx);
 int isac_timer_stop_ms(isac_ctx* ctx, double* elapsed_ms); /* synchronises */
 
+/* Per-kernel timing hook (bench.py's roofline entry): when enabled, the context brackets the dominant kernel of every
+ * isac_mono_static_sensing_fused_dev call -- the fused echo-synthesis + range-stage kernel -- with a pair of HIP events
+ * on the stream it is launched on; isac_profile_last_kernel_ms waits for the most recent pair and returns its duration. */
+int isac_profile_enable(isac_ctx* ctx, int on);
+int isac_profile_last_kernel_ms(isac_ctx* ctx, double* ms);
+
 /* ------------------------------------------------------------------ parameter blocks */
 
 /* carrier = nrCarrierConfig fields monoStaticSensing.m:8-10 sets, + nrOFDMInfo() */
@@ -98,7 +104,14 @@ typedef struct {
 typedef enum {
   ISAC_NOISE_NONE = 0,   /* noiseless (tests)                                                     */
   ISAC_NOISE_INJECTED = 1, /* caller supplies randn()+1j*randn() [T x A]; parity mode              */
-  ISAC_NOISE_PHILOX = 2  /* on-device Philox4x32-10 + Box-Muller, counter = t + T*a; perf mode    */
+  ISAC_NOISE_PHILOX = 2, /* on-device Philox4x32-10 + Box-Muller per time sample, counter = t + T*a    */
+  /* monoStaticSensing only -- AWGN drawn on the DEMODULATED grid.  The demodulator is linear and unitary up to
+   * sqrt(Nfft) per symbol window, the windows are disjoint and every phase factor has unit modulus, so the i.i.d.
+   * CN(0, N0) samples of basicRadarChannel.m:67-69 arrive on the kept subcarriers as i.i.d. CN(0, Nfft N0): the same
+   * distribution, K instead of Nfft+CP draws per symbol, and the echo reduces to  sum_q a_q[r] D_q[k,l] + W[k,l,r]
+   * with D_q the demodulated per-target coefficient vector (Q FFTs per symbol instead of A).                         */
+  ISAC_NOISE_PHILOX_SPECTRAL = 3,   /* W from Philox4x32-10, one call per element pair (csrc/echo_dev.hpp); perf mode */
+  ISAC_NOISE_INJECTED_SPECTRAL = 4  /* caller supplies unit W [n_sc x L_out x A] (randn+1j*randn); parity mode        */
 } isac_noise_mode;
 
 /* cfar2D.m:27-33 detector configuration + the CUT rectangle cfar2D.m:17-24 builds */
@@ -162,10 +175,12 @@ int isac_mono_static_sensing(isac_ctx* ctx, const isac_c64* tx_wave, int64_t T, 
                              const uint8_t* los, int noise_mode, const isac_c64* noise_unit,
                              uint64_t seed, isac_c64* echo_grid, int32_t* l_out);
 /* monoStaticSensing + the range stage of the fft2D call that follows it (fft2D.m:37-45), fused per
- * echo column while the column is still on chip.  Results are identical to the two separate calls;
- * the next isac_fft2d[_submit]_dev on this context with the same d_echo_grid / d_tx_grid / parameters
- * consumes the cached range rows instead of re-reading rxGrid (single use; any other echo or range
- * call on the context drops the cache).  Falls back to the plain path when Nfft != nIFFT. */
+ * echo column while the column is still on chip.  Results are identical to the two separate calls.
+ * The range rows stay cached on the context; isac_fft2d_submit_cached_dev (below) with the same
+ * d_echo_grid / d_tx_grid / parameter blocks consumes them instead of re-reading rxGrid.  Reuse is explicit:
+ * the plain isac_fft2d[_submit]_dev never uses the cache, and any echo / range / copy / memset / free call on the
+ * context drops it.  The caller must not modify echoGrid or txGrid between the two calls.
+ * Falls back to the plain path when Nfft != nIFFT (the cached submit then reports INVALID_ARG: use the plain one). */
 int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64* d_tx_wave, int64_t T, int32_t tx_dim_l,
                                        const isac_carrier* carrier, const isac_radar_channel_params* rp,
                                        const uint8_t* los, int noise_mode, const isac_c64* d_noise_unit,
@@ -206,6 +221,12 @@ int isac_fft2d_submit_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_c
                           const isac_c64* d_rx_grid, const isac_c64* d_tx_grid,
                           int32_t K, int32_t L, int32_t A);
 int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out);
+/* isac_fft2d_submit_dev that REQUIRES and consumes the range rows cached by the preceding
+ * isac_mono_static_sensing_fused_dev call on this context (same grids, same parameter blocks); ISAC_ERR_INVALID_ARG when
+ * there is no such cache.  Saves the K L A 16 B re-read of rxGrid by the range stage. */
+int isac_fft2d_submit_cached_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
+                                 const isac_c64* d_rx_grid, const isac_c64* d_tx_grid,
+                                 int32_t K, int32_t L, int32_t A);
 
 /* Range stage of fft2D alone (fft2D.m:37-45: conj-multiply, Kaiser window, nIFFT-point IFFT per
  * (symbol, antenna) column, CUT-row selection, range-axis window).  One kernel launch on the

@@ -30,5 +30,5 @@ from .radar_channel import basic_radar_channel, mono_static_sensing  # noqa: F40
 from .cfar import cfar2d_config, ca_cfar2d, cfar_threshold_factor  # noqa: F401
 from .fft2d import fft2d, rdm_literal, rdm_explicit, covariance  # noqa: F401
 from .music import music_doa, determine_num_targets, music2d, digital_bf, mvdr_bf  # noqa: F401
-from .philox import philox4x32_10, philox_normal_pairs  # noqa: F401
+from .philox import philox4x32_10, philox_normal_pairs, philox_spectral_noise  # noqa: F401
 from . import cdl, cqi  # noqa: F401

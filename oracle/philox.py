@@ -6,6 +6,10 @@ Philox4x32-10 (Salmon et al., SC'11; Random123 constants), one call per complex
 sample:  counter = (e_lo, e_hi, stream, 0) with e = t + T*a the column-major element
 index of rxWaveform(t, a);  key = (seed_lo, seed_hi).  Box-Muller on two 53-bit
 uniforms gives independent N(0,1) real and imaginary parts.
+
+``philox_spectral_noise`` restates the library's *spectral* noise mode (ISAC_NOISE_PHILOX_SPECTRAL,
+csrc/echo_dev.hpp): the AWGN is drawn directly on the demodulated grid, one Philox call per PAIR of grid
+elements, 32-bit Box-Muller uniforms.
 TEST INFRASTRUCTURE ONLY.
 """
 from __future__ import annotations
@@ -55,3 +59,26 @@ def philox_normal_pairs(elem_index, seed: int, stream: int = 0) -> np.ndarray:
     r = np.sqrt(-2.0 * np.log(u1))
     ang = 2.0 * np.pi * u2
     return r * np.cos(ang) + 1j * (r * np.sin(ang))
+
+
+def philox_spectral_noise(n_sc: int, n_sym: int, n_ants: int, seed: int) -> np.ndarray:
+    """Unit complex normals W [n_sc x n_sym x n_ants] of the spectral noise mode.
+
+    Element (k, l, a), column = l + n_sym * a:  slot = (k mod 256) + 256 * ((k div 256) div 2),
+    half = (k div 256) mod 2;  Philox4x32-10 counter = (slot + 2048 * column as 64 bits, stream word 2, 0), key = seed;
+    outputs (o[2 half], o[2 half + 1]) -> u1 = (o + 1) 2^-32 in (0, 1], theta = 2 pi o' 2^-32;
+    W = sqrt(-2 ln u1) (cos theta + j sin theta)."""
+    k = np.arange(n_sc, dtype=np.uint64)
+    slot = (k % np.uint64(256)) + np.uint64(256) * ((k // np.uint64(256)) // np.uint64(2))
+    half = ((k // np.uint64(256)) % np.uint64(2)).astype(np.int64)
+    col = np.arange(n_sym * n_ants, dtype=np.uint64)
+    ctr = slot[:, None] + np.uint64(2048) * col[None, :]
+    x = philox4x32_10((ctr & _MASK).astype(np.uint32), (ctr >> np.uint64(32)).astype(np.uint32), np.uint32(2), np.uint32(0),
+                      np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
+    h = half[:, None]
+    ur = np.where(h == 0, x[0], x[2]).astype(np.float64)
+    ua = np.where(h == 0, x[1], x[3]).astype(np.float64)
+    rad = np.sqrt(-2.0 * np.log((ur + 1.0) * 2.0 ** -32))
+    ang = 2.0 * np.pi * (ua * 2.0 ** -32)
+    w = rad * np.cos(ang) + 1j * (rad * np.sin(ang))
+    return np.asfortranarray(w.reshape(n_sc, n_sym, n_ants, order="F"))

@@ -78,3 +78,29 @@ def make_scene(n_ants=4, n_slots=2, nrb=273, targets=((100.0, 20.0, 1.5),), velo
     return SimpleNamespace(cell=cell, carrier=ci, wave=wi, rp=rp, tx_grid=np.asfortranarray(tx_grid),
                            tx_wave=np.asfortranarray(tx_wave), noise=None if noise is None else np.asfortranarray(noise),
                            los=np.ones(len(targets), dtype=np.uint8), K=k, L=l, A=n_ants, T=t, amp=amp)
+
+
+def spectral_to_time_noise(w_grid, n_total, nfft, scs_khz, fc, fs):
+    """Time-domain unit noise [T x A] whose oracle treatment (x sqrt(N0/2), x exp(-2j pi fc t), OFDM demodulation:
+    basicRadarChannel.m:67-74 + nrOFDMDemodulate) lands on the kept subcarriers as sqrt(N0/2) sqrt(Nfft) * w_grid
+    [K x L x A] exactly: the link between the library's spectral noise modes and the reference's time-domain AWGN.
+    (Zero outside the symbols' FFT windows and off the kept bins; the oracle does not care that it is not white.)"""
+    import oracle as O
+    from scipy import fft as sfft
+    k, l, a = w_grid.shape
+    starts, cps = O.symbol_starts(nfft, scs_khz, l)
+    first = (nfft - k) // 2
+    kbin = np.arange(k) + first - nfft // 2
+    ts = 1.0 / fs
+    noise = np.zeros((n_total, a), dtype=np.complex128, order="F")
+    for s in range(l):
+        cp = int(cps[s])
+        off = int(np.fix(cp * 0.5))
+        w0 = int(starts[s]) + off
+        d = cp - off
+        full = np.zeros((nfft, a), dtype=np.complex128)
+        full[first:first + k] = np.sqrt(nfft) * w_grid[:, s, :] * np.exp(-2j * np.pi * kbin * d / nfft)[:, None]
+        x = sfft.ifft(sfft.ifftshift(full, axes=0), axis=0)
+        phase_rx = np.exp(-2j * np.pi * fc * (np.arange(w0, w0 + nfft, dtype=np.float64) * ts))
+        noise[w0:w0 + nfft] = x * np.conj(phase_rx)[:, None]
+    return noise

@@ -64,7 +64,7 @@ def test_full_size_chain_on_device(pkg, name, live_oracle):
     # fused call sequence (range stage inside the demodulator) gives the same bits at this size
     if sc.wave.Nfft == 4096:
         e2 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, noise=d_noise, nfft=4096, fuse_fft2d=(rp, cf, d_txg))
-        est2, dbg2 = pkg.sensing.estimation.fft2D(rp, cf, e2, d_txg, return_debug=True)
+        est2, dbg2 = pkg.sensing.estimation.fft2D(rp, cf, e2, d_txg, return_debug=True, reuse_range=True)
         assert np.array_equal(dbg2.power_window, dbg.power_window) and detection_digest(dbg2.detections) == str(g["det_sha256"])
         assert np.array_equal(est2.aziEst, est.aziEst)
         del e2
@@ -84,3 +84,53 @@ def test_full_size_chain_on_device(pkg, name, live_oracle):
     assert np.array_equal(est.rngEst, want.rngEst) and np.array_equal(est.velEst, want.velEst) and np.array_equal(est.aziEst, want.aziEst)
     assert rel(dbg.Ra, odbg.Ra) < RTOL
     assert detection_digest(odbg.detections) == str(g["det_sha256"])     # the oracle still reproduces its own fixture
+
+
+@pytest.mark.parametrize("name", ["config2_a64"])
+def test_full_size_spectral_fused_path(pkg, name):
+    """The path bench.py times (per-target demodulation -> fused synthesis + range kernel with the AWGN on the demodulated grid
+    -> cached-range fft2D) at the benchmark shape, with an injected spectral noise field, against the oracle's time-domain
+    chain fed the equivalent time-domain noise: echo grid <= 1e-10, every antenna's CFAR list and all estimates exact."""
+    from conftest import spectral_to_time_noise
+    kw = dict(FULL[name]); kw["with_noise"] = False
+    sc = make_scene(**kw)
+    rng = np.random.default_rng(4242)
+    w = np.empty(sc.tx_grid.shape, dtype=np.complex128, order="F")
+    for a in range(sc.A):                                   # plane by plane: bounds the temporaries
+        w[:, :, a] = rng.standard_normal((sc.K, sc.L)) + 1j * rng.standard_normal((sc.K, sc.L))
+    ctx = pkg.Context()
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    cf = pkg.sensing.detection.cfar2D(rp)
+    d_wave, d_txg, d_w = ctx.to_device(sc.tx_wave), ctx.to_device(sc.tx_grid), ctx.to_device(w)
+    echo = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, spectral_noise=d_w, fuse_fft2d=(rp, cf, d_txg))
+    est, dbg = pkg.sensing.estimation.fft2D(rp, cf, echo, d_txg, return_debug=True, reuse_range=True)
+    h_echo = echo.numpy()
+    del d_wave, d_w
+    tnoise = spectral_to_time_noise(w, sc.T, 4096, 30, sc.rp.fc, sc.rp.fs)
+    del w
+    want_echo = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, tnoise, nfft=4096)
+    del tnoise
+    assert rel(h_echo, want_echo) < RTOL
+    ocf = O.cfar2d_config(sc.rp)
+    want, odbg = O.fft2d(sc.rp, ocf, want_echo, sc.tx_grid, return_debug=True, rdm_fn=O.rdm_explicit)
+    r0, c0 = dbg.first_row, dbg.first_col
+    nr, nc, _ = dbg.power_window.shape
+    assert rel(dbg.power_window, np.abs(odbg.rdm[r0 - 1:r0 - 1 + nr, c0 - 1:c0 - 1 + nc, :]) ** 2) < RTOL
+    margin = np.inf
+    for a in range(sc.A):
+        p = np.abs(odbg.rdm[:, :, a]) ** 2
+        _, thr = O.ca_cfar2d(p, ocf.CUTIdx, ocf.Pfa, return_threshold=True)
+        pc = p[ocf.CUTIdx[0] - 1, ocf.CUTIdx[1] - 1]
+        margin = min(margin, float(np.min(np.abs(pc - thr) / np.maximum(np.abs(thr), 1e-300))))
+        assert np.array_equal(dbg.detections[a], odbg.detections[a]), f"antenna {a}"
+    assert margin > 1e-7, "scene too close to a CFAR threshold to be a meaningful exact test"
+    assert sum(d.shape[1] for d in dbg.detections) > 100
+    assert np.array_equal(est.rngEst, want.rngEst) and np.array_equal(est.velEst, want.velEst) and np.array_equal(est.aziEst, want.aziEst)
+    assert rel(dbg.Ra, odbg.Ra) < RTOL
+    # unfused spectral sequence: same bits
+    e2 = pkg.sensing.monoStaticSensing(ctx.to_device(sc.tx_wave), sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, seed=99, noise_domain="spectral")
+    est2, dbg2 = pkg.sensing.estimation.fft2D(rp, cf, e2, d_txg, return_debug=True)
+    e3 = pkg.sensing.monoStaticSensing(ctx.to_device(sc.tx_wave), sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, seed=99, noise_domain="spectral", fuse_fft2d=(rp, cf, d_txg))
+    est3, dbg3 = pkg.sensing.estimation.fft2D(rp, cf, e3, d_txg, return_debug=True, reuse_range=True)
+    assert np.array_equal(dbg2.power_window, dbg3.power_window) and detection_digest(dbg2.detections) == detection_digest(dbg3.detections)
+    assert np.array_equal(est2.aziEst, est3.aziEst) and np.array_equal(est2.rngEst, est3.rngEst)

@@ -189,15 +189,18 @@ def test_fused_range_stage_is_identical(pkg, ctx):
     est0, dbg0 = pkg.sensing.estimation.fft2D(rp, cf, e0, d_txg, return_debug=True)
     e1 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, noise=d_noise, nfft=4096,
                                        fuse_fft2d=(rp, cf, d_txg))
-    est1, dbg1 = pkg.sensing.estimation.fft2D(rp, cf, e1, d_txg, return_debug=True)
+    est1, dbg1 = pkg.sensing.estimation.fft2D(rp, cf, e1, d_txg, return_debug=True, reuse_range=True)
     assert np.array_equal(e0.numpy(), e1.numpy())
     assert np.array_equal(dbg0.power_window, dbg1.power_window)
     assert all(np.array_equal(a, b) for a, b in zip(dbg0.detections, dbg1.detections))
     assert np.array_equal(est0.rngEst, est1.rngEst) and np.array_equal(est0.aziEst, est1.aziEst)
-    # the cache is single-use and keyed on the grids: a different rxGrid must not consume it
+    # reuse is explicit and keyed on the grids: a different rxGrid cannot consume the cache, a plain fft2D never does
+    other = ctx.to_device(np.asfortranarray(2.0 * e0.numpy()))
     e2 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, noise=d_noise, nfft=4096,
                                        fuse_fft2d=(rp, cf, d_txg))
-    other = ctx.to_device(np.asfortranarray(2.0 * e0.numpy()))
+    with pytest.raises(pkg.IsacError) as ei:
+        pkg.sensing.estimation.fft2D(rp, cf, other, d_txg, reuse_range=True)
+    assert ei.value.name == "INVALID_ARG"
     _, dbg2 = pkg.sensing.estimation.fft2D(rp, cf, other, d_txg, return_debug=True)
     assert np.allclose(dbg2.power_window, 4.0 * dbg0.power_window, rtol=1e-12)
     # padded symbol dimension (txDimension(2) > whole symbols) through the fused path

@@ -270,3 +270,25 @@ def test_ofdm_demodulate_against_a_plain_fft_model():
         spec = np.fft.fftshift(np.fft.fft(seg))
         mid = spec[nfft // 2 - k // 2: nfft // 2 + k // 2]
         assert np.abs(mid - grid[:, sym, 0]).max() < 1e-10
+
+
+def test_spectral_philox_noise_statistics():
+    """The spectral noise field (one Philox call per element pair, 32-bit Box-Muller uniforms) is white, circular, unit variance:
+    moments, real/imag and pair-half cross-correlations, lag correlations along subcarriers / symbols / antennas."""
+    w = O.philox_spectral_noise(3276, 28, 8, 0x5EED0002)
+    n = w.size
+    tol = 5.0 / np.sqrt(n)
+    assert abs(w.real.mean()) < tol and abs(w.imag.mean()) < tol
+    assert abs(w.real.var() - 1) < 3 * tol and abs(w.imag.var() - 1) < 3 * tol
+    assert abs((w.real * w.imag).mean()) < tol
+    assert abs((np.abs(w) ** 4).mean() / 8.0 - 1.0) < 0.02               # |z|^2 = 2 Exp(1)  ->  E|z|^4 = 8
+    assert abs((w.real ** 4).mean() / 3.0 - 1.0) < 0.02                  # Gaussian kurtosis
+    for ax in range(3):
+        a = np.moveaxis(w, ax, 0)
+        assert abs((a[1:] * np.conj(a[:-1])).mean()) < 2 * tol
+    # the two halves of one Philox call (elements k and k + 256 inside an even/odd 256-block pair) are uncorrelated
+    assert abs((w[0:256] * np.conj(w[256:512])).mean()) < 10 / np.sqrt(256 * 28 * 8)
+    assert abs((np.abs(w[0:256]) ** 2 * np.abs(w[256:512]) ** 2).mean() / 4.0 - 1.0) < 0.05
+    # tail: the radius never exceeds the 32-bit Box-Muller bound sqrt(-2 ln 2^-32)
+    assert np.abs(w).max() <= np.sqrt(-2 * np.log(2.0 ** -32)) + 1e-12
+    assert np.array_equal(w, O.philox_spectral_noise(3276, 28, 8, 0x5EED0002)) and not np.array_equal(w, O.philox_spectral_noise(3276, 28, 8, 1))

@@ -21,6 +21,15 @@ def timed(fn, reps=args.reps):
         ctx.sync(); ctx.timer_start(); t0 = time.perf_counter(); fn(); ms = ctx.timer_stop_ms(); ts.append((ms, 1e3 * (time.perf_counter() - t0)))
     a = np.array(ts); return a[:, 0].min(), np.median(a[:, 0]), np.median(a[:, 1])
 def mono(): pkg.sensing.monoStaticSensing(cell.tx_wave, (cell.K, cell.Lsym, cell.A), cell.carrier, cell.rp, cell.los, seed=cell.seed, nfft=4096, out=echo, ctx=ctx)
+def mono_spec(): pkg.sensing.monoStaticSensing(cell.tx_wave, (cell.K, cell.Lsym, cell.A), cell.carrier, cell.rp, cell.los, seed=cell.seed, noise_domain="spectral", nfft=4096, out=echo, ctx=ctx)
+def mono_spec_fused(): pkg.sensing.monoStaticSensing(cell.tx_wave, (cell.K, cell.Lsym, cell.A), cell.carrier, cell.rp, cell.los, seed=cell.seed, noise_domain="spectral", nfft=4096, out=echo, ctx=ctx,
+                                                     fuse_fft2d=(cell.rp, cell.cfar, cell.tx_grid))
+def mono_time_fused(): pkg.sensing.monoStaticSensing(cell.tx_wave, (cell.K, cell.Lsym, cell.A), cell.carrier, cell.rp, cell.los, seed=cell.seed, nfft=4096, out=echo, ctx=ctx,
+                                                     fuse_fft2d=(cell.rp, cell.cfar, cell.tx_grid))
+def fused_cpi():
+    mono_spec_fused()
+    try: pkg.sensing.estimation.fft2D(cell.rp, cell.cfar, echo, cell.tx_grid, ctx=ctx, reuse_range=True)
+    except pkg.IsacError: pass
 def mono_nonoise(): pkg.sensing.monoStaticSensing(cell.tx_wave, (cell.K, cell.Lsym, cell.A), cell.carrier, cell.rp, cell.los, nfft=4096, out=echo, ctx=ctx)
 def fft2d():
     try: pkg.sensing.estimation.fft2D(cell.rp, cell.cfar, echo, cell.tx_grid, ctx=ctx)
@@ -30,6 +39,7 @@ def cov(): ctx.check(lib.isac_covariance_dev(ctx.handle, C.c_void_p(echo.ptr), C
 h = np.asfortranarray(np.eye(cell.A) + 0j); w = np.zeros(cell.A)
 def eig():
     hh = ra.numpy(); ctx.check(lib.isac_eigh(ctx.handle, hh.ctypes.data_as(C.c_void_p), C.c_int32(cell.A), w.ctypes.data_as(C.c_void_p), None))
-for name, fn in [("monoStaticSensing (philox)", mono), ("monoStaticSensing (no noise)", mono_nonoise), ("fft2D (all)", fft2d), ("covariance", cov), ("eigh (incl. H2D/D2H)", eig), ("range stage (1 kernel)", lambda: cell.time_range_kernel(1)), ("whole step", cell.step)]:
+for name, fn in [("mono spectral philox (unfused)", mono_spec), ("mono spectral philox + range (fused)", mono_spec_fused), ("mono time philox + range (fused)", mono_time_fused),
+                 ("fused CPI: mono+range, cached fft2D", fused_cpi), ("monoStaticSensing (time philox)", mono), ("monoStaticSensing (no noise)", mono_nonoise), ("fft2D (all)", fft2d), ("covariance", cov), ("eigh (incl. H2D/D2H)", eig), ("whole step", cell.step)]:
     mn, med, wall = timed(fn)
     print(f"{name:32s} gpu min {mn:8.3f} ms  median {med:8.3f} ms   host wall median {wall:8.3f} ms")
