@@ -64,6 +64,15 @@ class Music2dParams(C.Structure):
     _fields_ = [("fc", C.c_double), ("t_sri", C.c_double), ("scs_hz", C.c_double), ("r_max", C.c_double), ("v_max", C.c_double)]
 
 
+ISAC_MAX_SUBBANDS = 70
+
+
+class CsiReport(C.Structure):
+    _fields_ = [("n_subbands_pmi", C.c_int32), ("n_subbands_cqi", C.c_int32), ("n_cqi", C.c_int32), ("reserved", C.c_int32),
+                ("i1", C.c_double * 3), ("i2", C.c_double * ISAC_MAX_SUBBANDS), ("cqi", C.c_double * (ISAC_MAX_SUBBANDS + 1)),
+                ("subband_cqi", C.c_double * (ISAC_MAX_SUBBANDS + 1)), ("sinr_per_subband_cw", C.c_double * (ISAC_MAX_SUBBANDS + 1))]
+
+
 class EstResult(C.Structure):
     _fields_ = [("n_rng", C.c_int32), ("n_vel", C.c_int32), ("n_azi", C.c_int32), ("num_dets", C.c_int32),
                 ("total_detections", C.c_int32), ("reserved", C.c_int32),
@@ -74,13 +83,13 @@ class EstResult(C.Structure):
 # every symbol include/isac.h declares (tests check the library exports all of them)
 EXPORTS = [
     "isac_abi_version", "isac_device_count", "isac_ctx_create", "isac_ctx_destroy", "isac_last_error",
-    "isac_ctx_get_stream", "isac_sync", "isac_dev_alloc", "isac_dev_free", "isac_memcpy_h2d", "isac_memcpy_d2h",
+    "isac_ctx_get_stream", "isac_sync", "isac_dev_alloc", "isac_dev_free", "isac_memcpy_h2d", "isac_memcpy_d2h", "isac_memcpy_d2d",
     "isac_memset_dev", "isac_timer_start", "isac_timer_stop_ms", "isac_profile_enable", "isac_profile_last_kernel_ms",
     "isac_basic_radar_channel_dev", "isac_basic_radar_channel", "isac_mono_static_sensing_dev",
-    "isac_mono_static_sensing", "isac_mono_static_sensing_fused_dev", "isac_ofdm_symbol_count", "isac_ofdm_demodulate_dev", "isac_ofdm_modulate_dev",
+    "isac_mono_static_sensing", "isac_mono_static_sensing_fused_dev", "isac_ofdm_symbol_count", "isac_ofdm_demodulate_dev", "isac_ofdm_modulate_dev", "isac_ofdm_modulate_windowed_dev", "isac_sentx_append_dev",
     "isac_ofdm_waveform_length", "isac_cfar2d_ca", "isac_fft2d_dev", "isac_fft2d", "isac_fft2d_submit_dev", "isac_fft2d_submit_cached_dev", "isac_fft2d_collect", "isac_fft2d_range_stage_dev", "isac_fft2d_get_detections",
     "isac_fft2d_get_power_window", "isac_fft2d_get_covariance", "isac_fft2d_get_music_spectrum",
-    "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_beamscan_doa", "isac_music2d_dev", "isac_eigh", "isac_cdl_apply_dev", "isac_precoded_sinr_cqi_dev", "isac_los_check_dev", "isac_winding_number_dev", "isac_synth_qpsk_grid_dev",
+    "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_beamscan_doa", "isac_music2d_dev", "isac_eigh", "isac_cdl_apply_dev", "isac_precoded_sinr_cqi_dev", "isac_type1sp_codebook", "isac_csi_report_dev", "isac_los_check_dev", "isac_winding_number_dev", "isac_synth_qpsk_grid_dev",
 ]
 
 

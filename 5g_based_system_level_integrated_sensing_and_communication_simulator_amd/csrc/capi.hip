@@ -184,6 +184,23 @@ int isac_get_logtab(isac_ctx* ctx, const c64** out) {
   return ISAC_OK;
 }
 
+// rising raised-cosine edge of the OFDM symbol window (toolbox form, oracle/ofdm.py raised_cosine_edge); kept in the Kaiser map
+// under the key (n, 2)
+int isac_get_rise_window(isac_ctx* ctx, int n_win, const double** out) {
+  isac_ctx& t = *ctx;
+  auto key = std::make_pair(n_win, 2);
+  auto it = t.kaiser3.find(key);
+  if (it == t.kaiser3.end()) {
+    std::vector<double> w((size_t)n_win);
+    for (int i = 1; i <= n_win; ++i) w[(size_t)i - 1] = 0.5 * (1.0 - std::sin(M_PI * (n_win + 1 - 2.0 * i) / (2.0 * n_win)));
+    DevBuf b;
+    ISAC_TRY(upload(ctx, b, w.data(), sizeof(double) * w.size()));
+    it = t.kaiser3.emplace(key, b).first;
+  }
+  *out = (const double*)it->second.p;
+  return ISAC_OK;
+}
+
 int isac_get_windows(isac_ctx* ctx, int K, int n_ifft, const double** win_k, const double** win_r) {
   isac_ctx& t = *ctx;
   auto get = [&](int n, int shifted, const double** out) -> int {
@@ -316,6 +333,13 @@ extern "C" int isac_memcpy_d2h(isac_ctx* ctx, void* dst_host, const void* src_de
   ISAC_ENTER(ctx);
   ISAC_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  return ISAC_OK;
+}
+extern "C" int isac_memcpy_d2d(isac_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes) {
+  if (!ctx || (!dst_dev && bytes) || (!src_dev && bytes)) return ISAC_ERR_INVALID_ARG;
+  ISAC_ENTER(ctx);
+  ctx->range_cache.touch(dst_dev, bytes);
+  ISAC_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   return ISAC_OK;
 }
 extern "C" int isac_memset_dev(isac_ctx* ctx, void* dst_dev, int value, size_t bytes) {

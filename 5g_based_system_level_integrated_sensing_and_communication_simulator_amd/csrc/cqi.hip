@@ -3,6 +3,8 @@
 // dlPMISelect.m:385-427,1825-1834; table lookup +communication/+phyLayer/cqiSelect.m:697-722 with the tables of
 // +communication/setupSINRtoCQIMappingTable.m:7-11.  One thread per RE: G = H W (Nr x nL, nL <= 8),
 // M = G^H G + sigma^2 I, Gauss-Jordan inverse in registers, sinr = sum_l 1/(sigma^2 (M^-1)_ll) - 1.
+#include <cstring>
+
 #include "isac_common.hpp"
 
 namespace isac {
@@ -69,6 +71,116 @@ __global__ __launch_bounds__(128) void precoded_sinr_kernel(const c64* __restric
     s += d.re / n2 - 1.0;
   }
   sinr[re] = s;
+}
+
+// ---------------------------------------------------------------- Type-I codebook PMI search (dlPMISelect.m:385-427,1825-1834)
+// One thread per (CSI-RS RE, codebook entry): per-layer LMMSE SINR  real(1 / (nVar (W^H H^H H W + nVar I)^-1)_ll - 1).
+// An all-zero (restricted) entry leaves NaN, as the reference's pre-filled SINRPerRE does.
+template <int NL>
+__global__ __launch_bounds__(128) void pmi_sinr_kernel(const c64* __restrict__ H /* [nRE x Nr x P] (RE fastest) */, long long n_re, int Nr, int P,
+                                                       const c64* __restrict__ W /* [P x NL x nE] */, double nvar,
+                                                       double* __restrict__ sinr /* [nRE x NL x nE] (RE fastest) */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* s_w = reinterpret_cast<c64*>(smem_raw);
+  __shared__ int s_any;
+  const int e = blockIdx.y;
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < P * NL; i += blockDim.x) {
+    const c64 v = W[(long long)e * P * NL + i];
+    s_w[i] = v;
+    if (v.re != 0.0 || v.im != 0.0) s_any = 1;
+  }
+  __syncthreads();
+  const long long re = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (re >= n_re) return;
+  double* out = sinr + re + n_re * (long long)NL * e;
+  if (!s_any) {
+#pragma unroll
+    for (int l = 0; l < NL; ++l) out[n_re * l] = __builtin_nan("");
+    return;
+  }
+  c64 m[NL][NL];
+#pragma unroll
+  for (int a = 0; a < NL; ++a)
+#pragma unroll
+    for (int b = 0; b < NL; ++b) m[a][b] = mk(a == b ? nvar : 0.0, 0.0);
+  for (int r = 0; r < Nr; ++r) {
+    c64 g[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) g[l] = mk(0.0, 0.0);
+    for (int p = 0; p < P; ++p) {
+      const c64 h = H[re + n_re * ((long long)r + (long long)Nr * p)];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) g[l] = fma(h, s_w[p + P * l], g[l]);
+    }
+#pragma unroll
+    for (int a = 0; a < NL; ++a)
+#pragma unroll
+      for (int b = 0; b < NL; ++b) m[a][b] = fma(conj(g[a]), g[b], m[a][b]);
+  }
+  c64 inv[NL][NL];
+#pragma unroll
+  for (int a = 0; a < NL; ++a)
+#pragma unroll
+    for (int b = 0; b < NL; ++b) inv[a][b] = mk(a == b ? 1.0 : 0.0, 0.0);
+#pragma unroll
+  for (int k = 0; k < NL; ++k) {
+    const double d2 = m[k][k].re * m[k][k].re + m[k][k].im * m[k][k].im;
+    const c64 pinv = mk(m[k][k].re / d2, -m[k][k].im / d2);
+#pragma unroll
+    for (int b = 0; b < NL; ++b) { m[k][b] = m[k][b] * pinv; inv[k][b] = inv[k][b] * pinv; }
+#pragma unroll
+    for (int a = 0; a < NL; ++a) {
+      if (a == k) continue;
+      const c64 f = m[a][k];
+#pragma unroll
+      for (int b = 0; b < NL; ++b) { m[a][b] = m[a][b] - f * m[k][b]; inv[a][b] = inv[a][b] - f * inv[k][b]; }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    const c64 d = mk(nvar * inv[l][l].re, nvar * inv[l][l].im);
+    const double n2 = d.re * d.re + d.im * d.im;
+    out[n_re * l] = d.re / n2 - 1.0;                         // real(1 / den_ll - 1)
+  }
+}
+
+// Fixed-order reductions of the per-RE SINRs (REs in the caller's order):
+//   thread t <  nE                       total[e]  = sum over REs and layers, NaN omitted              dlPMISelect.m:446
+//   thread t >= nE: (sb, layer, entry)   sb_sinr   = mean over symbols of (mean over the subband's REs of that symbol), NaN omitted
+//                                                    -- mean(mean(., 'omitnan'), 'omitnan')             dlPMISelect.m:481, cqiSelect.m:797
+__global__ __launch_bounds__(128) void pmi_reduce_kernel(const double* __restrict__ sinr, long long n_re, int NL, int nE, const int* __restrict__ re_sb,
+                                                         const int* __restrict__ re_sym, int n_sb, double* __restrict__ total /* [nE] or null */,
+                                                         double* __restrict__ sb_sinr /* [n_sb x NL x nE] */) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (total && t < nE) {
+    double acc = 0.0;
+    for (int l = 0; l < NL; ++l)
+      for (long long i = 0; i < n_re; ++i) {
+        const double v = sinr[i + n_re * ((long long)l + (long long)NL * t)];
+        if (v == v) acc += v;
+      }
+    total[t] = acc;
+  }
+  const int u = t - nE;
+  if (u < 0 || u >= n_sb * NL * nE) return;
+  const int sb = u % n_sb, l = (u / n_sb) % NL, e = u / (n_sb * NL);
+  double s[14];
+  int c[14];
+  for (int y = 0; y < 14; ++y) { s[y] = 0.0; c[y] = 0; }
+  const double* col = sinr + n_re * ((long long)l + (long long)NL * e);
+  for (long long i = 0; i < n_re; ++i)
+    if (re_sb[i] == sb) {
+      const double v = col[i];
+      const int y = re_sym[i];
+      if (v == v && y >= 0 && y < 14) { s[y] += v; ++c[y]; }
+    }
+  double acc = 0.0;
+  int ny = 0;
+  for (int y = 0; y < 14; ++y)
+    if (c[y]) { acc += s[y] / (double)c[y]; ++ny; }
+  sb_sinr[u] = ny ? acc / (double)ny : __builtin_nan("");
 }
 
 __global__ __launch_bounds__(256) void mean_kernel(const double* __restrict__ x, long long n, double* __restrict__ out) {
@@ -139,6 +251,277 @@ extern "C" int isac_precoded_sinr_cqi_dev(isac_ctx* ctx, const isac_c64* d_H, in
     }
   } else {
     ISAC_HIP(hipStreamSynchronize(ctx->stream));         // W staging must outlive the copy
+  }
+  return ISAC_OK;
+}
+
+
+// ------------------------------------------------------------------ Type-I single-panel codebook + CSI report (PMI search, subband CQI)
+namespace {
+
+c64 cis(double x) { return mk(std::cos(x), std::sin(x)); }
+
+// getVlm (dlPMISelect.m:1774-1782): element (a1, a2) at a2 + N2 * a1
+void vlm(int n1, int n2, int o1, int o2, int l, int m, c64* out) {
+  for (int a1 = 0; a1 < n1; ++a1)
+    for (int a2 = 0; a2 < n2; ++a2)
+      out[a2 + n2 * a1] = cis(2.0 * M_PI * l * a1 / (double)(o1 * n1)) * cis(2.0 * M_PI * m * a2 / (double)(o2 * n2));
+}
+
+const int kPanel[13][4] = {{2, 1, 4, 1}, {2, 2, 4, 4}, {4, 1, 4, 1}, {3, 2, 4, 4}, {6, 1, 4, 1}, {4, 2, 4, 4}, {8, 1, 4, 1},
+                           {4, 3, 4, 4}, {6, 2, 4, 4}, {12, 1, 4, 1}, {4, 4, 4, 4}, {8, 2, 4, 4}, {16, 1, 4, 1}};   // TS 38.214 Table 5.2.2.2.1-2
+
+double round4(double x) { return (x < 0 ? -1.0 : 1.0) * std::floor(std::fabs(x) * 1e4 + 0.5) / 1e4; }   // round(x, 4, 'decimal')
+
+double get_cqi(double lin, const double* table, int n) {                 // cqiSelect.m:697-722
+  if (std::isnan(lin)) return NAN;
+  const double s_db = 10.0 * std::log10(lin);
+  int c = 0;
+  for (int i = 0; i < n; ++i)
+    if (table[i] <= s_db) c = i + 1;
+  return (double)c;
+}
+
+struct Subbands { int n; std::vector<int> size; };
+Subbands subband_info(bool subband_mode, int n_start, int n_size, int nsb) {   // getSubbandInfo, cqiSelect.m:1209-1245
+  Subbands sb;
+  if (!subband_mode || n_size < 24) { sb.n = 1; sb.size = {n_size}; return sb; }
+  const int first = nsb - n_start % nsb;
+  const int last = ((n_start + n_size) % nsb) ? (n_start + n_size) % nsb : nsb;
+  sb.n = (n_size - (first + last)) / nsb + 2;
+  sb.size.assign((size_t)sb.n, nsb);
+  sb.size.front() = first;
+  sb.size.back() = last;
+  return sb;
+}
+
+}  // namespace
+
+extern "C" int isac_type1sp_codebook(int32_t n_ports, int32_t n1, int32_t n2, int32_t codebook_mode, int32_t n_layers, isac_c64* W_,
+                                     int64_t cap_elems, int32_t dims[4]) {
+  if (!dims || n_layers < 1 || n_layers > 2 || (codebook_mode != 1 && codebook_mode != 2)) return ISAC_ERR_UNSUPPORTED;
+  c64* W = reinterpret_cast<c64*>(W_);
+  const double r2 = std::sqrt(0.5);
+  if (n_ports == 2) {                                                    // TS 38.214 Table 5.2.2.2.1-1, dlPMISelect.m:892-916
+    dims[0] = n_layers == 1 ? 4 : 2; dims[1] = dims[2] = dims[3] = 1;
+    if (!W) return ISAC_OK;
+    if (cap_elems < 2LL * n_layers * dims[0]) return ISAC_ERR_CAPACITY;
+    if (n_layers == 1) {
+      const c64 second[4] = {mk(1, 0), mk(0, 1), mk(-1, 0), mk(0, -1)};
+      for (int i = 0; i < 4; ++i) { W[2 * i] = mk(r2, 0); W[2 * i + 1] = second[i] * r2; }
+    } else {
+      const c64 e0[4] = {mk(.5, 0), mk(.5, 0), mk(.5, 0), mk(-.5, 0)}, e1[4] = {mk(.5, 0), mk(0, .5), mk(.5, 0), mk(0, -.5)};   // column-major [1 1; 1 -1]/2, [1 1; j -j]/2
+      for (int i = 0; i < 4; ++i) { W[i] = e0[i]; W[4 + i] = e1[i]; }
+    }
+    return ISAC_OK;
+  }
+  int o1 = 0, o2 = 0;
+  for (const auto& p : kPanel) if (p[0] == n1 && p[1] == n2) { o1 = p[2]; o2 = p[3]; }
+  if (!o1 || n_ports != 2 * n1 * n2) return ISAC_ERR_INVALID_ARG;
+  const int P = n_ports, half = n1 * n2;
+  int i13l = 1, k1[4] = {0, 0, 0, 0}, k2[4] = {0, 0, 0, 0};
+  if (n_layers == 2) {                                                   // TS 38.214 Table 5.2.2.2.1-3, dlPMISelect.m:993-1012
+    if (n1 > n2 && n2 > 1) { i13l = 4; k1[1] = o1; k1[3] = 2 * o1; k2[2] = o2; }
+    else if (n1 == n2) { i13l = 4; k1[1] = o1; k1[3] = o1; k2[2] = o2; k2[3] = o2; }
+    else if (n1 == 2 && n2 == 1) { i13l = 2; k1[1] = o1; }
+    else { i13l = 4; k1[1] = o1; k1[2] = 2 * o1; k1[3] = 3 * o1; }
+  }
+  const int i11l = codebook_mode == 1 ? n1 * o1 : n1 * o1 / 2;
+  const int i12l = codebook_mode == 1 ? n2 * o2 : (n2 == 1 ? 1 : n2 * o2 / 2);
+  const int i2l = codebook_mode == 1 ? (n_layers == 1 ? 4 : 2) : (n_layers == 1 ? 16 : 8);
+  dims[0] = i2l; dims[1] = i11l; dims[2] = i12l; dims[3] = i13l;
+  if (!W) return ISAC_OK;
+  const long long n_e = (long long)i2l * i11l * i12l * i13l;
+  if (cap_elems < n_e * P * n_layers) return ISAC_ERR_CAPACITY;
+  std::vector<c64> v((size_t)half), vp((size_t)half);
+  const int add[4][2] = {{0, 0}, {1, 0}, {0, 1}, {1, 1}};
+  for (int i13 = 0; i13 < i13l; ++i13)
+    for (int i12 = 0; i12 < i12l; ++i12)
+      for (int i11 = 0; i11 < i11l; ++i11)
+        for (int i2 = 0; i2 < i2l; ++i2) {
+          int l, m, lp, mp, n;
+          if (codebook_mode == 1) { l = i11; m = i12; n = i2; lp = i11 + k1[i13]; mp = i12 + k2[i13]; }
+          else {
+            const int per = n_layers == 1 ? 4 : 2, f = i2 / per;
+            n = i2 % per;
+            if (n2 == 1) { l = 2 * i11 + f; m = 0; lp = l + k1[i13]; mp = 0; }
+            else { l = 2 * i11 + add[f][0]; m = 2 * i12 + add[f][1]; lp = l + k1[i13]; mp = m + k2[i13]; }
+          }
+          vlm(n1, n2, o1, o2, l, m, v.data());
+          const c64 ph = cis(M_PI * n / 2.0);                              // phi_n = exp(j pi n / 2)
+          c64* w = W + (size_t)P * n_layers * ((size_t)i2 + (size_t)i2l * ((size_t)i11 + (size_t)i11l * ((size_t)i12 + (size_t)i12l * i13)));
+          const double sc = 1.0 / std::sqrt((double)(n_layers * P));
+          for (int a = 0; a < half; ++a) { w[a] = v[(size_t)a] * sc; w[half + a] = (ph * v[(size_t)a]) * sc; }
+          if (n_layers == 2) {
+            vlm(n1, n2, o1, o2, lp, mp, vp.data());
+            for (int a = 0; a < half; ++a) { w[P + a] = vp[(size_t)a] * sc; w[P + half + a] = (ph * vp[(size_t)a]) * (-sc); }
+          }
+        }
+  return ISAC_OK;
+}
+
+template <int NL>
+static int launch_pmi_sinr(isac_ctx* ctx, const c64* H, long long n_re, int Nr, int P, const c64* W, int nE, double nvar, double* out) {
+  hipLaunchKernelGGL(pmi_sinr_kernel<NL>, dim3(cdiv(n_re, 128), (unsigned)nE), dim3(128), sizeof(c64) * (size_t)P * NL, ctx->stream, H, n_re, Nr, P, W,
+                     nvar, out);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+extern "C" int isac_csi_report_dev(isac_ctx* ctx, const isac_c64* d_H, int64_t n_re, int32_t Nr, int32_t P, const int32_t* re_k,
+                                   const int32_t* re_l, int32_t n_size_bwp, int32_t n_start_bwp, int32_t subband_size, int32_t pmi_subband,
+                                   int32_t cqi_subband, const isac_c64* W, int32_t n_layers, const int32_t dims[4], double nvar,
+                                   const double* sinr_table_db, int32_t n_table, isac_csi_report* out, double* total_sinr_out,
+                                   double* d_sinr_per_re_out) {
+  ISAC_ENTER(ctx);
+  if (!out) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  std::memset(out, 0, sizeof(*out));
+  if (!W || !dims || n_re < 0 || Nr <= 0 || Nr > kMaxRx || P <= 0 || n_layers < 1 || n_layers > 4 || !(nvar > 0) || n_size_bwp <= 0 || subband_size <= 0 ||
+      (n_re > 0 && (!d_H || !re_k || !re_l)))
+    return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments (1 <= layers <= 4, nVar > 0)");
+  const Subbands pmi_sb = subband_info(pmi_subband != 0, n_start_bwp, n_size_bwp, subband_size);
+  const Subbands cqi_sb = subband_info(cqi_subband != 0, n_start_bwp, n_size_bwp, subband_size);
+  if (pmi_sb.n > ISAC_MAX_SUBBANDS || cqi_sb.n > ISAC_MAX_SUBBANDS) return fail(ctx, ISAC_ERR_CAPACITY, "more subbands than ISAC_MAX_SUBBANDS");
+  out->n_subbands_pmi = pmi_sb.n;
+  out->n_subbands_cqi = cqi_sb.n;
+  const int nE = dims[0] * dims[1] * dims[2] * dims[3];
+  const int NL = n_layers;
+  for (double& v : out->i1) v = NAN;
+  for (int s = 0; s < pmi_sb.n; ++s) out->i2[s] = NAN;
+  const int n_out = (cqi_subband && cqi_sb.n > 1) || pmi_sb.n > 1 ? (cqi_subband ? cqi_sb.n + 1 : 1) : 1;
+  auto all_nan_report = [&]() {                                           // cqiSelect.m:633-647
+    const int n = cqi_sb.n == 1 ? 0 : cqi_sb.n;
+    out->n_cqi = n + 1;
+    for (int i = 0; i <= n; ++i) out->cqi[i] = out->subband_cqi[i] = out->sinr_per_subband_cw[i] = NAN;
+    return ISAC_OK;
+  };
+  (void)n_out;
+  if (n_re == 0 || nE == 0) return all_nan_report();                      // no CSI-RS in the BWP: dlPMISelect.m:364-376
+  // ---- subband membership of every RE (host, integer)
+  auto membership = [&](const Subbands& sb, std::vector<int>& dst) {
+    std::vector<int> rb2sb((size_t)n_size_bwp);
+    int rb = 0;
+    for (int s = 0; s < sb.n; ++s) for (int i = 0; i < sb.size[(size_t)s] && rb < n_size_bwp; ++i) rb2sb[(size_t)rb++] = s;
+    dst.resize((size_t)n_re);
+    for (long long i = 0; i < n_re; ++i) {
+      const int r = re_k[i] / 12;
+      dst[(size_t)i] = (re_k[i] >= 0 && r < n_size_bwp) ? rb2sb[(size_t)r] : -1;
+    }
+  };
+  std::vector<int> sb_pmi, sb_cqi, sym((size_t)n_re);
+  membership(pmi_sb, sb_pmi);
+  membership(cqi_sb, sb_cqi);
+  for (long long i = 0; i < n_re; ++i) sym[(size_t)i] = re_l[i];
+  // ---- device buffers: W | sinr | int tables | total | sb_sinr (pmi) | sb_sinr (cqi)
+  const size_t w_bytes = sizeof(c64) * (size_t)P * NL * nE, sinr_elems = (size_t)n_re * NL * nE;
+  ISAC_TRY(ensure(ctx, ctx->stage_c, w_bytes + 64));
+  double* d_sinr = d_sinr_per_re_out;
+  if (!d_sinr) { ISAC_TRY(ensure(ctx, ctx->stage_a, sizeof(double) * sinr_elems)); d_sinr = (double*)ctx->stage_a.p; }
+  const size_t n_sbp = (size_t)pmi_sb.n * NL * nE, n_sbc = (size_t)cqi_sb.n * NL * nE;
+  const size_t ints = sizeof(int) * (size_t)n_re * 3;
+  const size_t off_tot = (ints + 63) & ~(size_t)63, off_p = off_tot + sizeof(double) * (size_t)nE, off_c = off_p + sizeof(double) * n_sbp;
+  ISAC_TRY(ensure(ctx, ctx->stage_b, off_c + sizeof(double) * n_sbc + 64));
+  char* base = (char*)ctx->stage_b.p;
+  int* d_sbp = (int*)base; int* d_sbc = d_sbp + n_re; int* d_sym = d_sbc + n_re;
+  ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, W, w_bytes, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_HIP(hipMemcpyAsync(d_sbp, sb_pmi.data(), sizeof(int) * (size_t)n_re, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_HIP(hipMemcpyAsync(d_sbc, sb_cqi.data(), sizeof(int) * (size_t)n_re, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_HIP(hipMemcpyAsync(d_sym, sym.data(), sizeof(int) * (size_t)n_re, hipMemcpyHostToDevice, ctx->stream));
+  const c64* dW = (const c64*)ctx->stage_c.p;
+  switch (NL) {
+    case 1: ISAC_TRY(launch_pmi_sinr<1>(ctx, (const c64*)d_H, n_re, Nr, P, dW, nE, nvar, d_sinr)); break;
+    case 2: ISAC_TRY(launch_pmi_sinr<2>(ctx, (const c64*)d_H, n_re, Nr, P, dW, nE, nvar, d_sinr)); break;
+    case 3: ISAC_TRY(launch_pmi_sinr<3>(ctx, (const c64*)d_H, n_re, Nr, P, dW, nE, nvar, d_sinr)); break;
+    default: ISAC_TRY(launch_pmi_sinr<4>(ctx, (const c64*)d_H, n_re, Nr, P, dW, nE, nvar, d_sinr)); break;
+  }
+  double* d_tot = (double*)(base + off_tot);
+  double* d_p = (double*)(base + off_p);
+  double* d_c = (double*)(base + off_c);
+  hipLaunchKernelGGL(pmi_reduce_kernel, dim3(cdiv((long long)nE + (long long)n_sbp, 128)), dim3(128), 0, ctx->stream, (const double*)d_sinr, (long long)n_re,
+                     NL, nE, (const int*)d_sbp, (const int*)d_sym, pmi_sb.n, d_tot, d_p);
+  hipLaunchKernelGGL(pmi_reduce_kernel, dim3(cdiv((long long)nE + (long long)n_sbc, 128)), dim3(128), 0, ctx->stream, (const double*)d_sinr, (long long)n_re,
+                     NL, nE, (const int*)d_sbc, (const int*)d_sym, cqi_sb.n, (double*)nullptr, d_c);
+  ISAC_HIP(hipGetLastError());
+  std::vector<double> tot((size_t)nE), sp(n_sbp), sc(n_sbc);
+  ISAC_HIP(hipMemcpyAsync(tot.data(), d_tot, sizeof(double) * tot.size(), hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipMemcpyAsync(sp.data(), d_p, sizeof(double) * sp.size(), hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipMemcpyAsync(sc.data(), d_c, sizeof(double) * sc.size(), hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  if (total_sinr_out) std::memcpy(total_sinr_out, tot.data(), sizeof(double) * tot.size());
+  // "all(isnan(SINRPerRE))": every entry restricted (dlPMISelect.m:436-444) -- a subband mean is NaN for every entry then
+  bool any_valid = false;
+  for (double v : sp) any_valid |= !std::isnan(v);
+  if (!any_valid) return all_nan_report();
+  // ---- wideband PMI: first maximiser of the rounded totals in column-major (i2, i11, i12, i13) order   dlPMISelect.m:446-456
+  int best = 0;
+  double bv = round4(tot[0]);
+  for (int e = 1; e < nE; ++e) { const double v = round4(tot[(size_t)e]); if (v > bv) { bv = v; best = e; } }
+  const int i2w = best % dims[0], i1flat = best / dims[0];
+  const int i11 = i1flat % dims[1], i12 = (i1flat / dims[1]) % dims[2], i13 = i1flat / (dims[1] * dims[2]);
+  out->i1[0] = i11 + 1; out->i1[1] = i12 + 1; out->i1[2] = i13 + 1;
+  (void)i2w;
+  auto sbv = [&](const std::vector<double>& a, int n_sb, int s, int l, int i2) { return a[(size_t)s + (size_t)n_sb * ((size_t)l + (size_t)NL * ((size_t)i2 + (size_t)dims[0] * i1flat))]; };
+  for (int s = 0; s < pmi_sb.n; ++s) {                                   // per-subband i2   dlPMISelect.m:465-498
+    bool present = false;
+    for (int e = 0; e < nE && !present; ++e) for (int l = 0; l < NL; ++l) present |= !std::isnan(sp[(size_t)s + (size_t)pmi_sb.n * ((size_t)l + (size_t)NL * e)]);
+    if (!present) { out->i2[s] = NAN; continue; }
+    int bi = 0;
+    double bs = -INFINITY;
+    for (int i2 = 0; i2 < dims[0]; ++i2) {
+      double sum = 0.0;
+      for (int l = 0; l < NL; ++l) { const double v = sbv(sp, pmi_sb.n, s, l, i2); if (!std::isnan(v)) sum += v; }
+      sum = round4(sum);
+      if (sum > bs) { bs = sum; bi = i2; }
+    }
+    out->i2[s] = bi + 1;
+  }
+  // ---- SINR per CQI subband for the selected PMI, one codeword (<= 4 layers)   cqiSelect.m:578-630
+  std::vector<double> cw((size_t)cqi_sb.n, NAN);
+  for (int s = 0; s < cqi_sb.n; ++s) {
+    double i2sel;
+    if (pmi_sb.n == 1) i2sel = out->i2[0];                               // wideband PMI: the same i2 in every CQI subband
+    else i2sel = out->i2[s];                                             // PMI and CQI subbands share SubbandSize (getDownlinkCSISubbandInfo)
+    if (std::isnan(i2sel)) continue;
+    double sum = 0.0;
+    bool nan = false;
+    for (int l = 0; l < NL; ++l) {
+      const double v = (pmi_sb.n == 1 && cqi_sb.n > 1) || pmi_sb.n == cqi_sb.n ? sbv(sc, cqi_sb.n, s, l, (int)i2sel - 1) : NAN;
+      nan |= std::isnan(v);
+      sum += v;
+    }
+    cw[(size_t)s] = nan ? NAN : sum;
+  }
+  if (pmi_sb.n > 1 && cqi_sb.n == 1) {                                   // PMI 'Subband' + CQI 'Wideband': SINRperSubband has one row per PMI subband (:589-606)
+    cw.assign((size_t)pmi_sb.n, NAN);
+    for (int s = 0; s < pmi_sb.n; ++s) {
+      if (std::isnan(out->i2[s])) continue;
+      double sum = 0.0;
+      bool nan = false;
+      for (int l = 0; l < NL; ++l) { const double v = sbv(sp, pmi_sb.n, s, l, (int)out->i2[s] - 1); nan |= std::isnan(v); sum += v; }
+      cw[(size_t)s] = nan ? NAN : sum;
+    }
+  }
+  std::vector<double> sinr_cw;
+  if (cw.size() > 1) {                                                   // wideband value = mean of the subband values, NaN omitted (:628-630)
+    double s_ = 0.0; int n = 0;
+    for (double v : cw) if (!std::isnan(v)) { s_ += v; ++n; }
+    sinr_cw.push_back(n ? s_ / n : NAN);
+  }
+  sinr_cw.insert(sinr_cw.end(), cw.begin(), cw.end());
+  std::vector<double> cqi_all(sinr_cw.size());
+  for (size_t i = 0; i < sinr_cw.size(); ++i) cqi_all[i] = get_cqi(sinr_cw[i], sinr_table_db, n_table);      // :650
+  if (cqi_subband) {                                                     // differential values   :654-676
+    out->n_cqi = (int)cqi_all.size();
+    out->cqi[0] = cqi_all[0];
+    for (size_t i = 1; i < cqi_all.size(); ++i) {
+      const double d = cqi_all[i] - cqi_all[0];
+      out->cqi[i] = std::isnan(d) ? NAN : (d == 0 ? 0.0 : d == 1 ? 1.0 : d >= 2 ? 2.0 : 3.0);
+    }
+    for (size_t i = 0; i < cqi_all.size(); ++i) { out->subband_cqi[i] = cqi_all[i]; out->sinr_per_subband_cw[i] = sinr_cw[i]; }
+  } else {
+    out->n_cqi = 1;
+    out->cqi[0] = out->subband_cqi[0] = cqi_all[0];
+    out->sinr_per_subband_cw[0] = sinr_cw[0];
   }
   return ISAC_OK;
 }

@@ -367,11 +367,20 @@ __global__ __launch_bounds__(256, ISAC_ECHO_RANGE_WGS) void echo_range_kernel(in
       tid);
 }
 
-// ---------------------------------------------------------------- plain CP-OFDM modulator (no windowing)
+// ---------------------------------------------------------------- CP-OFDM modulator
+// Placement of one call's L symbols inside larger arrays (senTx accumulation, gNBPhy.m:604-612): the grid may be a column
+// range [l_off, l_off + L) of planes with `grid_cols` columns, the waveform a sample range starting at t_off of columns with
+// `wave_rows` samples; `sym0` is the index of the call's first symbol inside its subframe (CP pattern, carrier.NSlot).
+struct ModIo {
+  long long wave_rows, t_off;
+  int grid_cols, l_off, sym0, n_win;
+};
+
 template <class FFT>
-__global__ __launch_bounds__(256, 2) void mod_kernel(OfdmGeom g, long long T, int A, int L, const c64* __restrict__ tw,
+__global__ __launch_bounds__(256, 2) void mod_kernel(OfdmGeom g, ModIo io, int A, int L, const c64* __restrict__ tw,
                                                      const c64* __restrict__ grid, double scale /* amplitude / nfft */,
-                                                     c64* __restrict__ wave) {
+                                                     c64* __restrict__ wave, c64* __restrict__ head /* [n_win x L x A] or null */,
+                                                     const double* __restrict__ rise /* [n_win] */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);
   const int tid = threadIdx.x;
@@ -379,9 +388,10 @@ __global__ __launch_bounds__(256, 2) void mod_kernel(OfdmGeom g, long long T, in
   {
     const int col = blockIdx.x;                    // one (symbol, antenna) column per workgroup
     const int l = col % L, a = col / L;
-    const int cp = cp_of_symbol(l, g.cp_base, g.cp_long, g.sym_per_half);
-    const long long s0 = symbol_start(l, g.nfft, g.cp_base, g.cp_long, g.sym_per_half);
-    const c64* src = grid + (long long)g.n_sc * ((long long)l + (long long)L * a);
+    const int cp = cp_of_symbol(io.sym0 + l, g.cp_base, g.cp_long, g.sym_per_half);
+    const long long s0 = symbol_start(io.sym0 + l, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) -
+                         symbol_start(io.sym0, g.nfft, g.cp_base, g.cp_long, g.sym_per_half);
+    const c64* src = grid + (long long)g.n_sc * ((long long)(io.l_off + l) + (long long)io.grid_cols * a);
     const int half = g.n_sc / 2;
     fft.fill(
         [&](int n) {
@@ -394,15 +404,42 @@ __global__ __launch_bounds__(256, 2) void mod_kernel(OfdmGeom g, long long T, in
         tid);
     fft.init(lds, tw, tid);
     fft.template transform<+1>(lds, tw, tid);
-    c64* dst = wave + s0 + T * (long long)a;
+    c64* dst = wave + io.t_off + s0 + io.wave_rows * (long long)a;
+    c64* hd = head ? head + (long long)io.n_win * ((long long)l + (long long)L * a) : nullptr;
+    const int h0 = g.nfft - cp - io.n_win;          // the n_win samples in front of the CP (cyclic extension), tapered by the rising edge
     fft.drain(
         [&](int m, c64 v) {
           v = v * scale;
           dst[cp + m] = v;
           if (m >= g.nfft - cp) dst[m - (g.nfft - cp)] = v;
+          if (hd && m >= h0 && m < h0 + io.n_win) hd[m - h0] = v * rise[m - h0];
         },
         tid);
   }
+}
+
+// nrOFDMModulate-style windowing, second half: the last n_win samples of symbol l become  fall * own + rise * head(l + 1),
+// the last symbol of the call taking the first symbol's head (the waveform of one call loops seamlessly).
+__global__ __launch_bounds__(256) void mod_window_kernel(OfdmGeom g, ModIo io, int A, int L, const c64* __restrict__ head,
+                                                         const double* __restrict__ rise, c64* __restrict__ wave) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)io.n_win * L * A;
+  if (i >= n) return;
+  const int w = (int)(i % io.n_win), l = (int)((i / io.n_win) % L), a = (int)(i / ((long long)io.n_win * L));
+  const long long e = symbol_start(io.sym0 + l + 1, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) -
+                      symbol_start(io.sym0, g.nfft, g.cp_base, g.cp_long, g.sym_per_half);          // end of symbol l
+  c64* p = wave + io.t_off + io.wave_rows * (long long)a + e - io.n_win + w;
+  const c64 hv = head[(long long)io.n_win * ((long long)((l + 1) % L) + (long long)L * a) + w];     // already x rise
+  *p = *p * rise[io.n_win - 1 - w] + hv;                                                            // fall(w) = rise(n_win - 1 - w)
+}
+
+__global__ __launch_bounds__(256) void copy_slot_kernel(const c64* __restrict__ src /* [K x L x A] */, c64* __restrict__ dst, int K, int L, int A,
+                                                        int grid_cols, int l_off) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)K * L * A;
+  if (i >= n) return;
+  const long long k = i % K, l = (i / K) % L, a = i / ((long long)K * L);
+  dst[k + (long long)K * ((l_off + l) + (long long)grid_cols * a)] = src ? src[i] : mk(0.0, 0.0);
 }
 
 // ---------------------------------------------------------------- synthetic QPSK grid
@@ -795,30 +832,84 @@ extern "C" int isac_ofdm_demodulate_dev(isac_ctx* ctx, const isac_c64* d_wave, i
   return ISAC_OK;
 }
 
+int isac_get_rise_window(isac_ctx* ctx, int n_win, const double** out);   // capi.hip
+
 template <class FFT>
-static int launch_mod(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, int L, const c64* tw, const c64* grid,
-                      double scale, c64* wave) {
+static int launch_mod(isac_ctx* ctx, const OfdmGeom& g, const ModIo& io, int A, int L, const c64* tw, const c64* grid,
+                      double scale, c64* wave, c64* head, const double* rise) {
   size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
   auto kern = mod_kernel<FFT>;
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
-  hipLaunchKernelGGL(kern, dim3(fft_grid(L * A)), dim3(256), lds, ctx->stream, g, T, A, L, tw, grid, scale, wave);
+  hipLaunchKernelGGL(kern, dim3(fft_grid(L * A)), dim3(256), lds, ctx->stream, g, io, A, L, tw, grid, scale, wave, head, rise);
   ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+// modulate L symbols (first symbol `sym0` of its subframe) of grid columns [l_off, l_off + L) into wave rows [t_off, ...)
+static int modulate_into(isac_ctx* ctx, const isac_carrier* carrier, const c64* d_grid, int grid_cols, int l_off, int L, int A, int sym0,
+                         double amplitude, int n_win, c64* d_wave, long long wave_rows, long long t_off) {
+  OfdmGeom g = geom_of(carrier);
+  if (n_win < 0 || n_win > g.cp_base) return fail(ctx, ISAC_ERR_INVALID_ARG, "windowing must lie in 0..(short cyclic prefix length)");
+  const c64* tw = nullptr;
+  ISAC_TRY(isac_get_twiddles(ctx, g.nfft, &tw));
+  ModIo io{wave_rows, t_off, grid_cols, l_off, sym0, n_win};
+  c64* head = nullptr;
+  const double* rise = nullptr;
+  if (n_win > 0) {
+    ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)n_win * L * A));
+    head = (c64*)ctx->stage_c.p;
+    ISAC_TRY(isac_get_rise_window(ctx, n_win, &rise));
+  }
+  ISAC_FFT_DISPATCH(g.nfft, ISAC_TRY((launch_mod<FFT>(ctx, g, io, A, L, tw, d_grid, amplitude / g.nfft, d_wave, head, rise))));
+  if (n_win > 0) {
+    hipLaunchKernelGGL(mod_window_kernel, dim3(cdiv((long long)n_win * L * A, 256)), dim3(256), 0, ctx->stream, g, io, A, L, (const c64*)head, rise, d_wave);
+    ISAC_HIP(hipGetLastError());
+  }
   return ISAC_OK;
 }
 
 extern "C" int isac_ofdm_modulate_dev(isac_ctx* ctx, const isac_c64* d_grid, int32_t L, int32_t A,
                                       const isac_carrier* carrier, double amplitude, isac_c64* d_wave, int64_t T) {
+  return isac_ofdm_modulate_windowed_dev(ctx, d_grid, L, A, carrier, amplitude, 0, 0, d_wave, T);
+}
+
+extern "C" int isac_ofdm_modulate_windowed_dev(isac_ctx* ctx, const isac_c64* d_grid, int32_t L, int32_t A, const isac_carrier* carrier,
+                                               double amplitude, int32_t n_slot, int32_t windowing, isac_c64* d_wave, int64_t T) {
   ISAC_ENTER(ctx);
   ISAC_TRY(check_carrier(ctx, carrier));
-  if (!d_wave || !d_grid || A <= 0 || L <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  if (!d_wave || !d_grid || A <= 0 || L <= 0 || n_slot < 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   OfdmGeom g = geom_of(carrier);
-  long long need = symbol_start(L, g.nfft, g.cp_base, g.cp_long, g.sym_per_half);
+  const int sym0 = (n_slot % (carrier->scs_khz / 15)) * 14;           // first symbol of the slot inside its subframe (carrier.NSlot)
+  const long long need = symbol_start(sym0 + L, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) - symbol_start(sym0, g.nfft, g.cp_base, g.cp_long, g.sym_per_half);
   if (T < need) return fail(ctx, ISAC_ERR_CAPACITY, "waveform buffer shorter than L symbols");
   if (T > need) ISAC_HIP(hipMemsetAsync(d_wave, 0, sizeof(c64) * (size_t)T * A, ctx->stream));
-  const c64* tw = nullptr;
-  ISAC_TRY(isac_get_twiddles(ctx, g.nfft, &tw));
-  ISAC_FFT_DISPATCH(g.nfft, ISAC_TRY((launch_mod<FFT>(ctx, g, T, A, L, tw, (const c64*)d_grid, amplitude / g.nfft,
-                                                      (c64*)d_wave))));
+  return modulate_into(ctx, carrier, (const c64*)d_grid, L, 0, L, A, sym0, amplitude, windowing, (c64*)d_wave, T, 0);
+}
+
+// gNBPhy.phyTx's senTxGrid / senTxWave accumulation (gNBPhy.m:591-612) for one slot that carried PDSCH.
+extern "C" int isac_sentx_append_dev(isac_ctx* ctx, const isac_carrier* carrier, int32_t A, int32_t curr_slot, int32_t is_dl_slot,
+                                     const isac_c64* d_slot_grid, double signal_amp, int32_t windowing, isac_c64* d_sen_grid,
+                                     int32_t grid_cols, int32_t l_off, isac_c64* d_sen_wave, int64_t wave_rows, int64_t t_off,
+                                     int64_t* t_len) {
+  ISAC_ENTER(ctx);
+  ISAC_TRY(check_carrier(ctx, carrier));
+  if (!d_sen_grid || !d_sen_wave || A <= 0 || curr_slot < 0 || l_off < 0 || t_off < 0 || (is_dl_slot && !d_slot_grid))
+    return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  OfdmGeom g = geom_of(carrier);
+  const int L = 14;
+  const int sym0 = (curr_slot % (carrier->scs_khz / 15)) * L;
+  const long long need = symbol_start(sym0 + L, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) - symbol_start(sym0, g.nfft, g.cp_base, g.cp_long, g.sym_per_half);
+  if (t_len) *t_len = need;
+  if (l_off + L > grid_cols || t_off + need > wave_rows) return fail(ctx, ISAC_ERR_CAPACITY, "senTxGrid / senTxWave capacity exceeded");
+  ctx->range_cache.valid = false;
+  const long long n = (long long)g.n_sc * L * A;
+  // 'D' slot: the slot's grid (unscaled) and its waveform x signalAmp (:605-608); any other slot type: zeros of the same size (:609-612)
+  hipLaunchKernelGGL(copy_slot_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, is_dl_slot ? (const c64*)d_slot_grid : nullptr,
+                     (c64*)d_sen_grid, g.n_sc, L, A, grid_cols, l_off);
+  ISAC_HIP(hipGetLastError());
+  if (is_dl_slot)
+    return modulate_into(ctx, carrier, (const c64*)d_slot_grid, L, 0, L, A, sym0, signal_amp, windowing, (c64*)d_sen_wave, wave_rows, t_off);
+  ISAC_HIP(hipMemset2DAsync((c64*)d_sen_wave + t_off, sizeof(c64) * (size_t)wave_rows, 0, sizeof(c64) * (size_t)need, (size_t)A, ctx->stream));
   return ISAC_OK;
 }
 

@@ -66,6 +66,7 @@ int isac_dev_alloc(isac_ctx* ctx, size_t bytes, void** dptr);
 int isac_dev_free(isac_ctx* ctx, void* dptr);
 int isac_memcpy_h2d(isac_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int isac_memcpy_d2h(isac_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int isac_memcpy_d2d(isac_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);   /* asynchronous on the context stream */
 int isac_memset_dev(isac_ctx* ctx, void* dst_dev, int value, size_t bytes);
 
 /* GPU timing of the context's stream with HIP events (bench.py roofline leg). */
@@ -198,6 +199,24 @@ int isac_ofdm_demodulate_dev(isac_ctx* ctx, const isac_c64* d_wave, int64_t T, i
 int isac_ofdm_modulate_dev(isac_ctx* ctx, const isac_c64* d_grid, int32_t L, int32_t A,
                            const isac_carrier* carrier, double amplitude, isac_c64* d_wave, int64_t T);
 int isac_ofdm_waveform_length(const isac_carrier* carrier, int32_t L, int64_t* T);
+/* nrOFDMModulate(carrier, grid) with carrier.NSlot = n_slot (CP pattern of the slot inside its subframe) and the toolbox's
+ * raised-cosine windowing / overlap over `windowing` samples (pass nrOFDMInfo(carrier).Windowing; 0 = none): every symbol is
+ * cyclically extended by `windowing` samples in front of its CP, tapered, overlap-added with its neighbour; the head of the
+ * call's first symbol wraps onto the tail of its last (gNBPhy.m:599,615 call it once per slot).  T >= the call's sample count. */
+int isac_ofdm_modulate_windowed_dev(isac_ctx* ctx, const isac_c64* d_grid, int32_t L, int32_t A,
+                                    const isac_carrier* carrier, double amplitude, int32_t n_slot, int32_t windowing,
+                                    isac_c64* d_wave, int64_t T);
+
+/* Device-resident senTxGrid / senTxWave accumulation of gNBPhy.phyTx (+communication/+phyLayer/gNBPhy.m:591-612), one call per
+ * slot that carried PDSCH: the slot grid d_slot_grid [n_sc x 14 x A] is OFDM-modulated (:599) and scaled by signal_amp
+ * (:592,:602); in a 'D' slot of the TDD pattern (determineSlotType.m:5; is_dl_slot != 0) the UNSCALED grid goes to columns
+ * [l_off, l_off+14) of senTxGrid [n_sc x grid_cols x A] and the scaled waveform to rows [t_off, t_off + *t_len) of senTxWave
+ * [wave_rows x A] (:605-608); any other slot type stores zeros of the same size (:609-612).  Slots without PDSCH are not
+ * appended at all (the caller simply does not call).  Removes the 1 GB-per-CPI host round trip of the two accumulators. */
+int isac_sentx_append_dev(isac_ctx* ctx, const isac_carrier* carrier, int32_t A, int32_t curr_slot, int32_t is_dl_slot,
+                          const isac_c64* d_slot_grid, double signal_amp, int32_t windowing, isac_c64* d_sen_grid,
+                          int32_t grid_cols, int32_t l_off, isac_c64* d_sen_wave, int64_t wave_rows, int64_t t_off,
+                          int64_t* t_len);
 
 /* phased.CFARDetector2D step (fft2D.m:62) on an arbitrary power map and CUT list.
  * P [n_rows x n_cols] column-major, cut_idx [2 x n_cut] 1-based; det_idx [2 x cap]. */
@@ -309,6 +328,37 @@ int isac_cdl_apply_dev(isac_ctx* ctx, const isac_c64* d_x, int64_t T, int32_t Nt
 int isac_precoded_sinr_cqi_dev(isac_ctx* ctx, const isac_c64* d_H, int64_t n_re, int32_t Nr, int32_t P,
                                const isac_c64* W, int32_t n_layers, double sigma, const double* sinr_table_db,
                                int32_t n_table, double* d_sinr_per_re, double* mean_sinr, int32_t* cqi);
+
+/* Type-I single-panel codebook of TS 38.214 5.2.2.2.1 as dlPMISelect.m:853-1083 builds it (getPMIType1SinglePanelCodebook; ranks 1-2,
+ * codebook modes 1 / 2, 2 ports or 2 N1 N2 ports, no subset restriction): W [P x n_layers x nE] column-major, entries in MATLAB's index
+ * order (i2 fastest, then i11, i12, i13); dims = {i2Length, i11Length, i12Length, i13Length}.  W == NULL: size query.  Host-side scalar prep. */
+int isac_type1sp_codebook(int32_t n_ports, int32_t n1, int32_t n2, int32_t codebook_mode, int32_t n_layers, isac_c64* W,
+                          int64_t cap_elems, int32_t dims[4]);
+
+/* CSI report of uePhy.m:901-908: communication.phyLayer.cqiSelect(carrier, csirs, reportConfig, nLayers, H, nVar, SINRTable)
+ * (+communication/+phyLayer/cqiSelect.m:500-687, CSI-RS-object syntax without PRGSize) around dlPMISelect's exhaustive Type-I search
+ * (dlPMISelect.m:385-500): LMMSE SINR of every CSI-RS resource element for every codebook entry (one GPU thread each,
+ * dlPMISelect.m:1825-1834), totals rounded to four decimals and the first maximiser in index order -> i1 (:446-456), per-subband means
+ * -> i2 per subband (:465-498), SINR of the selected entries -> wideband + subband CQI through getCQI (cqiSelect.m:697-722) and the
+ * differential encoding of TS 38.214 Table 5.2.2.1-1 (:654-676).
+ * d_H [n_re x Nr x P] device (RE fastest): the channel estimate at the first CSI-RS port's REs; re_k / re_l (host): 0-based subcarrier
+ * (relative to the BWP) and symbol of each RE; pmi_subband / cqi_subband: 1 = 'Subband', 0 = 'Wideband' (a BWP below 24 PRBs is wideband
+ * either way); W / dims from isac_type1sp_codebook (any codebook in that layout works).  Values are doubles because the reference reports
+ * NaN where no CSI-RS is present. */
+#define ISAC_MAX_SUBBANDS 70
+typedef struct {
+  int32_t n_subbands_pmi, n_subbands_cqi, n_cqi, reserved;
+  double i1[3];                                   /* PMISet.i1 = [i11 i12 i13], 1-based                                   */
+  double i2[ISAC_MAX_SUBBANDS];                   /* PMISet.i2 per PMI subband, 1-based                                   */
+  double cqi[ISAC_MAX_SUBBANDS + 1];              /* CQI: wideband index, then the subband differential values (Subband)  */
+  double subband_cqi[ISAC_MAX_SUBBANDS + 1];      /* CQIInfo.SubbandCQI: absolute indices                                 */
+  double sinr_per_subband_cw[ISAC_MAX_SUBBANDS + 1]; /* CQIInfo.SINRPerSubbandPerCW (linear)                              */
+} isac_csi_report;
+int isac_csi_report_dev(isac_ctx* ctx, const isac_c64* d_H, int64_t n_re, int32_t Nr, int32_t P, const int32_t* re_k,
+                        const int32_t* re_l, int32_t n_size_bwp, int32_t n_start_bwp, int32_t subband_size, int32_t pmi_subband,
+                        int32_t cqi_subband, const isac_c64* W, int32_t n_layers, const int32_t dims[4], double nvar,
+                        const double* sinr_table_db, int32_t n_table, isac_csi_report* out, double* total_sinr_out,
+                        double* d_sinr_per_re_out);
 
 /* ------------------------------------------------------------------ line-of-sight blockage
  * Batched openStreetMapCity.checkLoS (+networkTopology/+blockages/openStreetMapCity.m:67-93): for every link

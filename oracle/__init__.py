@@ -25,10 +25,10 @@ from .matlab_compat import (  # noqa: F401
     LIGHTSPEED, BOLTZMANN, EPS,
 )
 from .radar_params import radar_params, default_cell_params, nr_ofdm_info  # noqa: F401
-from .ofdm import ofdm_modulate, ofdm_demodulate, cp_lengths, symbol_starts  # noqa: F401
+from .ofdm import ofdm_modulate, ofdm_demodulate, cp_lengths, symbol_starts, raised_cosine_edge  # noqa: F401
 from .radar_channel import basic_radar_channel, mono_static_sensing  # noqa: F401
 from .cfar import cfar2d_config, ca_cfar2d, cfar_threshold_factor  # noqa: F401
 from .fft2d import fft2d, rdm_literal, rdm_explicit, covariance  # noqa: F401
 from .music import music_doa, determine_num_targets, music2d, digital_bf, mvdr_bf  # noqa: F401
 from .philox import philox4x32_10, philox_normal_pairs, philox_spectral_noise  # noqa: F401
-from . import cdl, cqi  # noqa: F401
+from . import cdl, cqi, sentx  # noqa: F401

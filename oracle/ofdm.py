@@ -32,18 +32,33 @@ def cp_lengths(nfft: int, scs_khz: float, n_symbols: int, first_symbol: int = 0)
     return np.where(long_cp, base + extra, base).astype(np.int64)
 
 
-def symbol_starts(nfft: int, scs_khz: float, n_symbols: int) -> tuple[np.ndarray, np.ndarray]:
-    """(start sample of each symbol's CP, CP length)."""
-    cps = cp_lengths(nfft, scs_khz, n_symbols)
+def symbol_starts(nfft: int, scs_khz: float, n_symbols: int, first_symbol: int = 0) -> tuple[np.ndarray, np.ndarray]:
+    """(start sample of each symbol's CP, CP length); ``first_symbol``: index of the first symbol inside its subframe
+    (carrier.NSlot * 14 for a slot grid, gNBPhy.m:579)."""
+    cps = cp_lengths(nfft, scs_khz, n_symbols, first_symbol)
     lens = cps + nfft
     starts = np.concatenate([[0], np.cumsum(lens)[:-1]])
     return starts.astype(np.int64), cps
 
 
-def ofdm_modulate(grid: np.ndarray, nfft: int, scs_khz: float) -> np.ndarray:
-    """grid [K x L x A] -> waveform [T x A]; plain CP-OFDM, ifft (1/Nfft) scaling."""
+def raised_cosine_edge(n_w: int) -> np.ndarray:
+    """Rising edge of the OFDM symbol window, LTE/5G Toolbox form (lteOFDMModulate / nrOFDMModulate documentation):
+    w(i) = 0.5 (1 - sin(pi (N_W + 1 - 2 i) / (2 N_W))), i = 1..N_W; the falling edge is its mirror, rise + fall = 1."""
+    i = np.arange(1, n_w + 1, dtype=np.float64)
+    return 0.5 * (1.0 - np.sin(np.pi * (n_w + 1 - 2.0 * i) / (2.0 * n_w)))
+
+
+def ofdm_modulate(grid: np.ndarray, nfft: int, scs_khz: float, windowing: int = 0, first_symbol: int = 0) -> np.ndarray:
+    """grid [K x L x A] -> waveform [T x A]; CP-OFDM, ifft (1/Nfft) scaling.
+
+    ``windowing`` = N_W > 0 restates nrOFDMModulate's raised-cosine windowing and overlap (toolbox behaviour from its public
+    documentation -- UNVERIFIABLE here): every symbol is cyclically extended by N_W samples in front of its CP, the first
+    and last N_W samples of the extended symbol are tapered by the raised-cosine edge, consecutive symbols overlap-add over
+    N_W samples, and the head of the first symbol wraps onto the tail of the last one (the waveform loops seamlessly).
+    The reference calls nrOFDMModulate with the toolbox default (gNBPhy.m:599); that default value comes from
+    nrOFDMInfo(carrier).Windowing on the MATLAB side and is passed in explicitly here.  0 = no windowing."""
     k, l, a = grid.shape
-    starts, cps = symbol_starts(nfft, scs_khz, l)
+    starts, cps = symbol_starts(nfft, scs_khz, l, first_symbol)
     total = int(starts[-1] + cps[-1] + nfft) if l else 0
     wave = np.zeros((total, a), dtype=np.complex128)
     first = (nfft - k) // 2
@@ -55,6 +70,19 @@ def ofdm_modulate(grid: np.ndarray, nfft: int, scs_khz: float) -> np.ndarray:
         o = int(starts[s])
         wave[o:o + cp] = td[nfft - cp:, s, :]
         wave[o + cp:o + cp + nfft] = td[:, s, :]
+    n_w = int(windowing)
+    if n_w > 0 and l > 0:
+        if n_w > int(cps.min()):
+            raise ValueError("ofdm_modulate: windowing longer than the cyclic prefix")
+        rise = raised_cosine_edge(n_w)[:, None]
+        fall = rise[::-1]
+        for s in range(l):
+            cp = int(cps[s])
+            nxt = (s + 1) % l                                     # the last symbol's tail takes the FIRST symbol's head
+            cpn = int(cps[nxt])
+            e = int(starts[s]) + cp + nfft                        # end of symbol s
+            head = td[nfft - cpn - n_w:nfft - cpn, nxt, :]        # N_W samples in front of the next symbol's CP (cyclic extension)
+            wave[e - n_w:e] = fall * wave[e - n_w:e] + rise * head
     return wave
 
 

@@ -1,0 +1,82 @@
+"""CSI report on the device (isac_csi_report_dev: exhaustive Type-I PMI search + subband SINR -> CQI) against the oracle restatement of
+dlPMISelect.m:385-500 / cqiSelect.m:500-687 (oracle/pmi.py): PMI indices, CQI indices and differential values exact (integers),
+subband SINRs <= 1e-10.  Exact ties after round(., 4) (dlPMISelect.m:449) resolve to the first entry on both sides; a channel whose total
+lands within 1e-10 of a rounding boundary is skipped as rounding-defined, not tolerated."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+import oracle.cqi as OQ
+import oracle.pmi as OP
+from conftest import load_pkg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+def channel(rng, nrb, nr, p, taps=4):
+    """Frequency-selective [K x 14 x nRx x P] channel: a few random taps -> smooth variation over the subcarriers."""
+    k = 12 * nrb
+    g = (rng.standard_normal((taps, nr, p)) + 1j * rng.standard_normal((taps, nr, p))) / np.sqrt(2 * taps)
+    ph = np.exp(-2j * np.pi * np.outer(np.arange(k), rng.uniform(0, 40, taps)) / 4096)
+    h = np.einsum("kt,trp->krp", ph, g)
+    return np.ascontiguousarray(np.broadcast_to(h[:, None], (k, 14, nr, p)))
+
+
+def same(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return a.shape == b.shape and np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)])
+
+
+@pytest.mark.parametrize("nrb,ports,panel,layers,mode,sbsize,pmimode,cqimode,nstart", [
+    (273, 4, (2, 1), 1, 1, 16, "Subband", "Subband", 0),        # the reference's own configuration (setupCSIRS.m:5-23)
+    (273, 4, (2, 1), 2, 1, 32, "Subband", "Subband", 0),
+    (52, 4, (2, 1), 2, 2, 8, "Subband", "Subband", 5),          # unaligned BWP start: short first / last subband
+    (52, 8, (2, 2), 1, 1, 4, "Wideband", "Subband", 0),
+    (52, 8, (4, 1), 2, 1, 8, "Subband", "Wideband", 0),
+    (24, 2, (1, 1), 1, 1, 4, "Wideband", "Wideband", 0),
+    (24, 2, (1, 1), 2, 1, 4, "Subband", "Subband", 0),
+    (20, 16, (4, 2), 2, 1, 4, "Subband", "Subband", 0),         # < 24 PRBs: one subband whatever the mode
+])
+def test_csi_report_matches_oracle(pkg, nrb, ports, panel, layers, mode, sbsize, pmimode, cqimode, nstart):
+    rng = np.random.default_rng(nrb * 7 + ports + layers)
+    carrier = SimpleNamespace(NSizeGrid=nrb, NStartGrid=0, SymbolsPerSlot=14)
+    rep = SimpleNamespace(NSizeBWP=nrb, NStartBWP=nstart, PanelDimensions=panel, CodebookMode=mode, PMIMode=pmimode, CQIMode=cqimode, SubbandSize=sbsize)
+    h = channel(rng, nrb, 2, ports) * 3.0
+    k = np.concatenate([[12 * r + 1, 12 * r + 2] for r in range(nrb)])          # row-5-like: two REs of the first port per RB, symbol 1
+    l = np.ones_like(k)
+    if nrb == 52 and ports == 4:                                                    # CSI-RS absent from the third subband: i2 / CQI NaN there
+        sb = OP.subband_info(pmimode, nstart, nrb, sbsize)
+        lo = sum(sb.SubbandSizes[:2]) * 12
+        keep = (k <= lo) | (k > lo + sb.SubbandSizes[2] * 12)
+        k, l = k[keep], l[keep]
+    nvar = 0.02
+    csirs = SimpleNamespace(k=k, l=l)
+    want_cqi, want_pmi, want_ci, want_pi = OP.cqi_select(rep, layers, h, k, l, nvar, OQ.DOWNLINK_SINR90PC)
+    tot = np.nansum(want_pi.SINRPerRE, axis=(0, 1, 2)).reshape(-1, order="F")
+    got_cqi, got_pmi, got_ci, got_pi = pkg.communication.phyLayer.cqiSelect(carrier, csirs, rep, layers, h, nvar, OQ.DOWNLINK_SINR90PC)
+    got_tot = got_pi.TotalSINR.reshape(-1, order="F")
+    assert np.abs(got_tot - tot).max() <= 1e-10 * np.abs(tot).max()
+    if not np.array_equal(OP.matlab_round4(got_tot), OP.matlab_round4(tot)):      # a total within 1e-10 of a round(., 4) boundary
+        pytest.skip("a total SINR sits on a rounding boundary of round(., 4): the PMI is rounding-defined")
+    assert same(got_pmi.i1, want_pmi.i1) and same(got_pmi.i2, want_pmi.i2), (got_pmi, want_pmi)
+    assert same(got_cqi, want_cqi), (got_cqi, want_cqi)
+    assert same(got_ci.SubbandCQI, want_ci.SubbandCQI)
+    a, b = got_ci.SINRPerSubbandPerCW, want_ci.SINRPerSubbandPerCW
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.abs(a[~np.isnan(a)] - b[~np.isnan(b)]).max() <= 1e-10 * np.nanmax(np.abs(b))
+    assert not np.all(np.isnan(got_cqi)) and got_cqi[0] >= 1
+
+
+def test_csi_report_without_csirs_is_all_nan(pkg):
+    rep = SimpleNamespace(NSizeBWP=52, NStartBWP=0, PanelDimensions=(2, 1), CodebookMode=1, PMIMode="Subband", CQIMode="Subband", SubbandSize=8)
+    carrier = SimpleNamespace(NSizeGrid=52, NStartGrid=0, SymbolsPerSlot=14)
+    h = np.zeros((624, 14, 2, 4), dtype=np.complex128)
+    cqi, pmi, ci, _ = pkg.communication.phyLayer.cqiSelect(carrier, SimpleNamespace(k=np.zeros(0, int), l=np.zeros(0, int)), rep, 1, h, 0.1, OQ.DOWNLINK_SINR90PC)
+    assert cqi.size == 8 and np.all(np.isnan(cqi)) and np.all(np.isnan(pmi.i1)) and np.all(np.isnan(pmi.i2)) and pmi.i2.size == 7
