@@ -16,19 +16,21 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 constexpr int kCdlColTiles = 4;   // 16-column tiles per wave
 
 // X [T x Nt] column-major, Hm [Nt x Nc] column-major (Nc multiple of 16, zero padded), Z [T x Nc] column-major
+// rows [r0, r1) only (one gain block's output samples in the filter-first order); Z = scale * X Hm
 __global__ __launch_bounds__(256, 2) void cdl_contract_kernel(const c64* __restrict__ X, long long T, int Nt,
-                                                              const c64* __restrict__ Hm, int Nc, c64* __restrict__ Z) {
+                                                              const c64* __restrict__ Hm, int Nc, c64* __restrict__ Z,
+                                                              long long r0, long long r1, double scale) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const long long t0 = ((long long)blockIdx.x * 4 + wid) * 16;
-  if (t0 >= T) return;
+  const long long t0 = r0 + ((long long)blockIdx.x * 4 + wid) * 16;
+  if (t0 >= r1) return;
   const int c_base = blockIdx.y * kCdlColTiles * 16;
   v4f64 rr[kCdlColTiles], ii[kCdlColTiles], im[kCdlColTiles];
 #pragma unroll
   for (int u = 0; u < kCdlColTiles; ++u) rr[u] = ii[u] = im[u] = v4f64{0.0, 0.0, 0.0, 0.0};
   long long t = t0 + li;
-  const bool tok = t < T;
-  if (!tok) t = T - 1;
+  const bool tok = t < r1;
+  if (!tok) t = r1 - 1;
   for (int s0 = 0; s0 < Nt; s0 += 4) {
     const int s = s0 + kq;
     const bool sok = s < Nt;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void cdl_contract_kernel(const c64* __restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long long row = t0 + (lane >> 4) + 4 * r;             // f64 MFMA C/D layout
-      if (row < T) Z[row + T * (long long)c] = mk(rr[u][r] - ii[u][r], im[u][r]);
+      if (row < r1) Z[row + T * (long long)c] = mk((rr[u][r] - ii[u][r]) * scale, im[u][r] * scale);
     }
   }
 }
@@ -90,6 +92,28 @@ __global__ __launch_bounds__(256) void cdl_filter_kernel(const c64* __restrict__
   Y[t + T * (long long)u] = acc * scale;
 }
 
+// Filter-first order for Nr > Nt (uplink: 2 UE antennas -> 64 gNB antennas, cdl.m:78-85): the delay filters run on the Nt transmit
+// signals (n_paths * Nt filtered signals instead of n_paths * Nr reduced ones), the antenna contraction follows as a GEMM with
+// K = n_paths * Nt.  XF[t, n*Nt + s] = sum_k g[n][k] x_s[t - shift[n] - k]
+__global__ __launch_bounds__(256) void cdl_prefilter_kernel(const c64* __restrict__ X /* [T x Nt] */, long long T, int Nt, int n_paths, int n_taps,
+                                                            const double* __restrict__ taps, const int* __restrict__ shift,
+                                                            c64* __restrict__ XF /* [T x n_paths*Nt] */) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y, n = c / Nt, s_ = c % Nt;
+  if (t >= T) return;
+  const c64* xc = X + T * (long long)s_;
+  const long long base = t - shift[n];
+  c64 acc = mk(0.0, 0.0);
+  for (int k = 0; k < n_taps; ++k) {
+    const long long idx = base - k;
+    const c64 z = xc[idx >= 0 ? idx : 0];
+    const double g = idx >= 0 ? taps[n * n_taps + k] : 0.0;
+    acc.re = ::fma(g, z.re, acc.re);
+    acc.im = ::fma(g, z.im, acc.im);
+  }
+  XF[t + T * (long long)c] = acc;
+}
+
 }  // namespace isac
 
 using namespace isac;
@@ -101,6 +125,42 @@ extern "C" int isac_cdl_apply_dev(isac_ctx* ctx, const isac_c64* d_x, int64_t T,
   if (!d_x || !d_y || !H || !block_start || !taps || !shift) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
   if (T <= 0 || Nt <= 0 || Nr <= 0 || n_paths <= 0 || n_blocks <= 0 || n_taps <= 0 || n_taps > 64 || n_paths > 64)
     return fail(ctx, ISAC_ERR_INVALID_ARG, "bad dimensions");
+  if (Nr > Nt) {
+    // ---- filter first, contract second (see cdl_prefilter_kernel): Hm_b [Kc x Nrp], row c = n*Nt + s
+    const int Kc = n_paths * Nt, Nrp = (Nr + 15) / 16 * 16;
+    std::vector<c64> hm2((size_t)n_blocks * Kc * Nrp, mk(0.0, 0.0));
+    for (int b = 0; b < n_blocks; ++b)
+      for (int n = 0; n < n_paths; ++n)
+        for (int s = 0; s < Nt; ++s)
+          for (int u = 0; u < Nr; ++u) {
+            const isac_c64 v = H[(((size_t)b * n_paths + n) * Nt + s) * Nr + u];
+            hm2[(size_t)b * Kc * Nrp + (size_t)(n * Nt + s) + (size_t)Kc * u] = mk(v.re, v.im);
+          }
+    const size_t hm_bytes2 = sizeof(c64) * hm2.size(), tap_bytes2 = sizeof(double) * (size_t)n_paths * n_taps;
+    ISAC_TRY(ensure(ctx, ctx->stage_c, hm_bytes2 + tap_bytes2 + sizeof(int) * (size_t)n_paths + 64));
+    ISAC_TRY(ensure(ctx, ctx->stage_b, sizeof(c64) * (size_t)T * Kc));
+    char* dm2 = (char*)ctx->stage_c.p;
+    c64* d_hm2 = (c64*)dm2;
+    double* d_taps2 = (double*)(dm2 + hm_bytes2);
+    int* d_shift2 = (int*)(dm2 + hm_bytes2 + tap_bytes2);
+    ISAC_HIP(hipMemcpyAsync(d_hm2, hm2.data(), hm_bytes2, hipMemcpyHostToDevice, ctx->stream));
+    ISAC_HIP(hipMemcpyAsync(d_taps2, taps, tap_bytes2, hipMemcpyHostToDevice, ctx->stream));
+    ISAC_HIP(hipMemcpyAsync(d_shift2, shift, sizeof(int) * (size_t)n_paths, hipMemcpyHostToDevice, ctx->stream));
+    ISAC_HIP(hipStreamSynchronize(ctx->stream));   // host staging vectors go out of scope
+    c64* d_xf = (c64*)ctx->stage_b.p;
+    hipLaunchKernelGGL(cdl_prefilter_kernel, dim3(cdiv(T, 256), (unsigned)Kc), dim3(256), 0, ctx->stream, (const c64*)d_x, (long long)T, Nt, n_paths,
+                       n_taps, (const double*)d_taps2, (const int*)d_shift2, d_xf);
+    ISAC_HIP(hipGetLastError());
+    const unsigned gy2 = (unsigned)((Nrp / 16 + kCdlColTiles - 1) / kCdlColTiles);
+    for (int b = 0; b < n_blocks; ++b) {            // the gain block of an OUTPUT sample decides its H
+      const long long r0 = b == 0 ? 0 : block_start[b], r1 = b + 1 < n_blocks ? block_start[b + 1] : T;
+      if (r1 <= r0) continue;
+      hipLaunchKernelGGL(cdl_contract_kernel, dim3(cdiv(r1 - r0, 64), gy2), dim3(256), 0, ctx->stream, (const c64*)d_xf, (long long)T, Kc,
+                         (const c64*)(d_hm2 + (size_t)b * Kc * Nrp), Nr, (c64*)d_y, r0, r1, out_scale);
+      ISAC_HIP(hipGetLastError());
+    }
+    return ISAC_OK;
+  }
   const int Nc = n_paths * Nr;
   const int Ncp = (Nc + 15) / 16 * 16;
   // Hm [Nt x Ncp] per block, column c = n*Nr + u  <-  H [b][n][s][u]
@@ -133,7 +193,7 @@ extern "C" int isac_cdl_apply_dev(isac_ctx* ctx, const isac_c64* d_x, int64_t T,
   const unsigned gy = (unsigned)((Ncp / 16 + kCdlColTiles - 1) / kCdlColTiles);
   for (int b = 0; b < n_blocks; ++b) {
     hipLaunchKernelGGL(cdl_contract_kernel, dim3(gx, gy), dim3(256), 0, ctx->stream, (const c64*)d_x, (long long)T, Nt,
-                       (const c64*)(d_hm + (size_t)b * Nt * Ncp), Ncp, d_z + (size_t)b * (size_t)T * Ncp);
+                       (const c64*)(d_hm + (size_t)b * Nt * Ncp), Ncp, d_z + (size_t)b * (size_t)T * Ncp, 0LL, (long long)T, 1.0);
     ISAC_HIP(hipGetLastError());
   }
   const size_t lds = tap_bytes + sizeof(int) * (size_t)n_paths + 16;

@@ -11,9 +11,12 @@ Per cell (simulation/cellSimulation.m order):
   2. line of sight for every UE / target link        networkTopology.blockages.city.checkLoS      (los.hip)
   3. sensing CPI                                      sensing.monoStaticSensing -> estimation.fft2D (echo/rdm/music.hip)
   4. per UE: CDL-D (LoS) or CDL-A (NLoS) downlink channel over one slot   communication.channelModels (cdl.hip)
-  5. per UE: wideband CQI of a 4-port CSI-RS channel estimate             communication.phyLayer    (cqi.hip)
-What is NOT here (out of scope): scheduler, HARQ, LDPC/PDSCH chain, Type-I codebook search; the CSI-RS channel
-estimate is the channel's own frequency response (perfect estimation) and the precoder a fixed rank-1 vector.
+  5. per UE: CSI report of a 4-port CSI-RS channel estimate -- Type-I single-panel PMI search + wideband / subband CQI
+     (uePhy.m:901-908 -> cqiSelect -> dlPMISelect, setupCSIRS.m:5-23 configuration)              communication.phyLayer (cqi.hip)
+What is NOT here (out of scope): scheduler, HARQ, LDPC/PDSCH chain, rank selection (riSelect: one layer is reported); the
+CSI-RS channel estimate is the channel's own frequency response at the CSI-RS resource elements (perfect estimation).
+
+`PROBE = {"cell": c, "ue": u}` (set by tests) makes main() keep that UE's seam inputs / outputs in PROBE["capture"] for oracle checks.
 """
 from __future__ import annotations
 
@@ -42,12 +45,23 @@ def cell_layout(cell_id, n_ues, n_targets):
     return plans, heights, ue
 
 
-def freq_response(ch, n_re, scs_hz, ports):
-    """Perfect CSI-RS channel estimate: H[k, u, p] = sum_n h[n, p, u] exp(-2 pi j f_k tau_n) on n_re REs (one per RB)."""
+PROBE = None
+DOWNLINK_SINR90PC = np.array([-3.46, 1.54, 6.54, 11.05, 13.54, 16.04, 17.54, 20.04, 22.04, 24.43, 26.93, 27.43, 29.43, 32.43, 35.43])   # setupSINRtoCQIMappingTable.m:7-11
+
+
+def csirs_positions(nrb):
+    """First-port CSI-RS resource elements of the reference's row-5 / density-1 / symbol-0 configuration (setupCSIRS.m:8-11): two adjacent
+    subcarriers per RB on the slot's first symbol -- 1-based (k, l) subscripts as dlPMISelect.m:354-362 uses them."""
+    k = np.concatenate([[12 * r + 1, 12 * r + 2] for r in range(nrb)])
+    return k, np.ones_like(k)
+
+
+def freq_response(ch, k_sub, n_sc, scs_hz, ports):
+    """Perfect CSI-RS channel estimate at the subcarriers k_sub (1-based): H[i, u, p] = sum_n h[n, p, u] exp(-2 pi j f_i tau_n)."""
     h = ch.path_gains(ch.time)[:, :ports, :]                # [n, p, u]
     tau = ch.path_delays()
-    f = (np.arange(n_re) - n_re / 2) * 12 * scs_hz
-    e = np.exp(-2j * np.pi * f[:, None] * tau[None, :])     # [k, n]
+    f = ((np.asarray(k_sub) - 1) - n_sc / 2) * scs_hz
+    e = np.exp(-2j * np.pi * f[:, None] * tau[None, :])     # [i, n]
     return np.asfortranarray(np.einsum("kn,npu->kup", e, h))
 
 
@@ -112,24 +126,33 @@ def main():
         ctx.check(ctx.lib.isac_synth_qpsk_grid_dev(ctx.handle, bench.C.c_void_p(grid.ptr), cell.K, 14, args.ants, bench.C.c_uint64(0xD1 + c), 0))
         ctx.check(ctx.lib.isac_ofdm_modulate_dev(ctx.handle, bench.C.c_void_p(grid.ptr), 14, args.ants, bench.C.byref(car), bench.C.c_double(1.0),
                                                  bench.C.c_void_p(wave.ptr), bench.C.c_int64(slot_T)))
-        cqis = []
+        cqis, pmis = [], []
+        csi_k, csi_l = csirs_positions(273)
+        report = SimpleNamespace(NSizeBWP=273, NStartBWP=0, PanelDimensions=(2, 1), CodebookMode=1, PMIMode="Subband", CQIMode="Subband",
+                                 SubbandSize=16)                                            # setupCSIRS.m:17-23 (subbandSize.m: 16 or 32 at 273 PRBs)
+        carrier = SimpleNamespace(NSizeGrid=273, NStartGrid=0, SymbolsPerSlot=14)
         for u in range(args.ues):
             t4 = time.perf_counter()
             ch = CM.CDLChannel(DelayProfile=profiles[u], TransmitAntennaArraySize=nt_shape, Seed=73)     # cdl.m:57-64 (same seed for every UE)
-            CM.applyCDL(ch, wave, ctx=ctx)                       # rxWaveform [T x 2] stays on the device (the UE PHY is out of scope)
+            t_ch = ch.time
+            rx = CM.applyCDL(ch, wave, ctx=ctx)                  # rxWaveform [T x 2] stays on the device (the UE PHY is out of scope)
             ctx.sync()
             t5 = time.perf_counter(); t["cdl"] += t5 - t4
-            hf = freq_response(ch, 273, 30e3, 4)
-            w = np.ones((4, 1), dtype=np.complex128) / 2.0
+            hf = freq_response(ch, csi_k, cell.K, 30e3, 4)      # [nRE x nRx x 4 ports]
             dist_m = float(np.linalg.norm(ue[u] - gnb))
             pl_db = 32.4 + 20.0 * np.log10(3.5) + 30.0 * np.log10(max(dist_m, 10.0))       # distance-only path loss, 3.5 GHz
             noise_dbm = -174.0 + 10.0 * np.log10(100e6) + 7.0                               # 100 MHz, 7 dB noise figure
-            sigma = 10.0 ** (-(46.0 - pl_db - noise_dbm) / 20.0)                            # unit-power channel at 46 dBm
-            cqi, _ = PL.cqiFromChannel(hf, sigma, w, ctx=ctx)
+            nvar = 10.0 ** (-(46.0 - pl_db - noise_dbm) / 10.0)                             # unit-power channel at 46 dBm
+            cqi, pmi, cinfo, _ = PL.cqiSelect(carrier, SimpleNamespace(k=csi_k, l=csi_l), report, 1, ctx.to_device(hf), nvar, DOWNLINK_SINR90PC, ctx=ctx)
             t["cqi"] += time.perf_counter() - t5
-            cqis.append(-1 if isinstance(cqi, float) else cqi)
+            cqis.append(None if np.isnan(cqi[0]) else int(cqi[0]))
+            pmis.append([None if np.isnan(v) else int(v) for v in pmi.i1])
+            if PROBE is not None and PROBE.get("cell") == c and PROBE.get("ue") == u:
+                PROBE["capture"] = dict(profile=profiles[u], tx_size=nt_shape, t0=t_ch, wave=wave.numpy(), rx=rx.numpy() if hasattr(rx, "numpy") else np.asarray(rx),
+                                        hf=hf, nvar=nvar, report=report, csi_k=csi_k, csi_l=csi_l, cqi=cqi, pmi=pmi, subband_cqi=cinfo.SubbandCQI,
+                                        ue_los=bool(ue_los[u]), est=est)
         recs.append(d.make_record(c, est, time.perf_counter() - t0))
-        extra.append({"cell": c, "ue_los": int(ue_los.sum()), "cqi": cqis, "n_walls": town._tab().n_walls})
+        extra.append({"cell": c, "ue_los": int(ue_los.sum()), "cqi": cqis, "pmi_i1": pmis, "n_walls": town._tab().n_walls})
     recs = np.array(recs).reshape(-1, d.RECORD_LEN)
     on_gpu = dist is not None and dist.get_backend() == "nccl"
     allr = d.gather_records(recs, dist, torch.device("cuda", local_rank) if on_gpu else None)

@@ -363,24 +363,30 @@ def test_chain_against_golden_fixture(pkg, ctx):
 
 
 # ------------------------------------------------------------------ CDL MIMO channel apply
-@pytest.mark.parametrize("profile,tx_size,t_len,t0", [
-    ("CDL-D", (1, 4, 2, 1, 1), 7680 + 65, 0.0),
-    ("CDL-A", (1, 8, 2, 1, 1), 3000, 0.0),
-    ("CDL-A", (1, 3, 2, 1, 1), 4097, 1.0 / 640 - 1000 / 15.36e6),       # crosses a path-gain refresh inside the block
-    ("CDL-D", (1, 32, 2, 1, 1), 7680 + 65, 0.25),                        # 64 transmit elements (the benchmark array)
+UE_ARRAY, GNB64 = (1, 1, 2, 1, 1), (1, 32, 2, 1, 1)
+
+
+@pytest.mark.parametrize("profile,tx_size,rx_size,t_len,t0", [
+    ("CDL-D", (1, 4, 2, 1, 1), UE_ARRAY, 7680 + 65, 0.0),
+    ("CDL-A", (1, 8, 2, 1, 1), UE_ARRAY, 3000, 0.0),
+    ("CDL-A", (1, 3, 2, 1, 1), UE_ARRAY, 4097, 1.0 / 640 - 1000 / 15.36e6),       # crosses a path-gain refresh inside the block
+    ("CDL-D", GNB64, UE_ARRAY, 7680 + 65, 0.25),                                   # DL: 64 transmit elements (the benchmark array), cdl.m:57-64
+    ("CDL-D", UE_ARRAY, GNB64, 7680 + 65, 0.0),                                    # UL: Nt = 2 -> Nr = 64 (cdl.m:78-85, stepped at gNBPhy.m:838-840)
+    ("CDL-A", UE_ARRAY, GNB64, 4097, 1.0 / 640 - 1000 / 15.36e6),                  # UL, NLoS profile, across a path-gain refresh
+    ("CDL-A", UE_ARRAY, (1, 8, 2, 1, 1), 3000, 0.1),                               # UL into the reference's default 16-element array
 ])
-def test_cdl_apply_matches_oracle(pkg, ctx, profile, tx_size, t_len, t0):
+def test_cdl_apply_matches_oracle(pkg, ctx, profile, tx_size, rx_size, t_len, t0):
     import oracle.cdl as OC
     fs = 15.36e6
-    cfg = OC.cdl_config(profile, 3.5e9, tx_size, (1, 1, 2, 1, 1), fs)
-    ch = pkg.communication.channelModels.CDLChannel(profile, 300e-9, 3.5e9, tx_size, (1, 1, 2, 1, 1), fs)
+    cfg = OC.cdl_config(profile, 3.5e9, tx_size, rx_size, fs)
+    ch = pkg.communication.channelModels.CDLChannel(profile, 300e-9, 3.5e9, tx_size, rx_size, fs)
     ch.time = t0
-    nt = int(np.prod(tx_size))
-    rng = np.random.default_rng(nt)
+    nt, nr = int(np.prod(tx_size)), int(np.prod(rx_size))
+    rng = np.random.default_rng(nt + nr)
     x = np.asfortranarray(rng.standard_normal((t_len, nt)) + 1j * rng.standard_normal((t_len, nt)))
     want = OC.apply_cdl(cfg, x, t0)
     got = pkg.communication.channelModels.applyCDL(ch, x)
-    assert got.shape == (t_len, 2) and rel(got, want) < RTOL
+    assert got.shape == (t_len, nr) and rel(got, want) < RTOL
     assert ch.time == pytest.approx(t0 + t_len / fs)
     # device-resident call continues from the advanced channel time
     got2 = pkg.communication.channelModels.applyCDL(ch, ctx.to_device(x)).numpy()
