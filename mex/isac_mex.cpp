@@ -1,67 +1,159 @@
-// MEX gateway: forwards the reference's +sensing / +networkTopology calls to the C ABI of include/isac.h.
+// MEX gateway: forwards the reference's +sensing / +communication / +networkTopology calls to the C ABI of include/isac.h.
 //   mex -R2018a mex/isac_mex.cpp -Iinclude -L<package dir> -lisac_hip        (interleaved complex: mxGetComplexDoubles)
-// MATLAB side: the bodies of sensing.monoStaticSensing, sensing.channelModels.basicRadarChannel,
-// sensing.estimation.fft2D, sensing.estimation.doaEstimation.music and openStreetMapCity.checkLoS become one-line
-// calls isac_mex('<name>', ...).  Every non-zero isac_status becomes mexErrMsgIdAndTxt('isac:<CODE>', message), so the
+// MATLAB side (mex/matlab/): the bodies of the reference's package functions become one-line calls
+// isac_mex('<name>', ...).  Every non-zero isac_status becomes mexErrMsgIdAndTxt('isac:<CODE>', message), so the
 // reference's try/catch -> NaN convention (cellSimulation.m:196-202) keeps working.
-// This file is compile-checked here against mex/stub/mex.h (no MATLAB in the image); it is not part of libisac_hip.so.
+//
+// Device-resident arrays: isac_mex('toDevice', A) returns a uint64 HANDLE; every array argument of the sensing entries may be
+// such a handle instead of a MATLAB array, and an entry whose array inputs are handles returns handles -- the echo grid of
+// monoStaticSensing then never crosses PCIe on its way into fft2D (isac_mex('gather', h) / isac_mex('free', h)).
+// This file is compile-checked here against mex/stub/mex.h (no MATLAB in the image); the host-pointer and device-pointer call
+// sequences it issues are driven for real by tests/abi_host.c (plain C, linked against libisac_hip.so).
 #include "mex.h"
 #include "isac.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
-static isac_ctx* g_ctx = nullptr;
-static void at_exit() { if (g_ctx) { isac_ctx_destroy(g_ctx); g_ctx = nullptr; } }
-static isac_ctx* ctx() {
+namespace {
+
+isac_ctx* g_ctx = nullptr;
+struct DevArray { void* p = nullptr; mwSize dims[3] = {0, 0, 1}; bool cplx = true; };
+std::map<uint64_t, DevArray> g_arrays;         // handle (the device address) -> array
+bool g_fused_pending = false;                  // a monoStaticSensingFused call left range rows cached for the next fft2D
+
+void at_exit() {
+  if (!g_ctx) return;
+  for (auto& kv : g_arrays) isac_dev_free(g_ctx, kv.second.p);
+  g_arrays.clear();
+  isac_ctx_destroy(g_ctx);
+  g_ctx = nullptr;
+}
+isac_ctx* ctx() {
   if (!g_ctx) {
-    const char* dev = std::getenv("ISAC_DEVICE");                    // parallel workers: one process per GPU
+    const char* dev = std::getenv("ISAC_DEVICE");                    // parallel workers: one process per GPU (cellID mod nGPU)
     if (isac_ctx_create(dev ? std::atoi(dev) : 0, &g_ctx) != ISAC_OK) mexErrMsgIdAndTxt("isac:HIP", "no MI355X visible");
     mexAtExit(at_exit);
   }
   return g_ctx;
 }
-static void check(int st) {
+void check(int st) {
   static const char* id[] = {"isac:OK", "isac:INVALID_ARG", "isac:HIP", "isac:NO_LOS", "isac:NO_DETECTION",
                              "isac:CFAR_WINDOW", "isac:CAPACITY", "isac:UNSUPPORTED", "isac:SHORT_WAVEFORM"};
   if (st != ISAC_OK) mexErrMsgIdAndTxt(id[(st > 0 && st < 9) ? st : 2], "%s", isac_last_error(g_ctx));
 }
-static double fld(const mxArray* s, const char* f) { return mxGetScalar(mxGetField(s, 0, f)); }
-static const isac_c64* cplx(const mxArray* a) { return reinterpret_cast<const isac_c64*>(mxGetComplexDoubles(a)); }
-static isac_c64* cplx_out(mxArray* a) { return reinterpret_cast<isac_c64*>(mxGetComplexDoubles(a)); }
+double fld(const mxArray* s, const char* f) {
+  const mxArray* v = mxIsStruct(s) ? mxGetField(s, 0, f) : mxGetProperty(s, 0, f);   // struct or value object (phased.CFARDetector2D, nrCarrierConfig)
+  if (!v) mexErrMsgIdAndTxt("isac:INVALID_ARG", "missing field %s", f);
+  return mxGetScalar(v);
+}
+const mxArray* sub(const mxArray* s, const char* f) {
+  const mxArray* v = mxIsStruct(s) ? mxGetField(s, 0, f) : mxGetProperty(s, 0, f);
+  if (!v) mexErrMsgIdAndTxt("isac:INVALID_ARG", "missing field %s", f);
+  return v;
+}
+const isac_c64* cplx(const mxArray* a) { return reinterpret_cast<const isac_c64*>(mxGetComplexDoubles(a)); }
+isac_c64* cplx_out(mxArray* a) { return reinterpret_cast<isac_c64*>(mxGetComplexDoubles(a)); }
+
+bool is_handle(const mxArray* a) { return mxGetClassID(a) == mxUINT64_CLASS && mxGetNumberOfElements(a) == 1; }
+DevArray& lookup(const mxArray* a) {
+  auto it = g_arrays.find(*mxGetUint64s(a));
+  if (it == g_arrays.end()) mexErrMsgIdAndTxt("isac:INVALID_ARG", "unknown or freed device handle");
+  return it->second;
+}
+mxArray* make_handle(void* p, mwSize d0, mwSize d1, mwSize d2, bool cplx_) {
+  DevArray a; a.p = p; a.dims[0] = d0; a.dims[1] = d1; a.dims[2] = d2; a.cplx = cplx_;
+  g_arrays[(uint64_t)(uintptr_t)p] = a;
+  mxArray* h = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
+  *mxGetUint64s(h) = (uint64_t)(uintptr_t)p;
+  return h;
+}
+void dims3(const mxArray* a, mwSize d[3]) {
+  const mwSize* s = mxGetDimensions(a);
+  const mwSize n = mxGetNumberOfDimensions(a);
+  d[0] = s[0]; d[1] = n > 1 ? s[1] : 1; d[2] = n > 2 ? s[2] : 1;
+}
+// device view of a complex array argument: a handle as it is, a MATLAB array uploaded into a temporary
+struct DevIn {
+  const isac_c64* p = nullptr; mwSize d[3] = {0, 0, 1}; void* tmp = nullptr;
+  explicit DevIn(const mxArray* a) {
+    if (is_handle(a)) { DevArray& v = lookup(a); p = (const isac_c64*)v.p; std::memcpy(d, v.dims, sizeof(d)); return; }
+    dims3(a, d);
+    const size_t bytes = sizeof(isac_c64) * d[0] * d[1] * d[2];
+    check(isac_dev_alloc(ctx(), bytes, &tmp));
+    check(isac_memcpy_h2d(ctx(), tmp, mxGetComplexDoubles(a), bytes));
+    p = (const isac_c64*)tmp;
+  }
+  ~DevIn() { if (tmp) isac_dev_free(g_ctx, tmp); }
+};
 
 // radarParams struct (radarParams.m:54-65,125) -> isac_radar_channel_params
-static isac_radar_channel_params channel_block(const mxArray* rp) {
+isac_radar_channel_params channel_block(const mxArray* rp) {
   isac_radar_channel_params p{};
   p.fc = fld(rp, "fc"); p.fs = fld(rp, "fs"); p.n0 = fld(rp, "N0");
   p.n_ants = (int)fld(rp, "nTxAnts"); p.n_targets = (int)fld(rp, "nTargets");
-  p.range = mxGetDoubles(mxGetField(rp, 0, "range"));
-  p.velocity = mxGetDoubles(mxGetField(rp, 0, "velocity"));
-  p.large_scale_fading = mxGetDoubles(mxGetField(rp, 0, "largeScaleFading"));
-  p.rx_steering = cplx(mxGetField(rp, 0, "RxSteeringVec"));
+  p.range = mxGetDoubles(sub(rp, "range"));
+  p.velocity = mxGetDoubles(sub(rp, "velocity"));
+  p.large_scale_fading = mxGetDoubles(sub(rp, "largeScaleFading"));
+  p.rx_steering = cplx(sub(rp, "RxSteeringVec"));
   return p;
 }
 // radarEstParams (radarParams.m:69-78,127-140) -> isac_est_params
-static isac_est_params est_block(const mxArray* ep) {
+isac_est_params est_block(const mxArray* ep) {
   isac_est_params e{};
   e.n_ifft = (int)fld(ep, "nIFFT"); e.n_fft = (int)fld(ep, "nFFT");
   e.r_res = fld(ep, "rRes"); e.v_res = fld(ep, "vRes");
   e.azimuth_scan_scale = fld(ep, "azimuthScanScale"); e.azimuth_scan_granularity = fld(ep, "azimuthScanGranularity");
   e.elevation_scan_scale = fld(ep, "elevationScanScale"); e.elevation_scan_granularity = fld(ep, "elevationScanGranularity");
-  e.array_is_upa = mxIsClass(mxGetField(ep, 0, "antennaType"), "parameters.baseStation.antenna.upa") ? 1 : 0;
+  e.array_is_upa = mxIsClass(sub(ep, "antennaType"), "parameters.baseStation.antenna.upa") ? 1 : 0;
   return e;
 }
-static isac_carrier carrier_block(const mxArray* car) {
-  return isac_carrier{(int)(12 * fld(car, "NRBsDL")), 4096 /* nrOFDMInfo(NRB, SCS).Nfft at 100 MHz / 30 kHz */, (int)fld(car, "SubcarrierSpacing"), 0};
+// carrierInfo {SubcarrierSpacing, NRBsDL} (monoStaticSensing.m:8-10); Nfft as nrOFDMInfo(NRB, SCS) reports it (gNBPhy.m:772):
+// the smallest power of two >= 12 NRB / 0.85, at least 128
+isac_carrier carrier_block(const mxArray* car) {
+  const int nrb = (int)fld(car, "NRBsDL");
+  int nfft = 128;
+  while (nfft * 0.85 < 12.0 * nrb) nfft *= 2;
+  return isac_carrier{12 * nrb, nfft, (int)fld(car, "SubcarrierSpacing"), 0};
 }
-static void put(mxArray* s, const char* f, const double* v, int n) {
+// cfarConfig {CUTIdx, cfarDetector2D} (cfar2D.m:23-37): rectangle corners from the rows-fastest CUT list, detector properties from the object
+isac_cfar_config cfar_block(const mxArray* cf) {
+  const mxArray* cut = sub(cf, "CUTIdx");
+  const double* ci = mxGetDoubles(cut);
+  const mwSize n = mxGetN(cut);
+  if (mxGetM(cut) != 2 || n == 0) mexErrMsgIdAndTxt("isac:INVALID_ARG", "cfar.CUTIdx must be [2 x nCUT]");
+  const mxArray* det = sub(cf, "cfarDetector2D");
+  const double* g = mxGetDoubles(sub(det, "GuardBandSize"));
+  const double* t = mxGetDoubles(sub(det, "TrainingBandSize"));
+  isac_cfar_config c{};
+  c.pfa = fld(det, "ProbabilityFalseAlarm");
+  c.guard[0] = (int)g[0]; c.guard[1] = (int)g[mxGetNumberOfElements(sub(det, "GuardBandSize")) > 1 ? 1 : 0];
+  c.train[0] = (int)t[0]; c.train[1] = (int)t[mxGetNumberOfElements(sub(det, "TrainingBandSize")) > 1 ? 1 : 0];
+  c.row0 = (int)ci[0]; c.col0 = (int)ci[1]; c.row1 = (int)ci[2 * (n - 1)]; c.col1 = (int)ci[2 * (n - 1) + 1];
+  if ((mwSize)(c.row1 - c.row0 + 1) * (mwSize)(c.col1 - c.col0 + 1) != n)
+    mexErrMsgIdAndTxt("isac:UNSUPPORTED", "cfar.CUTIdx is not the rows-fastest rectangle sensing.detection.cfar2D builds");
+  return c;
+}
+void put(mxArray* s, const char* f, const double* v, int n) {
   mxArray* a = mxCreateDoubleMatrix(1, (mwSize)n, mxREAL);
   std::memcpy(mxGetDoubles(a), v, sizeof(double) * (size_t)n);
   mxSetField(s, 0, f, a);
 }
+mxArray* est_struct(const isac_est_result& r) {
+  const char* names[] = {"rngEst", "velEst", "aziEst", "eleEst"};              // fft2D.m:102,114-115
+  mxArray* s = mxCreateStructMatrix(1, 1, 4, names);
+  put(s, "rngEst", r.rng_est, r.n_rng); put(s, "velEst", r.vel_est, r.n_vel);
+  put(s, "aziEst", r.azi_est, r.n_azi); put(s, "eleEst", r.ele_est, r.n_azi);
+  return s;
+}
+uint64_t seed_of(const mxArray* a) { return a && !mxIsEmpty(a) ? (uint64_t)mxGetScalar(a) : 0x5EED0002ull; }
+
+}  // namespace
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   (void)nlhs;
@@ -69,56 +161,251 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
   char* name = mxArrayToString(prhs[0]);
   const std::string fn = name ? name : "";
   mxFree(name);
-  if (fn == "monoStaticSensing" || fn == "basicRadarChannel") {
-    // (txWaveform, txDimension | [], carrierInfo | [], radarParams, uint8(LoS), [noise])        monoStaticSensing.m:1, basicRadarChannel.m:1
+  // ------------------------------------------------------------------ device arrays
+  if (fn == "toDevice") {                                   // h = isac_mex('toDevice', complexArray)
+    mwSize d[3];
+    dims3(prhs[1], d);
+    const size_t bytes = sizeof(isac_c64) * d[0] * d[1] * d[2];
+    void* p = nullptr;
+    check(isac_dev_alloc(ctx(), bytes, &p));
+    check(isac_memcpy_h2d(ctx(), p, mxGetComplexDoubles(prhs[1]), bytes));
+    plhs[0] = make_handle(p, d[0], d[1], d[2], true);
+  } else if (fn == "gather") {                              // A = isac_mex('gather', h)
+    DevArray& a = lookup(prhs[1]);
+    plhs[0] = mxCreateNumericArray(3, a.dims, mxDOUBLE_CLASS, mxCOMPLEX);
+    check(isac_memcpy_d2h(ctx(), mxGetComplexDoubles(plhs[0]), a.p, sizeof(isac_c64) * a.dims[0] * a.dims[1] * a.dims[2]));
+  } else if (fn == "free") {
+    const uint64_t h = *mxGetUint64s(prhs[1]);
+    auto it = g_arrays.find(h);
+    if (it != g_arrays.end()) { check(isac_dev_free(ctx(), it->second.p)); g_arrays.erase(it); }
+  // ------------------------------------------------------------------ echo synthesis
+  } else if (fn == "monoStaticSensing" || fn == "basicRadarChannel" || fn == "monoStaticSensingFused") {
+    // (txWaveform | handle, txDimension | [], carrierInfo | [], radarParams, uint8(LoS), noise | [] , seed | [], noiseDomain 'time'|'spectral'
+    //  [, radarEstParams, cfar, txGrid | handle  -- Fused only])                                  monoStaticSensing.m:1, basicRadarChannel.m:1
     const mxArray *tx = prhs[1], *dim = prhs[2], *car = prhs[3], *rp = prhs[4], *los = prhs[5];
-    const mxArray* noise = nrhs > 6 ? prhs[6] : nullptr;
-    const mwSize T = mxGetM(tx), A = mxGetN(tx);
+    const mxArray* noise = (nrhs > 6 && !mxIsEmpty(prhs[6])) ? prhs[6] : nullptr;
+    const uint64_t seed = seed_of(nrhs > 7 ? prhs[7] : nullptr);
+    bool spectral = false;
+    if (nrhs > 8 && !mxIsEmpty(prhs[8])) { char* s = mxArrayToString(prhs[8]); spectral = s && std::string(s) == "spectral"; mxFree(s); }
     isac_radar_channel_params p = channel_block(rp);
-    const int mode = noise ? ISAC_NOISE_INJECTED : ISAC_NOISE_PHILOX;
+    const int mode = noise ? (spectral ? ISAC_NOISE_INJECTED_SPECTRAL : ISAC_NOISE_INJECTED) : (spectral ? ISAC_NOISE_PHILOX_SPECTRAL : ISAC_NOISE_PHILOX);
+    const bool dev = is_handle(tx);
     if (fn == "basicRadarChannel") {
+      if (dev) mexErrMsgIdAndTxt("isac:UNSUPPORTED", "basicRadarChannel takes a MATLAB array (the time-domain echo is a host-side product)");
+      const mwSize T = mxGetM(tx), A = mxGetN(tx);
       plhs[0] = mxCreateDoubleMatrix(T, A, mxCOMPLEX);
-      check(isac_basic_radar_channel(ctx(), cplx(tx), (int64_t)T, &p, (const uint8_t*)mxGetData(los), mode, noise ? cplx(noise) : nullptr,
-                                     0x5EED0002ull, cplx_out(plhs[0])));
+      check(isac_basic_radar_channel(ctx(), cplx(tx), (int64_t)T, &p, (const uint8_t*)mxGetData(los), mode, noise ? cplx(noise) : nullptr, seed,
+                                     cplx_out(plhs[0])));
       return;
     }
     isac_carrier c = carrier_block(car);
-    int L = 0;
-    check(isac_ofdm_symbol_count(&c, (int64_t)T, &L));
     const int want = (int)mxGetDoubles(dim)[1];
-    mwSize dims[3] = {(mwSize)c.n_sc, (mwSize)std::max(L, want), A};           // monoStaticSensing.m:19-21
-    plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxCOMPLEX);
-    check(isac_mono_static_sensing(ctx(), cplx(tx), (int64_t)T, want, &c, &p, (const uint8_t*)mxGetData(los), mode,
-                                   noise ? cplx(noise) : nullptr, 0x5EED0002ull, cplx_out(plhs[0]), &L));
-  } else if (fn == "fft2D") {
-    // (radarEstParams, cfar, rxGrid, txGrid)                                                      fft2D.m:1
-    const mxArray *ep = prhs[1], *cf = prhs[2], *rx = prhs[3], *txg = prhs[4];
-    const mwSize* d = mxGetDimensions(rx);
-    const int K = (int)d[0], L = (int)d[1], A = mxGetNumberOfDimensions(rx) > 2 ? (int)d[2] : 1;
-    const mxArray* cut = mxGetField(cf, 0, "CUTIdx");                          // cfar2D.m:24, [2 x nCUT], rows fastest
-    const double* ci = mxGetDoubles(cut);
-    const mwSize n = mxGetN(cut);
-    isac_cfar_config c{fld(ep, "Pfa"), {2, 2}, {1, 1}, (int)ci[0], (int)ci[2 * (n - 1)], (int)ci[1], (int)ci[2 * (n - 1) + 1]};   // cfar2D.m:27-33
+    if (!dev && fn == "monoStaticSensing") {              // host arrays in, host array out (the reference's own calling convention)
+      const mwSize T = mxGetM(tx), A = mxGetN(tx);
+      int L = 0;
+      check(isac_ofdm_symbol_count(&c, (int64_t)T, &L));
+      mwSize dims[3] = {(mwSize)c.n_sc, (mwSize)std::max(L, want), A};          // monoStaticSensing.m:19-21
+      plhs[0] = mxCreateNumericArray(3, dims, mxDOUBLE_CLASS, mxCOMPLEX);
+      check(isac_mono_static_sensing(ctx(), cplx(tx), (int64_t)T, want, &c, &p, (const uint8_t*)mxGetData(los), mode, noise ? cplx(noise) : nullptr,
+                                     seed, cplx_out(plhs[0]), &L));
+      return;
+    }
+    // device-resident: handle out.  Array arguments may be handles or MATLAB arrays (uploaded for the call).
+    DevIn d_tx(tx);
+    const int64_t T = (int64_t)d_tx.d[0];
+    const mwSize A = d_tx.d[1];
+    int L = 0;
+    check(isac_ofdm_symbol_count(&c, T, &L));
+    const mwSize Lo = (mwSize)std::max(L, want);
+    void* d_echo = nullptr;
+    check(isac_dev_alloc(ctx(), sizeof(isac_c64) * c.n_sc * Lo * A, &d_echo));
+    struct Guard { void* p; ~Guard() { if (p) isac_dev_free(g_ctx, p); } } guard{d_echo};
+    const isac_c64* d_nz = nullptr;
+    DevIn* nz_in = noise ? new DevIn(noise) : nullptr;
+    if (nz_in) d_nz = nz_in->p;
+    int st;
+    if (fn == "monoStaticSensingFused") {
+      isac_est_params e = est_block(prhs[9]);
+      isac_cfar_config cf = cfar_block(prhs[10]);
+      if (!is_handle(prhs[11])) { delete nz_in; mexErrMsgIdAndTxt("isac:INVALID_ARG", "monoStaticSensingFused needs txGrid as a device handle (it must outlive the call)"); }
+      st = isac_mono_static_sensing_fused_dev(ctx(), d_tx.p, T, want, &c, &p, (const uint8_t*)mxGetData(los), mode, d_nz, seed, (isac_c64*)d_echo, &L, &e, &cf,
+                                              (const isac_c64*)lookup(prhs[11]).p);
+      g_fused_pending = st == ISAC_OK;
+    } else {
+      st = isac_mono_static_sensing_dev(ctx(), d_tx.p, T, want, &c, &p, (const uint8_t*)mxGetData(los), mode, d_nz, seed, (isac_c64*)d_echo, &L);
+    }
+    if (st == ISAC_OK) st = isac_sync(ctx());               // temporaries (uploaded tx / noise) are released when this call returns
+    delete nz_in;
+    check(st);
+    guard.p = nullptr;
+    plhs[0] = make_handle(d_echo, (mwSize)c.n_sc, Lo, A, true);
+  // ------------------------------------------------------------------ estimation
+  } else if (fn == "fft2D" || fn == "music2D") {
+    // fft2D:   (radarEstParams, cfar, rxGrid | handle, txGrid | handle)                            fft2D.m:1
+    // music2D: (radarEstParams, scs_kHz, rxGrid | handle, txGrid | handle)                        music2D.m:1
+    const mxArray *ep = prhs[1], *arg2 = prhs[2], *rx = prhs[3], *txg = prhs[4];
     isac_est_params e = est_block(ep);
     isac_est_result r;
-    check(isac_fft2d(ctx(), &e, &c, cplx(rx), cplx(txg), K, L, A, &r));
-    const char* names[] = {"rngEst", "velEst", "aziEst", "eleEst"};            // fft2D.m:102,114-115
-    plhs[0] = mxCreateStructMatrix(1, 1, 4, names);
-    put(plhs[0], "rngEst", r.rng_est, r.n_rng); put(plhs[0], "velEst", r.vel_est, r.n_vel);
-    put(plhs[0], "aziEst", r.azi_est, r.n_azi); put(plhs[0], "eleEst", r.ele_est, r.n_azi);
-  } else if (fn == "music") {
-    // (numDets | [], radarEstParams, Ra) -> [L, aziEst, eleEst]                                   music.m:1
+    if (fn == "fft2D" && !is_handle(rx) && !is_handle(txg)) {         // host arrays: the host-pointer entry stages them itself
+      mwSize d[3];
+      dims3(rx, d);
+      isac_cfar_config c = cfar_block(arg2);
+      g_fused_pending = false;
+      check(isac_fft2d(ctx(), &e, &c, cplx(rx), cplx(txg), (int)d[0], (int)d[1], (int)d[2], &r));
+      plhs[0] = est_struct(r);
+      return;
+    }
+    DevIn d_rx(rx), d_tx(txg);
+    const int K = (int)d_rx.d[0], L = (int)d_rx.d[1], A = (int)d_rx.d[2];
+    if (fn == "fft2D") {
+      isac_cfar_config c = cfar_block(arg2);
+      // range rows cached by the preceding monoStaticSensingFused call on the same handles are consumed explicitly
+      const bool cached = g_fused_pending && is_handle(rx) && is_handle(txg);
+      g_fused_pending = false;
+      int st = cached ? isac_fft2d_submit_cached_dev(ctx(), &e, &c, d_rx.p, d_tx.p, K, L, A) : ISAC_ERR_INVALID_ARG;
+      if (st != ISAC_OK) st = isac_fft2d_submit_dev(ctx(), &e, &c, d_rx.p, d_tx.p, K, L, A);
+      check(st);
+      check(isac_fft2d_collect(ctx(), &r));
+    } else {
+      isac_music2d_params m{};                                        // music2D.m:29-46
+      m.fc = fld(ep, "fc"); m.t_sri = fld(ep, "Tsri"); m.scs_hz = mxGetScalar(arg2) * 1e3;
+      const double* zone = mxGetDoubles(sub(ep, "cfarEstZone"));     // [2 x 2] column-major: (1,2) = zone[2], (2,2) = zone[3]
+      m.r_max = zone[2]; m.v_max = zone[3] * 2.0;
+      check(isac_music2d_dev(ctx(), &e, &m, d_rx.p, d_tx.p, K, L, A, &r));
+    }
+    plhs[0] = est_struct(r);
+  } else if (fn == "music" || fn == "digitalBF" || fn == "mvdrBF") {
+    // music: (numDets | [], radarEstParams, Ra) -> [L, aziEst, eleEst]                           music.m:1
+    // digitalBF / mvdrBF: (numDets, radarEstParams, Ra) -> [aziEst, eleEst]                      digitalBF.m:1, mvdrBF.m:1
     const mxArray *nd = prhs[1], *ep = prhs[2], *ra = prhs[3];
     isac_est_params e = est_block(ep);
     const int A = (int)mxGetM(ra);
-    std::vector<double> azi((size_t)A), ele((size_t)A);
+    std::vector<double> azi((size_t)A + 1), ele((size_t)A + 1);
     int32_t L = 0, n_out = 0;
-    check(isac_music_doa(ctx(), mxIsEmpty(nd) ? -1 : (int)mxGetScalar(nd), &e, cplx(ra), A, &L, azi.data(), ele.data(), A, &n_out));
-    plhs[0] = mxCreateDoubleScalar((double)L);
-    plhs[1] = mxCreateDoubleMatrix(1, (mwSize)n_out, mxREAL);
-    plhs[2] = mxCreateDoubleMatrix(1, (mwSize)n_out, mxREAL);
-    std::memcpy(mxGetDoubles(plhs[1]), azi.data(), sizeof(double) * (size_t)n_out);
-    std::memcpy(mxGetDoubles(plhs[2]), ele.data(), sizeof(double) * (size_t)n_out);
+    int o = 0;
+    if (fn == "music") {
+      check(isac_music_doa(ctx(), mxIsEmpty(nd) ? -1 : (int)mxGetScalar(nd), &e, cplx(ra), A, &L, azi.data(), ele.data(), A, &n_out));
+      plhs[o++] = mxCreateDoubleScalar((double)L);
+    } else {
+      check(isac_beamscan_doa(ctx(), fn == "digitalBF" ? 1 : 2, (int)mxGetScalar(nd), &e, cplx(ra), A, azi.data(), ele.data(), A, &n_out));
+    }
+    plhs[o] = mxCreateDoubleMatrix(1, (mwSize)n_out, mxREAL);
+    plhs[o + 1] = mxCreateDoubleMatrix(1, (mwSize)n_out, mxREAL);
+    std::memcpy(mxGetDoubles(plhs[o]), azi.data(), sizeof(double) * (size_t)n_out);
+    std::memcpy(mxGetDoubles(plhs[o + 1]), ele.data(), sizeof(double) * (size_t)n_out);
+  } else if (fn == "cfarDetector") {
+    // detections = cfarDetector(P, CUTIdx) of fft2D.m:62: (P [rows x cols], CUTIdx [2 x nCUT], cfarDetector2D object) -> [2 x D]
+    const mxArray *P = prhs[1], *cut = prhs[2], *det = prhs[3];
+    const mwSize n = mxGetN(cut);
+    std::vector<int32_t> ci(2 * n), out(2 * n + 2);
+    const double* cd = mxGetDoubles(cut);
+    for (mwSize i = 0; i < 2 * n; ++i) ci[i] = (int32_t)cd[i];
+    const double *g = mxGetDoubles(sub(det, "GuardBandSize")), *t = mxGetDoubles(sub(det, "TrainingBandSize"));
+    const int32_t guard[2] = {(int32_t)g[0], (int32_t)g[1]}, train[2] = {(int32_t)t[0], (int32_t)t[1]};
+    int32_t nd = 0;
+    check(isac_cfar2d_ca(ctx(), mxGetDoubles(P), (int)mxGetM(P), (int)mxGetN(P), ci.data(), (int)n, guard, train, fld(det, "ProbabilityFalseAlarm"),
+                         out.data(), (int)n, &nd));
+    plhs[0] = mxCreateDoubleMatrix(2, (mwSize)nd, mxREAL);
+    for (int i = 0; i < 2 * nd; ++i) mxGetDoubles(plhs[0])[i] = out[(size_t)i];
+  // ------------------------------------------------------------------ communication seams
+  } else if (fn == "applyCDL") {
+    // (waveform [T x Nt], pathGains [Ncs x Np x Nt x Nr], sampleTimes [Ncs x 1], pathFilters [Nh x Np], sampleRate, normalizeOutputs)
+    // with the nrCDLChannel of cdl.m:57-64 run in ChannelFiltering = false mode on the MATLAB side: the toolbox keeps drawing the
+    // TR 38.901 path gains (its own RNG and ray tables -- exact parity with the reference by construction), the filtering and the
+    // antenna contraction it would do inside step() run here.                                   uePhy.m:729-731, gNBPhy.m:838-840
+    const mxArray *wv = prhs[1], *pg = prhs[2], *stm = prhs[3], *pf = prhs[4];
+    const double fs = mxGetScalar(prhs[5]);
+    const bool norm = nrhs > 6 ? mxGetScalar(prhs[6]) != 0 : true;
+    const mwSize T = mxGetM(wv), Nt = mxGetN(wv);
+    const mwSize* gd = mxGetDimensions(pg);
+    const mwSize ng = mxGetNumberOfDimensions(pg);
+    const int Ncs = (int)gd[0], Np = (int)gd[1], Nr = ng > 3 ? (int)gd[3] : 1;
+    if ((ng > 2 ? gd[2] : 1) != Nt) mexErrMsgIdAndTxt("isac:INVALID_ARG", "pathGains / waveform transmit dimensions differ");
+    const int Nh = (int)mxGetM(pf);
+    // H [b][n][s][u] <- pathGains(b, n, s, u);  block b starts at the first sample at or after sampleTimes(b)
+    std::vector<isac_c64> H((size_t)Ncs * Np * Nt * Nr);
+    const mxComplexDouble* g = mxGetComplexDoubles(pg);
+    for (int b = 0; b < Ncs; ++b) for (int n = 0; n < Np; ++n) for (mwSize s = 0; s < Nt; ++s) for (int u = 0; u < Nr; ++u) {
+      const mxComplexDouble v = g[(size_t)b + (size_t)Ncs * ((size_t)n + (size_t)Np * (s + Nt * (size_t)u))];
+      H[(((size_t)b * Np + n) * Nt + s) * Nr + u] = isac_c64{v.real, v.imag};
+    }
+    std::vector<int64_t> start((size_t)Ncs);
+    const double* st = mxGetDoubles(stm);
+    for (int b = 0; b < Ncs; ++b) start[(size_t)b] = b == 0 ? 0 : (int64_t)std::llround((st[b] - st[0]) * fs);
+    std::vector<double> taps((size_t)Np * Nh);                      // pathFilters [Nh x Np] -> taps [Np x Nh]; the filters carry their own delay
+    const double* f = mxGetDoubles(pf);
+    for (int n = 0; n < Np; ++n) for (int k = 0; k < Nh; ++k) taps[(size_t)n * Nh + k] = f[(size_t)k + (size_t)Nh * n];
+    std::vector<int32_t> shift((size_t)Np, 0);
+    DevIn d_x(wv);
+    void* d_y = nullptr;
+    check(isac_dev_alloc(ctx(), sizeof(isac_c64) * T * Nr, &d_y));
+    int s2 = isac_cdl_apply_dev(ctx(), d_x.p, (int64_t)T, (int)Nt, Nr, Np, H.data(), Ncs, start.data(), taps.data(), Nh, shift.data(),
+                                norm ? 1.0 / std::sqrt((double)Nr) : 1.0, (isac_c64*)d_y);
+    plhs[0] = mxCreateDoubleMatrix(T, (mwSize)Nr, mxCOMPLEX);
+    if (s2 == ISAC_OK) s2 = isac_memcpy_d2h(ctx(), mxGetComplexDoubles(plhs[0]), d_y, sizeof(isac_c64) * T * Nr);
+    isac_dev_free(ctx(), d_y);
+    check(s2);
+  } else if (fn == "precodedSINR") {
+    // sinr = precodedSINR(H [Nr x P], sigma, W [P x nLayers])                                    precodedSINR.m:11-17
+    const mxArray *h = prhs[1], *w = prhs[3];
+    const double sigma = mxGetScalar(prhs[2]);
+    const int Nr = (int)mxGetM(h), P = (int)mxGetN(h), nl = (int)mxGetN(w);
+    DevIn d_h(h);                                                   // one RE: [1 x Nr x P] has the same memory image as [Nr x P]
+    double mean = 0.0;
+    check(isac_precoded_sinr_cqi_dev(ctx(), d_h.p, 1, Nr, P, cplx(w), nl, sigma, nullptr, 0, nullptr, &mean, nullptr));
+    plhs[0] = mxCreateDoubleScalar(mean);
+  } else if (fn == "csiReport") {
+    // [CQI, i1, i2, subbandCQI, sinrPerSubband] = (Hre [nRE x nRx x P] at the first CSI-RS port's REs, k, l (1-based, BWP relative), reportConfig struct
+    //   {NSizeBWP, NStartBWP, PanelDimensions, CodebookMode, PMIMode, CQIMode, SubbandSize}, nLayers, nVar, SINRTable)      uePhy.m:901-908 -> cqiSelect.m
+    const mxArray *h = prhs[1], *kk = prhs[2], *ll = prhs[3], *rc = prhs[4];
+    const int nl = (int)mxGetScalar(prhs[5]);
+    const double nvar = mxGetScalar(prhs[6]);
+    const mxArray* tab = prhs[7];
+    mwSize d[3];
+    dims3(h, d);
+    const int64_t n_re = (int64_t)d[0];
+    std::vector<int32_t> k((size_t)n_re), l((size_t)n_re);
+    for (int64_t i = 0; i < n_re; ++i) { k[(size_t)i] = (int32_t)mxGetDoubles(kk)[i] - 1; l[(size_t)i] = (int32_t)mxGetDoubles(ll)[i] - 1; }
+    const double* pd = mxGetDoubles(sub(rc, "PanelDimensions"));
+    const int P = (int)d[2];
+    int32_t dims[4];
+    check(isac_type1sp_codebook(P, P > 2 ? (int)pd[0] : 1, P > 2 ? (int)pd[1] : 1, (int)fld(rc, "CodebookMode"), nl, nullptr, 0, dims));
+    std::vector<isac_c64> W((size_t)P * nl * dims[0] * dims[1] * dims[2] * dims[3]);
+    check(isac_type1sp_codebook(P, P > 2 ? (int)pd[0] : 1, P > 2 ? (int)pd[1] : 1, (int)fld(rc, "CodebookMode"), nl, W.data(), (int64_t)W.size(), dims));
+    auto is_sub = [&](const char* f) { char* s = mxArrayToString(sub(rc, f)); const bool r = s && (s[0] == 'S' || s[0] == 's'); mxFree(s); return r; };
+    DevIn d_h(h);
+    isac_csi_report rep;
+    check(isac_csi_report_dev(ctx(), d_h.p, n_re, (int)d[1], P, k.data(), l.data(), (int)fld(rc, "NSizeBWP"), (int)fld(rc, "NStartBWP"), (int)fld(rc, "SubbandSize"),
+                              is_sub("PMIMode"), is_sub("CQIMode"), W.data(), nl, dims, nvar, mxGetDoubles(tab), (int)mxGetNumberOfElements(tab), &rep, nullptr, nullptr));
+    auto vec = [](const double* v, int n, bool col) { mxArray* a = col ? mxCreateDoubleMatrix((mwSize)n, 1, mxREAL) : mxCreateDoubleMatrix(1, (mwSize)n, mxREAL);
+                                                     std::memcpy(mxGetDoubles(a), v, sizeof(double) * (size_t)n); return a; };
+    plhs[0] = vec(rep.cqi, rep.n_cqi, true);
+    plhs[1] = vec(rep.i1, 3, false);
+    plhs[2] = vec(rep.i2, rep.n_subbands_pmi, false);
+    plhs[3] = vec(rep.subband_cqi, rep.n_cqi, true);
+    plhs[4] = vec(rep.sinr_per_subband_cw, rep.n_cqi, true);
+  } else if (fn == "senTxAppend") {
+    // [senTxGrid_h, senTxWave_h] state kept in handles: (gridHandle, waveHandle, txGrid [K x 14 x A], currSlot, isDLslot, carrierInfo, signalAmp, windowing,
+    //  slotsAlready)                                                                           gNBPhy.m:591-612
+    DevArray& sg = lookup(prhs[1]);
+    DevArray& sw = lookup(prhs[2]);
+    DevIn d_g(prhs[3]);
+    isac_carrier c = carrier_block(prhs[6]);
+    const int done = (int)mxGetScalar(prhs[9]);
+    int64_t t_len = 0, t_slot = 0;
+    check(isac_ofdm_waveform_length(&c, 14, &t_slot));
+    check(isac_sentx_append_dev(ctx(), &c, (int)sg.dims[2], (int)mxGetScalar(prhs[4]), mxGetScalar(prhs[5]) != 0, d_g.p, mxGetScalar(prhs[7]), (int)mxGetScalar(prhs[8]),
+                                (isac_c64*)sg.p, (int)sg.dims[1], 14 * done, (isac_c64*)sw.p, (int64_t)sw.dims[0], t_slot * done, &t_len));
+    check(isac_sync(ctx()));
+  } else if (fn == "allocDevice") {                         // h = isac_mex('allocDevice', [d0 d1 d2]) zero-filled complex array (senTx accumulators)
+    const double* d = mxGetDoubles(prhs[1]);
+    const mwSize n = mxGetNumberOfElements(prhs[1]);
+    const mwSize d0 = (mwSize)d[0], d1 = n > 1 ? (mwSize)d[1] : 1, d2 = n > 2 ? (mwSize)d[2] : 1;
+    void* p = nullptr;
+    check(isac_dev_alloc(ctx(), sizeof(isac_c64) * d0 * d1 * d2, &p));
+    check(isac_memset_dev(ctx(), p, 0, sizeof(isac_c64) * d0 * d1 * d2));
+    plhs[0] = make_handle(p, d0, d1, d2, true);
+  // ------------------------------------------------------------------ topology
   } else if (fn == "checkLoS") {
     // (wallTable, uePos [3 x n], antPos [3 x n]) -> logical [1 x n]                               openStreetMapCity.m:67-93
     // wallTable: struct with corners [3 x C], offsets int32 [W+1] (0-based), normals [3 x W], normDist [1 x W], packed once

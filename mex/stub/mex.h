@@ -28,6 +28,10 @@ mxArray* mxGetField(const mxArray*, mwIndex, const char*);
 mxArray* mxGetProperty(const mxArray*, mwIndex, const char*);
 void mxSetField(mxArray*, mwIndex, const char*, mxArray*);
 mxDouble* mxGetDoubles(const mxArray*);
+uint64_t* mxGetUint64s(const mxArray*);
+mxClassID mxGetClassID(const mxArray*);
+bool mxIsStruct(const mxArray*);
+mxArray* mxCreateNumericMatrix(mwSize, mwSize, mxClassID, mxComplexity);
 mxComplexDouble* mxGetComplexDoubles(const mxArray*);
 void* mxGetData(const mxArray*);
 char* mxArrayToString(const mxArray*);
