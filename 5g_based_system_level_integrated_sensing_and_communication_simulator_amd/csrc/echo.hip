@@ -188,88 +188,6 @@ __global__ __launch_bounds__(256, 2) void demod_kernel(OfdmGeom g, long long T, 
   }
 }
 
-// ---------------------------------------------------------------- fused: echo column -> OFDM demod -> range stage of fft2D
-// While a demodulated echo column is still on chip it is also pushed through the range stage of the
-// following fft2D call (fft2D.m:37-45): multiply by conj(txGrid) and the Kaiser window, nIFFT-point IFFT,
-// keep the CUT rows.  echoGrid is still written (covariance + API output) but never re-read by the
-// range kernel: saves K*L*A*16 B of HBM reads per CPI and lets the VALU-bound noise synthesis of one
-// workgroup overlap the HBM-bound loads of another inside the same launch.  Requires Nfft == nIFFT.
-template <class FFT, int QT = 0>
-__global__ __launch_bounds__(256, 2) void demod_range_kernel(OfdmGeom g, long long T, int A, int L_whole, int L_out,
-                                                             const c64* __restrict__ tw, int Q_rt, const c64* __restrict__ coef,
-                                                             const c64* __restrict__ steer_rq, const c64* __restrict__ phase_rx,
-                                                             int noise_mode, const c64* __restrict__ noise, double n0s,
-                                                             uint64_t seed, c64* __restrict__ grid,
-                                                             const c64* __restrict__ txg, const double* __restrict__ win_k,
-                                                             const double* __restrict__ win_r, double inv_n, double sqrt_n,
-                                                             int row_lo, int n_rows, c64* __restrict__ ymid,
-                                                             const c64* __restrict__ logtab_g) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  c64* lds = reinterpret_cast<c64*>(smem_raw);
-  const int tid = threadIdx.x;
-  FFT fft;
-  const int Q = QT ? QT : Q_rt;
-  const int col = blockIdx.x;
-  const int l = col % L_whole, r = col / L_whole;  // symbol fastest (see demod_kernel)
-  const int cp = cp_of_symbol(l, g.cp_base, g.cp_long, g.sym_per_half);
-  const int off = cp / 2;
-  const long long w0 = symbol_start(l, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) + off;
-  const int dshift = cp - off;
-  const c64* sr = steer_rq + (long long)r * Q;
-  if (noise_mode == ISAC_NOISE_PHILOX && QT == 0) {  // any target count: libm generator (the table path spills here)
-    fft.template fill<4>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, ISAC_NOISE_PHILOX, noise, n0s, seed); }, tid);
-    fft.init(lds, tw, tid);
-  } else if (noise_mode == ISAC_NOISE_PHILOX) {      // table-driven Box-Muller (see demod_kernel)
-    c64* lt = lds + FFT::LDS_ELEMS;
-    if (tid < kLogTabSize) lt[tid] = logtab_g[tid];
-    fft.init_table(lds, tw, tid);
-    const c64* w256 = lds + FFT::IMG;
-    fft.template fill<4>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, ISAC_NOISE_PHILOX, noise, n0s, seed, w256, lt); }, tid);
-    fft.init_twiddles(tw, tid);
-  } else {
-    const int nm = (noise_mode == ISAC_NOISE_INJECTED) ? ISAC_NOISE_INJECTED : ISAC_NOISE_NONE;
-    fft.template fill<8>([&](int n) { return rx_sample(w0 + n, r, T, Q, coef, sr, phase_rx, nm, noise, n0s, seed); }, tid);
-    fft.init(lds, tw, tid);
-  }
-  fft.template transform<-1>(lds, tw, tid);
-  const long long colg = (long long)l + (long long)L_out * r;
-  c64* dst = grid + (long long)g.n_sc * colg;
-  const int half = g.n_sc / 2;
-  fft.release();                                   // pass-3 reads of every thread are done: the image can be reused
-  fft.drain(
-      [&](int k, c64 v) {
-        const int kb = (k < g.nfft / 2) ? k : k - g.nfft;
-        const int row = kb + half;
-        const c64 ph = fft.phase_ramp(lds, tw, kb, dshift);
-        if (row >= 0 && row < g.n_sc) {
-          const c64 e = v * ph;
-          dst[row] = e;                                // echoGrid(row, l, r)
-          lds[row] = e;                                // staged in subcarrier order for the range stage
-        }
-      },
-      tid);
-  __syncthreads();
-  const c64* ptx = txg + (long long)g.n_sc * colg;
-  const int K = g.n_sc;
-  fft.fill(
-      [&](int n) {
-        const int nc = n < K ? n : K - 1;
-        c64 v = mul_conj(lds[nc], ptx[nc]) * win_k[nc];    // fft2D.m:37,:43
-        return n < K ? v : mk(0.0, 0.0);
-      },
-      tid);
-  __syncthreads();                                 // staging reads done before pass 1 overwrites the image
-  fft.template transform<+1>(lds, tw, tid);
-  c64* yd = ymid + (long long)n_rows * colg;
-  fft.drain(
-      [&](int n, c64 v) {
-        const int rr = n - row_lo;
-        const double wr = win_r[n];
-        if (rr >= 0 && rr < n_rows) yd[rr] = ((v * inv_n) * sqrt_n) * wr;   // fft2D.m:44-45
-      },
-      tid);
-}
-
 // ---------------------------------------------------------------- spectral echo synthesis (performance noise modes)
 // By linearity of the OFDM demodulator the echo grid of basicRadarChannel.m:64-74 + nrOFDMDemodulate is
 //     echoGrid[k,l,r] = sum_q a_q[r] * D_q[k,l] + W[k,l,r],   D_q = OFDM-demodulate(coef_q)   (Q columns per symbol, not A)
@@ -298,7 +216,7 @@ __global__ __launch_bounds__(256) void echo_spectral_kernel(int K, int L_whole, 
   c64* dst = grid + (long long)K * colg;
   struct None_ {};
   c64 acc[16];
-  spectral_echo_column<QT, NZ, 4>(tid, K, Q, D + (long long)K * l, (long long)K * L_whole, steer_rq + (long long)r * Q, sig, seed, colg,
+  spectral_echo_column<QT, NZ, 4, 256, 1>(tid, K, Q, D + (long long)K * l, (long long)K * L_whole, steer_rq + (long long)r * Q, sig, seed, colg,
                                   NZ == 2 ? noise + (long long)K * colg : nullptr, s_w256, s_lt, acc, [](int) { return None_{}; },
                                   [&](int, int k, c64 v, None_) {
                                     if (k < K) {
@@ -309,9 +227,8 @@ __global__ __launch_bounds__(256) void echo_spectral_kernel(int K, int L_whole, 
                                   });
 }
 
-// Register budget: the LDS image allows two workgroups per CU anyway, so up to 256 VGPRs per lane are free.  (A 154-VGPR
-// variant that leaves a third of the register file to a co-resident covariance / beam-sum wave measured 6 % slower in isolation
-// and 4 % slower pipelined: the kernel is latency-bound at two waves per SIMD and needs the loads in flight.)
+// 512-thread workgroups on the 8-points-per-thread transform (Fft4096W): two workgroups per CU = 16 wavefronts = four per SIMD, which
+// needs <= 128 VGPRs per lane.  (The 256-thread / 16-points-per-thread form was latency-bound at two waves per SIMD: 477 us.)
 #ifndef ISAC_ECHO_RANGE_WGS
 #define ISAC_ECHO_RANGE_WGS 2
 #endif
@@ -319,8 +236,8 @@ __global__ __launch_bounds__(256) void echo_spectral_kernel(int K, int L_whole, 
 // registers: echoGrid is written once (API output + covariance input) and never re-read by the range stage; txGrid is read
 // once.  HBM traffic of the launch = K L A 16 B written + K L A 16 B read (+ the CUT rows) -- the algorithmic minimum for
 // monoStaticSensing's output + fft2D's range-Doppler input.  Requires nIFFT == 4096 (the FFT the registers are laid out for).
-template <int QT, int NZ, int GROUP = (QT == 1 ? 8 : 4)>   // loads in flight per thread: 2 x GROUP elements (measured: 8 beats 4 by 6 % at Q = 1)
-__global__ __launch_bounds__(256, ISAC_ECHO_RANGE_WGS) void echo_range_kernel(int K, int L_whole, int L_out, int A, int Q_rt, const c64* __restrict__ D,
+template <int QT, int NZ, int GROUP = (QT <= 1 ? 4 : 2)>   // loads in flight per thread: 2 x GROUP elements
+__global__ __launch_bounds__(Fft4096W::NT, ISAC_ECHO_RANGE_WGS) void echo_range_kernel(int K, int L_whole, int L_out, int A, int Q_rt, const c64* __restrict__ D,
                                                             const c64* __restrict__ steer_rq, double sig, uint64_t seed,
                                                             const c64* __restrict__ noise, const c64* __restrict__ tw,
                                                             const c64* __restrict__ logtab_g, c64* __restrict__ grid,
@@ -329,7 +246,7 @@ __global__ __launch_bounds__(256, ISAC_ECHO_RANGE_WGS) void echo_range_kernel(in
                                                             int row_lo, int n_rows, c64* __restrict__ ymid) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);
-  using FFT = Fft4096;
+  using FFT = Fft4096W;
   const int tid = threadIdx.x;
   FFT fft;
   const int Q = QT ? QT : Q_rt;
@@ -338,23 +255,24 @@ __global__ __launch_bounds__(256, ISAC_ECHO_RANGE_WGS) void echo_range_kernel(in
   const long long colg = (long long)l + (long long)L_out * r;
   c64* lt = lds + FFT::LDS_ELEMS;
   if (NZ == 1 && tid < kLogTabSize) lt[tid] = logtab_g[tid];
-  fft.init_table(lds, tw, tid);                      // W256 (generator angle + second-pass twiddles); barrier inside
+  fft.init_table(lds, tw, tid);                      // W512 (generator angle table at stride 2, FFT twiddles); barrier inside
   c64* dst = grid + (long long)K * colg;
   const c64* ptx = txg + (long long)K * colg;
 #pragma unroll
   for (int j = 0; j < FFT::PER; ++j) fft.x[j] = mk(0.0, 0.0);       // ifft(., nIFFT, 1) zero-pads at the end
   struct TxWin { c64 tx; double w; };
-  spectral_echo_column<QT, NZ, GROUP>(tid, K, Q, D + (long long)K * l, (long long)K * L_whole, steer_rq + (long long)r * Q, sig, seed, colg,
-                                  NZ == 2 ? noise + (long long)K * colg : nullptr, lds + FFT::IMG, lt, fft.x,
-                                  [&](int kc) { return TxWin{ptx[kc], win_k[kc]}; },   // txGrid sample + range window, loads unconditional
-                                  [&](int, int k, c64 v, TxWin t) {
-                                    if (k < K) {
-                                      __builtin_nontemporal_store(v.re, &dst[k].re);   // echoGrid(k, l, r)
-                                      __builtin_nontemporal_store(v.im, &dst[k].im);
-                                    }
-                                    const c64 y = mul_conj(v, t.tx) * t.w;              // fft2D.m:37,:43 (same order as range_kernel)
-                                    return k < K ? y : mk(0.0, 0.0);                    // ifft(., nIFFT, 1) zero-pads at the end
-                                  });
+  spectral_echo_column<QT, NZ, GROUP, FFT::NT, FFT::kW256Stride>(
+      tid, K, Q, D + (long long)K * l, (long long)K * L_whole, steer_rq + (long long)r * Q, sig, seed, colg,
+      NZ == 2 ? noise + (long long)K * colg : nullptr, lds + FFT::IMG, lt, fft.x,
+      [&](int kc) { return TxWin{ptx[kc], win_k[kc]}; },   // txGrid sample + range window, loads unconditional
+      [&](int, int k, c64 v, TxWin t) {
+        if (k < K) {
+          __builtin_nontemporal_store(v.re, &dst[k].re);   // echoGrid(k, l, r)
+          __builtin_nontemporal_store(v.im, &dst[k].im);
+        }
+        const c64 y = mul_conj(v, t.tx) * t.w;              // fft2D.m:37,:43 (same order as range_kernel)
+        return k < K ? y : mk(0.0, 0.0);                    // ifft(., nIFFT, 1) zero-pads at the end
+      });
   fft.init_twiddles(tw, tid);
   fft.template transform<+1>(lds, tw, tid);
   c64* yd = ymid + (long long)n_rows * colg;
@@ -721,21 +639,7 @@ extern "C" int isac_mono_static_sensing_dev(isac_ctx* ctx, const isac_c64* d_tx_
 
 int isac_get_windows(isac_ctx* ctx, int K, int n_ifft, const double** win_k, const double** win_r);   // capi.hip
 
-template <class FFT, int QT = 0>
-static int launch_demod_range(isac_ctx* ctx, const OfdmGeom& g, long long T, int A, int L_whole, int L_out, const c64* tw, int Q,
-                              int noise_mode, const c64* noise, double n0s, uint64_t seed, c64* grid, const c64* txg,
-                              const double* wk, const double* wr, int n_ifft, int row_lo, int nr, c64* ymid) {
-  size_t lds = sizeof(c64) * (FFT::LDS_ELEMS + kLogTabSize);
-  const c64* logtab = nullptr;
-  ISAC_TRY(isac_get_logtab(ctx, &logtab));
-  auto kern = demod_range_kernel<FFT, QT>;
-  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
-  hipLaunchKernelGGL(kern, dim3((unsigned)(L_whole * A)), dim3(256), lds, ctx->stream, g, T, A, L_whole, L_out, tw, Q,
-                     (const c64*)ctx->coef.p, (const c64*)ctx->steer.p + (size_t)A * Q, (const c64*)ctx->phase_rx.p, noise_mode,
-                     noise, n0s, seed, grid, txg, wk, wr, 1.0 / n_ifft, std::sqrt((double)n_ifft), row_lo, nr, ymid, logtab);
-  ISAC_HIP(hipGetLastError());
-  return ISAC_OK;
-}
+int isac_range_stage_into_cache(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, const c64* d_rx, const c64* d_tx, int K, int L, int A);   // rdm.hip
 
 extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64* d_tx_wave, int64_t T, int32_t tx_dim_l,
                                                   const isac_carrier* carrier, const isac_radar_channel_params* rp,
@@ -756,14 +660,19 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
     return isac_mono_static_sensing_dev(ctx, d_tx_wave, T, tx_dim_l, carrier, rp, los, noise_mode, d_noise_unit, seed, d_echo_grid, l_out);
   if (noise_mode < ISAC_NOISE_NONE || noise_mode > ISAC_NOISE_INJECTED_SPECTRAL) return fail(ctx, ISAC_ERR_INVALID_ARG, "unknown noise mode");
   if (noise_mode == ISAC_NOISE_INJECTED_SPECTRAL && !d_noise_unit) return fail(ctx, ISAC_ERR_INVALID_ARG, "noise buffer missing");
-  int Q = 0, L_whole = 0;
   const bool spectral = spectral_mode(noise_mode);
-  if (spectral) {
-    ISAC_TRY(spectral_prepare(ctx, (const c64*)d_tx_wave, T, rp, los, g, &Q, &L_whole));
-  } else {
-    ISAC_TRY(prepare_echo(ctx, (const c64*)d_tx_wave, T, rp, los, &Q));
-    L_whole = whole_symbols(g, T);
+  if (!spectral) {
+    // time-domain noise modes (NONE / INJECTED / PHILOX per sample): the per-antenna demodulation kernel, then the range stage of the
+    // following fft2D launched right behind it -- same contract (cached range rows for isac_fft2d_submit_cached_dev), no fused kernel
+    // (the 256-thread demodulator and the 512-thread range transform do not share a workgroup shape; the fused time-domain kernel of
+    // round 1 was slower than the two launches anyway).
+    int32_t lo = 0;
+    ISAC_TRY(isac_mono_static_sensing_dev(ctx, d_tx_wave, T, tx_dim_l, carrier, rp, los, noise_mode, d_noise_unit, seed, d_echo_grid, &lo));
+    if (l_out) *l_out = lo;
+    return isac_range_stage_into_cache(ctx, ep, cf, (const c64*)d_echo_grid, (const c64*)d_tx_grid, g.n_sc, lo, rp->n_ants);
   }
+  int Q = 0, L_whole = 0;
+  ISAC_TRY(spectral_prepare(ctx, (const c64*)d_tx_wave, T, rp, los, g, &Q, &L_whole));
   const int A = rp->n_ants;
   if (L_whole <= 0) return fail(ctx, ISAC_ERR_SHORT_WAVEFORM, "waveform shorter than one OFDM symbol");
   const int L_out = L_whole < tx_dim_l ? tx_dim_l : L_whole;
@@ -779,16 +688,13 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
   ISAC_TRY(isac_get_twiddles(ctx, g.nfft, &tw));
   ISAC_TRY(isac_get_windows(ctx, g.n_sc, ep->n_ifft, &wk, &wr));
   const double n0s = std::sqrt(rp->n0 / 2.0);
-#define ISAC_FUSED_Q(QT) ISAC_TRY((launch_demod_range<Fft4096, QT>(ctx, g, T, A, L_whole, L_out, tw, Q, noise_mode, (const c64*)d_noise_unit, \
-                                                                   n0s, seed, (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, ep->n_ifft, \
-                                                                   row_lo, nr, (c64*)ctx->ymid.p)))
   if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));   // isac_profile_*: brackets exactly the fused kernel below
-  if (spectral) {
+  {
     const c64* logtab = nullptr;
     ISAC_TRY(isac_get_logtab(ctx, &logtab));
     const double sig = n0s * std::sqrt((double)g.nfft);
-    const size_t lds = sizeof(c64) * (Fft4096::LDS_ELEMS + kLogTabSize);
-    const dim3 gr((unsigned)spectral_grid_size(L_whole, A)), bl(256);
+    const size_t lds = sizeof(c64) * (Fft4096W::LDS_ELEMS + kLogTabSize);
+    const dim3 gr((unsigned)spectral_grid_size(L_whole, A)), bl(Fft4096W::NT);
     const c64* D = (const c64*)ctx->dgrid.p;
     const c64* srq = (const c64*)ctx->steer.p + (size_t)A * Q;
 #define ISAC_SPEC(QT, NZ)                                                                                                            \
@@ -804,10 +710,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
 #undef ISAC_SPEC_Q
 #undef ISAC_SPEC
     ISAC_HIP(hipGetLastError());
-  } else {
-    switch (Q) { case 1: ISAC_FUSED_Q(1); break; case 2: ISAC_FUSED_Q(2); break; case 3: ISAC_FUSED_Q(3); break; case 4: ISAC_FUSED_Q(4); break; default: ISAC_FUSED_Q(0); break; }
   }
-#undef ISAC_FUSED_Q
   if (ctx->profile) { ISAC_HIP(hipEventRecord(ctx->ev_k1, ctx->stream)); ctx->profile_recorded = true; }
   RangeCache& rc = ctx->range_cache;
   rc.rx = d_echo_grid; rc.tx = d_tx_grid; rc.K = g.n_sc; rc.L = L_out; rc.A = A; rc.n_ifft = ep->n_ifft; rc.row_lo = row_lo; rc.nr = nr;

@@ -126,13 +126,15 @@ __device__ __forceinline__ c64 philox_normal_pair_tab(uint64_t e, uint64_t seed,
 // Generator: ONE Philox4x32-10 call per PAIR of grid elements -- (o0, o1) -> element "half 0", (o2, o3) -> "half 1";
 // each Box-Muller transform takes a 32-bit radius uniform u1 = (o + 1) 2^-32 in (0, 1] and a 32-bit angle 2 pi o' 2^-32
 // (the resolution cuRAND's single-precision normals use; |z| <= sqrt(-2 ln 2^-32) = 6.66 sigma), evaluated in fp64.
-// Pairing (defined on the subcarrier index k only, so every kernel shape draws the same field):
-//   slot(k) = (k mod 256) + 256 * ((k div 256) div 2),  half(k) = (k div 256) mod 2,
+// Pairing (defined on the subcarrier index k only, so every kernel shape draws the same field): elements k and k + 512 share a call,
+//   slot(k) = (k mod 512) + 512 * ((k div 512) div 2),  half(k) = (k div 512) mod 2,
 //   counter = slot + 2048 * column,  column = l + L * a  (the grid's own column index),  key = seed, stream word = 2.
+// (A thread of a 256-thread kernel owns k = tid + 256 j and so both halves j, j + 2; a thread of the 512-thread kernel owns j, j + 1.)
 constexpr uint32_t kSpectralStream = 2u;
 constexpr int kSpectralSlotsPerColumn = 2048;
 
-__device__ __forceinline__ c64 box_muller32_tab(uint32_t ur, uint32_t ua, const c64* __restrict__ w256 /* LDS: exp(-2 pi j i / 256) */,
+template <int WSTRIDE = 1>
+__device__ __forceinline__ c64 box_muller32_tab(uint32_t ur, uint32_t ua, const c64* __restrict__ w256 /* LDS: exp(-2 pi j i / 256) at [WSTRIDE i] */,
                                                 const c64* __restrict__ logtab /* LDS: (1/c_i, ln c_i) */) {
   // ---- radius
   const double u1 = ((double)ur + 1.0) * 0x1.0p-32;                 // exact
@@ -161,7 +163,7 @@ __device__ __forceinline__ c64 box_muller32_tab(uint32_t ur, uint32_t ua, const 
   const double p2 = phi * phi;
   const double sphi = phi * ::fma(p2, ::fma(p2, ::fma(p2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
   const double cphi = ::fma(p2, ::fma(p2, ::fma(p2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
-  const c64 w = w256[i];                                             // (cos a, -sin a)
+  const c64 w = w256[WSTRIDE * i];                                   // (cos a, -sin a)
   const double c = ::fma(w.re, cphi, w.im * sphi);
   const double sn = ::fma(w.re, sphi, -w.im * cphi);
   return c64{rad * c, rad * sn};
@@ -188,30 +190,33 @@ __device__ __forceinline__ bool spectral_tile_map(int wg, int L_whole, int A, in
   return r < A && l < L_whole;
 }
 
-// One column's synthesis for 256 threads: thread `tid` owns the elements k = tid + 256 j, j = 0..15.  `acc[j]` receives
-// the unit noise first and then whatever emit(j, k, value, aux) returns for the element (the fused kernel keeps the
+// One column's synthesis for NT threads (256 or 512): thread `tid` owns the elements k = tid + NT j, j = 0..4096/NT - 1.  `acc[j]`
+// receives the unit noise first and then whatever emit(j, k, value, aux) returns for the element (the fused kernel keeps the
 // range-FFT input there, so the FFT's own register file is the only per-element storage):
 //   value = sum_q D_q[k] * s_q  (+ sig * unit noise);   emit stores it only when k < K.
 // NZ: 0 = noiseless, 1 = Philox spectral (above), 2 = injected unit noise column `nz`.
-// Memory-level parallelism is laid out by hand (a CU holds only two of the FFT kernel's workgroups, so every round trip
-// that is not overlapped shows up in the launch time): the loads of a GROUP of elements -- the caller's `pre(kc)` (e.g. the
-// txGrid sample and window) and the D values -- are issued one group ahead of their use, the first group before the
-// generator's VALU work.  GROUP bounds the registers held by loads in flight (GROUP x (4 Q + sizeof(pre)/4) VGPRs).
-template <int QT, int NZ, int GROUP, class PRE, class E>
+// Memory-level parallelism is laid out by hand: the loads of a GROUP of elements -- the caller's `pre(kc)` (e.g. the txGrid sample and
+// window) and the D values -- are issued one group ahead of their use, the first group before the generator's VALU work.  GROUP bounds
+// the registers held by loads in flight (2 x GROUP x (4 Q + sizeof(pre)/4) VGPRs).
+template <int QT, int NZ, int GROUP, int NT, int WSTRIDE, class PRE, class E>
 __device__ __forceinline__ void spectral_echo_column(int tid, int K, int Q_rt, const c64* __restrict__ Dl /* D + K*l */,
                                                      long long d_stride /* K * L_whole */, const c64* __restrict__ sr /* [Q] */,
                                                      double sig, uint64_t seed, long long column, const c64* __restrict__ nz,
-                                                     const c64* __restrict__ w256, const c64* __restrict__ logtab, c64 (&acc)[16],
+                                                     const c64* __restrict__ w256, const c64* __restrict__ logtab, c64 (&acc)[4096 / NT],
                                                      PRE&& pre, E&& emit) {
   constexpr int QM = QT ? QT : 1;
-  constexpr int NG = 16 / GROUP;
+  constexpr int PER = 4096 / NT;
+  constexpr int NG = PER / GROUP;
+  constexpr int NCALL = PER / 2;                                     // Philox calls per thread: one per element pair (k, k + 512)
+  constexpr int JSTEP = 512 / NT;                                    // the pair partner of element j is j + JSTEP
   const int Q = QT ? QT : Q_rt;
-  const int n_el = 2 * ((K + 511) / 512);                            // elements j < n_el exist for some thread (uniform)
+  const int n_el = (K + NT - 1) / NT;                                // elements j < n_el exist for some thread (uniform)
+  const int wave_k0 = __builtin_amdgcn_readfirstlane(tid & ~63);     // first subcarrier of this wavefront's run in element 0
   using Aux = decltype(pre(0));
   Aux aux[2][GROUP];
   c64 dv[2][GROUP][QM];
   c64 nzv[2][GROUP];
-  auto kc_of = [&](int j) { const int k = tid + 256 * j; return k < K ? k : K - 1; };   // unconditional loads, select afterwards
+  auto kc_of = [&](int j) { const int k = tid + NT * j; return k < K ? k : K - 1; };   // unconditional loads, select afterwards
   auto load_group = [&](int g, int b) {
 #pragma unroll
     for (int u = 0; u < GROUP; ++u) {
@@ -232,13 +237,14 @@ __device__ __forceinline__ void spectral_echo_column(int tid, int K, int Q_rt, c
   // ---- generator: VALU only, runs under the loads above
   if constexpr (NZ == 1) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      if (2 * p < n_el) {
-        const uint64_t ctr = (uint64_t)(tid + 256 * p) + (uint64_t)kSpectralSlotsPerColumn * (uint64_t)column;
+    for (int c = 0; c < NCALL; ++c) {
+      const int j0 = (NT == 512) ? 2 * c : 4 * (c / 2) + (c % 2), j1 = j0 + JSTEP;
+      if (wave_k0 + NT * j0 < K) {                                   // (wavefront-uniform) the wave's whole run of element j0 lies beyond K: nothing to draw
+        const uint64_t ctr = (uint64_t)(tid + NT * c) + (uint64_t)kSpectralSlotsPerColumn * (uint64_t)column;   // slot = tid + NT c
         uint32_t o[4];
         philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), kSpectralStream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
-        acc[2 * p] = box_muller32_tab(o[0], o[1], w256, logtab);
-        acc[2 * p + 1] = box_muller32_tab(o[2], o[3], w256, logtab);
+        acc[j0] = box_muller32_tab<WSTRIDE>(o[0], o[1], w256, logtab);
+        if (wave_k0 + NT * j1 < K) acc[j1] = box_muller32_tab<WSTRIDE>(o[2], o[3], w256, logtab);
       }
     }
   }
@@ -261,7 +267,7 @@ __device__ __forceinline__ void spectral_echo_column(int tid, int K, int Q_rt, c
         }
         if constexpr (NZ == 1) v = v + acc[j] * sig;
         if constexpr (NZ == 2) v = v + nzv[b][u] * sig;
-        acc[j] = emit(j, tid + 256 * j, v, aux[b][u]);
+        acc[j] = emit(j, tid + NT * j, v, aux[b][u]);
       }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -91,6 +91,7 @@ struct Fft4096 {
   static constexpr int SE = 17;   // second-digit stride
   static constexpr int IMG = 16 * SK;          // data image
   static constexpr int LDS_ELEMS = IMG + 256;  // + W256 table (second-pass twiddles and OFDM phase ramps)
+  static constexpr int kW256Stride = 1;
   c64 x[PER];
   c64 wb[4];  // W4096^(tid * {1,2,4,8}); the other first-pass twiddles are products of at most 4 of these
 
@@ -186,6 +187,137 @@ struct Fft4096 {
   __device__ __forceinline__ void release() { __syncthreads(); }
 };
 
+// 8-point DFT in registers, natural order in and out (decimation in frequency: one radix-2 stage with W8 twiddles, two DFT4s).
+template <int DIR>
+__device__ __forceinline__ void dft8(c64 (&x)[8]) {
+  constexpr double s = (DIR < 0) ? -1.0 : 1.0;       // forward W8 = (1 - j)/sqrt2, inverse its conjugate
+  const c64 u0 = x[0] + x[4], u1 = x[1] + x[5], u2 = x[2] + x[6], u3 = x[3] + x[7];
+  c64 v0 = x[0] - x[4], v1 = x[1] - x[5], v2 = x[2] - x[6], v3 = x[3] - x[7];
+  v1 = c64{(v1.re - s * v1.im) * kR2, (v1.im + s * v1.re) * kR2};        // * (1 + s j)/sqrt2
+  v2 = c64{-s * v2.im, s * v2.re};                                       // * (s j)
+  v3 = c64{(-v3.re - s * v3.im) * kR2, (s * v3.re - v3.im) * kR2};       // * (-1 + s j)/sqrt2
+  auto dft4 = [&](c64 a0, c64 a1, c64 a2, c64 a3, c64& o0, c64& o1, c64& o2, c64& o3) {
+    const c64 p0 = a0 + a2, p1 = a1 + a3, p2 = a0 - a2, d = a1 - a3;
+    const c64 p3 = c64{-s * d.im, s * d.re};                             // * (s j)
+    o0 = p0 + p1; o2 = p0 - p1; o1 = p2 + p3; o3 = p2 - p3;
+  };
+  dft4(u0, u1, u2, u3, x[0], x[2], x[4], x[6]);
+  dft4(v0, v1, v2, v3, x[1], x[3], x[5], x[7]);
+}
+
+// 4096 = 8^4 on 512 threads (8 wavefronts), 8 points per thread: half the registers per thread of Fft4096 and, with the same
+// 64 KB exchange image per column, twice the wavefronts per CU (two workgroups = four waves per SIMD) -- for kernels that do real
+// VALU work beside the transform (the fused echo-synthesis + range kernel).  x[j] = in[tid + 512 j] -> x[i] = OUT[tid + 512 i].
+// Index algebra (n = b + 512 a, b = 64 c + d, d = 8 f + g;  k = k1 + 8 e + 64 h + 512 i):
+//   pass 1  thread b:                DFT8 over a -> k1, twiddle W4096^(b k1)
+//   pass 2  thread (d, k1 = wave):   DFT8 over c -> e,  twiddle W512^(d e)      reads and writes the same LDS locations (in place)
+//   pass 3  thread (g, e, k1 = wave): DFT8 over f -> h, twiddle W64^(g h)
+//   pass 4  thread (k1, e, h = wave): DFT8 over g -> i
+// LDS images (complex slots, unpadded 4096), chosen so that every ds_write_b128 lane group (8 contiguous lanes, 32-bank modulus) and
+// every ds_read_b128 lane group (16 lanes, 64-bank modulus) touches distinct 16-byte slots:
+//   images 1 / 2:  512 k1 + 64 c + ((d + 8 (c & 1)) mod 64)            (c becomes e in place)
+//   image 3:       ((g + k1) mod 8) + 8 e + 64 h + 512 k1
+struct Fft4096W {
+  static constexpr int N = 4096;
+  static constexpr int NT = 512;
+  static constexpr int PER = 8;
+  static constexpr int IMG = 4096;
+  static constexpr int LDS_ELEMS = IMG + 512;        // + W512 table (second / third pass twiddles, OFDM phase ramps, the generator's angle table)
+  static constexpr int kW256Stride = 2;              // W256^i = table[2 i]
+  c64 x[PER];
+  c64 wb[3];                                         // W4096^(tid * {1, 2, 4})
+
+  __device__ __forceinline__ void init(c64* __restrict__ lds, const c64* __restrict__ tw, int tid) {
+    init_twiddles(tw, tid);
+    init_table(lds, tw, tid);
+  }
+  __device__ __forceinline__ void init_table(c64* __restrict__ lds, const c64* __restrict__ tw, int tid) {
+    lds[IMG + tid] = tw[8 * tid];                    // W512^tid
+    __syncthreads();
+  }
+  __device__ __forceinline__ void init_twiddles(const c64* __restrict__ tw, int tid) {
+    wb[0] = tw[tid];
+    wb[1] = tw[2 * tid];
+    wb[2] = tw[4 * tid];
+  }
+  __device__ __forceinline__ c64 phase_ramp(const c64* __restrict__ lds, const c64* __restrict__, int kb, int dshift) const {
+    return conj(lds[IMG + ((kb * (dshift >> 3)) & 511)]);       // exp(+2 pi j kb dshift / 4096), dshift a multiple of 8
+  }
+  template <int GROUP = 8, class F>
+  __device__ __forceinline__ void fill(F&& f, int tid) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      x[j] = f(tid + NT * j);
+      if ((j % GROUP) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  template <int GROUP = 8, class G>
+  __device__ __forceinline__ void drain(G&& g, int tid) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      g(tid + NT * j, x[j]);
+      if ((j % GROUP) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  template <int DIR>
+  __device__ __forceinline__ void transform(c64* __restrict__ lds, const c64* __restrict__, int tid) {
+    const c64* t512 = lds + IMG;
+    // ---- pass 1
+    dft8<DIR>(x);
+    {
+      const int c = tid >> 6, d = tid & 63;
+      c64* o = lds + 64 * c + ((d + 8 * (c & 1)) & 63);
+      const c64 w1 = tw_dir<DIR>(wb[0]), w2 = tw_dir<DIR>(wb[1]), w4 = tw_dir<DIR>(wb[2]);
+      const c64 w3 = w1 * w2;
+      o[0] = x[0];
+      o[512 * 1] = x[1] * w1;
+      o[512 * 2] = x[2] * w2;
+      o[512 * 3] = x[3] * w3;
+      o[512 * 4] = x[4] * w4;
+      o[512 * 5] = x[5] * (w4 * w1);
+      o[512 * 6] = x[6] * (w4 * w2);
+      o[512 * 7] = x[7] * (w4 * w3);
+    }
+    __syncthreads();
+    // ---- pass 2 (in place)
+    {
+      const int d = tid & 63, k1 = tid >> 6;
+      c64* base = lds + 512 * k1;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) x[c] = base[64 * c + ((d + 8 * (c & 1)) & 63)];
+      dft8<DIR>(x);
+      base[d] = x[0];
+#pragma unroll
+      for (int e = 1; e < 8; ++e) base[64 * e + ((d + 8 * (e & 1)) & 63)] = x[e] * tw_dir<DIR>(t512[d * e]);
+    }
+    __syncthreads();
+    // ---- pass 3
+    const int lo3 = tid & 7, e = (tid >> 3) & 7, hi = tid >> 6;
+    {
+      const int g = lo3, k1 = hi;
+      const c64* base = lds + 512 * k1 + 64 * e;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) x[f] = base[(8 * f + g + 8 * (e & 1)) & 63];
+      dft8<DIR>(x);
+      __syncthreads();                                             // every read of image 2 is done before image 3 overwrites it
+      c64* o = lds + ((g + k1) & 7) + 8 * e + 512 * k1;
+      o[0] = x[0];
+#pragma unroll
+      for (int h = 1; h < 8; ++h) o[64 * h] = x[h] * tw_dir<DIR>(t512[8 * g * h]);      // W64^(g h)
+    }
+    __syncthreads();
+    // ---- pass 4
+    {
+      const int k1 = lo3, h = hi;
+      const c64* base = lds + 8 * e + 64 * h + 512 * k1;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) x[g] = base[(g + k1) & 7];
+      dft8<DIR>(x);
+    }
+  }
+  __device__ __forceinline__ void release() { __syncthreads(); }
+};
+
 template <int N_>
 struct FftStockham {
   static constexpr int N = N_;
@@ -251,6 +383,19 @@ struct FftStockham {
   }
   __device__ __forceinline__ void release() { __syncthreads(); }
 };
+
+// Range stage of fft2D (rdm.hip range_kernel, echo.hip echo_range_kernel): the 512-thread transform at 4096 points.
+#define ISAC_FFT_DISPATCH_RANGE(nfft, CALL)             \
+  switch (nfft) {                                       \
+    case 4096: { using FFT = isac::Fft4096W; CALL; } break;         \
+    case 2048: { using FFT = isac::FftStockham<2048>; CALL; } break; \
+    case 1024: { using FFT = isac::FftStockham<1024>; CALL; } break; \
+    case 512: { using FFT = isac::FftStockham<512>; CALL; } break;   \
+    case 256: { using FFT = isac::FftStockham<256>; CALL; } break;   \
+    case 128: { using FFT = isac::FftStockham<128>; CALL; } break;   \
+    case 64: { using FFT = isac::FftStockham<64>; CALL; } break;     \
+    default: return isac::fail(ctx, ISAC_ERR_UNSUPPORTED, "FFT length must be a power of two in 64..4096"); \
+  }
 
 // Dispatch a callable templated on the FFT policy for a runtime power-of-two length.
 #define ISAC_FFT_DISPATCH(nfft, CALL)                   \

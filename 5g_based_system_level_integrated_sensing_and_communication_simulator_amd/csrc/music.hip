@@ -87,44 +87,75 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
     colp[b] = G + N * (long long)(colok[b] ? a : 0);
   }
   const long long lane_off = 4 * kq + SPL * phase;              // first sample of this lane inside a slab
-  auto load = [&](c64 (&dst)[NB][SPL], long long slab) {
+  // Loads are unconditional (clamped indices) and the out-of-range mask is applied when a slab is CONSUMED, not when it is loaded: a
+  // select at load time makes the compiler predicate the loads (branches + `s_waitcnt vmcnt(0)` before the MFMAs), a multiply at load time
+  // waits for the data right away -- either way the prefetch of the next slab would not fly under the current slab's MFMAs (ISA-checked).
+  auto load_raw = [&](c64 (&dst)[NB][SPL], long long slab) {
     const long long n0 = slab * 16 + lane_off;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int e = 0; e < SPL; ++e) {
         long long n = n0 + e;
-        const bool ok = (n < N) && colok[b];
         if (n >= N) n = N - 1;
-        c64 v = colp[b][n];
-        dst[b][e] = ok ? v : mk(0.0, 0.0);
+        dst[b][e] = colp[b][n];
       }
   };
-  auto mfmas = [&](const c64 (&cur)[NB][SPL]) {
-    static_for<0, NT>([&](auto uc) {
-      constexpr int u = decltype(uc)::value;
-      constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);   // row-major upper-triangular tile order
+  auto mask = [&](c64 (&v)[NB][SPL], long long slab) {               // padding antennas and samples past N contribute 0
+    const long long n0 = slab * 16 + lane_off;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int e = 0; e < SPL; ++e) {
-        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].re, re[u], 0, 0, 0);
-        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].im, re[u], 0, 0, 0);
-        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].im, im[u], 0, 0, 0);
-        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cur[I][e].im, cur[J][e].re, im[u], 0, 0, 0);
+        const double m = ((n0 + e < N) && colok[b]) ? 1.0 : 0.0;
+        v[b][e] = mk(v[b][e].re * m, v[b][e].im * m);
       }
-    });
+  };
+  // Issue order: the four products of a k-step are issued tile by tile in four sweeps, so that two MFMAs into the same accumulator are
+  // 2 NT issues apart -- back-to-back dependent v_mfma_f64_16x16x4 stall for the 64-cycle pass of their predecessor.
+  auto mfmas = [&](const c64 (&cur)[NB][SPL]) {
+#pragma unroll
+    for (int e = 0; e < SPL; ++e) {
+      static_for<0, NT>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);   // row-major upper-triangular tile order
+        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].re, re[u], 0, 0, 0);
+      });
+      static_for<0, NT>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);
+        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].im, im[u], 0, 0, 0);
+      });
+      static_for<0, NT>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);
+        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].im, re[u], 0, 0, 0);
+      });
+      static_for<0, NT>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);
+        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cur[I][e].im, cur[J][e].re, im[u], 0, 0, 0);
+      });
+    }
   };
   if constexpr (DB) {
     // register double buffer: the loads of slab s+1 fly under the MFMAs of slab s
     c64 cur[NB][SPL], nxt[NB][SPL];
-    if (s_begin < s_end) load(cur, s_begin);
+    if (s_begin < s_end) { load_raw(cur, s_begin); mask(cur, s_begin); }
     for (long long slab = s_begin; slab < s_end; ++slab) {
       if constexpr (BAR) __builtin_amdgcn_s_barrier();
-      if (slab + 1 < s_end) load(nxt, slab + 1);
+      // the prefetch is unconditional (the last iteration re-reads its own slab): a branch around the loads makes the compiler's
+      // vmcnt bookkeeping pessimistic and the wait for THIS slab's data would also wait for the prefetch
+      const long long nx = slab + 1 < s_end ? slab + 1 : slab;
+      load_raw(nxt, nx);
+      __builtin_amdgcn_sched_barrier(0);
       mfmas(cur);
+      __builtin_amdgcn_sched_barrier(0);              // the wait for the next slab's data belongs AFTER this slab's MFMAs have been issued
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int e = 0; e < SPL; ++e) cur[b][e] = nxt[b][e];
+      mask(cur, nx);
     }
   } else {
     for (long long slab = s_begin; slab < s_end; ++slab) {
@@ -132,7 +163,8 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
       // shared through L1/L2 (without this the waves drift apart and rocprof FETCH_SIZE doubles)
       if constexpr (BAR) __builtin_amdgcn_s_barrier();
       c64 cur[NB][SPL];
-      load(cur, slab);
+      load_raw(cur, slab);
+      mask(cur, slab);
       mfmas(cur);
     }
   }

@@ -20,7 +20,7 @@ namespace isac {
 
 // ---------------------------------------------------------------- range: conj-multiply + window + IFFT, keep needed rows
 template <class FFT>
-__global__ __launch_bounds__(256, 2) void range_kernel(const c64* __restrict__ rx, const c64* __restrict__ tx, int K, int L,
+__global__ __launch_bounds__(FFT::NT, 2) void range_kernel(const c64* __restrict__ rx, const c64* __restrict__ tx, int K, int L,
                                                        int A, const c64* __restrict__ tw, const double* __restrict__ win_k,
                                                        const double* __restrict__ win_r /* fftshift(kaiser(nIFFT)) */,
                                                        double inv_n, double sqrt_n, int row_lo, int n_rows,
@@ -353,7 +353,7 @@ static int launch_range(isac_ctx* ctx, hipStream_t st, const c64* rx, const c64*
   size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
   auto kern = range_kernel<FFT>;
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
-  hipLaunchKernelGGL(kern, dim3(fft_grid2(L * A)), dim3(256), lds, st, rx, tx, K, L, A, tw, wk, wr, 1.0 / n_ifft,
+  hipLaunchKernelGGL(kern, dim3(fft_grid2(L * A)), dim3(FFT::NT), lds, st, rx, tx, K, L, A, tw, wk, wr, 1.0 / n_ifft,
                      std::sqrt((double)n_ifft), row_lo, n_rows, ymid);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
@@ -389,7 +389,7 @@ int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_c
       return fail(ctx, ISAC_ERR_INVALID_ARG, "fft2d_submit_cached: no range rows cached for these grids / parameters on this context "
                                               "(call isac_mono_static_sensing_fused_dev with the same echoGrid, txGrid, est and cfar blocks first)");
     if (!use_cached_range)
-      ISAC_FFT_DISPATCH(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, d_rx, d_tx, K, L, A, tw, wk, wr, n_ifft, row_lo, nr,
+      ISAC_FFT_DISPATCH_RANGE(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, d_rx, d_tx, K, L, A, tw, wk, wr, n_ifft, row_lo, nr,
                                                             (c64*)ctx->ymid.p))));
   }
   const int Lu = L < n_fft ? L : n_fft;
@@ -493,6 +493,27 @@ extern "C" int isac_cfar2d_ca(isac_ctx* ctx, const double* P, int32_t n_rows, in
 // Range stage alone (conj-multiply + Kaiser window + nIFFT-point IFFT + row selection + range-axis
 // window, fft2D.m:37-45) for every (symbol, antenna) column -- the dominant HBM-bound kernel of fft2D;
 // exposed so bench.py can time exactly this launch with HIP events for the roofline entry.
+// Range stage into the context's cache (used by the fused echo entry for the time-domain noise modes): the rows the next
+// isac_fft2d_submit_cached_dev on the same grids consumes.
+int isac_range_stage_into_cache(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, const c64* d_rx, const c64* d_tx, int K,
+                                int L, int A) {
+  const int n_ifft = ep->n_ifft;
+  const int hr = cf->guard[0] + cf->train[0];
+  const int row_lo = cf->row0 - 1 - hr, row_hi = cf->row1 - 1 + hr;
+  if (row_lo < 0 || row_hi >= n_ifft) return fail(ctx, ISAC_ERR_CFAR_WINDOW, "CUT training window exceeds the range-Doppler map");
+  const int nr = row_hi - row_lo + 1;
+  const c64* tw = nullptr;
+  const double *wk = nullptr, *wr = nullptr;
+  ISAC_TRY(isac_get_twiddles(ctx, n_ifft, &tw));
+  ISAC_TRY(isac_get_windows(ctx, K, n_ifft, &wk, &wr));
+  ISAC_TRY(ensure(ctx, ctx->ymid, sizeof(c64) * (size_t)nr * L * A));
+  ISAC_FFT_DISPATCH_RANGE(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, d_rx, d_tx, K, L, A, tw, wk, wr, n_ifft, row_lo, nr, (c64*)ctx->ymid.p))));
+  RangeCache& rc = ctx->range_cache;
+  rc.rx = d_rx; rc.tx = d_tx; rc.K = K; rc.L = L; rc.A = A; rc.n_ifft = n_ifft; rc.row_lo = row_lo; rc.nr = nr;
+  rc.valid = true;
+  return ISAC_OK;
+}
+
 extern "C" int isac_fft2d_range_stage_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf,
                                           const isac_c64* d_rx_grid, const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A) {
   ISAC_ENTER(ctx);
@@ -508,7 +529,7 @@ extern "C" int isac_fft2d_range_stage_dev(isac_ctx* ctx, const isac_est_params* 
   ISAC_TRY(isac_get_twiddles(ctx, n_ifft, &tw));
   ISAC_TRY(isac_get_windows(ctx, K, n_ifft, &wk, &wr));
   ISAC_TRY(ensure(ctx, ctx->ymid, sizeof(c64) * (size_t)nr * L * A));
-  ISAC_FFT_DISPATCH(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, (const c64*)d_rx_grid, (const c64*)d_tx_grid, K, L, A, tw,
+  ISAC_FFT_DISPATCH_RANGE(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, (const c64*)d_rx_grid, (const c64*)d_tx_grid, K, L, A, tw,
                                                         wk, wr, n_ifft, row_lo, nr, (c64*)ctx->ymid.p))));
   return ISAC_OK;
 }
@@ -526,7 +547,7 @@ extern "C" int isac_rdm_plane_dev(isac_ctx* ctx, const isac_est_params* ep, cons
   ISAC_TRY(ensure(ctx, ctx->stage_a, sizeof(c64) * (size_t)n_ifft * L));
   const c64* rx = (const c64*)d_rx_grid + (size_t)K * L * ant;
   const c64* tx = (const c64*)d_tx_grid + (size_t)K * L * ant;
-  ISAC_FFT_DISPATCH(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, rx, tx, K, L, 1, tw, wk, wr, n_ifft, 0, n_ifft,
+  ISAC_FFT_DISPATCH_RANGE(n_ifft, ISAC_TRY((launch_range<FFT>(ctx, ctx->stream, rx, tx, K, L, 1, tw, wk, wr, n_ifft, 0, n_ifft,
                                                         (c64*)ctx->stage_a.p))));
   hipLaunchKernelGGL(doppler_full_kernel, dim3(cdiv((long long)n_ifft * n_fft, 256)), dim3(256), 0, ctx->stream,
                      (const c64*)ctx->stage_a.p, n_ifft, L, n_fft, twd, std::sqrt((double)n_fft), (c64*)d_rdm);

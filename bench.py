@@ -358,12 +358,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prime-ms", type=float, default=300.0, help="untimed device priming (hot-path steps) before the warm-up steps; 0 = none")
     args = ap.parse_args()
-    # eigensolver trade-off (music.hip isac_eigh_dev): with several CPIs in flight the one-workgroup Jacobi solver (1.4 ms at
-    # A = 64, hidden behind the other CPIs, one CU) gives a 3-5 % higher rate than the latency-optimised tridiagonal pipeline
-    # (0.9 ms, up to five CUs); a blocking caller (--inflight 1, the reference's call order) gets the pipeline
-    if args.inflight > 1:
-        os.environ.setdefault("ISAC_EIG_JACOBI_MAX", "64")
-
+    # (round 1 selected the one-CU Jacobi eigensolver for pipelined runs; with this round's kernels the library default -- the tridiagonal
+    # pipeline above 16 antennas -- is as fast or faster pipelined and 0.7 ms shorter in the drain tail: no override any more)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_torchrun(args.gpus))
     rank = int(os.environ.get("RANK", "0"))

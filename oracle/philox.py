@@ -64,13 +64,14 @@ def philox_normal_pairs(elem_index, seed: int, stream: int = 0) -> np.ndarray:
 def philox_spectral_noise(n_sc: int, n_sym: int, n_ants: int, seed: int) -> np.ndarray:
     """Unit complex normals W [n_sc x n_sym x n_ants] of the spectral noise mode.
 
-    Element (k, l, a), column = l + n_sym * a:  slot = (k mod 256) + 256 * ((k div 256) div 2),
-    half = (k div 256) mod 2;  Philox4x32-10 counter = (slot + 2048 * column as 64 bits, stream word 2, 0), key = seed;
+    Element (k, l, a), column = l + n_sym * a:  slot = (k mod 512) + 512 * ((k div 512) div 2),
+    half = (k div 512) mod 2  (elements k and k + 512 share a call);  Philox4x32-10 counter = (slot + 2048 * column as 64 bits,
+    stream word 2, 0), key = seed;
     outputs (o[2 half], o[2 half + 1]) -> u1 = (o + 1) 2^-32 in (0, 1], theta = 2 pi o' 2^-32;
     W = sqrt(-2 ln u1) (cos theta + j sin theta)."""
     k = np.arange(n_sc, dtype=np.uint64)
-    slot = (k % np.uint64(256)) + np.uint64(256) * ((k // np.uint64(256)) // np.uint64(2))
-    half = ((k // np.uint64(256)) % np.uint64(2)).astype(np.int64)
+    slot = (k % np.uint64(512)) + np.uint64(512) * ((k // np.uint64(512)) // np.uint64(2))
+    half = ((k // np.uint64(512)) % np.uint64(2)).astype(np.int64)
     col = np.arange(n_sym * n_ants, dtype=np.uint64)
     ctr = slot[:, None] + np.uint64(2048) * col[None, :]
     x = philox4x32_10((ctr & _MASK).astype(np.uint32), (ctr >> np.uint64(32)).astype(np.uint32), np.uint32(2), np.uint32(0),

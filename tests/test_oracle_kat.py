@@ -286,9 +286,9 @@ def test_spectral_philox_noise_statistics():
     for ax in range(3):
         a = np.moveaxis(w, ax, 0)
         assert abs((a[1:] * np.conj(a[:-1])).mean()) < 2 * tol
-    # the two halves of one Philox call (elements k and k + 256 inside an even/odd 256-block pair) are uncorrelated
-    assert abs((w[0:256] * np.conj(w[256:512])).mean()) < 10 / np.sqrt(256 * 28 * 8)
-    assert abs((np.abs(w[0:256]) ** 2 * np.abs(w[256:512]) ** 2).mean() / 4.0 - 1.0) < 0.05
+    # the two halves of one Philox call (elements k and k + 512) are uncorrelated
+    assert abs((w[0:512] * np.conj(w[512:1024])).mean()) < 10 / np.sqrt(512 * 28 * 8)
+    assert abs((np.abs(w[0:512]) ** 2 * np.abs(w[512:1024]) ** 2).mean() / 4.0 - 1.0) < 0.05
     # tail: the radius never exceeds the 32-bit Box-Muller bound sqrt(-2 ln 2^-32)
     assert np.abs(w).max() <= np.sqrt(-2 * np.log(2.0 ** -32)) + 1e-12
     assert np.array_equal(w, O.philox_spectral_noise(3276, 28, 8, 0x5EED0002)) and not np.array_equal(w, O.philox_spectral_noise(3276, 28, 8, 1))

@@ -16,6 +16,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rm -rf /tmp/q6 && ISAC_SINGLE_STREAM=1 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES -d /tmp/q6 -- $B --steps 3 --warmup 1 > /dev/null 2>&1
 $PS $(db /tmp/q6) --pmc --csv $OUT/${TAG}_pmc_valu_busy.csv > /dev/null
+rm -rf /tmp/q7 && ISAC_SINGLE_STREAM=1 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS -d /tmp/q7 -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+$PS $(db /tmp/q7) --pmc --csv $OUT/${TAG}_pmc_lds.csv > /dev/null
+rm -rf /tmp/q8 && ISAC_SINGLE_STREAM=1 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES -d /tmp/q8 -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+$PS $(db /tmp/q8) --pmc --csv $OUT/${TAG}_pmc_wait.csv > /dev/null
+grep -E "echo_range|range_kernel" $OUT/${TAG}_pmc_lds.csv $OUT/${TAG}_pmc_wait.csv | sed 's/_ZN4isac//; s/ILi[^"]*kd"/"/; s/INS_[^"]*kd"/"/' | cut -c1-160
 head -14 $OUT/${TAG}_kernel_stats_single_stream.txt
 grep -E "echo_range|range_kernel|cov_mfma|beamsum" $OUT/${TAG}_pmc_fetch_size.csv $OUT/${TAG}_pmc_write_size.csv | cut -c1-220
 grep -E "echo_range" $OUT/${TAG}_pmc_valu_busy.csv | cut -c1-220

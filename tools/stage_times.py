@@ -37,9 +37,12 @@ def fft2d():
 ra = ctx.empty((cell.A, cell.A))
 def cov(): ctx.check(lib.isac_covariance_dev(ctx.handle, C.c_void_p(echo.ptr), C.c_int64(cell.K * cell.Lsym), C.c_int32(cell.A), C.c_void_p(ra.ptr)))
 h = np.asfortranarray(np.eye(cell.A) + 0j); w = np.zeros(cell.A)
+_m = importlib.import_module(bench.PKG + ".sensing.estimation.fft2D"); _mm = importlib.import_module(bench.PKG + ".sensing._marshal")
+_cf = _m._cfar_block(cell.cfar); _ep = _mm.est_block(cell.rp)
+def range_stage(): ctx.check(lib.isac_fft2d_range_stage_dev(ctx.handle, C.byref(_ep), C.byref(_cf), C.c_void_p(echo.ptr), C.c_void_p(cell.tx_grid.ptr), cell.K, cell.Lsym, cell.A))
 def eig():
     hh = ra.numpy(); ctx.check(lib.isac_eigh(ctx.handle, hh.ctypes.data_as(C.c_void_p), C.c_int32(cell.A), w.ctypes.data_as(C.c_void_p), None))
 for name, fn in [("mono spectral philox (unfused)", mono_spec), ("mono spectral philox + range (fused)", mono_spec_fused), ("mono time philox + range (fused)", mono_time_fused),
-                 ("fused CPI: mono+range, cached fft2D", fused_cpi), ("monoStaticSensing (time philox)", mono), ("monoStaticSensing (no noise)", mono_nonoise), ("fft2D (all)", fft2d), ("covariance", cov), ("eigh (incl. H2D/D2H)", eig), ("whole step", cell.step)]:
+                 ("fused CPI: mono+range, cached fft2D", fused_cpi), ("monoStaticSensing (time philox)", mono), ("monoStaticSensing (no noise)", mono_nonoise), ("fft2D (all)", fft2d), ("range stage alone (range_kernel)", range_stage), ("covariance", cov), ("eigh (incl. H2D/D2H)", eig), ("whole step", cell.step)]:
     mn, med, wall = timed(fn)
     print(f"{name:32s} gpu min {mn:8.3f} ms  median {med:8.3f} ms   host wall median {wall:8.3f} ms")
