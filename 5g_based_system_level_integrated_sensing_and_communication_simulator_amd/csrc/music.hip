@@ -1197,6 +1197,7 @@ static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long lo
   ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * ((size_t)n_part + 32) * P::kTiles * 2 * 256));
   // register double buffer, no per-slab barrier, three workgroups per CU: 0.303 ms at A = 64 (barrier + single buffer 0.325;
   // the barrier kept the four waves on one slab so that it was fetched once -- with the prefetch they stay close enough)
+  // (with the per-slab barrier back on top of the prefetch: isolated 0.27 ms, but 9-11 % lower pipelined rate -- rejected)
   hipLaunchKernelGGL((cov_mfma_small_kernel<NB, true, false, 3>), dim3((unsigned)gx), dim3(256), 0, st, G, N, A, per, (double*)ctx->cov_part.p);
   ISAC_HIP(hipGetLastError());
   const int S = 32;

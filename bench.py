@@ -430,6 +430,13 @@ def main():
         cell.profile_sink = None
     dom_ms_timed = float(np.mean(sink)) if sink else None                       # fused kernel, launches of the timed region (other CPIs co-running)
     dom_ms_iso = cells[0].time_dominant_kernel_isolated() if (rank == 0 and args.fuse) else None
+    blocking_ms = None
+    if rank == 0:                                            # latency of one blocking CPI (submit + collect, nothing else in flight)
+        cells[0].step()
+        tb = time.perf_counter()
+        for _ in range(3):
+            cells[0].step()
+        blocking_ms = 1e3 * (time.perf_counter() - tb) / 3
     stages = stage_table(cells[0]) if rank == 0 else []
     # per-cell result record gather -- the only collective (KB-scale, RCCL over xGMI); max over ranks of the timed region
     recs = np.array([d.make_record(cid, cell.last, dt) for cid, cell in zip(my_cells, cells)]).reshape(-1, d.RECORD_LEN)
@@ -445,6 +452,9 @@ def main():
             "metric": "sensing slots/sec (CDL echo->2D-FFT->2D-CFAR)", "value": round(slots / dt, 2), "unit": "sensing slots/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "strong" if args.cells > 0 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "pipeline": {"cpis_in_flight": args.inflight, "blocking_cpi_ms": None if blocking_ms is None else round(blocking_ms, 3),
+                         "note": "the timed region starts with an empty device and ends fully drained: its K steps include one pipeline fill and "
+                                 "one drain (about one blocking CPI latency in total); steady-state rate = the same command with --steps 100"},
             "priming": {"untimed_steps_before_warmup": prime_steps, "ms": round(prime_ms, 1),
                         "why": "idle GPU ramps to sustained clocks; timed region = exactly `steps` CPIs between barriers"},
             "config": {"workload": f"{(str(args.cells) + ' cells round-robin over the ranks') if args.cells > 0 else (str(args.cells_per_gpu) + ' cell(s)/GPU')}, {args.ants}-antenna ULA echo -> 2D-FFT -> 2D-CFAR -> MUSIC, "
