@@ -261,6 +261,7 @@ __global__ __launch_bounds__(Fft4096W::NT, ISAC_ECHO_RANGE_WGS) void echo_range_
 #pragma unroll
   for (int j = 0; j < FFT::PER; ++j) fft.x[j] = mk(0.0, 0.0);       // ifft(., nIFFT, 1) zero-pads at the end
   struct TxWin { c64 tx; double w; };
+  bool live = false;                                       // any non-zero (or NaN) matched-filter sample in this column?
   spectral_echo_column<QT, NZ, GROUP, FFT::NT, FFT::kW256Stride>(
       tid, K, Q, D + (long long)K * l, (long long)K * L_whole, steer_rq + (long long)r * Q, sig, seed, colg,
       NZ == 2 ? noise + (long long)K * colg : nullptr, lds + FFT::IMG, lt, fft.x,
@@ -270,12 +271,20 @@ __global__ __launch_bounds__(Fft4096W::NT, ISAC_ECHO_RANGE_WGS) void echo_range_
           __builtin_nontemporal_store(v.re, &dst[k].re);   // echoGrid(k, l, r)
           __builtin_nontemporal_store(v.im, &dst[k].im);
         }
-        const c64 y = mul_conj(v, t.tx) * t.w;              // fft2D.m:37,:43 (same order as range_kernel)
-        return k < K ? y : mk(0.0, 0.0);                    // ifft(., nIFFT, 1) zero-pads at the end
+        c64 y = mul_conj(v, t.tx) * t.w;                    // fft2D.m:37,:43 (same order as range_kernel)
+        y = k < K ? y : mk(0.0, 0.0);                       // ifft(., nIFFT, 1) zero-pads at the end
+        live |= (y.re != 0.0) | (y.im != 0.0);
+        return y;
       });
+  c64* yd = ymid + (long long)n_rows * colg;
+  // Columns of the zero-filled 'S' slots (gNBPhy.m:609-612): rx .* conj(0) is identically zero and so is its IFFT.  Decided on
+  // the products themselves, so the shortcut is exact for any input (NaN / Inf products compare unequal to zero).
+  if (!__syncthreads_or(live)) {
+    for (int rr = tid; rr < n_rows; rr += FFT::NT) yd[rr] = mk(0.0, 0.0);
+    return;
+  }
   fft.init_twiddles(tw, tid);
   fft.template transform<+1>(lds, tw, tid);
-  c64* yd = ymid + (long long)n_rows * colg;
   fft.drain(
       [&](int n, c64 v) {
         const int rr = n - row_lo;

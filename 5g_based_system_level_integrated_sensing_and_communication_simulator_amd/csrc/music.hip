@@ -33,10 +33,16 @@ __device__ __forceinline__ void tile_ij(int t, int nb, int& I, int& J) {
 
 // ---- specialised schedule for A <= 64 (NB = ceil(A/16) <= 4 antenna blocks): every wave keeps ALL blocks'
 // operands of its samples in registers and owns a static group of <= 5 output tiles, so the four waves of a
-// workgroup issue exactly the same number of MFMAs (balanced SIMDs), share one 16-sample x A slab through
-// L1, and the next slab is prefetched under the current slab's MFMAs.
-//   wave = (tile group g, sample phase s):  NB=4: 2 groups x 2 phases,  NB=3: 2 x 2,  NB=2: 1 x 4,  NB=1: 1 x 4
-//   lane (i = lane&15, kq = lane>>4) holds samples  n0 + (16/S) ... see smp() below.
+// workgroup issue exactly the same number of MFMAs (balanced SIMDs), and the next slab is prefetched under the
+// current slab's MFMAs.
+//   wave = (tile group g, sample phase p):  NB=4: 2 groups x 2 phases,  NB=3: 2 x 2,  NB=2: 1 x 4,  NB=1: 1 x 4
+//   phase p owns the contiguous samples [16 p / kPhases, 16 (p + 1) / kPhases) of a 16-sample slab -- at two phases one whole
+//   128-byte line per antenna, requested by the two tile groups of that phase only; lane (i = lane&15, kq = lane>>4) holds
+//   kSamplesPerLane consecutive samples of antenna 16 b + i in every block b.
+// Three real MFMAs per tile and k-step instead of four (3M / Gauss form, see cov_group_body): 30 instead of 40 per four samples
+// at A = 64.  Measured at A = 64 (733 824 samples): 4M, interleaved sample map, 3 workgroups per CU 276 us / 1.37 GB fetched;
+// 3M + line map, 2 workgroups per CU 209 us / 1.05 GB; + a workgroup barrier every 8 slabs 215 us / 0.73 GB (= the input, once).
+constexpr int kCovSyncSlabs = 8;                                // power of two
 template <int NB>
 struct CovPlan {
   static constexpr int kTiles = NB * (NB + 1) / 2;
@@ -64,7 +70,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int NB, int GRP, bool DB, bool BAR>
+template <int NB, int GRP>
 __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long long N, int A, int n_tiles, int phase, int lane,
                                                long long s_begin, long long s_end, int part_index,
                                                double* __restrict__ part) {
@@ -73,10 +79,14 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
   constexpr int NT = (T0 + P::kPerGroup <= P::kTiles) ? P::kPerGroup : (P::kTiles - T0);
   constexpr int SPL = P::kSamplesPerLane;
   const int li = lane & 15, kq = lane >> 4;
-  // Re += Gr_I Gr_J + Gi_I Gi_J ;  Im += Gr_I Gi_J + (-Gi_I) Gr_J   (one accumulator each: 16 VGPRs per tile)
-  v4f64 re[NT], im[NT];
+  // 3M form: three real products per tile and k-step --
+  //   off-diagonal tile:  S1 += Gr_I Gr_J,  S2 += Gi_I Gi_J,  S3 += (Gr_I - Gi_I)(Gr_J + Gi_J)  =>  Re = S1 + S2,  Im = (S3 - S1) + S2
+  //   diagonal tile    :  Re += Gr Gr + Gi Gi,  M += Gr Gi  =>  Im = M - M^T, formed by the reducer (exactly antisymmetric)
+  // re = S1 (or Re), im = S2 (or M), s3 = S3 (off-diagonal tiles only; the unused ones are dead code).  The cancellation in Im is
+  // against terms of the size of the tile's own entries (|S1|, |S2| <~ |Re|): errors stay at a few ulp of the matrix norm.
+  v4f64 re[NT], im[NT], s3[NT];
 #pragma unroll
-  for (int u = 0; u < NT; ++u) re[u] = im[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+  for (int u = 0; u < NT; ++u) re[u] = im[u] = s3[u] = v4f64{0.0, 0.0, 0.0, 0.0};
   // column pointers of this lane's antenna in each block (clamped: loads stay unconditional)
   const c64* colp[NB];
   bool colok[NB];
@@ -86,7 +96,7 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
     colok[b] = a < A;
     colp[b] = G + N * (long long)(colok[b] ? a : 0);
   }
-  const long long lane_off = 4 * kq + SPL * phase;              // first sample of this lane inside a slab
+  const long long lane_off = (16 / P::kPhases) * phase + SPL * kq;   // first sample of this lane inside a slab (see above)
   // Loads are unconditional (clamped indices) and the out-of-range mask is applied when a slab is CONSUMED, not when it is loaded: a
   // select at load time makes the compiler predicate the loads (branches + `s_waitcnt vmcnt(0)` before the MFMAs), a multiply at load time
   // waits for the data right away -- either way the prefetch of the next slab would not fly under the current slab's MFMAs (ISA-checked).
@@ -116,6 +126,9 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
   auto mfmas = [&](const c64 (&cur)[NB][SPL]) {
 #pragma unroll
     for (int e = 0; e < SPL; ++e) {
+      double dm[NB], sp[NB];                          // Gr - Gi (row operand), Gr + Gi (column operand)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { dm[b] = cur[b][e].re - cur[b][e].im; sp[b] = cur[b][e].re + cur[b][e].im; }
       static_for<0, NT>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);   // row-major upper-triangular tile order
@@ -124,26 +137,25 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
       static_for<0, NT>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);
-        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].im, im[u], 0, 0, 0);
+        if constexpr (I == J) im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].im, im[u], 0, 0, 0);
+        else                  im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].im, im[u], 0, 0, 0);
       });
       static_for<0, NT>([&](auto uc) {
         constexpr int u = decltype(uc)::value;
         constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);
-        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].im, re[u], 0, 0, 0);
-      });
-      static_for<0, NT>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);
-        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-cur[I][e].im, cur[J][e].re, im[u], 0, 0, 0);
+        if constexpr (I == J) re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].im, re[u], 0, 0, 0);
+        else                  s3[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(dm[I], sp[J], s3[u], 0, 0, 0);
       });
     }
   };
-  if constexpr (DB) {
+  {
     // register double buffer: the loads of slab s+1 fly under the MFMAs of slab s
     c64 cur[NB][SPL], nxt[NB][SPL];
     if (s_begin < s_end) { load_raw(cur, s_begin); mask(cur, s_begin); }
     for (long long slab = s_begin; slab < s_end; ++slab) {
-      if constexpr (BAR) __builtin_amdgcn_s_barrier();
+      // every kCovSyncSlabs slabs the four waves re-align, so that a line is still in L1 / L2 when the other tile group asks for it
+      // (a barrier on EVERY slab costs 9-11 % of the pipelined rate: one delayed wave then stalls the workgroup each time)
+      if (((slab - s_begin) & (kCovSyncSlabs - 1)) == 0) __builtin_amdgcn_s_barrier();   // (workgroup-uniform)
       // the prefetch is unconditional (the last iteration re-reads its own slab): a branch around the loads makes the compiler's
       // vmcnt bookkeeping pessimistic and the wait for THIS slab's data would also wait for the prefetch
       const long long nx = slab + 1 < s_end ? slab + 1 : slab;
@@ -157,32 +169,28 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
         for (int e = 0; e < SPL; ++e) cur[b][e] = nxt[b][e];
       mask(cur, nx);
     }
-  } else {
-    for (long long slab = s_begin; slab < s_end; ++slab) {
-      // keep the four waves of the workgroup on the same 16-sample slab so that it is fetched from HBM once and
-      // shared through L1/L2 (without this the waves drift apart and rocprof FETCH_SIZE doubles)
-      if constexpr (BAR) __builtin_amdgcn_s_barrier();
-      c64 cur[NB][SPL];
-      load_raw(cur, slab);
-      mask(cur, slab);
-      mfmas(cur);
-    }
   }
-#pragma unroll
-  for (int u = 0; u < NT; ++u) {
+  static_for<0, NT>([&](auto uc) {
+    constexpr int u = decltype(uc)::value;
+    constexpr bool diag = cov_tile_i(NB, T0 + u) == cov_tile_j(NB, T0 + u);
     double* o = part + (((long long)part_index * n_tiles + (T0 + u)) * 2) * 256;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      o[0 * 256 + r * 64 + lane] = re[u][r];
-      o[1 * 256 + r * 64 + lane] = im[u][r];
+      if constexpr (!diag) {
+        o[0 * 256 + r * 64 + lane] = re[u][r] + im[u][r];
+        o[1 * 256 + r * 64 + lane] = (s3[u][r] - re[u][r]) + im[u][r];
+      } else {
+        o[0 * 256 + r * 64 + lane] = re[u][r];
+        o[1 * 256 + r * 64 + lane] = im[u][r];             // diagonal tile: M, antisymmetrised by cov_reduce_kernel
+      }
     }
-  }
+  });
 }
 
-template <int NB, bool DB = true, bool BAR = false, int WGS = 3>
-__global__ __launch_bounds__(256, WGS) void cov_mfma_small_kernel(const c64* __restrict__ G, long long N, int A,
-                                                                  long long slabs_per_wg,
-                                                                  double* __restrict__ part /* [gridX*kPhases][kTiles][2][256] */) {
+template <int NB>
+__global__ __launch_bounds__(256, 2) void cov_mfma_small_kernel(const c64* __restrict__ G, long long N, int A,
+                                                                long long slabs_per_wg,
+                                                                double* __restrict__ part /* [gridX*kPhases][kTiles][2][256] */) {
   using P = CovPlan<NB>;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -192,9 +200,9 @@ __global__ __launch_bounds__(256, WGS) void cov_mfma_small_kernel(const c64* __r
   long long s_end = s_begin + slabs_per_wg;
   if (s_end > total) s_end = total;
   const int pidx = blockIdx.x * P::kPhases + phase;
-  if (grp == 0) cov_group_body<NB, 0, DB, BAR>(G, N, A, P::kTiles, phase, lane, s_begin, s_end, pidx, part);
+  if (grp == 0) cov_group_body<NB, 0>(G, N, A, P::kTiles, phase, lane, s_begin, s_end, pidx, part);
   if constexpr (P::kGroups > 1) {
-    if (grp == 1) cov_group_body<NB, 1, DB, BAR>(G, N, A, P::kTiles, phase, lane, s_begin, s_end, pidx, part);
+    if (grp == 1) cov_group_body<NB, 1>(G, N, A, P::kTiles, phase, lane, s_begin, s_end, pidx, part);
   }
 }
 
@@ -256,9 +264,15 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_block_kernel(const c64* __res
     s_col[j] = G + N * (long long)(s_ok[j] ? ant : 0);
     s_lds[j] = (blk * 16 + s_smp) * kCovPitch + l16;
   }
-  v4f64 re[4], im[4];
+  // 3M form, as in cov_group_body: off-diagonal tile re = S1, im = S2, s3 = S3; diagonal tile (of a diagonal block pair) re + s3 = Re,
+  // im = M.  Which form a tile takes is wave-uniform but only known at run time here: the operands are selected, not branched on.
+  bool td[4];
+  v4f64 re[4], im[4], s3[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) re[u] = im[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+  for (int u = 0; u < 4; ++u) {
+    re[u] = im[u] = s3[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+    td[u] = diag && tI[u] == tJ[u];
+  }
   const long long total = (N + 15) / 16;
   const long long s_begin = (long long)chunk * slabs_per_wg;
   long long s_end = s_begin + slabs_per_wg;
@@ -298,9 +312,8 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_block_kernel(const c64* __res
       for (int e = 0; e < 4; ++e) {
         const c64 xa = pa[e * kCovPitch], xb = pb[e * kCovPitch];
         re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xb.re, re[u], 0, 0, 0);
-        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.im, xb.im, re[u], 0, 0, 0);
-        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xb.im, im[u], 0, 0, 0);
-        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(-xa.im, xb.re, im[u], 0, 0, 0);
+        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(td[u] ? xa.re : xa.im, xb.im, im[u], 0, 0, 0);
+        s3[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(td[u] ? xa.im : xa.re - xa.im, td[u] ? xb.im : xb.re + xb.im, s3[u], 0, 0, 0);
       }
     }
     if (more) stash(buf ^ 1);
@@ -312,8 +325,8 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_block_kernel(const c64* __res
     double* o = part + ((((long long)chunk * n_pairs + pair) * 16 + (tI[u] * 4 + tJ[u])) * 2) * 256;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      o[r * 64 + lane] = re[u][r];
-      o[256 + r * 64 + lane] = im[u][r];
+      o[r * 64 + lane] = td[u] ? re[u][r] + s3[u][r] : re[u][r] + im[u][r];
+      o[256 + r * 64 + lane] = td[u] ? im[u][r] /* M: antisymmetrised by cov_block_reduce_kernel */ : (s3[u][r] - re[u][r]) + im[u][r];
     }
   }
 }
@@ -346,6 +359,11 @@ __global__ __launch_bounds__(1024) void cov_block_reduce_kernel(const double* __
   sr = ((s_sum[0][0][e] + s_sum[0][1][e]) + s_sum[0][2][e]) + s_sum[0][3][e];
   si = ((s_sum[1][0][e] + s_sum[1][1][e]) + s_sum[1][2][e]) + s_sum[1][3][e];
   const int r = e >> 6, lane = e & 63;
+  if (BI == BJ && I == J) {                         // diagonal tile: the partials hold M, Im = M - M^T
+    const int row = (lane >> 4) + 4 * r, col = lane & 15;
+    const int et = (col >> 2) * 64 + ((col & 3) << 4) + row;
+    si -= ((s_sum[1][0][et] + s_sum[1][1][et]) + s_sum[1][2][et]) + s_sum[1][3][et];
+  }
   const int a = 64 * BI + 16 * I + (lane >> 4) + 4 * r;   // f64 MFMA C/D layout: row = (lane>>4) + 4*reg, col = lane&15
   const int b = 64 * BJ + 16 * J + (lane & 15);
   if (a >= A || b >= A) return;
@@ -376,7 +394,8 @@ __global__ __launch_bounds__(256) void cov_reduce_slice_kernel(const double* __r
 
 // fixed-order reduction over workgroup partials + Hermitian fill + 1/N.
 __global__ __launch_bounds__(1024) void cov_reduce_kernel(const double* __restrict__ part, int n_wg, int n_tiles, int A,
-                                                          double inv_n, c64* __restrict__ Ra /* [A x A] column-major */) {
+                                                          double inv_n, c64* __restrict__ Ra /* [A x A] column-major */,
+                                                          int diag_antisym /* diagonal tiles hold M: Im = M - M^T */) {
   __shared__ double s_sum[2][4][256];
   const int t = blockIdx.x;
   const int nb = (A + 15) / 16;
@@ -401,6 +420,10 @@ __global__ __launch_bounds__(1024) void cov_reduce_kernel(const double* __restri
   if (g != 0) return;
   sr = ((s_sum[0][0][e] + s_sum[0][1][e]) + s_sum[0][2][e]) + s_sum[0][3][e];
   si = ((s_sum[1][0][e] + s_sum[1][1][e]) + s_sum[1][2][e]) + s_sum[1][3][e];
+  if (diag_antisym && I == J) {
+    const int et = (col >> 2) * 64 + ((col & 3) << 4) + row;          // the (col, row) entry of the same tile
+    si -= ((s_sum[1][0][et] + s_sum[1][1][et]) + s_sum[1][2][et]) + s_sum[1][3][et];
+  }
   const int a = I * 16 + row, b = J * 16 + col;
   if (a < A && b < A) {
     c64 v = mk(sr * inv_n, si * inv_n);
@@ -1189,16 +1212,13 @@ template <int NB>
 static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long long N, int A, c64* Ra) {
   using P = CovPlan<NB>;
   const long long total = (N + 15) / 16;
-  long long gx = 768;                       // 3 workgroups per CU (register-limited occupancy of the kernel)
+  long long gx = NB == 4 ? 512 : 768;       // NB = 4: 2 workgroups per CU (register-limited occupancy: 192 VGPRs)
   if (gx > total) gx = total;
   const long long per = (total + gx - 1) / gx;
   gx = (total + per - 1) / per;
   const int n_part = (int)gx * P::kPhases;
   ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * ((size_t)n_part + 32) * P::kTiles * 2 * 256));
-  // register double buffer, no per-slab barrier, three workgroups per CU: 0.303 ms at A = 64 (barrier + single buffer 0.325;
-  // the barrier kept the four waves on one slab so that it was fetched once -- with the prefetch they stay close enough)
-  // (with the per-slab barrier back on top of the prefetch: isolated 0.27 ms, but 9-11 % lower pipelined rate -- rejected)
-  hipLaunchKernelGGL((cov_mfma_small_kernel<NB, true, false, 3>), dim3((unsigned)gx), dim3(256), 0, st, G, N, A, per, (double*)ctx->cov_part.p);
+  hipLaunchKernelGGL((cov_mfma_small_kernel<NB>), dim3((unsigned)gx), dim3(256), 0, st, G, N, A, per, (double*)ctx->cov_part.p);
   ISAC_HIP(hipGetLastError());
   const int S = 32;
   double* part2 = (double*)ctx->cov_part.p + (size_t)n_part * P::kTiles * 2 * 256;
@@ -1206,7 +1226,7 @@ static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long lo
                      part2);
   ISAC_HIP(hipGetLastError());
   hipLaunchKernelGGL(cov_reduce_kernel, dim3(P::kTiles), dim3(256, 4), 0, st, (const double*)part2, S, P::kTiles, A,
-                     1.0 / (double)N, Ra);
+                     1.0 / (double)N, Ra, 1);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }

@@ -34,15 +34,24 @@ __global__ __launch_bounds__(FFT::NT, 2) void range_kernel(const c64* __restrict
     const int col = blockIdx.x;                    // one (symbol, antenna) column per workgroup
     const c64* prx = rx + (long long)K * col;
     const c64* ptx = tx + (long long)K * col;
+    bool live = false;                             // any non-zero (or NaN) matched-filter sample in this column?
     fft.fill(
         [&](int n) {
           const int nc = n < K ? n : K - 1;                      // unconditional loads, select afterwards
           c64 v = mul_conj(prx[nc], ptx[nc]) * win_k[nc];        // fft2D.m:37,:43
-          return n < K ? v : mk(0.0, 0.0);                       // ifft(., nIFFT, 1) zero-pads at the end
+          v = n < K ? v : mk(0.0, 0.0);                          // ifft(., nIFFT, 1) zero-pads at the end
+          live |= (v.re != 0.0) | (v.im != 0.0);
+          return v;
         },
         tid);
-    fft.template transform<+1>(lds, tw, tid);
     c64* dst = ymid + (long long)n_rows * col;
+    // zero-filled 'S'-slot columns (gNBPhy.m:609-612): the IFFT of an identically zero column is zero (exact for any input:
+    // NaN / Inf products compare unequal to zero and take the full path)
+    if (!__syncthreads_or(live)) {
+      for (int rr = tid; rr < n_rows; rr += FFT::NT) dst[rr] = mk(0.0, 0.0);
+      return;
+    }
+    fft.template transform<+1>(lds, tw, tid);
     fft.drain(
         [&](int n, c64 v) {
           int rr = n - row_lo;
