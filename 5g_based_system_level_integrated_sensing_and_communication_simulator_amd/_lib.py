@@ -108,6 +108,9 @@ def load():
             raise RuntimeError(
                 f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the sensing hot path.")
+        # every HIP stream of up to eight pipelined contexts gets its own hardware queue (two streams per context; streams that
+        # share a queue serialise -- profiles/r02_queue_sweep.txt).  Only effective before the HIP runtime initialises.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         if "torch" not in sys.modules and os.environ.get("ISAC_NO_TORCH_PRELOAD") != "1":
             try:
                 import torch  # noqa: F401

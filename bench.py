@@ -30,10 +30,11 @@ from types import SimpleNamespace
 
 import numpy as np
 
-# 4 CPIs in flight x 2 HIP streams each: give every stream its own hardware queue (the ROCm default of 4 makes
-# streams share queues, and a 1.4 ms single-CU eig kernel at the head of a shared queue stalls the wide kernels
-# behind it).  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# 8 CPIs in flight x 2 HIP streams each: give every stream its own hardware queue (streams that share a queue serialise: a
+# 1 ms few-CU eigensolver kernel at the head of a shared queue stalls the wide kernels behind it).  Measured at 100 steps
+# (profiles/r02_queue_sweep.txt): 8 queues / 4 CPIs 15.6-16.6 k slots/s, 16 / 6 17.3 k, 16 / 8 17.6-17.7 k, 32 / 8 the same, more CPIs
+# than queues / 2 collapses (16 / 12: 16.0 k, 32 / 12: 8.5 k).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -351,7 +352,7 @@ def main():
     ap.add_argument("--cells-per-gpu", type=int, default=1)
     ap.add_argument("--cells", type=int, default=0, help="total number of cells, sharded cell c -> rank c mod world (BASELINE configs[2]: 7 cells on "
                                                          "2/4/8 GPUs, inherently imbalanced); 0 = --cells-per-gpu cells on every rank (weak scaling)")
-    ap.add_argument("--inflight", type=int, default=4, help="CPIs in flight per cell (contexts)")
+    ap.add_argument("--inflight", type=int, default=8, help="CPIs in flight per cell (contexts)")
     ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="separate monoStaticSensing and fft2D range kernels (the range stage re-reads echoGrid)")
     ap.add_argument("--noise-domain", choices=("spectral", "time"), default="spectral",
                     help="Philox AWGN drawn on the demodulated grid (default; same distribution, include/isac.h isac_noise_mode) or per time sample")
