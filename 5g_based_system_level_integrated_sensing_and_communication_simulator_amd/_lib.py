@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libisac_hip.so")
 _lib = None
 _lock = threading.Lock()
 
-ISAC_MAX_EST = 1024
+ISAC_MAX_EST = 4096
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX, NOISE_PHILOX_SPECTRAL, NOISE_INJECTED_SPECTRAL = 0, 1, 2, 3, 4
 
 STATUS_NAMES = {0: "OK", 1: "INVALID_ARG", 2: "HIP", 3: "NO_LOS", 4: "NO_DETECTION", 5: "CFAR_WINDOW",

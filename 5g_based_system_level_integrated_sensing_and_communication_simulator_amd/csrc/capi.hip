@@ -483,7 +483,9 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   ISAC_TRY(isac_rdm_power_window(ctx, ep, cfar, rx, tx, K, L, A, &nr, &nc, use_cached_range));          // fft2D.m:37-46,61
   const int n_cut_rows = cfar->row1 - cfar->row0 + 1, n_cut_cols = cfar->col1 - cfar->col0 + 1;
   const long long n_cut = (long long)n_cut_rows * n_cut_cols;
-  const int cap = (int)std::min<long long>(n_cut, 4096);
+  // per-antenna detection capacity: every CUT of the zone, bounded only by a 256 MB scratch budget (A x cap x 12 B) -- at the default
+  // zone (8 510 CUTs) and any A <= 2500 an antenna can report every CUT, as phased.CFARDetector2D would
+  const int cap = (int)std::min<long long>(n_cut, std::max<long long>(4096, (256ll << 20) / 12 / A));
   ISAC_TRY(isac_cfar_window(ctx, cfar, nr, nc, A, cap));                                 // fft2D.m:62 (+ numDets on device)
   ISAC_HIP(hipEventRecord(ctx->ev_cfar, ctx->stream));
   ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_cfar, 0));
@@ -547,7 +549,7 @@ extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
   const int total = hdr[0];
   const int num_dets_dev = hdr[1];
   if (hdr[2] & 2) return fail(ctx, ISAC_ERR_HIP, "eigensolver did not finish (rotation storage exceeded or a replay block timed out)");
-  if (hdr[2] & 1) return fail(ctx, ISAC_ERR_CAPACITY, "an antenna produced more CFAR detections than the per-antenna capacity (4096)");
+  if (hdr[2] & 1) return fail(ctx, ISAC_ERR_CAPACITY, "an antenna produced more CFAR detections than the per-antenna capacity (256 MB of scratch / 12 B / antennas)");
   std::vector<int> cut((size_t)total);
   std::vector<double> pw((size_t)total);
   if (total <= pack_first) {

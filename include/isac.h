@@ -32,7 +32,8 @@ extern "C" {
 #endif
 
 #define ISAC_ABI_VERSION 1
-#define ISAC_MAX_EST 1024 /* capacity of the estimate vectors in isac_est_result */
+#define ISAC_MAX_EST 4096 /* capacity of the estimate vectors in isac_est_result: unique range bins <= nIFFT (<= 4096 for every
+                             * NR numerology), unique velocity bins <= nFFT, azimuth peaks <= 180 -- never the binding limit */
 
 typedef struct isac_ctx isac_ctx;
 

@@ -178,6 +178,27 @@ def test_fft2d_small(pkg, ctx):
     assert np.array_equal(got2.rngEst, got.rngEst) and np.array_equal(got2.aziEst, got.aziEst)
 
 
+def test_fft2d_every_other_cut_detects(pkg, ctx):
+    """Pfa = 0.5: more than 4096 detections per antenna (the default zone has 8 510 CUTs) -- phased.CFARDetector2D reports
+    every one of them (fft2D.m:62-78), so must the device path: detection lists, their CUT order and the estimates stay exact."""
+    sc = make_scene(n_ants=2, n_slots=4, nrb=273, targets=((100.0, 20.0, 1.5),), velocity=(7.0,), seed=21)
+    sc.rp.Pfa = 0.5
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    rp.Pfa = 0.5
+    cf = pkg.sensing.detection.cfar2D(rp)
+    ocf = O.cfar2d_config(sc.rp)
+    rx = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, sc.noise, nfft=sc.wave.Nfft)
+    want, dbg = O.fft2d(sc.rp, ocf, rx, sc.tx_grid, return_debug=True)
+    got, gd = pkg.sensing.estimation.fft2D(rp, cf, rx, sc.tx_grid, return_debug=True)
+    assert min(d.shape[1] for d in dbg.detections) > 4096
+    for a in range(sc.A):
+        assert _guard_band_ok(np.abs(dbg.rdm[:, :, a]) ** 2, ocf.CUTIdx, ocf.Pfa), "scene too close to a threshold"
+        assert np.array_equal(gd.detections[a], dbg.detections[a]), f"antenna {a}"
+    assert np.array_equal(got.rngEst, want.rngEst) and np.array_equal(got.velEst, want.velEst)
+    assert np.array_equal(got.aziEst, want.aziEst)
+    assert got.rngEst.size > 300                      # practically every range row of the zone
+
+
 def test_fused_range_stage_is_identical(pkg, ctx):
     """monoStaticSensing(fuse_fft2d=...) + fft2D must give bit-identical echo grid, |rdm|^2 window and
     detections to the unfused call sequence (full-size numerology: the fused kernel needs Nfft == nIFFT == 4096)."""
