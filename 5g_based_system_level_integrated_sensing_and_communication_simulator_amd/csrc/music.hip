@@ -149,26 +149,36 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
     }
   };
   {
-    // register double buffer: the loads of slab s+1 fly under the MFMAs of slab s
-    c64 cur[NB][SPL], nxt[NB][SPL];
-    if (s_begin < s_end) { load_raw(cur, s_begin); mask(cur, s_begin); }
-    for (long long slab = s_begin; slab < s_end; ++slab) {
+    // Three register buffers in rotation: the loads of slabs s+1 and s+2 fly under the MFMAs of slab s (one slab of MFMAs is ~0.8 us,
+    // less than a loaded HBM round trip: a single prefetched slab still stalled).  Loads are unconditional (indices clamped to the
+    // run's last slab): a branch around loads makes the compiler's vmcnt bookkeeping pessimistic.  Padding antennas / samples past N
+    // exist only when A is not a multiple of 16 or in the very last slab: the 0/1 mask multiply runs only then (wave-uniform branch) --
+    // VALU instructions do not overlap v_mfma_f64 on this hardware (tools/cobench.hip), every one of them is paid in full.
+    const bool ants_full = (A == 16 * NB);
+    const long long last = s_end - 1;
+    auto step = [&](c64 (&use)[NB][SPL], c64 (&fill)[NB][SPL], long long slab) {
       // every kCovSyncSlabs slabs the four waves re-align, so that a line is still in L1 / L2 when the other tile group asks for it
       // (a barrier on EVERY slab costs 9-11 % of the pipelined rate: one delayed wave then stalls the workgroup each time)
       if (((slab - s_begin) & (kCovSyncSlabs - 1)) == 0) __builtin_amdgcn_s_barrier();   // (workgroup-uniform)
-      // the prefetch is unconditional (the last iteration re-reads its own slab): a branch around the loads makes the compiler's
-      // vmcnt bookkeeping pessimistic and the wait for THIS slab's data would also wait for the prefetch
-      const long long nx = slab + 1 < s_end ? slab + 1 : slab;
-      load_raw(nxt, nx);
+      load_raw(fill, slab + 2 < s_end ? slab + 2 : last);
       __builtin_amdgcn_sched_barrier(0);
-      mfmas(cur);
-      __builtin_amdgcn_sched_barrier(0);              // the wait for the next slab's data belongs AFTER this slab's MFMAs have been issued
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int e = 0; e < SPL; ++e) cur[b][e] = nxt[b][e];
-      mask(cur, nx);
+      if (!ants_full || slab * 16 + 16 > N) mask(use, slab);          // (wave-uniform, rare)
+      mfmas(use);
+      __builtin_amdgcn_sched_barrier(0);              // waits for later slabs' data belong AFTER this slab's MFMAs have been issued
+    };
+    c64 b0[NB][SPL], b1[NB][SPL], b2[NB][SPL];
+    if (s_begin < s_end) {
+      load_raw(b0, s_begin);
+      load_raw(b1, s_begin + 1 < s_end ? s_begin + 1 : last);
     }
+    long long slab = s_begin;
+    for (; slab + 3 <= s_end; slab += 3) {
+      step(b0, b2, slab);
+      step(b1, b0, slab + 1);
+      step(b2, b1, slab + 2);
+    }
+    if (slab < s_end) step(b0, b2, slab);
+    if (slab + 1 < s_end) step(b1, b0, slab + 1);
   }
   static_for<0, NT>([&](auto uc) {
     constexpr int u = decltype(uc)::value;

@@ -61,8 +61,9 @@ def philox_normal_pairs(elem_index, seed: int, stream: int = 0) -> np.ndarray:
     return r * np.cos(ang) + 1j * (r * np.sin(ang))
 
 
-def philox_spectral_noise(n_sc: int, n_sym: int, n_ants: int, seed: int) -> np.ndarray:
-    """Unit complex normals W [n_sc x n_sym x n_ants] of the spectral noise mode.
+def philox_spectral_noise(n_sc: int, n_sym: int, n_ants: int, seed: int, columns=None) -> np.ndarray:
+    """Unit complex normals W [n_sc x n_sym x n_ants] of the spectral noise mode (`columns`: only these columns
+    l + n_sym * a, returned as [n_sc x len(columns)] -- for spot checks at the full benchmark size).
 
     Element (k, l, a), column = l + n_sym * a:  slot = (k mod 512) + 512 * ((k div 512) div 2),
     half = (k div 512) mod 2  (elements k and k + 512 share a call);  Philox4x32-10 counter = (slot + 2048 * column as 64 bits,
@@ -72,7 +73,7 @@ def philox_spectral_noise(n_sc: int, n_sym: int, n_ants: int, seed: int) -> np.n
     k = np.arange(n_sc, dtype=np.uint64)
     slot = (k % np.uint64(512)) + np.uint64(512) * ((k // np.uint64(512)) // np.uint64(2))
     half = ((k // np.uint64(512)) % np.uint64(2)).astype(np.int64)
-    col = np.arange(n_sym * n_ants, dtype=np.uint64)
+    col = np.arange(n_sym * n_ants, dtype=np.uint64) if columns is None else np.asarray(columns, dtype=np.uint64)
     ctr = slot[:, None] + np.uint64(2048) * col[None, :]
     x = philox4x32_10((ctr & _MASK).astype(np.uint32), (ctr >> np.uint64(32)).astype(np.uint32), np.uint32(2), np.uint32(0),
                       np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
@@ -82,4 +83,6 @@ def philox_spectral_noise(n_sc: int, n_sym: int, n_ants: int, seed: int) -> np.n
     rad = np.sqrt(-2.0 * np.log((ur + 1.0) * 2.0 ** -32))
     ang = 2.0 * np.pi * (ua * 2.0 ** -32)
     w = rad * np.cos(ang) + 1j * (rad * np.sin(ang))
+    if columns is not None:
+        return np.asfortranarray(w)
     return np.asfortranarray(w.reshape(n_sc, n_sym, n_ants, order="F"))

@@ -134,3 +134,15 @@ def test_full_size_spectral_fused_path(pkg, name):
     est3, dbg3 = pkg.sensing.estimation.fft2D(rp, cf, e3, d_txg, return_debug=True, reuse_range=True)
     assert np.array_equal(dbg2.power_window, dbg3.power_window) and detection_digest(dbg2.detections) == detection_digest(dbg3.detections)
     assert np.array_equal(est2.aziEst, est3.aziEst) and np.array_equal(est2.rngEst, est3.rngEst)
+    # the Philox field itself at the benchmark size (counters up to 2048 x 14 336 columns): sampled columns, element by element,
+    # against the restated generator
+    clean = pkg.sensing.monoStaticSensing(ctx.to_device(sc.tx_wave), sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096).numpy()
+    h3 = e3.numpy()
+    sig = np.sqrt(sc.rp.N0 / 2.0) * np.sqrt(4096.0)
+    pick = [(0, 0), (1, 0), (223, 0), (100, 37), (0, 63), (223, 63), (57, 13)]
+    wcol = O.philox_spectral_noise(sc.K, sc.L, sc.A, 99, columns=[l + sc.L * a for l, a in pick])
+    for j, (l, a) in enumerate(pick):
+        nz = (h3[:, l, a] - clean[:, l, a]) / sig
+        assert np.abs(nz - wcol[:, j]).max() < 1e-6, (l, a)
+    nz_all = (h3[:, :, 5] - clean[:, :, 5]) / sig
+    assert abs(nz_all.real.std() - 1) < 0.01 and abs(nz_all.imag.std() - 1) < 0.01 and abs(nz_all.mean()) < 0.01

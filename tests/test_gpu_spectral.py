@@ -149,3 +149,31 @@ def test_basic_radar_channel_rejects_spectral_modes(pkg, ctx):
     st = ctx.lib.isac_basic_radar_channel_dev(ctx.handle, C.c_void_p(d_w.ptr), C.c_int64(sc.T), C.byref(cb.block), los.ctypes.data_as(C.c_void_p),
                                               C.c_int(3), C.c_void_p(0), C.c_uint64(1), C.c_void_p(d_o.ptr))
     assert st == 1
+
+
+@pytest.mark.parametrize("n_ants,targets,vel", [(40, ((80.0, 20.0, 1.5), (60.0, -40.0, 1.5)), (7.0, -3.0)),
+                                                 (64, ((90.0, 40.0, 1.5),), (0.0,)),
+                                                 (49, ((70.0, 20.0, 1.5), (60.0, -50.0, 1.5), (90.0, 10.0, 1.5)), (7.0, -3.0, 1.0))])
+def test_fused_synthesis_covariance_kernel(pkg, ctx, n_ants, targets, vel):
+    """33..64 antennas: the fused entry may run the synthesis inside the covariance kernel (echo_cov_kernel).  Whatever the
+    library picks, the echo grid is bit-identical to the unfused spectral synthesis, Ra matches X X^H / N of that grid, and the
+    cached fft2D gives the estimates of the plain call sequence."""
+    sc = make_scene(n_ants=n_ants, n_slots=4, nrb=273, targets=targets, velocity=vel, seed=31, with_noise=False)
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    cf = pkg.sensing.detection.cfar2D(rp)
+    rng = np.random.default_rng(5)
+    w = np.asfortranarray(rng.standard_normal(sc.tx_grid.shape) + 1j * rng.standard_normal(sc.tx_grid.shape))
+    d_wave, d_txg, d_w = ctx.to_device(sc.tx_wave), ctx.to_device(sc.tx_grid), ctx.to_device(w)
+    for kw in (dict(spectral_noise=d_w), dict(seed=77, noise_domain="spectral")):
+        e0 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, **kw)
+        est0, dbg0 = pkg.sensing.estimation.fft2D(rp, cf, e0, d_txg, return_debug=True)
+        e1 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, fuse_fft2d=(rp, cf, d_txg), **kw)
+        est1, dbg1 = pkg.sensing.estimation.fft2D(rp, cf, e1, d_txg, return_debug=True, reuse_range=True)
+        h0 = e0.numpy()
+        assert np.array_equal(h0, e1.numpy())
+        g = h0.reshape(-1, sc.A, order="F")
+        ra = g.conj().T @ g / g.shape[0]
+        assert rel(dbg1.Ra, ra) < RTOL and rel(dbg0.Ra, ra) < RTOL and np.array_equal(dbg1.Ra, dbg1.Ra.conj().T)
+        assert np.array_equal(dbg0.power_window, dbg1.power_window)
+        assert all(np.array_equal(a, b) for a, b in zip(dbg0.detections, dbg1.detections))
+        assert np.array_equal(est0.rngEst, est1.rngEst) and np.array_equal(est0.velEst, est1.velEst) and np.array_equal(est0.aziEst, est1.aziEst)
