@@ -166,7 +166,7 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
       mfmas(use);
       __builtin_amdgcn_sched_barrier(0);              // waits for later slabs' data belong AFTER this slab's MFMAs have been issued
     };
-    c64 b0[NB][SPL], b1[NB][SPL], b2[NB][SPL];
+    c64 b0[NB][SPL], b1[NB][SPL], b2[NB][SPL];       // (two buffers / one slab ahead: same isolated time, -0.8 % pipelined)
     if (s_begin < s_end) {
       load_raw(b0, s_begin);
       load_raw(b1, s_begin + 1 < s_end ? s_begin + 1 : last);
