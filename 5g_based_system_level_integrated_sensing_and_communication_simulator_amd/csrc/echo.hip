@@ -283,15 +283,16 @@ __global__ __launch_bounds__(Fft4096W::NT, ISAC_ECHO_RANGE_WGS) void echo_range_
     for (int rr = tid; rr < n_rows; rr += FFT::NT) yd[rr] = mk(0.0, 0.0);
     return;
   }
-  fft.init_twiddles(tw, tid);
-  fft.template transform<+1>(lds, tw, tid);
-  fft.drain(
-      [&](int n, c64 v) {
-        const int rr = n - row_lo;
-        const double wr = win_r[n];
-        if (rr >= 0 && rr < n_rows) yd[rr] = ((v * inv_n) * sqrt_n) * wr;            // fft2D.m:44-45
-      },
-      tid);
+  fft.init_twiddles_lds(lds, tid);
+  const int blk = FFT::block_of_rows(row_lo, n_rows);     // (uniform) the CUT rows usually sit inside one 512-row block of the IFFT output
+  fft.template transform<+1>(lds, tw, tid, blk);
+  auto put = [&](int n, c64 v) {
+    const int rr = n - row_lo;
+    const double wr = win_r[n];
+    if (rr >= 0 && rr < n_rows) yd[rr] = ((v * inv_n) * sqrt_n) * wr;            // fft2D.m:44-45
+  };
+  if (blk >= 0) fft.drain_block(put, tid, blk);
+  else fft.drain(put, tid);
 }
 
 // ---------------------------------------------------------------- CP-OFDM modulator

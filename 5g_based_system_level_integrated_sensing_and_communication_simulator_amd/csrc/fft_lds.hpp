@@ -205,6 +205,31 @@ __device__ __forceinline__ void dft8(c64 (&x)[8]) {
   dft4(v0, v1, v2, v3, x[1], x[3], x[5], x[7]);
 }
 
+// Output i alone of the same 8-point DFT, by exactly the operations dft8 spends on it (bit-identical): 7 complex additions for i = 0
+// instead of the full butterfly.  `i` is uniform (a kernel argument), the branches are scalar.
+template <int DIR>
+__device__ __forceinline__ c64 dft8_one(const c64 (&x)[8], int i) {
+  constexpr double s = (DIR < 0) ? -1.0 : 1.0;
+  c64 a0, a1, a2, a3;
+  if ((i & 1) == 0) {
+    a0 = x[0] + x[4]; a1 = x[1] + x[5]; a2 = x[2] + x[6]; a3 = x[3] + x[7];
+  } else {
+    const c64 v1 = x[1] - x[5], v2 = x[2] - x[6], v3 = x[3] - x[7];
+    a0 = x[0] - x[4];
+    a1 = c64{(v1.re - s * v1.im) * kR2, (v1.im + s * v1.re) * kR2};
+    a2 = c64{-s * v2.im, s * v2.re};
+    a3 = c64{(-v3.re - s * v3.im) * kR2, (s * v3.re - v3.im) * kR2};
+  }
+  const int q = i >> 1;                                  // dft4 output q of (a0, a1, a2, a3)
+  if ((q & 1) == 0) {
+    const c64 p0 = a0 + a2, p1 = a1 + a3;
+    return q == 0 ? p0 + p1 : p0 - p1;
+  }
+  const c64 p2 = a0 - a2, d = a1 - a3;
+  const c64 p3 = c64{-s * d.im, s * d.re};
+  return q == 1 ? p2 + p3 : p2 - p3;
+}
+
 // 4096 = 8^4 on 512 threads (8 wavefronts), 8 points per thread: half the registers per thread of Fft4096 and, with the same
 // 64 KB exchange image per column, twice the wavefronts per CU (two workgroups = four waves per SIMD) -- for kernels that do real
 // VALU work beside the transform (the fused echo-synthesis + range kernel).  x[j] = in[tid + 512 j] -> x[i] = OUT[tid + 512 i].
@@ -222,23 +247,28 @@ struct Fft4096W {
   static constexpr int NT = 512;
   static constexpr int PER = 8;
   static constexpr int IMG = 4096;
-  static constexpr int LDS_ELEMS = IMG + 512;        // + W512 table (second / third pass twiddles, OFDM phase ramps, the generator's angle table)
+  static constexpr int LDS_ELEMS = IMG + 512 + 8;    // + W512 table (second / third pass twiddles, OFDM phase ramps, the generator's angle table)
+                                                     //   + W4096^0..7 (first-pass twiddles are rebuilt from the tables, see init_twiddles_lds)
   static constexpr int kW256Stride = 2;              // W256^i = table[2 i]
   c64 x[PER];
   c64 wb[3];                                         // W4096^(tid * {1, 2, 4})
 
   __device__ __forceinline__ void init(c64* __restrict__ lds, const c64* __restrict__ tw, int tid) {
-    init_twiddles(tw, tid);
     init_table(lds, tw, tid);
+    init_twiddles_lds(lds, tid);
   }
   __device__ __forceinline__ void init_table(c64* __restrict__ lds, const c64* __restrict__ tw, int tid) {
     lds[IMG + tid] = tw[8 * tid];                    // W512^tid
+    if (tid < 8) lds[IMG + 512 + tid] = tw[tid];     // W4096^tid
     __syncthreads();
   }
-  __device__ __forceinline__ void init_twiddles(const c64* __restrict__ tw, int tid) {
-    wb[0] = tw[tid];
-    wb[1] = tw[2 * tid];
-    wb[2] = tw[4 * tid];
+  // First-pass twiddles W4096^(tid {1, 2, 4}) from the LDS tables (W4096^tid = W512^(tid div 8) W4096^(tid mod 8), then two squarings;
+  // a few ulp from the table values) instead of three global loads: in the fused echo kernel those loads sat behind the column's
+  // echoGrid stores, and a wait for a load is a wait for every earlier store's acknowledgement as well (one in-order vmcnt on gfx9).
+  __device__ __forceinline__ void init_twiddles_lds(const c64* __restrict__ lds, int tid) {
+    wb[0] = lds[IMG + (tid >> 3)] * lds[IMG + 512 + (tid & 7)];
+    wb[1] = wb[0] * wb[0];
+    wb[2] = wb[1] * wb[1];
   }
   __device__ __forceinline__ c64 phase_ramp(const c64* __restrict__ lds, const c64* __restrict__, int kb, int dshift) const {
     return conj(lds[IMG + ((kb * (dshift >> 3)) & 511)]);       // exp(+2 pi j kb dshift / 4096), dshift a multiple of 8
@@ -259,8 +289,10 @@ struct Fft4096W {
       if ((j % GROUP) == GROUP - 1) __builtin_amdgcn_sched_barrier(0);
     }
   }
+  // `only_block` >= 0: the caller needs OUT[512 only_block .. 512 only_block + 511] alone (a range window inside one 512-row block):
+  // the last pass then forms that one output per thread, x[0] = OUT[tid + 512 only_block] (drain_block), bit-identical to the full pass.
   template <int DIR>
-  __device__ __forceinline__ void transform(c64* __restrict__ lds, const c64* __restrict__, int tid) {
+  __device__ __forceinline__ void transform(c64* __restrict__ lds, const c64* __restrict__, int tid, int only_block = -1) {
     const c64* t512 = lds + IMG;
     // ---- pass 1
     dft8<DIR>(x);
@@ -312,8 +344,15 @@ struct Fft4096W {
       const c64* base = lds + 8 * e + 64 * h + 512 * k1;
 #pragma unroll
       for (int g = 0; g < 8; ++g) x[g] = base[(g + k1) & 7];
-      dft8<DIR>(x);
+      if (only_block >= 0) x[0] = dft8_one<DIR>(x, only_block);      // (uniform)
+      else dft8<DIR>(x);
     }
+  }
+  template <class G>
+  __device__ __forceinline__ void drain_block(G&& g, int tid, int only_block) { g(tid + NT * only_block, x[0]); }
+  // the 512-row output block that holds rows [row_lo, row_lo + n_rows), or -1 when they straddle blocks
+  __host__ __device__ static inline int block_of_rows(int row_lo, int n_rows) {
+    return (n_rows > 0 && (row_lo >> 9) == ((row_lo + n_rows - 1) >> 9)) ? (row_lo >> 9) : -1;
   }
   __device__ __forceinline__ void release() { __syncthreads(); }
 };

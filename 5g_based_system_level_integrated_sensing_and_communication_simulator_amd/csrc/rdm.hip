@@ -14,6 +14,8 @@
 // Only the rows/columns the CFAR stage can touch (CUT rectangle +- guard+training) are ever
 // formed: the range kernel keeps those rows of each column FFT (coalesced run), the Doppler
 // kernel evaluates just the needed Doppler bins, and |.|^2 is written as a small power window.
+#include <type_traits>
+
 #include "fft_lds.hpp"
 
 namespace isac {
@@ -51,14 +53,20 @@ __global__ __launch_bounds__(FFT::NT, 2) void range_kernel(const c64* __restrict
       for (int rr = tid; rr < n_rows; rr += FFT::NT) dst[rr] = mk(0.0, 0.0);
       return;
     }
-    fft.template transform<+1>(lds, tw, tid);
-    fft.drain(
-        [&](int n, c64 v) {
-          int rr = n - row_lo;
-          const double wr = win_r[n];
-          if (rr >= 0 && rr < n_rows) dst[rr] = ((v * inv_n) * sqrt_n) * wr;         // :44-45
-        },
-        tid);
+    auto put = [&](int n, c64 v) {
+      int rr = n - row_lo;
+      const double wr = win_r[n];
+      if (rr >= 0 && rr < n_rows) dst[rr] = ((v * inv_n) * sqrt_n) * wr;         // :44-45
+    };
+    if constexpr (std::is_same<FFT, Fft4096W>::value) {
+      const int blk = FFT::block_of_rows(row_lo, n_rows);   // (uniform) CUT rows inside one 512-row block: one output per thread
+      fft.template transform<+1>(lds, tw, tid, blk);
+      if (blk >= 0) fft.drain_block(put, tid, blk);
+      else fft.drain(put, tid);
+    } else {
+      fft.template transform<+1>(lds, tw, tid);
+      fft.drain(put, tid);
+    }
   }
 }
 

@@ -199,6 +199,44 @@ def test_fft2d_every_other_cut_detects(pkg, ctx):
     assert got.rngEst.size > 300                      # practically every range row of the zone
 
 
+@pytest.mark.parametrize("area,blocks", [(((650.0, 1000.0), (-50.0, 50.0)), "one block, not the first"),
+                                         (((500.0, 800.0), (-50.0, 50.0)), "straddles two 512-row blocks"),
+                                         (((50.0, 500.0), (-50.0, 50.0)), "default: inside the first block")])
+def test_fft2d_range_window_position(pkg, ctx, area, blocks):
+    """The range transform forms only the 512-row output block the CUT rows need when they fit in one (pruned last radix-8 pass),
+    all eight otherwise: zones in a later block and across a block boundary against the oracle, fused and unfused (Pfa = 0.5 so that
+    far zones detect at all)."""
+    sc = make_scene(n_ants=3, n_slots=4, nrb=273, targets=((100.0, 20.0, 1.5),), velocity=(7.0,), seed=17, detection_area=area)
+    sc.rp.Pfa = 0.5
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    rp.Pfa = 0.5
+    cf = pkg.sensing.detection.cfar2D(rp)
+    ocf = O.cfar2d_config(sc.rp)
+    rows = ocf.CUTIdx[0]
+    if "not the first" in blocks:
+        assert rows.min() - 3 >= 513 and rows.max() + 3 <= 1024
+    if "straddles" in blocks:
+        assert rows.min() < 512 < rows.max()
+    rx = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, sc.noise, nfft=sc.wave.Nfft)
+    want, dbg = O.fft2d(sc.rp, ocf, rx, sc.tx_grid, return_debug=True)
+    d_wave, d_noise, d_txg = ctx.to_device(sc.tx_wave), ctx.to_device(sc.noise), ctx.to_device(sc.tx_grid)
+    e0 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, noise=d_noise, nfft=4096)
+    got, gd = pkg.sensing.estimation.fft2D(rp, cf, e0, d_txg, return_debug=True)
+    r0, c0 = gd.first_row - 1, gd.first_col - 1
+    nr, nc, _ = gd.power_window.shape
+    assert rel(gd.power_window, np.abs(dbg.rdm[r0:r0 + nr, c0:c0 + nc, :]) ** 2) < RTOL
+    for a in range(sc.A):
+        assert _guard_band_ok(np.abs(dbg.rdm[:, :, a]) ** 2, ocf.CUTIdx, ocf.Pfa), "scene too close to a threshold"
+        assert np.array_equal(gd.detections[a], dbg.detections[a]), f"antenna {a}"
+    assert np.array_equal(got.rngEst, want.rngEst) and np.array_equal(got.velEst, want.velEst) and np.array_equal(got.aziEst, want.aziEst)
+    # the fused spectral kernel takes the same decision about the block: bit-identical to its unfused sequence
+    e1 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, seed=5, noise_domain="spectral")
+    _, g1 = pkg.sensing.estimation.fft2D(rp, cf, e1, d_txg, return_debug=True)
+    e2 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, seed=5, noise_domain="spectral", fuse_fft2d=(rp, cf, d_txg))
+    _, g2 = pkg.sensing.estimation.fft2D(rp, cf, e2, d_txg, return_debug=True, reuse_range=True)
+    assert np.array_equal(g1.power_window, g2.power_window)
+
+
 def test_fused_range_stage_is_identical(pkg, ctx):
     """monoStaticSensing(fuse_fft2d=...) + fft2D must give bit-identical echo grid, |rdm|^2 window and
     detections to the unfused call sequence (full-size numerology: the fused kernel needs Nfft == nIFFT == 4096)."""
