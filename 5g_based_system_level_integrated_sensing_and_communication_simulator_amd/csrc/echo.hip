@@ -228,16 +228,17 @@ __global__ __launch_bounds__(256) void echo_spectral_kernel(int K, int L_whole, 
 }
 
 // 512-thread workgroups on the 8-points-per-thread transform (Fft4096W): two workgroups per CU = 16 wavefronts = four per SIMD, which
-// needs <= 128 VGPRs per lane.  (The 256-thread / 16-points-per-thread form was latency-bound at two waves per SIMD: 477 us.)
-#ifndef ISAC_ECHO_RANGE_WGS
-#define ISAC_ECHO_RANGE_WGS 2
-#endif
+// needs <= 128 VGPRs per lane -- the second __launch_bounds__ argument is HIP's "minimum waves per execution unit (SIMD)", not CUDA's
+// blocks per multiprocessor.  (The 256-thread / 16-points-per-thread form was latency-bound at two waves per SIMD: 477 us.)
+// One column per workgroup: a workgroup that walks several columns (LDS tables set up once) compiles to a loop with spills and
+// branches around the loads -- 0.53-0.63 ms instead of 0.40.
+constexpr int kEchoRangeWavesPerSimd = 4;
 // The same synthesis with the range stage of the following fft2D call (fft2D.m:37-45) applied while the column is still in
 // registers: echoGrid is written once (API output + covariance input) and never re-read by the range stage; txGrid is read
 // once.  HBM traffic of the launch = K L A 16 B written + K L A 16 B read (+ the CUT rows) -- the algorithmic minimum for
 // monoStaticSensing's output + fft2D's range-Doppler input.  Requires nIFFT == 4096 (the FFT the registers are laid out for).
 template <int QT, int NZ, int GROUP = (QT <= 1 ? 4 : 2)>   // loads in flight per thread: 2 x GROUP elements
-__global__ __launch_bounds__(Fft4096W::NT, ISAC_ECHO_RANGE_WGS) void echo_range_kernel(int K, int L_whole, int L_out, int A, int Q_rt, const c64* __restrict__ D,
+__global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_range_kernel(int K, int L_whole, int L_out, int A, int Q_rt, const c64* __restrict__ D,
                                                             const c64* __restrict__ steer_rq, double sig, uint64_t seed,
                                                             const c64* __restrict__ noise, const c64* __restrict__ tw,
                                                             const c64* __restrict__ logtab_g, c64* __restrict__ grid,

@@ -22,7 +22,8 @@ namespace isac {
 
 // ---------------------------------------------------------------- range: conj-multiply + window + IFFT, keep needed rows
 template <class FFT>
-__global__ __launch_bounds__(FFT::NT, 2) void range_kernel(const c64* __restrict__ rx, const c64* __restrict__ tx, int K, int L,
+__global__ __launch_bounds__(FFT::NT, FFT::NT / 128) void range_kernel(   // (second argument: minimum WAVES per SIMD -> two workgroups per CU)
+    const c64* __restrict__ rx, const c64* __restrict__ tx, int K, int L,
                                                        int A, const c64* __restrict__ tw, const double* __restrict__ win_k,
                                                        const double* __restrict__ win_r /* fftshift(kaiser(nIFFT)) */,
                                                        double inv_n, double sqrt_n, int row_lo, int n_rows,
