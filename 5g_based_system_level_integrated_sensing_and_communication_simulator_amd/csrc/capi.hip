@@ -162,6 +162,25 @@ int isac_get_twiddles(isac_ctx* ctx, int n, const c64** out) {
 }
 int isac_get_twiddles2(isac_ctx* ctx, int n, const c64** out) { return isac_get_twiddles(ctx, n, out); }
 
+// {W512^0..511, W4096^0..7}: the LDS tables of Fft4096W in one contiguous run (bit-identical to entries 8 i / i of the 4096 table)
+int isac_get_w512_pack(isac_ctx* ctx, const c64** out) {
+  isac_ctx& t = *ctx;
+  const int key = -4096;                                 // lives in the same map under a key no FFT length uses
+  auto it = t.twiddles.find(key);
+  if (it == t.twiddles.end()) {
+    std::vector<c64> w(520);
+    const long double two_pi = 2.0L * 3.14159265358979323846264338327950288L;
+    for (int m = 0; m < 512; ++m) { const long double a = -two_pi * (long double)(8 * m) / 4096.0L; w[(size_t)m] = mk((double)cosl(a), (double)sinl(a)); }
+    for (int m = 0; m < 8; ++m) { const long double a = -two_pi * (long double)m / 4096.0L; w[(size_t)512 + m] = mk((double)cosl(a), (double)sinl(a)); }
+    w[0] = mk(1.0, 0.0); w[128] = mk(0.0, -1.0); w[256] = mk(-1.0, 0.0); w[384] = mk(0.0, 1.0); w[512] = mk(1.0, 0.0);
+    DevBuf b;
+    ISAC_TRY(upload(ctx, b, w.data(), sizeof(c64) * w.size()));
+    it = t.twiddles.emplace(key, b).first;
+  }
+  *out = (const c64*)it->second.p;
+  return ISAC_OK;
+}
+
 // (1 / c_i, ln c_i) for the kLogTabSize mantissa buckets of the table-driven Box-Muller radius (echo_dev.hpp); c_i is
 // the bucket centre in [0.5, 1); ln is taken of the reciprocal actually stored so that ln m = ln c_i + log1p(m / c_i - 1)
 // holds to rounding.  Kept in the twiddle map under a negative key (freed with the context).

@@ -395,6 +395,7 @@ using namespace isac;
 
 int isac_get_twiddles(isac_ctx* ctx, int n, const c64** out);  // capi.hip
 int isac_get_logtab(isac_ctx* ctx, const c64** out);           // capi.hip
+int isac_get_w512_pack(isac_ctx* ctx, const c64** out);        // capi.hip
 
 static int check_carrier(isac_ctx* ctx, const isac_carrier* c) {
   if (!c) return fail(ctx, ISAC_ERR_INVALID_ARG, "carrier is NULL");
@@ -696,7 +697,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
   }
   const c64* tw = nullptr;
   const double *wk = nullptr, *wr = nullptr;
-  ISAC_TRY(isac_get_twiddles(ctx, g.nfft, &tw));
+  ISAC_TRY(isac_get_w512_pack(ctx, &tw));            // Fft4096W's packed LDS tables (the fused kernel needs nothing else of the 4096 table)
   ISAC_TRY(isac_get_windows(ctx, g.n_sc, ep->n_ifft, &wk, &wr));
   const double n0s = std::sqrt(rp->n0 / 2.0);
   if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));   // isac_profile_*: brackets exactly the fused kernel below

@@ -92,6 +92,7 @@ struct Fft4096 {
   static constexpr int IMG = 16 * SK;          // data image
   static constexpr int LDS_ELEMS = IMG + 256;  // + W256 table (second-pass twiddles and OFDM phase ramps)
   static constexpr int kW256Stride = 1;
+  static constexpr bool kPackedTable = false;
   c64 x[PER];
   c64 wb[4];  // W4096^(tid * {1,2,4,8}); the other first-pass twiddles are products of at most 4 of these
 
@@ -257,9 +258,12 @@ struct Fft4096W {
     init_table(lds, tw, tid);
     init_twiddles_lds(lds, tid);
   }
-  __device__ __forceinline__ void init_table(c64* __restrict__ lds, const c64* __restrict__ tw, int tid) {
-    lds[IMG + tid] = tw[8 * tid];                    // W512^tid
-    if (tid < 8) lds[IMG + 512 + tid] = tw[tid];     // W4096^tid
+  // `pack` = the contiguous 520-entry table {W512^0..511, W4096^0..7} (isac_get_w512_pack): 65 cache lines per workgroup; picking
+  // W512^i = W4096^(8 i) out of the 4096-entry table touched 512 different lines for the same 8 KB.
+  static constexpr bool kPackedTable = true;
+  __device__ __forceinline__ void init_table(c64* __restrict__ lds, const c64* __restrict__ pack, int tid) {
+    lds[IMG + tid] = pack[tid];                      // W512^tid
+    if (tid < 8) lds[IMG + 512 + tid] = pack[512 + tid];   // W4096^tid
     __syncthreads();
   }
   // First-pass twiddles W4096^(tid {1, 2, 4}) from the LDS tables (W4096^tid = W512^(tid div 8) W4096^(tid mod 8), then two squarings;
@@ -359,6 +363,7 @@ struct Fft4096W {
 
 template <int N_>
 struct FftStockham {
+  static constexpr bool kPackedTable = false;
   static constexpr int N = N_;
   static constexpr int NT = 256;
   static constexpr int PER = (N + NT - 1) / NT;

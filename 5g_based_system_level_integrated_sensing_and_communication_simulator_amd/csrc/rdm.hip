@@ -18,6 +18,8 @@
 
 #include "fft_lds.hpp"
 
+int isac_get_w512_pack(isac_ctx* ctx, const isac::c64** out);   // capi.hip
+
 namespace isac {
 
 // ---------------------------------------------------------------- range: conj-multiply + window + IFFT, keep needed rows
@@ -371,6 +373,7 @@ static int launch_range(isac_ctx* ctx, hipStream_t st, const c64* rx, const c64*
   size_t lds = sizeof(c64) * FFT::LDS_ELEMS;
   auto kern = range_kernel<FFT>;
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
+  if (FFT::kPackedTable) ISAC_TRY(isac_get_w512_pack(ctx, &tw));          // the 512-thread transform builds everything from its packed table
   hipLaunchKernelGGL(kern, dim3(fft_grid2(L * A)), dim3(FFT::NT), lds, st, rx, tx, K, L, A, tw, wk, wr, 1.0 / n_ifft,
                      std::sqrt((double)n_ifft), row_lo, n_rows, ymid);
   ISAC_HIP(hipGetLastError());
