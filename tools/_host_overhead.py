@@ -2,8 +2,8 @@ import importlib, sys, time
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 pkg = importlib.import_module(bench.PKG)
-pool = bench.SlotPool(pkg, 0, 4)
-cell = bench.Cell(pkg, 0, 0, 4, 2, 1, pool=pool, n_buf=4)     # 4 antennas, 2 slots: negligible GPU work
+pool = bench.SlotPool(pkg, 0, 8)
+cell = bench.Cell(pkg, 0, 0, 4, 2, 1, pool=pool, n_buf=8)     # 4 antennas, 2 slots: negligible GPU work
 for _ in range(20): pool.submit(cell)
 pool.drain(); pool.sync()
 t0 = time.perf_counter()
