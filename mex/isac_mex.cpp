@@ -7,8 +7,9 @@
 // Device-resident arrays: isac_mex('toDevice', A) returns a uint64 HANDLE; every array argument of the sensing entries may be
 // such a handle instead of a MATLAB array, and an entry whose array inputs are handles returns handles -- the echo grid of
 // monoStaticSensing then never crosses PCIe on its way into fft2D (isac_mex('gather', h) / isac_mex('free', h)).
-// This file is compile-checked here against mex/stub/mex.h (no MATLAB in the image); the host-pointer and device-pointer call
-// sequences it issues are driven for real by tests/abi_host.c (plain C, linked against libisac_hip.so).
+// No MATLAB in the build image: this file is compiled against mex/stub/mex.h (prototypes only) and run against the in-process
+// implementation of those functions under tests/mex_runtime/ -- tests/mex_host.cpp calls mexFunction() for every entry below with
+// MATLAB-shaped arguments (tests/test_gpu_mex_host.py); tests/abi_host.c issues the same ABI call sequences from plain C.
 #include "mex.h"
 #include "isac.h"
 

@@ -1,6 +1,7 @@
 /* Minimal declaration-only stand-in for MATLAB's mex.h / matrix.h (R2018a interleaved-complex API), just enough to
- * COMPILE-CHECK mex/isac_mex.cpp in an image without MATLAB (`g++ -fsyntax-only`, see __graft_entry__.build()).
- * It defines no behaviour and is never linked; with a real MATLAB the gateway is built against MATLAB's own header:
+ * compile mex/isac_mex.cpp in an image without MATLAB (`g++ -fsyntax-only` in __graft_entry__.build(); linked against the test
+ * runtime tests/mex_runtime/mx_runtime.cpp for tests/mex_host).  It defines no behaviour; with a real MATLAB the gateway is built
+ * against MATLAB's own header:
  *     mex -R2018a mex/isac_mex.cpp -Iinclude -L<package dir> -lisac_hip                                              */
 #ifndef ISAC_MEX_STUB_H
 #define ISAC_MEX_STUB_H

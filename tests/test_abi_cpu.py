@@ -105,3 +105,13 @@ def test_mex_gateway_compiles_against_the_header():
     sys.path.insert(0, root)
     import __graft_entry__ as g
     g.check_mex_gateway()
+
+
+def test_mex_gateway_links_against_the_test_runtime():
+    """tests/_build/mex_host = the gateway + the in-process mx runtime + libisac_hip.so: it must link here (no GPU needed for that);
+    without arguments it prints its usage and exits 1 before touching the device."""
+    import subprocess
+    import __graft_entry__ as g
+    exe = g.build_mex_host()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "usage" in r.stderr
