@@ -83,3 +83,9 @@ def test_c_host_pointer_path_timing_beside_device_resident():
     assert res["device_resident_cpi_ms"] > 0 and res["device_resident_fused_cpi_ms"] > 0
     assert res["host_pointer_cpi_ms"] > 3 * res["device_resident_cpi_ms"]          # the PCIe hop dominates the host-pointer path
     assert 90.0 < res["rngEst0"] < 120.0
+
+
+def test_graft_entry_smoke_runs():
+    """The driver's own entry point: __graft_entry__.smoke() end to end (it is not otherwise part of the test suite)."""
+    import __graft_entry__ as g
+    g.smoke()
