@@ -75,8 +75,8 @@ def cell_params(n_ants, targets, velocity):
 
 class SlotPool:
     """`n` execution slots of one GPU (context = HIP streams + scratch) shared by all the cells it hosts: at most `n`
-    CPIs are in flight on the GPU however many cells there are (more than 4 contexts = 8 streams oversubscribe the
-    hardware queues and lose 10-25 %).  Results are collected in submission order."""
+    CPIs are in flight on the GPU however many cells there are (two HIP streams per context: keep 2 n within
+    GPU_MAX_HW_QUEUES -- 24 streams collapse to half the rate, profiles/r02_queue_sweep.txt).  Results are collected in submission order."""
 
     def __init__(self, pkg, device, n):
         self.ctxs = [pkg.Context(device) for _ in range(max(1, n))]
