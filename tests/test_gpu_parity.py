@@ -201,7 +201,8 @@ def test_fft2d_every_other_cut_detects(pkg, ctx):
 
 @pytest.mark.parametrize("area,blocks", [(((650.0, 1000.0), (-50.0, 50.0)), "one block, not the first"),
                                          (((500.0, 800.0), (-50.0, 50.0)), "straddles two 512-row blocks"),
-                                         (((50.0, 500.0), (-50.0, 50.0)), "default: inside the first block")])
+                                         (((50.0, 500.0), (-50.0, 50.0)), "default: inside the first block")] +
+                                        [(((625.0 * i + 20, 625.0 * (i + 1) - 25), (-50.0, 50.0)), f"block {i}") for i in range(2, 8)])
 def test_fft2d_range_window_position(pkg, ctx, area, blocks):
     """The range transform forms only the 512-row output block the CUT rows need when they fit in one (pruned last radix-8 pass),
     all eight otherwise: zones in a later block and across a block boundary against the oracle, fused and unfused (Pfa = 0.5 so that
@@ -217,6 +218,9 @@ def test_fft2d_range_window_position(pkg, ctx, area, blocks):
         assert rows.min() - 3 >= 513 and rows.max() + 3 <= 1024
     if "straddles" in blocks:
         assert rows.min() < 512 < rows.max()
+    if blocks.startswith("block "):                              # every output digit of the single-output last pass (dft8_one)
+        i = int(blocks.split()[1])
+        assert (rows.min() - 4) // 512 == i == (rows.max() + 2) // 512
     rx = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, sc.noise, nfft=sc.wave.Nfft)
     want, dbg = O.fft2d(sc.rp, ocf, rx, sc.tx_grid, return_debug=True)
     d_wave, d_noise, d_txg = ctx.to_device(sc.tx_wave), ctx.to_device(sc.noise), ctx.to_device(sc.tx_grid)
