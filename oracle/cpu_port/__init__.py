@@ -66,8 +66,10 @@ def _f(a, dtype):
     return np.ascontiguousarray(np.asarray(a, dtype=dtype).reshape(-1))
 
 
-def mono_static_sensing(tx_waveform, tx_dimension, carrier_info, rp, los, noise_unit=None, nfft=4096, seed=0):
-    """Same contract as oracle.mono_static_sensing; ``noise_unit`` [T x A] injected, or ``seed`` != 0 for the port's own AWGN."""
+def mono_static_sensing(tx_waveform, tx_dimension, carrier_info, rp, los, noise_unit=None, nfft=4096, seed=0, out=None):
+    """Same contract as oracle.mono_static_sensing; ``noise_unit`` [T x A] injected, or ``seed`` != 0 for the port's own AWGN.
+    ``out``: an echo grid to overwrite (a caller that processes CPI after CPI keeps its buffer: a fresh 0.75 GB array per call costs
+    0.2 s of page faults on a 128-thread host)."""
     lib = load()
     tx = np.asfortranarray(np.asarray(tx_waveform, dtype=np.complex128))
     t_len, a = tx.shape
@@ -78,7 +80,10 @@ def mono_static_sensing(tx_waveform, tx_dimension, carrier_info, rp, los, noise_
     los = _f(np.asarray(los).reshape(-1) == 1, np.uint8)
     lw = lib.isac_cpu_symbol_count(int(nfft), int(carrier_info.SubcarrierSpacing), t_len)
     l_out = max(lw, int(tx_dimension[1]), 1)
-    out = np.empty((k, l_out, a), dtype=np.complex128, order="F")
+    if out is None:
+        out = np.empty((k, l_out, a), dtype=np.complex128, order="F")
+    elif out.shape != (k, l_out, a) or out.dtype != np.complex128 or not out.flags.f_contiguous:
+        raise ValueError("out must be a Fortran-ordered complex128 array of the echo grid's shape")
     nz = None if noise_unit is None else np.asfortranarray(np.asarray(noise_unit, dtype=np.complex128))
     lo = C.c_int(0)
     st = lib.isac_cpu_mono_static_sensing(tx.ctypes.data_as(C.c_void_p), C.c_longlong(t_len), C.c_int(int(tx_dimension[1])), C.c_int(k), C.c_int(int(nfft)),

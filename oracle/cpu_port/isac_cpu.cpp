@@ -245,12 +245,15 @@ int isac_cpu_mono_static_sensing(const double* tx_wave_, long long T, int tx_dim
   const int L_out = std::max(Lw, tx_dim_l);                                        // monoStaticSensing.m:19-21
   if (l_out) *l_out = L_out;
   const int Q = (int)qs.size();
+  const bool dbg = std::getenv("ISAC_CPU_DEBUG") != nullptr;
+  double t_ = omp_get_wtime();
+  auto lap = [&](const char* what) { if (dbg) { const double n = omp_get_wtime(); std::fprintf(stderr, "[isac_cpu] %-12s %.3f s\n", what, n - t_); t_ = n; } };
   // per-target coefficient vectors: coef_q[t] = lsf e^{j wd t} e^{j w (t-d) Ts} (sum_a tx[t-d,a] a_q[a]) e^{-j w t Ts}
   std::vector<cd> coef((size_t)Q * T), prx((size_t)T);
   const cd* steer = reinterpret_cast<const cd*>(rp->steering);
   std::vector<long long> shift((size_t)Q);
   for (int q = 0; q < Q; ++q) shift[(size_t)q] = (long long)std::ceil((2.0 * rp->range[qs[(size_t)q]] / kC0) / Ts);   // :21-22
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 4096)        // (dynamic everywhere: on a shared host a descheduled thread must not hold a static share)
   for (long long t = 0; t < T; ++t) {
     const double tt = (double)t * Ts;
     prx[(size_t)t] = cd(std::cos(w * tt), -std::sin(w * tt));                     // :72-73
@@ -271,6 +274,7 @@ int isac_cpu_mono_static_sensing(const double* tx_wave_, long long T, int tx_dim
       coef[(size_t)q * T + t] = out;
     }
   }
+  lap("coef");
   const double n0s = std::sqrt(rp->n0 / 2.0);                                      // :67
   const FftPlan plan(nfft);
   const int half = n_sc / 2;
@@ -303,6 +307,7 @@ int isac_cpu_mono_static_sensing(const double* tx_wave_, long long T, int tx_dim
         }
       }
   }
+  lap("echo+demod");
   return 0;
 }
 
@@ -431,25 +436,39 @@ int isac_cpu_fft2d(const double* rx_, const double* tx_, int K, int L, int A, co
     { n_thr = omp_get_num_threads(); acc_all.assign((size_t)n_thr * 2 * A * A, 0.0); }
     double* __restrict__ ar = &acc_all[(size_t)omp_get_thread_num() * 2 * A * A];
     double* __restrict__ ai = ar + (size_t)A * A;
-    constexpr int BS = 256;
-    std::vector<double> br((size_t)BS * A), bi((size_t)BS * A);
-#pragma omp for schedule(static)
+    // register-blocked rank-BS update: a 2 (columns b) x 8 (rows a) block of the accumulator lives in vector registers over a block of
+    // BS samples (AVX2: 8 FMA accumulators, 4 loads + 4 broadcasts per 16 FMAs); the antenna axis is padded to a multiple of 8
+    constexpr int BS = 256, RB = 8, CB = 2;
+    const int Ap = (A + RB - 1) / RB * RB;
+    std::vector<double> br((size_t)BS * Ap, 0.0), bi((size_t)BS * Ap, 0.0);
+#pragma omp for schedule(dynamic, 4)
     for (long long n0 = 0; n0 < N; n0 += BS) {
       const int nb = (int)std::min<long long>(BS, N - n0);
       for (int a = 0; a < A; ++a)                                                  // transpose: antennas contiguous per sample
-        for (int i = 0; i < nb; ++i) { const cd v = rx[(size_t)(n0 + i) + (size_t)N * a]; br[(size_t)i * A + a] = v.real(); bi[(size_t)i * A + a] = v.imag(); }
-      for (int i = 0; i < nb; ++i) {
-        const double* __restrict__ gr_ = &br[(size_t)i * A];
-        const double* __restrict__ gi_ = &bi[(size_t)i * A];
-        for (int b = 0; b < A; ++b) {
-          const double xr = gr_[b], xi = gi_[b];
-          double* __restrict__ cr = ar + (size_t)b * A;
-          double* __restrict__ ci = ai + (size_t)b * A;
+        for (int i = 0; i < nb; ++i) { const cd v = rx[(size_t)(n0 + i) + (size_t)N * a]; br[(size_t)i * Ap + a] = v.real(); bi[(size_t)i * Ap + a] = v.imag(); }
+      for (int bb = 0; bb < A; bb += CB) {
+        const int b_hi = std::min(bb + CB, A) - 1;
+        for (int ab = 0; ab <= b_hi; ab += RB) {
+          double cr[CB][RB] = {}, ci[CB][RB] = {};
+          for (int i = 0; i < nb; ++i) {
+            const double* __restrict__ gr_ = &br[(size_t)i * Ap];
+            const double* __restrict__ gi_ = &bi[(size_t)i * Ap];
+#pragma GCC unroll 2
+            for (int u = 0; u < CB; ++u) {
+              const int b = std::min(bb + u, A - 1);
+              const double xr = gr_[b], xi = gi_[b];
 #pragma omp simd
-          for (int a = 0; a <= b; ++a) {                                           // conj(g[a]) * g[b]
-            cr[a] += gr_[a] * xr + gi_[a] * xi;
-            ci[a] += gr_[a] * xi - gi_[a] * xr;
+              for (int v = 0; v < RB; ++v) {                                       // conj(g[a]) * g[b]
+                cr[u][v] += gr_[ab + v] * xr + gi_[ab + v] * xi;
+                ci[u][v] += gr_[ab + v] * xi - gi_[ab + v] * xr;
+              }
+            }
           }
+          for (int u = 0; u < CB && bb + u < A; ++u)
+            for (int v = 0; v < RB && ab + v <= bb + u; ++v) {
+              ar[(size_t)(bb + u) * A + ab + v] += cr[u][v];
+              ai[(size_t)(bb + u) * A + ab + v] += ci[u][v];
+            }
         }
       }
     }
