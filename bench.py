@@ -270,7 +270,7 @@ def stage_table(cell, reps=5):
 
 
 def cpu_baseline(cell, budget_s=12.0):
-    """The reference's chain on the host cores: the C++17 / OpenMP port under oracle/cpu_port (kind "port-c++": the MATLAB reference cannot
+    """The reference's chain on the host cores: the C++17 / OpenMP port under oracle/cpu_port (kind "port": the MATLAB reference cannot
     run here -- no MATLAB, no toolboxes).  Same workload as the GPU line at FULL size (all antennas, all 224 symbols): the transmit
     waveform and grid are copied back from the device, the port draws its own AWGN (inside the timed call, as randn is inside
     basicRadarChannel), every OpenMP thread the host offers.  Bounded sample: whole CPIs until `budget_s` seconds have elapsed
@@ -291,7 +291,7 @@ def cpu_baseline(cell, budget_s=12.0):
         times.append(time.perf_counter() - t0)
     cpi_s = float(np.median(times))
     n_slots = cell.Lsym // 14
-    return {"value": round(n_slots / cpi_s, 3), "unit": "sensing slots/sec", "cores": P.threads(), "kind": "port-c++",
+    return {"value": round(n_slots / cpi_s, 3), "unit": "sensing slots/sec", "cores": P.threads(), "kind": "port", "language": "C++17 + OpenMP (oracle/cpu_port)",
             "sample": f"{len(times)} whole CPIs of the bench workload ({cell.A} antennas, K={cell.K}, L={cell.Lsym}, T={cell.T}) through oracle/cpu_port "
                       f"(C++17 + OpenMP, own radix-4 FFT, fp64, AWGN drawn inside the timed call), median {cpi_s:.3f} s per CPI, "
                       f"{P.threads()} OpenMP threads; first estimates rng {None if est is None else np.round(est.rngEst[:2], 3).tolist()} "

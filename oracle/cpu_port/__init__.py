@@ -1,6 +1,6 @@
 """ctypes binding of the C++/OpenMP CPU port (oracle/cpu_port/isac_cpu.cpp) -- TEST / BASELINE INFRASTRUCTURE ONLY.
 
-Two uses, both outside the product path: (1) `bench.py`'s ``cpu_baseline`` leg (kind "port-c++": the MATLAB reference
+Two uses, both outside the product path: (1) `bench.py`'s ``cpu_baseline`` leg (kind "port": the MATLAB reference
 cannot run here or on the GPU box) and (2) a second independent implementation of the reference's chain that the NumPy
 oracle is cross-checked against (tests/test_cpu_port.py).  Built by ``__graft_entry__.build()`` into
 ``oracle/_build/libisac_cpu.so`` (git-ignored, travels to the GPU box with the snapshot).

@@ -1,4 +1,4 @@
-"""The C++/OpenMP CPU port (oracle/cpu_port: bench.py's `cpu_baseline`, kind "port-c++") against the NumPy oracle: two
+"""The C++/OpenMP CPU port (oracle/cpu_port: bench.py's `cpu_baseline`, kind "port") against the NumPy oracle: two
 independent restatements of the same reference lines (monoStaticSensing.m:1-23, basicRadarChannel.m:21-74, fft2D.m:37-115,
 music.m:19-104) must agree -- echo grid / |rdm|^2 / Ra to 1e-10, CFAR index lists and all estimates exactly."""
 import numpy as np
