@@ -161,3 +161,65 @@ def test_sinr_cqi_on_random_configuration(pkg, seed):
     edges = 10.0 ** (np.asarray(OQ.DOWNLINK_SINR90PC) / 10.0)
     if np.min(np.abs(want.mean() / edges - 1.0)) > 1e-9:      # away from a table edge the integer CQI is exact
         assert cqi == OQ.get_cqi(want.mean(), OQ.DOWNLINK_SINR90PC)
+
+
+N_SPECTRAL = max(8, N_CASES // 2)
+
+
+@pytest.mark.parametrize("seed", range(N_SPECTRAL))
+def test_spectral_fused_path_on_random_scene(pkg, seed):
+    """The route bench.py times, fuzzed: per-target demodulation -> fused synthesis + range kernel with the AWGN on the demodulated grid ->
+    cached fft2D, for random antenna counts (incl. the 33..64 range), 1..6 targets (compile-time kernels 1..4 and the run-time one),
+    zero-filled 'S' slots or not.  (a) injected spectral field W: echo grid, CFAR lists and estimates against the oracle's TIME-domain chain fed
+    the equivalent time-domain noise; (b) Philox spectral mode: echo grid against the oracle fed the restated generator's field;
+    (c) fused == unfused bit for bit."""
+    from conftest import spectral_to_time_noise
+    rng = np.random.default_rng(9000 + seed)
+    q = int(rng.integers(1, 7))
+    n_ants = int(rng.choice([1, 2, 3, 5, 8, 17, 40]))
+    n_slots = int(rng.choice([2, 4] if n_ants > 8 else [2, 3, 4]))
+    r = rng.uniform(60.0, 300.0, q)
+    az = np.deg2rad(rng.uniform(-70.0, 70.0, q))
+    targets = tuple((float(r[i] * np.cos(az[i])), float(r[i] * np.sin(az[i])), 1.5) for i in range(q))
+    sc = make_scene(n_ants=n_ants, n_slots=n_slots, nrb=273, targets=targets, velocity=tuple(float(v) for v in rng.integers(-10, 11, q)),
+                    seed=seed, zero_s_slots=bool(rng.integers(0, 2)), with_noise=False)
+    ctx = pkg.default_context()
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    cf = pkg.sensing.detection.cfar2D(rp)
+    d_wave, d_txg = ctx.to_device(sc.tx_wave), ctx.to_device(sc.tx_grid)
+    w = np.asfortranarray(rng.standard_normal(sc.tx_grid.shape) + 1j * rng.standard_normal(sc.tx_grid.shape))
+    d_w = ctx.to_device(w)
+    e_f = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, spectral_noise=d_w, fuse_fft2d=(rp, cf, d_txg))
+    ref_echo = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los,
+                                     spectral_to_time_noise(w, sc.T, 4096, 30, sc.rp.fc, sc.rp.fs), nfft=4096)
+    g_f = e_f.numpy()
+    assert rel(g_f, ref_echo) < RTOL
+    e_u = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, spectral_noise=d_w)
+    assert np.array_equal(g_f, e_u.numpy())
+    # Philox spectral mode against the restated generator
+    e_p = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, seed=0x77 + seed, noise_domain="spectral",
+                                        fuse_fft2d=(rp, cf, d_txg))
+    wp = O.philox_spectral_noise(sc.K, sc.L, sc.A, 0x77 + seed)
+    ref_p = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los,
+                                  spectral_to_time_noise(wp, sc.T, 4096, 30, sc.rp.fc, sc.rp.fs), nfft=4096)
+    assert rel(e_p.numpy(), ref_p) < RTOL
+    # detections / estimates of the injected-field run against the oracle
+    ocf = O.cfar2d_config(sc.rp)
+    e_f = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, spectral_noise=d_w, fuse_fft2d=(rp, cf, d_txg))
+    try:
+        want, dbg = O.fft2d(sc.rp, ocf, ref_echo, sc.tx_grid, return_debug=True, rdm_fn=O.rdm_explicit)
+    except ValueError:
+        with pytest.raises(pkg.IsacError) as ei:
+            pkg.sensing.estimation.fft2D(rp, cf, e_f, d_txg, reuse_range=True)
+        assert ei.value.name == "NO_DETECTION"
+        return
+    if not all(_guard_band_ok(np.abs(dbg.rdm[:, :, a]) ** 2, ocf.CUTIdx, ocf.Pfa) for a in range(sc.A)):
+        pytest.skip("a CUT sits within 1e-9 of its CFAR threshold: rounding-defined scene")
+    got, gd = pkg.sensing.estimation.fft2D(rp, cf, e_f, d_txg, return_debug=True, reuse_range=True)
+    assert all(np.array_equal(x, y) for x, y in zip(gd.detections, dbg.detections))
+    assert np.array_equal(got.rngEst, want.rngEst) and np.array_equal(got.velEst, want.velEst)
+    ev = np.sort(np.linalg.eigvalsh(dbg.Ra))[::-1]                   # same rule as the time-domain fuzz above
+    n_sig = min(int(want.rngEst.size), sc.A - 1)
+    if n_sig >= 1 and (ev[n_sig - 1] - ev[n_sig]) < 1e-9 * ev[0]:
+        pytest.skip("signal/noise split inside a degenerate eigenvalue cluster: MUSIC peaks undefined")
+    assert np.array_equal(got.aziEst, want.aziEst)
