@@ -668,8 +668,17 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
   const int hr = cf->guard[0] + cf->train[0];
   const int row_lo = cf->row0 - 1 - hr, row_hi = cf->row1 - 1 + hr;
   const bool fusable = (g.nfft == 4096 && ep->n_ifft == g.nfft && row_lo >= 0 && row_hi < ep->n_ifft && cf->row1 >= cf->row0);
-  if (!fusable)   // other numerologies: plain path, fft2D will run its own range stage
-    return isac_mono_static_sensing_dev(ctx, d_tx_wave, T, tx_dim_l, carrier, rp, los, noise_mode, d_noise_unit, seed, d_echo_grid, l_out);
+  if (!fusable) {
+    // other numerologies (Nfft != 4096 or nIFFT != Nfft): the plain synthesis, then the range stage of the following fft2D launched right
+    // behind it -- the contract (stage results cached for isac_fft2d_submit_cached_dev) holds for every carrier.  A CUT window that
+    // leaves the map is fft2D's error to report: nothing is cached then.
+    int32_t lo = 0;
+    ISAC_TRY(isac_mono_static_sensing_dev(ctx, d_tx_wave, T, tx_dim_l, carrier, rp, los, noise_mode, d_noise_unit, seed, d_echo_grid, &lo));
+    if (l_out) *l_out = lo;
+    const bool window_ok = row_lo >= 0 && row_hi < ep->n_ifft && cf->row1 >= cf->row0 && ep->n_ifft >= g.n_sc && (ep->n_ifft & (ep->n_ifft - 1)) == 0;
+    if (!window_ok) return ISAC_OK;
+    return isac_range_stage_into_cache(ctx, ep, cf, (const c64*)d_echo_grid, (const c64*)d_tx_grid, g.n_sc, lo, rp->n_ants);
+  }
   if (noise_mode < ISAC_NOISE_NONE || noise_mode > ISAC_NOISE_INJECTED_SPECTRAL) return fail(ctx, ISAC_ERR_INVALID_ARG, "unknown noise mode");
   if (noise_mode == ISAC_NOISE_INJECTED_SPECTRAL && !d_noise_unit) return fail(ctx, ISAC_ERR_INVALID_ARG, "noise buffer missing");
   const bool spectral = spectral_mode(noise_mode);

@@ -182,7 +182,9 @@ int isac_mono_static_sensing(isac_ctx* ctx, const isac_c64* tx_wave, int64_t T, 
  * d_echo_grid / d_tx_grid / parameter blocks consumes them instead of re-reading rxGrid.  Reuse is explicit:
  * the plain isac_fft2d[_submit]_dev never uses the cache, and any echo / range / copy / memset / free call on the
  * context drops it.  The caller must not modify echoGrid or txGrid between the two calls.
- * Falls back to the plain path when Nfft != nIFFT (the cached submit then reports INVALID_ARG: use the plain one). */
+ * One kernel does both for the spectral noise modes at Nfft = nIFFT = 4096; for every other carrier / noise mode the synthesis is
+ * followed by the range stage as a second launch -- the contract (cached rows for the next isac_fft2d_submit_cached_dev) is the
+ * same.  Only when the CUT window leaves the map nothing is cached (the following fft2D reports ISAC_ERR_CFAR_WINDOW). */
 int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64* d_tx_wave, int64_t T, int32_t tx_dim_l,
                                        const isac_carrier* carrier, const isac_radar_channel_params* rp,
                                        const uint8_t* los, int noise_mode, const isac_c64* d_noise_unit,

@@ -177,3 +177,31 @@ def test_fused_synthesis_covariance_kernel(pkg, ctx, n_ants, targets, vel):
         assert np.array_equal(dbg0.power_window, dbg1.power_window)
         assert all(np.array_equal(a, b) for a, b in zip(dbg0.detections, dbg1.detections))
         assert np.array_equal(est0.rngEst, est1.rngEst) and np.array_equal(est0.velEst, est1.velEst) and np.array_equal(est0.aziEst, est1.aziEst)
+
+
+@pytest.mark.parametrize("nrb", [24, 106, 133])
+def test_fused_contract_holds_for_every_carrier(pkg, ctx, nrb):
+    """Nfft != 4096 (24 / 106 / 133 PRB -> 512 / 2048 / 2048): the fused entry has no fused kernel for these, but the contract is the
+    same -- monoStaticSensing(fuse_fft2d=...) followed by fft2D(reuse_range=True) -- and the results equal the plain sequence bit for bit."""
+    sc = make_scene(n_ants=3, n_slots=4, nrb=nrb, targets=((90.0, 20.0, 1.5),), velocity=(5.0,), seed=41, with_noise=False, num_slots_param=6)
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    cf = pkg.sensing.detection.cfar2D(rp)
+    d_wave, d_txg = ctx.to_device(sc.tx_wave), ctx.to_device(sc.tx_grid)
+    for kw in (dict(seed=3, noise_domain="spectral"), dict(seed=3)):
+        e0 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=sc.wave.Nfft, **kw)
+        try:
+            est0, dbg0 = pkg.sensing.estimation.fft2D(rp, cf, e0, d_txg, return_debug=True)
+        except pkg.IsacError as err:
+            assert err.name == "NO_DETECTION"
+            est0 = None
+        # (the cache is single-use and per context: the fused call and its cached fft2D are consecutive)
+        e1 = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=sc.wave.Nfft, fuse_fft2d=(rp, cf, d_txg), **kw)
+        assert np.array_equal(e0.numpy(), e1.numpy())
+        if est0 is None:
+            with pytest.raises(pkg.IsacError) as ei:
+                pkg.sensing.estimation.fft2D(rp, cf, e1, d_txg, reuse_range=True)
+            assert ei.value.name == "NO_DETECTION"
+            continue
+        est1, dbg1 = pkg.sensing.estimation.fft2D(rp, cf, e1, d_txg, return_debug=True, reuse_range=True)
+        assert np.array_equal(dbg0.power_window, dbg1.power_window)
+        assert np.array_equal(est0.rngEst, est1.rngEst) and np.array_equal(est0.aziEst, est1.aziEst)
