@@ -761,6 +761,92 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
   }
 }
 
+// ---- n <= 64: the same zhetd2 reduction on four wavefronts with TWO barriers per step instead of ten.  Lane i owns row i; every wave
+// derives the reflector of the step redundantly (column read, norm by a wave reduction, zlarfg scalars) and keeps its own copy of v and
+// w in LDS for broadcast reads, so nothing of that needs a workgroup barrier; wave g handles the columns j = k+1+g, k+5+g, ... of the
+// matrix-vector product (partials exchanged through LDS: barrier 1) and of the rank-2 update (barrier 2 before the next step reads the
+// updated column).  The matrix lives in LDS, the reflectors go straight to the scratch zungtr reads.  222 -> ~120 us at n = 64
+// (host-call time of the whole eigensolver 0.905 -> 0.807 ms).
+__global__ __launch_bounds__(256) void eigh_tridiag_small_kernel(const c64* __restrict__ Hin, int n, void* scratch, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  EighScratch S(scratch, n);
+  c64* M = reinterpret_cast<c64*>(smem_raw);                     // [n x n] column-major working matrix
+  c64* spart = M + (size_t)n * n;                                 // [4][64] partial matrix-vector products
+  c64* svw = spart + 4 * 64;                                      // [4 waves][2][64]: each wave's own copy of v and w
+  double* sred = reinterpret_cast<double*>(svw + 4 * 2 * 64);     // [32] scratch of eigh_safe_scale
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  c64* my_v = svw + (size_t)wid * 128;
+  c64* my_w = my_v + 64;
+  const long long t_start = clock64();
+  const double scl = eigh_safe_scale(Hin, n * n, sred);
+  for (int i = tid; i < n * n; i += 256) M[i] = Hin[i] * scl;
+  if (tid == 0) *S.scale = scl;
+  if (tid < 8) S.cnt[tid] = 0;                                    // publication counters of the next two stages
+  __syncthreads();
+  auto wave_sum = [](double x) { for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o); return x; };
+  for (int k = 0; k < n - 1; ++k) {                               // zhetd2, lower
+    const bool below = lane > k + 1 && lane < n;
+    const c64 xi = below ? M[lane + n * k] : mk(0.0, 0.0);
+    const c64 alpha = M[k + 1 + n * k];                           // (broadcast read)
+    const double xnorm2 = wave_sum(xi.re * xi.re + xi.im * xi.im);
+    c64 tau = mk(0.0, 0.0), scale = mk(0.0, 0.0);
+    double beta = alpha.re;
+    if (xnorm2 != 0.0 || alpha.im != 0.0) {                       // zlarfg
+      beta = -copysign(sqrt(alpha.re * alpha.re + alpha.im * alpha.im + xnorm2), alpha.re);
+      tau = mk((beta - alpha.re) / beta, -alpha.im / beta);
+      const c64 dlt = mk(alpha.re - beta, alpha.im);
+      const double dn = dlt.re * dlt.re + dlt.im * dlt.im;
+      scale = mk(dlt.re / dn, -dlt.im / dn);                      // 1 / (alpha - beta)
+    }
+    const c64 vi = lane == k + 1 ? mk(1.0, 0.0) : (below ? xi * scale : mk(0.0, 0.0));
+    my_v[lane] = vi;                                              // (wave-private: no barrier, LDS operations of a wave are in order)
+    if (wid == 0) {
+      if (below) S.M[lane + n * k] = vi;                          // the reflector, where zungtr expects it
+      if (lane == 0) { S.d[k] = M[k + n * k].re; S.e[k] = beta; S.tau[k] = tau; }
+    }
+    if (tau.re != 0.0 || tau.im != 0.0) {                         // (uniform)
+      // p = tau A22 v: my columns' share of row `lane`
+      // (four columns per trip, their LDS reads issued together: a single dependent chain waits ~130 cycles per column)
+      c64 acc = mk(0.0, 0.0);
+      if (lane < n) {
+        c64 a0 = mk(0.0, 0.0), a1 = a0, a2_ = a0, a3 = a0;
+        int j = k + 1 + wid;
+        for (; j + 12 < n; j += 16) {
+          const c64 m0 = M[lane + n * j], m1 = M[lane + n * (j + 4)], m2 = M[lane + n * (j + 8)], m3 = M[lane + n * (j + 12)];
+          const c64 v0 = my_v[j], v1 = my_v[j + 4], v2 = my_v[j + 8], v3 = my_v[j + 12];
+          a0 = fma(m0, v0, a0); a1 = fma(m1, v1, a1); a2_ = fma(m2, v2, a2_); a3 = fma(m3, v3, a3);
+        }
+        for (; j < n; j += 4) a0 = fma(M[lane + n * j], my_v[j], a0);
+        acc = (a0 + a1) + (a2_ + a3);
+      }
+      spart[wid * 64 + lane] = acc;
+      __syncthreads();
+      const c64 pi = lane > k && lane < n ? tau * (((spart[lane] + spart[64 + lane]) + spart[128 + lane]) + spart[192 + lane]) : mk(0.0, 0.0);
+      const c64 t = mul_conj(vi, pi);                             // conj(p_i) v_i
+      const c64 a2 = mk(-0.5, 0.0) * (tau * mk(wave_sum(t.re), wave_sum(t.im)));   // -1/2 tau (p^H v)   (zhetd2: zdotc(tau-scaled p, v))
+      const c64 wi = pi + a2 * vi;
+      my_w[lane] = wi;
+      // A22 -= v w^H + w v^H on my columns
+      if (lane > k && lane < n) {
+        int j = k + 1 + wid;
+        for (; j + 12 < n; j += 16) {
+          c64 m[4], wj[4], vj[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { m[u] = M[lane + n * (j + 4 * u)]; wj[u] = my_w[j + 4 * u]; vj[u] = my_v[j + 4 * u]; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) M[lane + n * (j + 4 * u)] = m[u] - mul_conj(vi, wj[u]) - mul_conj(wi, vj[u]);
+        }
+        for (; j < n; j += 4) M[lane + n * j] = M[lane + n * j] - mul_conj(vi, my_w[j]) - mul_conj(wi, my_v[j]);
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    S.d[n - 1] = M[n - 1 + n * (n - 1)].re; S.e[n - 1] = 0.0;
+    if (info) info[1] = (int)((clock64() - t_start) >> 6);
+  }
+}
+
 template <bool LDS, bool LIVE>
 __device__ __forceinline__ void eigh_replay_body(int n, const EighScratch& S, c64* __restrict__ V_out, char* smem_raw, int block,
                                                  int bt, int* __restrict__ info);
@@ -1294,10 +1380,10 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
     ISAC_TRY(ensure(ctx, ctx->eig_scratch, EighScratch::bytes(n)));
     void* gs = ctx->eig_scratch.p;
     const size_t lds1 = sizeof(c64) * 6 * (size_t)n + sizeof(double) * 32 + 64;
-    if (n <= 64) {
-      const size_t lds1m = lds1 + sizeof(c64) * (size_t)n * n;
-      ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_tridiag_kernel<true>), (size_t)(100 * 1024)));
-      hipLaunchKernelGGL(eigh_tridiag_kernel<true>, dim3(1), dim3(256), lds1m, st, d_H, n, gs, info);   // small matrix: 4 waves, cheap barriers
+    if (n <= 64) {       // four waves, two barriers per step, matrix in LDS (the general kernel with its matrix in LDS: 222 us at n = 64; this one ~120)
+      const size_t ldss = sizeof(c64) * ((size_t)n * n + 4 * 64 + 4 * 2 * 64) + sizeof(double) * 32 + 64;
+      ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_tridiag_small_kernel), (size_t)(100 * 1024)));
+      hipLaunchKernelGGL(eigh_tridiag_small_kernel, dim3(1), dim3(256), ldss, st, d_H, n, gs, info);
     } else {
       hipLaunchKernelGGL(eigh_tridiag_kernel<false>, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
     }
