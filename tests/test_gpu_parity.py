@@ -305,7 +305,8 @@ def test_fft2d_zero_detections_is_an_error(pkg, ctx):
 
 # ------------------------------------------------------------------ covariance / eig / MUSIC
 @pytest.mark.parametrize("n,a", [(8064, 4), (4096 + 37, 19), (733824, 16), (65536, 64), (20000, 100), (8192, 256), (5003, 65), (3001, 130), (40000, 200),
-                                 (1, 3), (15, 5), (17, 64), (1, 70), (31, 129), (16, 256)])
+                                 (1, 3), (15, 5), (17, 64), (1, 70), (31, 129), (16, 256),
+                                 (5000, 40), (777, 33), (12345, 48), (100003, 17), (4099, 32)])     # 2 and 3 antenna blocks, ragged sample counts
 def test_covariance_mfma(pkg, ctx, n, a):
     rng = np.random.default_rng(a)
     g = np.asfortranarray(rng.standard_normal((n, a)) + 1j * rng.standard_normal((n, a)))
