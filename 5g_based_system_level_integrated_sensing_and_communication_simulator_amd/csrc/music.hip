@@ -1010,12 +1010,17 @@ __global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratc
       // hand the sweep to the replay: rotations at a 128-byte aligned offset (no cache line is shared by two sweeps, so
       // a replay block that runs concurrently never holds a line that is written later), then the descriptor, then --
       // after a fence -- the published sweep count
+      // Publication runs ONE SWEEP BEHIND: the release of sweep q (fence = wait for its stores' acknowledgements, ~1 us when issued right
+      // behind them) is issued after the chase of sweep q + 1, when those stores have long landed; the replay is faster than the
+      // recurrence anyway, and the last sweep is released by the final store below.
+      if (sweeps > 0) {
+        __threadfence();
+        if (lane == 0) __hip_atomic_store(&S.cnt[0], sweeps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
       for (int k = lane; k < mm - l; k += 64) S.rot[nrot + k] = rec[k];
       if (lane == 0) { S.desc[4 * sweeps] = mm; S.desc[4 * sweeps + 1] = l; S.desc[4 * sweeps + 2] = (int)nrot; S.desc[4 * sweeps + 3] = 0; }
       nrot += (mm - l + 7) & ~7;
       ++sweeps;
-      __threadfence();
-      if (lane == 0) __hip_atomic_store(&S.cnt[0], sweeps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       if (underflow) { de[mm].im = 0.0; continue; }
       { const double dl = de[l].re - p; de[l] = mk(dl, g); de[mm].im = 0.0; }
     }
@@ -1024,6 +1029,7 @@ __global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratc
     const double scl = *S.scale;                    // undo the safe scaling (power of two: exact)
     for (int i = lane; i < n; i += 64) w_out[i] = de[i].re / scl;
   }
+  __threadfence();                                  // the last sweep's rotations (stored by every lane) before its release below
   if (lane == 0) {
     S.cnt[1] = (int)nrot; S.cnt[2] = overflow;
     __hip_atomic_store(&S.cnt[0], sweeps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
