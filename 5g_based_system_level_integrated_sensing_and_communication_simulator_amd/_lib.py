@@ -14,6 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libisac_hip.so")
 _lib = None
 _lock = threading.Lock()
 
+ISAC_ABI_VERSION = 3          # include/isac.h ISAC_ABI_VERSION this binding was written against (checked at load)
 ISAC_MAX_EST = 4096
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX, NOISE_PHILOX_SPECTRAL, NOISE_INJECTED_SPECTRAL = 0, 1, 2, 3, 4
 
@@ -82,14 +83,14 @@ class EstResult(C.Structure):
 
 # every symbol include/isac.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "isac_abi_version", "isac_device_count", "isac_ctx_create", "isac_ctx_destroy", "isac_last_error",
+    "isac_abi_version", "isac_abi_sizeof", "isac_device_count", "isac_ctx_create", "isac_ctx_destroy", "isac_last_error",
     "isac_ctx_get_stream", "isac_sync", "isac_dev_alloc", "isac_dev_free", "isac_memcpy_h2d", "isac_memcpy_d2h", "isac_memcpy_d2d",
     "isac_memset_dev", "isac_timer_start", "isac_timer_stop_ms", "isac_profile_enable", "isac_profile_last_kernel_ms",
     "isac_basic_radar_channel_dev", "isac_basic_radar_channel", "isac_mono_static_sensing_dev",
     "isac_mono_static_sensing", "isac_mono_static_sensing_fused_dev", "isac_ofdm_symbol_count", "isac_ofdm_demodulate_dev", "isac_ofdm_modulate_dev", "isac_ofdm_modulate_windowed_dev", "isac_sentx_append_dev",
     "isac_ofdm_waveform_length", "isac_cfar2d_ca", "isac_fft2d_dev", "isac_fft2d", "isac_fft2d_submit_dev", "isac_fft2d_submit_cached_dev", "isac_fft2d_collect", "isac_fft2d_range_stage_dev", "isac_fft2d_get_detections",
     "isac_fft2d_get_power_window", "isac_fft2d_get_covariance", "isac_fft2d_get_music_spectrum",
-    "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_beamscan_doa", "isac_music2d_dev", "isac_eigh", "isac_cdl_apply_dev", "isac_precoded_sinr_cqi_dev", "isac_type1sp_codebook", "isac_csi_report_dev", "isac_los_check_dev", "isac_winding_number_dev", "isac_synth_qpsk_grid_dev",
+    "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_music_set_route", "isac_eigh_top", "isac_beamscan_doa", "isac_music2d_dev", "isac_eigh", "isac_cdl_apply_dev", "isac_precoded_sinr_cqi_dev", "isac_type1sp_codebook", "isac_csi_report_dev", "isac_los_check_dev", "isac_winding_number_dev", "isac_synth_qpsk_grid_dev",
 ]
 
 
@@ -108,9 +109,9 @@ def load():
             raise RuntimeError(
                 f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the sensing hot path.")
-        # every HIP stream of up to eight pipelined contexts gets its own hardware queue (two streams per context; streams that
-        # share a queue serialise -- profiles/r02_queue_sweep.txt).  Only effective before the HIP runtime initialises.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        # (The loader does not touch the process environment.  Pipelined hosts want one hardware queue per HIP stream --
+        # GPU_MAX_HW_QUEUES >= 2 x contexts in flight, set by the APPLICATION before the HIP runtime starts: INTEGRATION.md section 4,
+        # bench.py and examples/ do so and report the effective value.)
         if "torch" not in sys.modules and os.environ.get("ISAC_NO_TORCH_PRELOAD") != "1":
             try:
                 import torch  # noqa: F401
@@ -122,6 +123,14 @@ def load():
             fn = getattr(lib, name)  # AttributeError here = ABI drift between isac.h and the .so
             if name != "isac_last_error":
                 fn.restype = C.c_int
+        # the library writes whole structs into caller memory: version AND struct sizes must match this binding's mirrors
+        if lib.isac_abi_version() != ISAC_ABI_VERSION:
+            raise RuntimeError(f"{_LIB_PATH}: ABI version {lib.isac_abi_version()} but this binding was written for {ISAC_ABI_VERSION}; rebuild the library")
+        for which, (name, cls) in enumerate((("isac_est_result", EstResult), ("isac_est_params", EstParams), ("isac_cfar_config", CfarConfig),
+                                             ("isac_radar_channel_params", RadarChannelParams), ("isac_carrier", Carrier),
+                                             ("isac_music2d_params", Music2dParams), ("isac_csi_report", CsiReport))):
+            if lib.isac_abi_sizeof(C.c_int32(which)) != C.sizeof(cls):
+                raise RuntimeError(f"{_LIB_PATH}: sizeof({name}) = {lib.isac_abi_sizeof(C.c_int32(which))} in the library, {C.sizeof(cls)} in the binding")
         _lib = lib
         return lib
 
@@ -211,6 +220,19 @@ class Context:
         d = self.empty(a.shape, a.dtype)
         self.check(self.lib.isac_memcpy_h2d(self.handle, C.c_void_p(d.ptr), _np_ptr(a), C.c_size_t(a.nbytes)))
         return d
+
+    def set_music_route(self, route: int):
+        """0 = MUSIC through the signal-subspace eigensolver (default), 1 = always the full eigendecomposition (isac_music_set_route)."""
+        self.check(self.lib.isac_music_set_route(self.handle, C.c_int32(int(route))))
+
+    def eigh_top(self, h, n_top: int):
+        """(w, U): all eigenvalues ascending + the eigenvectors of the n_top largest (descending order) -- isac_eigh_top."""
+        h = as_c128_f(h)
+        a = h.shape[0]
+        w = np.zeros(a)
+        u = np.zeros((a, max(int(n_top), 1)), dtype=np.complex128, order="F")
+        self.check(self.lib.isac_eigh_top(self.handle, _np_ptr(h), C.c_int32(a), C.c_int32(int(n_top)), _np_ptr(w), _np_ptr(u)))
+        return w, u[:, : int(n_top)]
 
     def timer_start(self):
         self.check(self.lib.isac_timer_start(self.handle))

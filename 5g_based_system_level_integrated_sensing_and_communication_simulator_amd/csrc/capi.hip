@@ -20,11 +20,17 @@ static int eig_status(isac_ctx* ctx, int A) {
   int sweeps = 0;
   ISAC_HIP(hipMemcpy(&sweeps, (const char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(int), hipMemcpyDeviceToHost));
   if (sweeps < 0) return isac::fail(ctx, ISAC_ERR_HIP, sweeps == -1 ? "eigensolver: QL recurrence exceeded its rotation storage (no convergence)"
+                                                     : sweeps == -3 ? "eigensolver: the signal-subspace vectors are not finite (NaN / Inf in the covariance)"
                                                                      : "eigensolver: a replay block timed out waiting for the recurrence");
   return ISAC_OK;
 }
 int isac_music_scan_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num_dets_host, const double* d_sind, int n_steps,
-                        double d_ratio, double* d_spec, hipStream_t st, int mode = 0);
+                        double d_ratio, double* d_spec, hipStream_t st, int mode = 0, const int* ctl = nullptr);
+// MUSIC's signal-subspace eigensolver (music.hip): usable for this order?  first half (before numDets), second half (after), its control block
+bool isac_music_subspace_ok(isac_ctx* ctx, int A);
+int isac_music_tridiag_bisect_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st);
+int isac_music_subspace_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num_dets_host, hipStream_t st);
+const int* isac_music_ctl(isac_ctx* ctx);
 int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra);
 
 namespace {
@@ -247,6 +253,18 @@ int isac_get_windows(isac_ctx* ctx, int K, int n_ifft, const double** win_k, con
 
 // ------------------------------------------------------------------ context
 extern "C" int isac_abi_version(void) { return ISAC_ABI_VERSION; }
+extern "C" int isac_abi_sizeof(int32_t which) {
+  switch (which) {
+    case ISAC_SIZEOF_EST_RESULT: return (int)sizeof(isac_est_result);
+    case ISAC_SIZEOF_EST_PARAMS: return (int)sizeof(isac_est_params);
+    case ISAC_SIZEOF_CFAR_CONFIG: return (int)sizeof(isac_cfar_config);
+    case ISAC_SIZEOF_RADAR_CHANNEL_PARAMS: return (int)sizeof(isac_radar_channel_params);
+    case ISAC_SIZEOF_CARRIER: return (int)sizeof(isac_carrier);
+    case ISAC_SIZEOF_MUSIC2D_PARAMS: return (int)sizeof(isac_music2d_params);
+    case ISAC_SIZEOF_CSI_REPORT: return (int)sizeof(isac_csi_report);
+    default: return -1;
+  }
+}
 
 extern "C" int isac_device_count(int* count) {
   if (!count) return ISAC_ERR_INVALID_ARG;
@@ -492,7 +510,8 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   // MUSIC branch on the second stream, concurrent with the range-Doppler/CFAR branch:
   //   stream2: covariance (fp64 MFMA) -> eig (one CU)      stream: range IFFT -> Doppler -> CFAR
   ISAC_TRY(ensure(ctx, ctx->cov, sizeof(c64) * (size_t)A * A));
-  ISAC_TRY(ensure(ctx, ctx->misc, 256));
+  ISAC_TRY(ensure(ctx, ctx->misc, 512));
+  const bool sub = !upa && isac_music_subspace_ok(ctx, A);      // MUSIC needs the numDets signal vectors only (music.m:27-29)
   if (!upa) {
     ISAC_TRY(get_sind_table(ctx, ep, &d_sind, &n_steps));
     ISAC_TRY(ensure(ctx, ctx->spec, sizeof(double) * (size_t)n_steps));
@@ -502,7 +521,10 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   ISAC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
   ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
   ISAC_TRY(isac_covariance_on(ctx, s2, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
-  if (!upa) ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, s2));                         // music.m:19
+  if (!upa) {                                                                                    // music.m:19
+    if (sub) ISAC_TRY(isac_music_tridiag_bisect_dev(ctx, (const c64*)ctx->cov.p, A, s2));        // reflectors + eigenvalues: independent of numDets
+    else ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, s2));
+  }
   int nr = 0, nc = 0;
   ISAC_TRY(isac_rdm_power_window(ctx, ep, cfar, rx, tx, K, L, A, &nr, &nc, use_cached_range));          // fft2D.m:37-46,61
   const int n_cut_rows = cfar->row1 - cfar->row0 + 1, n_cut_cols = cfar->col1 - cfar->col0 + 1;
@@ -513,8 +535,10 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   ISAC_TRY(isac_cfar_window(ctx, cfar, nr, nc, A, cap));                                 // fft2D.m:62 (+ numDets on device)
   ISAC_HIP(hipEventRecord(ctx->ev_cfar, ctx->stream));
   ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_cfar, 0));
-  if (!upa)   // numDets comes from the CFAR branch, still on the device                   music.m:12,82-91
-    ISAC_TRY(isac_music_scan_dev(ctx, A, (const int*)ctx->misc.p, 0, d_sind, n_steps, 0.5, (double*)ctx->spec.p, s2));
+  if (!upa) {   // numDets comes from the CFAR branch, still on the device                   music.m:12,82-91
+    if (sub) ISAC_TRY(isac_music_subspace_dev(ctx, A, (const int*)ctx->misc.p, 0, s2));          // the numDets signal vectors (or the QL fallback)
+    ISAC_TRY(isac_music_scan_dev(ctx, A, (const int*)ctx->misc.p, 0, d_sind, n_steps, 0.5, (double*)ctx->spec.p, s2, 0, sub ? isac_music_ctl(ctx) : nullptr));
+  }
   ISAC_HIP(hipEventRecord(ctx->ev_join, s2));
   ISAC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   // pack + one device->host copy
@@ -572,7 +596,7 @@ extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
   const int* hdr = (const int*)h;
   const int total = hdr[0];
   const int num_dets_dev = hdr[1];
-  if (hdr[2] & 2) return fail(ctx, ISAC_ERR_HIP, "eigensolver did not finish (rotation storage exceeded or a replay block timed out)");
+  if (hdr[2] & 2) return fail(ctx, ISAC_ERR_HIP, "eigensolver did not finish (non-finite covariance, rotation storage exceeded or a replay block timed out)");
   if (hdr[2] & 1) return fail(ctx, ISAC_ERR_CAPACITY, "an antenna produced more CFAR detections than the per-antenna capacity (256 MB of scratch / 12 B / antennas)");
   std::vector<int> cut((size_t)total);
   std::vector<double> pw((size_t)total);
@@ -756,7 +780,9 @@ static int doa_scan(isac_ctx* ctx, int mode, int32_t num_dets, const isac_est_pa
   *n_est = 0;
   ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)A * A));
   ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, Ra, sizeof(c64) * (size_t)A * A, hipMemcpyHostToDevice, ctx->stream));
-  ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));                                    // music.m:19
+  const bool sub = mode == 0 && !ep->array_is_upa && isac_music_subspace_ok(ctx, A);   // MUSIC: the L signal vectors are enough
+  if (sub) ISAC_TRY(isac_music_tridiag_bisect_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));
+  else ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));                               // music.m:19
   int L = num_dets;
   if (num_dets < 0) {                                                                              // music.m:21-22
     std::vector<double> wv((size_t)A);
@@ -765,13 +791,14 @@ static int doa_scan(isac_ctx* ctx, int mode, int32_t num_dets, const isac_est_pa
     std::sort(wv.begin(), wv.end());
     L = determine_num_targets(wv);
   }
+  if (sub) ISAC_TRY(isac_music_subspace_dev(ctx, A, nullptr, L, nullptr));
   if (L_out) *L_out = L;
   if (ep->array_is_upa) return fail(ctx, ISAC_ERR_UNSUPPORTED, "UPA DoA: music.m:69 calls tools.find2DPeaks, which the reference does not define");
   int n_steps = 0;
   const double* d_sind = nullptr;
   ISAC_TRY(get_sind_table(ctx, ep, &d_sind, &n_steps));
   ISAC_TRY(ensure(ctx, ctx->spec, sizeof(double) * (size_t)n_steps));
-  ISAC_TRY(isac_music_scan_dev(ctx, A, nullptr, L, d_sind, n_steps, 0.5, (double*)ctx->spec.p, nullptr, mode));
+  ISAC_TRY(isac_music_scan_dev(ctx, A, nullptr, L, d_sind, n_steps, 0.5, (double*)ctx->spec.p, nullptr, mode, sub ? isac_music_ctl(ctx) : nullptr));
   std::vector<double> spec((size_t)n_steps);
   ISAC_HIP(hipMemcpyAsync(spec.data(), ctx->spec.p, sizeof(double) * (size_t)n_steps, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
@@ -789,6 +816,47 @@ static int doa_scan(isac_ctx* ctx, int mode, int32_t num_dets, const isac_est_pa
     if (azi_est) azi_est[i] = locs[i] * ep->azimuth_scan_granularity - ep->azimuth_scan_scale / 2.0;
     if (ele_est) ele_est[i] = NAN;
   }
+  return ISAC_OK;
+}
+
+// eigenvalues (all, ascending) + the eigenvectors of the n_top largest, through MUSIC's signal-subspace route
+extern "C" int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_t n_top, double* w, isac_c64* U) {
+  ISAC_ENTER(ctx);
+  if (!H || !w || A <= 0 || n_top < 0 || n_top > A || (n_top > 0 && !U)) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
+  if (A < 3 || A > 256) return fail(ctx, ISAC_ERR_UNSUPPORTED, "isac_eigh_top: orders 3..256 (use isac_eigh)");
+  ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)A * A));
+  ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, H, sizeof(c64) * (size_t)A * A, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_TRY(isac_music_tridiag_bisect_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));
+  ISAC_HIP(hipMemcpyAsync(w, ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));                      // (the fallback below overwrites eig_w with unsorted values)
+  if (n_top == 0) return ISAC_OK;
+  ISAC_TRY(isac_music_subspace_dev(ctx, A, nullptr, n_top, nullptr));
+  int ctl[2] = {0, 0};
+  ISAC_HIP(hipMemcpyAsync(ctl, isac_music_ctl(ctx), sizeof(ctl), hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  ISAC_TRY(eig_status(ctx, A));
+  if (ctl[0] == 1 && n_top < A) {                                   // the subspace kernel delivered the vectors, descending eigenvalue order
+    ISAC_HIP(hipMemcpy(U, ctx->eig_v.p, sizeof(c64) * (size_t)A * n_top, hipMemcpyDeviceToHost));
+    return ISAC_OK;
+  }
+  // n_top beyond the subspace kernel's capacity (or the whole basis): the QL pipeline ran; pick the columns of the n_top largest
+  std::vector<double> wv((size_t)A);
+  std::vector<c64> vv((size_t)A * A);
+  if (n_top == A) ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));
+  ISAC_HIP(hipMemcpy(wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost));
+  ISAC_HIP(hipMemcpy(vv.data(), ctx->eig_v.p, sizeof(c64) * (size_t)A * A, hipMemcpyDeviceToHost));
+  ISAC_TRY(eig_status(ctx, A));
+  std::vector<int> order((size_t)A);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return wv[(size_t)p] > wv[(size_t)q]; });
+  for (int i = 0; i < n_top; ++i) std::memcpy(U + (size_t)A * i, vv.data() + (size_t)A * order[(size_t)i], sizeof(c64) * (size_t)A);
+  return ISAC_OK;
+}
+
+extern "C" int isac_music_set_route(isac_ctx* ctx, int32_t route) {
+  ISAC_ENTER(ctx);
+  if (route != 0 && route != 1) return fail(ctx, ISAC_ERR_INVALID_ARG, "route: 0 = signal-subspace eigensolver (default), 1 = full eigendecomposition");
+  ctx->music_route = route;
   return ISAC_OK;
 }
 

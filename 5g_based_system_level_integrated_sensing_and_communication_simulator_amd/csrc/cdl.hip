@@ -125,6 +125,7 @@ extern "C" int isac_cdl_apply_dev(isac_ctx* ctx, const isac_c64* d_x, int64_t T,
   if (!d_x || !d_y || !H || !block_start || !taps || !shift) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
   if (T <= 0 || Nt <= 0 || Nr <= 0 || n_paths <= 0 || n_blocks <= 0 || n_taps <= 0 || n_taps > 64 || n_paths > 64)
     return fail(ctx, ISAC_ERR_INVALID_ARG, "bad dimensions");
+  ctx->range_cache.touch(d_y, sizeof(c64) * (size_t)T * Nr);   // an output that overlaps a cached grid drops the cached range rows
   if (Nr > Nt) {
     // ---- filter first, contract second (see cdl_prefilter_kernel): Hm_b [Kc x Nrp], row c = n*Nt + s
     const int Kc = n_paths * Nt, Nrp = (Nr + 15) / 16 * 16;

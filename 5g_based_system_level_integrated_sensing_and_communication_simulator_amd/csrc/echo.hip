@@ -748,6 +748,7 @@ extern "C" int isac_ofdm_demodulate_dev(isac_ctx* ctx, const isac_c64* d_wave, i
   const int L_whole = whole_symbols(g, T);
   if (L_whole <= 0) return fail(ctx, ISAC_ERR_SHORT_WAVEFORM, "waveform shorter than one OFDM symbol");
   if (L < L_whole) return fail(ctx, ISAC_ERR_CAPACITY, "grid has fewer symbol columns than the waveform holds");
+  ctx->range_cache.touch(d_grid, sizeof(c64) * (size_t)g.n_sc * L * A);   // a cached grid overwritten here drops the cached range rows
   if (L > L_whole) ISAC_HIP(hipMemsetAsync(d_grid, 0, sizeof(c64) * (size_t)g.n_sc * L * A, ctx->stream));
   const c64* tw = nullptr;
   ISAC_TRY(isac_get_twiddles(ctx, g.nfft, &tw));
@@ -806,6 +807,7 @@ extern "C" int isac_ofdm_modulate_windowed_dev(isac_ctx* ctx, const isac_c64* d_
   const int sym0 = (n_slot % (carrier->scs_khz / 15)) * 14;           // first symbol of the slot inside its subframe (carrier.NSlot)
   const long long need = symbol_start(sym0 + L, g.nfft, g.cp_base, g.cp_long, g.sym_per_half) - symbol_start(sym0, g.nfft, g.cp_base, g.cp_long, g.sym_per_half);
   if (T < need) return fail(ctx, ISAC_ERR_CAPACITY, "waveform buffer shorter than L symbols");
+  ctx->range_cache.touch(d_wave, sizeof(c64) * (size_t)T * A);
   if (T > need) ISAC_HIP(hipMemsetAsync(d_wave, 0, sizeof(c64) * (size_t)T * A, ctx->stream));
   return modulate_into(ctx, carrier, (const c64*)d_grid, L, 0, L, A, sym0, amplitude, windowing, (c64*)d_wave, T, 0);
 }
@@ -842,6 +844,7 @@ extern "C" int isac_synth_qpsk_grid_dev(isac_ctx* ctx, isac_c64* d_grid, int32_t
   ISAC_ENTER(ctx);
   if (!d_grid || K <= 0 || L <= 0 || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   long long n = (long long)K * L * A;
+  ctx->range_cache.touch(d_grid, sizeof(c64) * (size_t)n);
   hipLaunchKernelGGL(synth_qpsk_kernel, dim3(cdiv(n, 256)), dim3(256), 0, ctx->stream, (c64*)d_grid, K, L, A, seed,
                      zero_s_slots);
   ISAC_HIP(hipGetLastError());

@@ -91,6 +91,7 @@ struct isac_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cfar = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // isac_profile_*: around the dominant kernel of the last fused echo call
   bool profile = false, profile_recorded = false;
+  int music_route = 0;             // isac_music_set_route: 0 = signal-subspace eigensolver for MUSIC (default), 1 = always the full eigendecomposition
   std::string err;
   // cached device tables
   std::map<const void*, size_t> lds_allowed;                        // kernel -> dynamic LDS bytes enabled on this context's device

@@ -626,11 +626,12 @@ __global__ __launch_bounds__(1024) void jacobi_eigh_kernel(const c64* __restrict
 struct EighScratch {   // carve of ctx->eig_scratch for order n
   c64 *M, *Z, *tau, *rot;
   double *d, *e, *scale;
+  double* wsc;         // [n] eigenvalues of the (safe-scaled) tridiagonal, ascending -- eigh_bisect_kernel
   int *desc, *cnt;     // desc: (mm, l, first rotation, -) per sweep; cnt: {sweeps published, n_rot, overflow, zungtr done, QL done}
   long long rot_cap;
   int desc_cap;
   __host__ __device__ static size_t bytes(int n) {
-    return sizeof(c64) * ((size_t)2 * n * n + n + (size_t)16 * n * n) + sizeof(double) * (2 * n + 4) + sizeof(int) * (4 * (size_t)(30 * n + 2) + 8) + 256;
+    return sizeof(c64) * ((size_t)2 * n * n + n + (size_t)16 * n * n) + sizeof(double) * (3 * n + 4) + sizeof(int) * (4 * (size_t)(30 * n + 2) + 8) + 256;
   }
   __host__ __device__ EighScratch(void* base, int n) {
     c64* p = reinterpret_cast<c64*>(base);
@@ -644,6 +645,7 @@ struct EighScratch {   // carve of ctx->eig_scratch for order n
     desc_cap = 30 * n + 2;
     desc = reinterpret_cast<int*>(scale + 2);       // 16-byte aligned (rot is, and n + (n & 1) + 2 doubles follow)
     cnt = desc + 4 * (size_t)desc_cap;
+    wsc = reinterpret_cast<double*>(cnt + 8);       // 16-byte aligned (desc is, 16 desc_cap + 32 bytes follow)
   }
 };
 
@@ -853,8 +855,9 @@ __device__ __forceinline__ void eigh_replay_body(int n, const EighScratch& S, c6
 
 // block 0: zungtr; block 1 (first wavefront): tql2 recurrence, rotations recorded; blocks >= 2: live replay
 __global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratch, double* __restrict__ w_out, int* __restrict__ info,
-                                                             c64* __restrict__ V_out, int replay_bt) {
+                                                             c64* __restrict__ V_out, int replay_bt, const int* __restrict__ ctl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (ctl && ctl[0] == 1) return;                   // (grid-uniform) music_subspace_kernel has delivered the signal vectors: no full basis needed
   EighScratch S(scratch, n);
   const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
   const long long t0 = clock64();
@@ -1186,10 +1189,255 @@ __device__ __forceinline__ void eigh_replay_body(int n, const EighScratch& S, c6
 }
 
 template <bool LDS>
-__global__ __launch_bounds__(256) void eigh_replay_kernel(int n, void* scratch, c64* __restrict__ V_out, int* __restrict__ info) {
+__global__ __launch_bounds__(256) void eigh_replay_kernel(int n, void* scratch, c64* __restrict__ V_out, int* __restrict__ info,
+                                                          const int* __restrict__ ctl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (ctl && ctl[0] == 1) return;
   EighScratch S(scratch, n);
   eigh_replay_body<LDS, false>(n, S, V_out, smem_raw, (int)blockIdx.x, (int)blockDim.x, info);
+}
+
+// ---------------------------------------------------------------- Hermitian eigensolver III: the SIGNAL SUBSPACE only (MUSIC, music.m:19-29)
+// music.m needs Uan Uan' = I - Us Us' only, with Us the eigenvectors of the L = numDets largest eigenvalues: the full basis the QL pipeline
+// above produces (its single-wavefront recurrence was the longest kernel of a CPI) is not needed.  Route (restated in NumPy for CPU-side
+// numerics checks: oracle/subspace_music.py):
+//   K1  eigh_tridiag_*           as above: Householder reflectors (S.M, S.tau) and the real tridiagonal (S.d, S.e)
+//   K2  eigh_bisect_kernel       ALL eigenvalues by Sturm counts (negative pivots of T - x I, dstebz-style pivmin clamp): one wavefront per
+//                                eigenvalue, its 64 lanes cut the bracket into 65 parts per round (6 bits; ~9 rounds to eps ||T||)
+//   K3  music_subspace_kernel    after numDets is known (CFAR branch): block inverse iteration on T for the L largest eigenvalues -- one lane
+//                                per vector, Gaussian elimination with partial pivoting (dlagtf / dlagts), three rounds from pseudo-random
+//                                start vectors with modified Gram-Schmidt in descending-eigenvalue order in between (exactly degenerate
+//                                clusters end up with an orthonormal basis of their eigenspace, like dstein) -- then U = Q Z through the
+//                                reflectors, one wavefront per vector
+//   K4  music_scan_kernel        a' Uan Uan' a = || a - Us Us' a ||^2  (a sum of squares: no cancellation at the peaks)
+// L >= A (empty noise space) and L <= 0 need no vectors; L beyond the LDS capacity of K3 falls back to the QL pipeline, whose kernels are
+// always enqueued behind K3 and return at once when K3 reports success in `ctl` (numDets lives on the device: no host decision).
+struct MusicCtl { enum { kRoute = 0, kLsub = 1 }; };     // ctl[kRoute]: 1 = subspace vectors delivered (kLsub of them; >= n: empty noise space)
+
+__device__ __forceinline__ double rcp_fast(double q) {   // 1/q: hardware estimate r0 + one third-order step  r0 (1 + h + h^2), h = 1 - q r0
+  const double r0 = __builtin_amdgcn_rcp(q);
+  const double h = ::fma(-q, r0, 1.0);
+  return ::fma(r0, ::fma(h, h, h), r0);
+}
+__device__ __forceinline__ double wave_sum(double x) { for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o); return x; }
+__device__ __forceinline__ double wave_max(double x) { for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o)); return x; }
+__device__ __forceinline__ double wave_min(double x) { for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o)); return x; }
+
+constexpr int kBisectWaves = 16;                         // eigenvalues per workgroup (one wavefront each)
+__global__ __launch_bounds__(1024) void eigh_bisect_kernel(int n, void* scratch, double* __restrict__ w_out /* [n] ascending */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  EighScratch S(scratch, n);
+  c64* de = reinterpret_cast<c64*>(smem_raw);            // [n]  (.re = d_i, .im = e_{i-1}^2 with e_{-1} = 0)
+  double* sred = reinterpret_cast<double*>(de + n);      // [3][16]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  double gl = 1.7976931348623157e308, gu = -1.7976931348623157e308, e2m = 0.0;
+  for (int i = tid; i < n; i += 1024) {                  // Gershgorin interval
+    const double d = S.d[i];
+    const double el = i > 0 ? S.e[i - 1] : 0.0, er = i < n - 1 ? S.e[i] : 0.0;
+    de[i] = mk(d, el * el);
+    const double rad = fabs(el) + fabs(er);
+    gl = fmin(gl, d - rad); gu = fmax(gu, d + rad); e2m = fmax(e2m, el * el);
+  }
+  gl = wave_min(gl); gu = wave_max(gu); e2m = wave_max(e2m);
+  if (lane == 0) { sred[wid] = gl; sred[16 + wid] = gu; sred[32 + wid] = e2m; }
+  __syncthreads();
+  for (int w = 0; w < 16; ++w) { gl = fmin(gl, sred[w]); gu = fmax(gu, sred[16 + w]); e2m = fmax(e2m, sred[32 + w]); }
+  const double bnorm = fmax(fabs(gl), fabs(gu));
+  const double pivmin = 2.2250738585072014e-308 * fmax(1.0, e2m);
+  const double eps = 2.220446049250313e-16;
+  const double widen = 2.0 * bnorm * eps * (double)n + 2.0 * pivmin;
+  gl -= widen; gu += widen;
+  const double tol = 2.0 * eps * bnorm + 2.0 * pivmin;   // absolute: eps ||T|| is what a backward-stable eigensolver delivers
+  const int ei = blockIdx.x * kBisectWaves + wid;        // this wavefront's eigenvalue (ascending index)
+  if (ei >= n) return;                                   // (wave-uniform; no barrier below)
+  double lo = gl, hi = gu;
+  for (int it = 0; it < 48; ++it) {                      // (bounded also for NaN input)
+    if (!(hi - lo > tol)) break;
+    const double x = ::fma(hi - lo, (double)(lane + 1) * (1.0 / 65.0), lo);
+    int c = 0;
+    double q = 1.0;                                      // q_0 = d_0 - x  (e_{-1}^2 = 0)
+    for (int i = 0; i < n; ++i) {
+      const c64 v = de[i];                               // (broadcast read)
+      q = ::fma(-v.im, rcp_fast(q), v.re - x);
+      q = fabs(q) < pivmin ? -pivmin : q;
+      c += q < 0.0 ? 1 : 0;
+    }
+    double nlo = wave_max(c <= ei ? x : lo), nhi = wave_min(c > ei ? x : hi);
+    if (nlo > nhi) nlo = nhi = 0.5 * (nlo + nhi);        // (counts within rounding distance of the eigenvalue need not be monotone)
+    if (nlo == lo && nhi == hi) break;
+    lo = nlo; hi = nhi;
+  }
+  if (lane == 0) {
+    const double w = 0.5 * (lo + hi);
+    S.wsc[ei] = w;
+    w_out[ei] = w / *S.scale;                            // undo the safe scaling (power of two: exact)
+  }
+}
+
+// K3.  LDS: four [n][lv] arrays (1 / pivot, the two superdiagonals of U, the vectors), lane v owns column v: consecutive lanes touch
+// consecutive doubles.  R = rows per lane in the wave-per-vector phases (n <= 64 R).
+template <int R>
+__global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scratch, const int* __restrict__ num_dets_dev, int num_dets_host,
+                                                              int lmax, int lv, c64* __restrict__ U_out /* [n x L] */, int* __restrict__ ctl,
+                                                              int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ int s_bad;
+  __shared__ double s_red[16];
+  EighScratch S(scratch, n);
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int L = num_dets_dev ? *num_dets_dev : num_dets_host;        // music.m:21-25
+  if (L <= 0 || L >= n || L > lmax) {                                // (uniform) nothing to compute / beyond this kernel's capacity
+    if (tid == 0) {
+      const bool done = L <= 0 || L >= n;
+      ctl[MusicCtl::kRoute] = done ? 1 : 0;
+      ctl[MusicCtl::kLsub] = L <= 0 ? 0 : L;
+      if (done && info) { info[0] = 0; info[5] = -3; }
+    }
+    return;
+  }
+  const size_t plane = (size_t)n * lv;
+  double* u0 = reinterpret_cast<double*>(smem_raw);                  // 1 / pivot
+  double* u1 = u0 + plane;
+  double* u2 = u1 + plane;
+  double* y = u2 + plane;                                            // right-hand sides / solutions = the vectors, [row][vector]
+  double* sd = y + plane;                                            // [n] d
+  double* se = sd + n;                                               // [n] e (e[n-1] = 0)
+  double tn = 0.0;
+  for (int i = tid; i < n; i += 1024) {
+    const double d = S.d[i], e = i < n - 1 ? S.e[i] : 0.0;
+    sd[i] = d; se[i] = e;
+    tn = fmax(tn, fmax(fabs(d), fabs(e)));
+  }
+  tn = wave_max(tn);
+  if (tid == 0) s_bad = 0;
+  if (lane == 0) s_red[wid] = tn;
+  __syncthreads();
+  tn = 0.0;
+  for (int w = 0; w < 16; ++w) tn = fmax(tn, s_red[w]);
+  const double tiny = 2.220446049250313e-16 * fmax(tn, 2.2250738585072014e-308);
+  const bool solver = wid == 0 && lane < L;                          // one lane per vector, descending eigenvalue order
+  const double lam = solver ? S.wsc[n - 1 - lane] : 0.0;
+  if (solver) {                                                      // deterministic pseudo-random start vectors (same LCG as the restatement)
+    unsigned s = 0x9E3779B9u * (unsigned)(lane + 1) + 0x7F4A7C15u;
+    for (int i = 0; i < n; ++i) {
+      s = 1664525u * s + 1013904223u;
+      y[(size_t)i * lv + lane] = (double)(s >> 8) * (1.0 / 16777216.0) - 0.5;
+    }
+  }
+  __syncthreads();
+  for (int round = 0; round < 3; ++round) {
+    if (solver) {
+      // ---- (T - lam I) y = x : elimination with row interchanges; the forward substitution rides along
+      double a = sd[0] - lam, b = se[0];
+      double ycur = y[lane];
+      for (int i = 0; i < n - 1; ++i) {
+        const double c = se[i], dn = sd[i + 1] - lam, en = se[i + 1];
+        const double ynext = y[(size_t)(i + 1) * lv + lane];
+        const bool swap = fabs(a) < fabs(c);
+        const double piv = swap ? c : (a == 0.0 ? tiny : a);
+        const double inv = rcp_fast(piv);
+        const double m = (swap ? a : c) * inv;
+        const size_t o = (size_t)i * lv + lane;
+        u0[o] = inv;
+        u1[o] = swap ? dn : b;
+        u2[o] = swap ? en : 0.0;
+        const double an = swap ? ::fma(-m, dn, b) : ::fma(-m, b, dn);
+        b = swap ? -m * en : en;
+        a = an;
+        const double yi = swap ? ynext : ycur, yo = swap ? ycur : ynext;
+        y[o] = yi;
+        ycur = ::fma(-m, yi, yo);
+      }
+      if (fabs(a) < tiny) a = a < 0.0 ? -tiny : tiny;               // singular to working precision: dlagts' pivot perturbation
+      {
+        const size_t o = (size_t)(n - 1) * lv + lane;
+        u0[o] = rcp_fast(a); u1[o] = 0.0; u2[o] = 0.0;
+        y[o] = ycur;
+      }
+      double y1 = 0.0, y2 = 0.0;
+      for (int i = n - 1; i >= 0; --i) {
+        const size_t o = (size_t)i * lv + lane;
+        const double v = ::fma(-u2[o], y2, ::fma(-u1[o], y1, y[o])) * u0[o];
+        y[o] = v;
+        y2 = y1; y1 = v;
+      }
+    }
+    __syncthreads();
+    if (wid == 0) {
+      // ---- modified Gram-Schmidt, descending-eigenvalue order (lanes = rows); twice after the last round
+      const int passes = round == 2 ? 2 : 1;
+      for (int p = 0; p < passes; ++p)
+        for (int j = 0; j < L; ++j) {
+          double zj[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) { const int i = lane + 64 * r; zj[r] = i < n ? y[(size_t)i * lv + j] : 0.0; }
+          for (int i2 = 0; i2 < j; ++i2) {
+            double zi[R], dot = 0.0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int i = lane + 64 * r; zi[r] = i < n ? y[(size_t)i * lv + i2] : 0.0; dot = ::fma(zi[r], zj[r], dot); }
+            dot = wave_sum(dot);
+#pragma unroll
+            for (int r = 0; r < R; ++r) zj[r] = ::fma(-dot, zi[r], zj[r]);
+          }
+          double nrm = 0.0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) nrm = ::fma(zj[r], zj[r], nrm);
+          nrm = wave_sum(nrm);
+          const bool ok = nrm > 0.0 && nrm < 1.7976931348623157e308;
+          const double inv = ok ? 1.0 / sqrt(nrm) : 0.0;
+          if (!ok && lane == 0) s_bad = 1;
+#pragma unroll
+          for (int r = 0; r < R; ++r) { const int i = lane + 64 * r; if (i < n) y[(size_t)i * lv + j] = zj[r] * inv; }
+        }
+    }
+    __syncthreads();
+  }
+  // ---- U = Q Z, Q = H_0 ... H_{n-2} (zungtr's product, applied to L vectors instead of formed): one wavefront per vector; the
+  // reflector of the next step is fetched under the current one
+  const c64* M = S.M;
+  auto load_col = [&](c64 (&dst)[R], int k) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = lane + 64 * r;
+      const c64 raw = M[(size_t)(i < n ? i : n - 1) + (size_t)n * k];                 // (unconditional, clamped)
+      dst[r] = (i > k + 1 && i < n) ? raw : mk(i == k + 1 ? 1.0 : 0.0, 0.0);
+    }
+  };
+  bool bad = false;
+  for (int v = wid; v < L; v += 16) {
+    c64 u[R], vk[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { const int i = lane + 64 * r; u[r] = mk(i < n ? y[(size_t)i * lv + v] : 0.0, 0.0); }
+    load_col(vk, n - 2);
+    for (int k = n - 2; k >= 0; --k) {
+      c64 vn[R];
+      load_col(vn, k > 0 ? k - 1 : 0);
+      const c64 tau = S.tau[k];
+      c64 sacc = mk(0.0, 0.0);
+#pragma unroll
+      for (int r = 0; r < R; ++r) sacc = fma(conj(vk[r]), u[r], sacc);
+      sacc.re = wave_sum(sacc.re); sacc.im = wave_sum(sacc.im);
+      const c64 t = tau * sacc;
+#pragma unroll
+      for (int r = 0; r < R; ++r) { u[r] = u[r] - t * vk[r]; vk[r] = vn[r]; }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int i = lane + 64 * r;
+      if (i < n) {
+        U_out[(size_t)i + (size_t)n * v] = u[r];
+        bad = bad || !(fabs(u[r].re) <= 2.0 && fabs(u[r].im) <= 2.0);               // unit vectors; catches NaN / Inf input
+      }
+    }
+  }
+  if (__any(bad) && lane == 0) s_bad = 1;
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    ctl[MusicCtl::kRoute] = 1;
+    ctl[MusicCtl::kLsub] = L;
+    if (info) { info[0] = s_bad ? -3 : 0; info[5] = -3; }
+  }
 }
 
 // ---------------------------------------------------------------- MUSIC pseudo-spectrum (ULA), music.m:82-91
@@ -1199,9 +1447,10 @@ __global__ __launch_bounds__(256) void eigh_replay_kernel(int n, void* scratch, 
 __global__ __launch_bounds__(256) void music_scan_kernel(const double* __restrict__ w, const c64* __restrict__ V, int A,
                                                          const int* __restrict__ num_dets_dev, int num_dets_host,
                                                          const double* __restrict__ sind_tab, double d_ratio, double eps1,
-                                                         double* __restrict__ p_out, int mode) {
+                                                         double* __restrict__ p_out, int mode, const int* __restrict__ ctl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* s_a = reinterpret_cast<c64*>(smem_raw);     // steering vector [A]
+  c64* s_c = s_a + A;                              // [<= 32] u_s' a (subspace route)
   __shared__ double s_red[4];
   const int tid = threadIdx.x;
   const int Lsig = num_dets_dev ? *num_dets_dev : num_dets_host;
@@ -1216,21 +1465,43 @@ __global__ __launch_bounds__(256) void music_scan_kernel(const double* __restric
   }
   __syncthreads();
   double acc = 0.0;
-  for (int v = tid; v < A; v += blockDim.x) {
-    // descending rank of eigenvalue v (stable: ties keep index order)
-    const double wv = w[v];
-    double weight = 1.0;
-    if (mode == 0) {
-      int rank = 0;
-      for (int j = 0; j < A; ++j) rank += (w[j] > wv || (w[j] == wv && j < v)) ? 1 : 0;
-      if (rank < Lsig) continue;                    // signal subspace
-    } else {
-      weight = (mode == 1) ? wv : 1.0 / wv;
+  const bool subspace = mode == 0 && ctl && ctl[MusicCtl::kRoute] == 1;       // (grid-uniform)
+  if (subspace) {
+    // a' Uan Uan' a = || a - Us Us' a ||^2 with the Ls signal vectors of music_subspace_kernel in V[:, 0..Ls)
+    const int Ls = ctl[MusicCtl::kLsub];
+    if (Ls < A) {                                  // (Ls >= A: empty noise space, the quadratic form is 0 -- music.m:28 with L >= nAnts)
+      const int lane = tid & 63, wid = tid >> 6;
+      for (int sv = wid; sv < Ls; sv += 4) {
+        const c64* col = V + (long long)A * sv;
+        c64 y = mk(0.0, 0.0);
+        for (int m = lane; m < A; m += 64) y = fma(conj(col[m]), s_a[m], y);
+        y.re = wave_sum(y.re); y.im = wave_sum(y.im);
+        if (lane == 0) s_c[sv] = y;
+      }
+      __syncthreads();
+      for (int m = tid; m < A; m += blockDim.x) {
+        c64 r = s_a[m];
+        for (int sv = 0; sv < Ls; ++sv) r = r - V[m + (long long)A * sv] * s_c[sv];
+        acc = ::fma(r.re, r.re, ::fma(r.im, r.im, acc));
+      }
     }
-    c64 y = mk(0.0, 0.0);
-    const c64* col = V + (long long)A * v;
-    for (int m = 0; m < A; ++m) y = fma(conj(col[m]), s_a[m], y);
-    acc += weight * (y.re * y.re + y.im * y.im);
+  } else {
+    for (int v = tid; v < A; v += blockDim.x) {
+      // descending rank of eigenvalue v (stable: ties keep index order)
+      const double wv = w[v];
+      double weight = 1.0;
+      if (mode == 0) {
+        int rank = 0;
+        for (int j = 0; j < A; ++j) rank += (w[j] > wv || (w[j] == wv && j < v)) ? 1 : 0;
+        if (rank < Lsig) continue;                    // signal subspace
+      } else {
+        weight = (mode == 1) ? wv : 1.0 / wv;
+      }
+      c64 y = mk(0.0, 0.0);
+      const c64* col = V + (long long)A * v;
+      for (int m = 0; m < A; ++m) y = fma(conj(col[m]), s_a[m], y);
+      acc += weight * (y.re * y.re + y.im * y.im);
+    }
   }
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
   if ((tid & 63) == 0) s_red[tid >> 6] = acc;
@@ -1366,6 +1637,98 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
   }
 }
 
+// Householder tridiagonalisation of H (order n >= 3) into ctx->eig_scratch, on stream st
+static int launch_tridiag(isac_ctx* ctx, const c64* d_H, int n, hipStream_t st, int* info) {
+  ISAC_TRY(ensure(ctx, ctx->eig_scratch, EighScratch::bytes(n)));
+  void* gs = ctx->eig_scratch.p;
+  const size_t lds1 = sizeof(c64) * 6 * (size_t)n + sizeof(double) * 32 + 64;
+  if (n <= 64) {       // four waves, two barriers per step, matrix in LDS (the general kernel with its matrix in LDS: 222 us at n = 64; this one ~120)
+    const size_t ldss = sizeof(c64) * ((size_t)n * n + 4 * 64 + 4 * 2 * 64) + sizeof(double) * 32 + 64;
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_tridiag_small_kernel), (size_t)(100 * 1024)));
+    hipLaunchKernelGGL(eigh_tridiag_small_kernel, dim3(1), dim3(256), ldss, st, d_H, n, gs, info);
+  } else {
+    hipLaunchKernelGGL(eigh_tridiag_kernel<false>, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
+  }
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+// zungtr || QL recurrence || replay on the tridiagonal form in ctx->eig_scratch -> ctx->eig_w / eig_v.  `ctl` (device, may be null): the
+// kernels return at once when ctl[0] == 1 (music_subspace_kernel has already delivered what MUSIC needs).
+static int launch_ql(isac_ctx* ctx, int n, hipStream_t st, int* info, const int* ctl) {
+  void* gs = ctx->eig_scratch.p;
+  // (forcing the zungtr block and the lone recurrence wavefront onto different CUs with an oversized LDS request made no
+  // difference to the recurrence -- 345 vs 350 cycles per rotation at the time -- and cost CU capacity in pipelined runs)
+  const size_t lds2 = sizeof(c64) * 3 * (size_t)n + sizeof(double) * 4 * (size_t)n + 64;
+  int bt = 64;                                       // threads per replay workgroup: its rows must fit LDS
+  if ((size_t)bt * n * sizeof(double) > 150 * 1024) bt = 32;
+  const size_t rows3 = (size_t)bt * n * sizeof(double), stage3 = sizeof(c64) * 2 * (size_t)n;
+  const size_t lds3 = rows3 + stage3;
+  const bool lds_replay = rows3 <= 150 * 1024 && n <= 8 * bt;
+  static const bool no_overlap = std::getenv("ISAC_EIG_NO_OVERLAP") != nullptr;   // development switch
+  const bool live = lds_replay && !no_overlap;       // replay blocks ride along with zungtr and the recurrence
+  const int n_replay = (2 * n + bt - 1) / bt;
+  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_formq_ql_kernel), (size_t)(160 * 1024)));
+  hipLaunchKernelGGL(eigh_formq_ql_kernel, dim3(live ? 2 + n_replay : 2), dim3(1024), live ? std::max(lds2, lds3) : lds2, st, n, gs,
+                     (double*)ctx->eig_w.p, info, (c64*)ctx->eig_v.p, bt, ctl);
+  ISAC_HIP(hipGetLastError());
+  if (!live) {
+    if (lds_replay) {
+      ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_replay_kernel<true>), lds3));
+      hipLaunchKernelGGL(eigh_replay_kernel<true>, dim3((unsigned)n_replay), dim3(bt), lds3, st, n, gs, (c64*)ctx->eig_v.p, info, ctl);
+    } else {
+      hipLaunchKernelGGL(eigh_replay_kernel<false>, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), stage3, st, n, gs, (c64*)ctx->eig_v.p, info, ctl);
+    }
+    ISAC_HIP(hipGetLastError());
+  }
+  return ISAC_OK;
+}
+
+// ---- MUSIC's signal-subspace route (eigensolver III above): supported orders, and the two halves around the wait for numDets
+static int* music_ctl(isac_ctx* ctx) { return reinterpret_cast<int*>((char*)ctx->misc.p + 256); }   // (ctx->misc: >= 512 bytes here)
+bool isac_music_subspace_ok(isac_ctx* ctx, int A) {
+  static const bool env_full = std::getenv("ISAC_MUSIC_FULL_EIG") != nullptr;      // development switch: always the full eigendecomposition
+  return !env_full && ctx->music_route == 0 && A >= 3 && A <= 256;
+}
+// first half: reflectors + all eigenvalues (ascending, ctx->eig_w); independent of numDets
+int isac_music_tridiag_bisect_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
+  if (!st) st = ctx->stream;
+  const int n = A;
+  ISAC_TRY(ensure(ctx, ctx->eig_w, sizeof(double) * (size_t)A + 64));
+  ISAC_TRY(ensure(ctx, ctx->eig_v, sizeof(c64) * (size_t)A * A));
+  ISAC_TRY(ensure(ctx, ctx->misc, 512));
+  int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
+  ISAC_TRY(launch_tridiag(ctx, d_H, n, st, info));
+  const size_t lds = sizeof(c64) * (size_t)n + sizeof(double) * 48 + 64;
+  hipLaunchKernelGGL(eigh_bisect_kernel, dim3((unsigned)((n + kBisectWaves - 1) / kBisectWaves)), dim3(1024), lds, st, n, ctx->eig_scratch.p,
+                     (double*)ctx->eig_w.p);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+// second half: the L = numDets signal vectors into ctx->eig_v[:, 0..L) (L from the device -- the CFAR branch -- or from the host), then the
+// QL pipeline as the conditional fallback (L beyond the subspace kernel's capacity)
+int isac_music_subspace_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num_dets_host, hipStream_t st) {
+  if (!st) st = ctx->stream;
+  const int n = A;
+  int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
+  int* ctl = music_ctl(ctx);
+  int lmax = (int)(122880 / (32 * (size_t)n));
+  lmax = lmax > 32 ? 32 : (lmax < 1 ? 1 : lmax);
+  const int lv = lmax | 1;                           // odd pitch
+  const size_t lds = sizeof(double) * ((size_t)4 * n * lv + 2 * (size_t)n) + 64;
+#define ISAC_SUBSPACE(RR)                                                                                                         \
+  do {                                                                                                                            \
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(music_subspace_kernel<RR>), (size_t)(150 * 1024)));                     \
+    hipLaunchKernelGGL(music_subspace_kernel<RR>, dim3(1), dim3(1024), lds, st, n, ctx->eig_scratch.p, d_num_dets, num_dets_host, \
+                       lmax, lv, (c64*)ctx->eig_v.p, ctl, info);                                                                  \
+  } while (0)
+  if (n <= 64) ISAC_SUBSPACE(1); else if (n <= 128) ISAC_SUBSPACE(2); else ISAC_SUBSPACE(4);
+#undef ISAC_SUBSPACE
+  ISAC_HIP(hipGetLastError());
+  return launch_ql(ctx, n, st, info, ctl);
+}
+const int* isac_music_ctl(isac_ctx* ctx) { return music_ctl(ctx); }
+
 // device eig: H [A x A] (device) -> ctx->eig_w [A], ctx->eig_v [A x A] (unsorted)
 int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
   if (!st) st = ctx->stream;
@@ -1382,43 +1745,8 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
   int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
   static const bool force_ql = std::getenv("ISAC_EIG_QL") != nullptr;             // development switch: A <= 64 through the pipeline
   if (A >= 3 && (big || force_ql)) {
-    const int n = A;
-    ISAC_TRY(ensure(ctx, ctx->eig_scratch, EighScratch::bytes(n)));
-    void* gs = ctx->eig_scratch.p;
-    const size_t lds1 = sizeof(c64) * 6 * (size_t)n + sizeof(double) * 32 + 64;
-    if (n <= 64) {       // four waves, two barriers per step, matrix in LDS (the general kernel with its matrix in LDS: 222 us at n = 64; this one ~120)
-      const size_t ldss = sizeof(c64) * ((size_t)n * n + 4 * 64 + 4 * 2 * 64) + sizeof(double) * 32 + 64;
-      ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_tridiag_small_kernel), (size_t)(100 * 1024)));
-      hipLaunchKernelGGL(eigh_tridiag_small_kernel, dim3(1), dim3(256), ldss, st, d_H, n, gs, info);
-    } else {
-      hipLaunchKernelGGL(eigh_tridiag_kernel<false>, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
-    }
-    ISAC_HIP(hipGetLastError());
-    // (forcing the zungtr block and the lone recurrence wavefront onto different CUs with an oversized LDS request made no
-    // difference to the recurrence -- 345 vs 350 cycles per rotation at the time -- and cost CU capacity in pipelined runs)
-    const size_t lds2 = sizeof(c64) * 3 * (size_t)n + sizeof(double) * 4 * (size_t)n + 64;
-    int bt = 64;                                       // threads per replay workgroup: its rows must fit LDS
-    if ((size_t)bt * n * sizeof(double) > 150 * 1024) bt = 32;
-    const size_t rows3 = (size_t)bt * n * sizeof(double), stage3 = sizeof(c64) * 2 * (size_t)n;
-    const size_t lds3 = rows3 + stage3;
-    const bool lds_replay = rows3 <= 150 * 1024 && n <= 8 * bt;
-    static const bool no_overlap = std::getenv("ISAC_EIG_NO_OVERLAP") != nullptr;   // development switch
-    const bool live = lds_replay && !no_overlap;       // replay blocks ride along with zungtr and the recurrence
-    const int n_replay = (2 * n + bt - 1) / bt;
-    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_formq_ql_kernel), (size_t)(160 * 1024)));
-    hipLaunchKernelGGL(eigh_formq_ql_kernel, dim3(live ? 2 + n_replay : 2), dim3(1024), live ? std::max(lds2, lds3) : lds2, st, n, gs,
-                       (double*)ctx->eig_w.p, info, (c64*)ctx->eig_v.p, bt);
-    ISAC_HIP(hipGetLastError());
-    if (!live) {
-      if (lds_replay) {
-        ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_replay_kernel<true>), lds3));
-        hipLaunchKernelGGL(eigh_replay_kernel<true>, dim3((unsigned)n_replay), dim3(bt), lds3, st, n, gs, (c64*)ctx->eig_v.p, info);
-      } else {
-        hipLaunchKernelGGL(eigh_replay_kernel<false>, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), stage3, st, n, gs, (c64*)ctx->eig_v.p, info);
-      }
-      ISAC_HIP(hipGetLastError());
-    }
-    return ISAC_OK;
+    ISAC_TRY(launch_tridiag(ctx, d_H, A, st, info));
+    return launch_ql(ctx, A, st, info, nullptr);
   }
   const int n = (A + 1) & ~1;
   size_t lds = sizeof(c64) * ((size_t)2 * n * n + n / 2) + sizeof(double) * (n / 2) + sizeof(int) * (n + 1) + 64;
@@ -1430,11 +1758,11 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
 
 // scan: uses ctx->eig_w / eig_v; L from device pointer (fused pipeline) or host value
 int isac_music_scan_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num_dets_host, const double* d_sind, int n_steps,
-                        double d_ratio, double* d_spec, hipStream_t st, int mode) {
+                        double d_ratio, double* d_spec, hipStream_t st, int mode, const int* ctl) {
   if (!st) st = ctx->stream;
-  hipLaunchKernelGGL(music_scan_kernel, dim3(n_steps), dim3(256), sizeof(c64) * (size_t)A, st,
+  hipLaunchKernelGGL(music_scan_kernel, dim3(n_steps), dim3(256), sizeof(c64) * ((size_t)A + 32), st,
                      (const double*)ctx->eig_w.p, (const c64*)ctx->eig_v.p, A, d_num_dets, num_dets_host, d_sind, d_ratio,
-                     2.220446049250313e-16, d_spec, mode);
+                     2.220446049250313e-16, d_spec, mode, ctl);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }

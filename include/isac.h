@@ -31,7 +31,11 @@
 extern "C" {
 #endif
 
-#define ISAC_ABI_VERSION 1
+/* Bumped on EVERY change of a struct layout, enum value or entry-point signature below (1: round 1; 2: ISAC_MAX_EST 1024 -> 4096,
+ * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_eig_* controls).  A host must
+ * compare isac_abi_version() with the ISAC_ABI_VERSION it was compiled against AND isac_abi_sizeof() with its own sizeof of every
+ * struct it passes: the library writes whole structs (isac_est_result is 128 KB) into caller memory. */
+#define ISAC_ABI_VERSION 3
 #define ISAC_MAX_EST 4096 /* capacity of the estimate vectors in isac_est_result: unique range bins <= nIFFT (<= 4096 for every
                              * NR numerology), unique velocity bins <= nFFT, azimuth peaks <= 180 -- never the binding limit */
 
@@ -54,6 +58,10 @@ typedef enum {
 
 /* ------------------------------------------------------------------ context */
 int isac_abi_version(void);
+/* sizeof() of the library's build of struct `which` (ISAC_SIZEOF_*), -1 for an unknown selector. */
+enum { ISAC_SIZEOF_EST_RESULT = 0, ISAC_SIZEOF_EST_PARAMS = 1, ISAC_SIZEOF_CFAR_CONFIG = 2, ISAC_SIZEOF_RADAR_CHANNEL_PARAMS = 3,
+       ISAC_SIZEOF_CARRIER = 4, ISAC_SIZEOF_MUSIC2D_PARAMS = 5, ISAC_SIZEOF_CSI_REPORT = 6 };
+int isac_abi_sizeof(int32_t which);
 int isac_device_count(int* count);
 int isac_ctx_create(int device, isac_ctx** out);
 int isac_ctx_destroy(isac_ctx* ctx);
@@ -181,7 +189,9 @@ int isac_mono_static_sensing(isac_ctx* ctx, const isac_c64* tx_wave, int64_t T, 
  * The range rows stay cached on the context; isac_fft2d_submit_cached_dev (below) with the same
  * d_echo_grid / d_tx_grid / parameter blocks consumes them instead of re-reading rxGrid.  Reuse is explicit:
  * the plain isac_fft2d[_submit]_dev never uses the cache, and any echo / range / copy / memset / free call on the
- * context drops it.  The caller must not modify echoGrid or txGrid between the two calls.
+ * context drops it, and so does every library call that writes into either grid (copies, memsets, frees, the OFDM
+ * (de)modulators, the grid generator, isac_cdl_apply_dev).  The caller must not modify echoGrid or txGrid between the two calls
+ * by any other means -- its own kernels, or library calls made through a DIFFERENT context on the same device: those are not seen.
  * One kernel does both for the spectral noise modes at Nfft = nIFFT = 4096; for every other carrier / noise mode the synthesis is
  * followed by the range stage as a second launch -- the contract (cached rows for the next isac_fft2d_submit_cached_dev) is the
  * same.  Only when the CUT window leaves the map nothing is cached (the following fft2D reports ISAC_ERR_CFAR_WINDOW). */
@@ -278,6 +288,19 @@ int isac_rdm_plane_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_c64*
 /* Array covariance of fft2D.m:106-107: Ra = X*X'/N with X = reshape(G, N, A)' (conjugate
  * transpose!), i.e. Ra[a,b] = sum_n conj(G[n,a]) G[n,b] / N.  fp64 MFMA. */
 int isac_covariance_dev(isac_ctx* ctx, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra);
+
+/* Partial Hermitian eigendecomposition, the operator behind MUSIC's default route (below): ALL eigenvalues w [A] ascending (Householder
+ * tridiagonalisation + Sturm-count bisection) and the orthonormal eigenvectors U [A x n_top] of the n_top LARGEST eigenvalues, in
+ * descending eigenvalue order (inverse iteration on the tridiagonal form, back-transformed).  3 <= A <= 256; n_top = 0: eigenvalues only. */
+int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_t n_top, double* w, isac_c64* U);
+
+/* How doaEstimation.music obtains Uan*Uan' (music.m:19-29), for fft2D and isac_music_doa on this context:
+ *   0 (default)  the signal-subspace route: Householder tridiagonalisation, all eigenvalues by bisection, the L = numDets eigenvectors of
+ *                the largest eigenvalues by inverse iteration, a' Uan Uan' a = || a - Us Us' a ||^2  (arrays of 3..256 elements; falls back
+ *                to route 1 by itself when L exceeds what one workgroup's LDS holds: 32 vectors up to 64 antennas, 15 at 256);
+ *   1            always the full eigendecomposition eig(Ra) (Jacobi / tridiagonal QL pipeline) and the explicit sum over the noise vectors.
+ * Both give the same aziEst (tests/test_gpu_music_subspace.py); route 0 removes the longest kernel of a blocking CPI. */
+int isac_music_set_route(isac_ctx* ctx, int32_t route);
 
 /* sensing.estimation.doaEstimation.music(numDets, radarEstParams, Ra) (music.m:1), ULA branch.
  * num_dets < 0 means [] (model order from determineNumTargets, music.m:109-125). */

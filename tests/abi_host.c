@@ -157,7 +157,10 @@ static int timing(int A, int reps) {
 
 int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: abi_host chain <in> <out> | time <A> <reps>\n"); return 1; }
-  if (isac_abi_version() != ISAC_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 1; }
+  if (isac_abi_version() != ISAC_ABI_VERSION || isac_abi_sizeof(ISAC_SIZEOF_EST_RESULT) != (int)sizeof(isac_est_result) ||
+      isac_abi_sizeof(ISAC_SIZEOF_EST_PARAMS) != (int)sizeof(isac_est_params) || isac_abi_sizeof(ISAC_SIZEOF_CFAR_CONFIG) != (int)sizeof(isac_cfar_config)) {
+    fprintf(stderr, "ABI version / struct size mismatch\n"); return 1;
+  }
   const char* dev = getenv("ISAC_DEVICE");
   if (isac_ctx_create(dev ? atoi(dev) : 0, &ctx) != ISAC_OK) { fprintf(stderr, "no MI355X visible\n"); return 1; }
   int rc = 1;

@@ -33,7 +33,13 @@ def test_header_symbols_all_exported(lib_path):
     assert not missing, f"declared in isac.h but not exported: {missing}"
     pkg = load_pkg()
     assert set(pkg._lib.EXPORTS) == declared
-    assert lib.isac_abi_version() == 1
+    m = re.search(r"#define ISAC_ABI_VERSION (\d+)", hdr)
+    assert lib.isac_abi_version() == int(m.group(1)) == pkg._lib.ISAC_ABI_VERSION >= 3
+    # struct sizes as the library was built == the ctypes mirrors (the loader refuses a mismatch)
+    L = pkg._lib
+    for which, cls in enumerate((L.EstResult, L.EstParams, L.CfarConfig, L.RadarChannelParams, L.Carrier, L.Music2dParams, L.CsiReport)):
+        assert lib.isac_abi_sizeof(ctypes.c_int32(which)) == ctypes.sizeof(cls)
+    assert lib.isac_abi_sizeof(ctypes.c_int32(99)) == -1
 
 
 def test_size_queries_need_no_gpu(lib_path):
