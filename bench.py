@@ -13,9 +13,12 @@ Inputs are synthetic and generated ON THE DEVICE before the timed region (QPSK t
 txWaveform, Philox AWGN inside the kernels).  Prints one JSON line on rank 0.
 
 `--gpus N` without a torchrun environment launches N ranks itself (one per GPU, RCCL); under torchrun the
-launcher's RANK / LOCAL_RANK / WORLD_SIZE are used.  `roofline` quotes the kernel with the largest share of GPU time
-(the fused echo-synthesis + range-stage kernel) timed with HIP events inside the run; `cpu_baseline` is the C++/OpenMP
-port of the same chain (oracle/cpu_port) on every host core at full size.
+launcher's RANK / LOCAL_RANK / WORLD_SIZE are used.  `roofline` quotes the dominant HBM-bound kernel (the fused
+echo-synthesis + range-stage kernel: the largest share of the wide kernels' time and of the bytes), timed with HIP
+events inside the run; `roofline.top_by_time` names whichever kernel has the largest time share in the committed
+rocprofv3 single-stream summary (profiles/rNN_kernel_stats_single_stream.csv), and `roofline.traffic` is read from the
+committed PMC passes (profiles/rNN_pmc_*.csv).  `cpu_baseline` is the un-tuned C++/OpenMP port of the same chain
+(oracle/cpu_port) on every host core at full size.
 """
 from __future__ import annotations
 
@@ -40,13 +43,59 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "5g_based_system_level_integrated_sensing_and_communication_simulator_amd"
 
-# HBM bytes per launch of the dominant kernel (echo_range_kernel<1,1>: fused echo synthesis + fft2D range stage) at the
-# A=64 / 224-symbol shape, from separate rocprofv3 --pmc passes (profiles/r02_pmc_fetch_size.csv, r02_pmc_write_size.csv):
-# 2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half, MI355X_MICROARCH.md) + WRITE_SIZE, KB -> B.  Not measurable from
-# inside this process; quoted "from profile" and only for the shape it was collected at.
-DOMINANT_KERNEL_HBM_BYTES_A64 = int((2 * 413115 + 830427) * 1024)   # 1.70e9 B vs 1.503e9 B algorithmic (+86 MB range rows, +0.1 GB D)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix (= vector) dense peak
+DOMINANT_KERNEL = "echo_range_kernel"
+
+
+def profile_facts():
+    """What the committed rocprofv3 summaries (profiles/, newest round) say -- read, not hard-coded:
+      top_by_time  the kernel with the largest share of GPU time in rNN_kernel_stats_single_stream.csv (blocking call order, one stream);
+      traffic      HBM bytes per launch of the dominant kernel at the A = 64 / 224-symbol shape from the separate --pmc passes:
+                   2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half, MI355X_MICROARCH.md) + WRITE_SIZE, KB -> B.
+    Not measurable from inside this process; quoted "from profile" and only for the shape it was collected at."""
+    import csv
+    import glob
+    import re
+    out = {"top_by_time": None, "traffic": None, "traffic_source": None}
+    pdir = os.path.join(ROOT, "profiles")
+
+    def newest(suffix):
+        best = None
+        for f in glob.glob(os.path.join(pdir, "r[0-9][0-9]_" + suffix)):
+            m = re.match(r"r(\d\d)_", os.path.basename(f))
+            if m and (best is None or int(m.group(1)) > best[0]):
+                best = (int(m.group(1)), f)
+        return best[1] if best else None
+
+    def short(name):
+        m = re.match(r"_ZN4isac\d+([A-Za-z0-9_]+?)(?:I|E)", name.strip('"'))
+        return m.group(1) if m else name.strip('"')[:48]
+    try:
+        f = newest("kernel_stats_single_stream.csv")
+        if f:
+            rows = list(csv.DictReader(open(f)))
+            top = max(rows, key=lambda r: float(r["total_us"]))
+            dom = [r for r in rows if DOMINANT_KERNEL in r["kernel"]]
+            out["top_by_time"] = {"kernel": short(top["kernel"]), "share": round(float(top["pct"]) / 100.0, 4), "avg_us": float(top["avg_us"]),
+                                  "dominant_hbm_kernel_share": round(float(dom[0]["pct"]) / 100.0, 4) if dom else None,
+                                  "dominant_hbm_kernel_avg_us": float(dom[0]["avg_us"]) if dom else None,
+                                  "source": "profiles/" + os.path.basename(f)}
+        ff, fw = newest("pmc_fetch_size.csv"), newest("pmc_write_size.csv")
+        if ff and fw:
+            def kb(path, counter):
+                for r in csv.DictReader(open(path)):
+                    if DOMINANT_KERNEL in r["kernel"] and r["counter"] == counter:
+                        return float(r["avg_value"])
+                return None
+            fe, wr = kb(ff, "FETCH_SIZE"), kb(fw, "WRITE_SIZE")
+            if fe is not None and wr is not None:
+                out["traffic"] = int((2.0 * fe + wr) * 1024)
+                out["traffic_source"] = (f"from profile: profiles/{os.path.basename(ff)} (x2, gfx950) + profiles/{os.path.basename(fw)}, "
+                                         "separate --pmc passes, A = 64 / 224-symbol shape")
+    except Exception as e:                                     # a malformed summary must not break the benchmark
+        out["error"] = repr(e)
+    return out
 
 
 def cell_params(n_ants, targets, velocity):
@@ -292,6 +341,8 @@ def cpu_baseline(cell, budget_s=12.0):
     cpi_s = float(np.median(times))
     n_slots = cell.Lsym // 14
     return {"value": round(n_slots / cpi_s, 3), "unit": "sensing slots/sec", "cores": P.threads(), "kind": "port", "language": "C++17 + OpenMP (oracle/cpu_port)",
+            "tuning": "un-tuned port (plain OpenMP loops, own radix-4 FFT, no BLAS): a reported baseline, not evidence of kernel quality",
+            "cpi_s": {"median": round(cpi_s, 4), "min": round(float(np.min(times)), 4), "max": round(float(np.max(times)), 4), "n": len(times)},
             "sample": f"{len(times)} whole CPIs of the bench workload ({cell.A} antennas, K={cell.K}, L={cell.Lsym}, T={cell.T}) through oracle/cpu_port "
                       f"(C++17 + OpenMP, own radix-4 FFT, fp64, AWGN drawn inside the timed call), median {cpi_s:.3f} s per CPI, "
                       f"{P.threads()} OpenMP threads; first estimates rng {None if est is None else np.round(est.rngEst[:2], 3).tolist()} "
@@ -300,13 +351,16 @@ def cpu_baseline(cell, budget_s=12.0):
 
 
 def roofline_entry(cell, args, ms_timed, ms_iso, n_launches, stages, cpi_bytes, per_cpi_ms):
-    """`roofline` for the kernel with the largest share of GPU time (profiles/r02_kernel_stats_*.csv): the fused echo-synthesis +
-    range-stage kernel.  achieved = algorithmic bytes per launch / average launch duration measured with HIP events inside this run."""
+    """`roofline` for the dominant HBM-bound kernel: the fused echo-synthesis + range-stage kernel (the largest share of the wide kernels'
+    time and of the bytes moved).  achieved = algorithmic bytes per launch / average launch duration measured with HIP events inside
+    this run; `top_by_time` and `traffic` come from the committed rocprofv3 summaries (profile_facts)."""
+    facts = profile_facts()
     whole = {"algorithmic_bytes": cpi_bytes, "ms": round(per_cpi_ms, 4), "achieved_GBps": round(cpi_bytes / 1e9 / (per_cpi_ms / 1e3), 1),
              "frac": round(cpi_bytes / 1e9 / (per_cpi_ms / 1e3) / HBM_PEAK_GBS, 4),
              "note": "SURVEY 8d bytes per CPI (txWaveform + echoGrid + rxGrid + txGrid) / driver-visible time per CPI"}
     if not args.fuse or ms_iso is None:
         return {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "top_by_time": facts["top_by_time"],
                 "note": "--no-fuse: per-kernel event timing is wired to the fused kernel only", "other_stages": stages, "whole_cpi": whole}
     nb = cell.dominant_kernel_bytes()
     # The launch duration that defines the kernel's own roofline fraction is the one with the device to itself: in the timed region up to
@@ -317,14 +371,15 @@ def roofline_entry(cell, args, ms_timed, ms_iso, n_launches, stages, cpi_bytes, 
     return {"bound": "hbm", "kernel": "echo_range_kernel<1,1> (fused: per-target rank-1 echo synthesis + Philox AWGN on the demodulated grid -> echoGrid; "
                                       "rx.*conj(tx), Kaiser, 4096-pt range IFFT, CUT rows)",
             "achieved": round(nb / 1e9 / (ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
-            "traffic": DOMINANT_KERNEL_HBM_BYTES_A64 if at_shape else None,
-            "traffic_source": "from profile: profiles/r02_pmc_fetch_size.csv (x2, gfx950) + r02_pmc_write_size.csv, separate --pmc passes" if at_shape else None,
+            "traffic": facts["traffic"] if at_shape else None,
+            "traffic_source": facts["traffic_source"] if at_shape else None,
+            "top_by_time": facts["top_by_time"],
             "avg_launch_ms": round(ms, 4), "launches_averaged": 10,
             "avg_launch_ms_in_timed_region": None if not ms_timed else round(ms_timed, 4), "launches_in_timed_region": n_launches,
             "frac_in_timed_region": None if not ms_timed else round(nb / 1e9 / (ms_timed / 1e3) / HBM_PEAK_GBS, 4),
             "timing": "HIP events recorded by the library around every launch of this kernel, on the stream of the launch: `avg_launch_ms` with the "
                       "device to itself (10 launches right after the timed region; this is what rocprofv3 reports for the single-stream run, "
-                      "profiles/r02_kernel_stats_single_stream.csv), `..._in_timed_region` with the other in-flight CPIs' kernels sharing the GPU",
+                      "profiles/rNN_kernel_stats_single_stream.csv), `..._in_timed_region` with the other in-flight CPIs' kernels sharing the GPU",
             "algorithmic_bytes_per_launch": nb, "algorithmic_bytes_note": "txGrid read once + echoGrid written once = 2 K L A 16 B; echoGrid is not re-read by the range stage",
             "other_stages": stages, "whole_cpi": whole}
 
@@ -359,6 +414,9 @@ def main():
                     help="Philox AWGN drawn on the demodulated grid (default; same distribution, include/isac.h isac_noise_mode) or per time sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prime-ms", type=float, default=300.0, help="untimed device priming (hot-path steps) before the warm-up steps; 0 = none")
+    ap.add_argument("--n1-value", type=float, default=None, help="N > 1: the N = 1 value of the same per-GPU workload (slots/s) -> `efficiency_vs_n1` in the line")
+    ap.add_argument("--n1-leg", action="store_true", help="N > 1: before the timed region rank 0 times the same per-GPU workload ALONE (the other ranks idle at a "
+                                                          "barrier) and the line carries `n1_in_run` + `efficiency_vs_n1`: the whole scaling point in one command")
     args = ap.parse_args()
     # (round 1 selected the one-CU Jacobi eigensolver for pipelined runs; with this round's kernels the library default -- the tridiagonal
     # pipeline above 16 antennas -- is as fast or faster pipelined and 0.7 ms shorter in the drain tail: no override any more)
@@ -411,6 +469,18 @@ def main():
         for cell in cells:
             pool.submit(cell)
     pool.drain()
+    # optional in-run N = 1 leg (multi-GPU only): rank 0 runs `steps` CPIs of ITS per-GPU workload with every other GPU idle
+    n1_in_run = None
+    if world > 1 and args.n1_leg:
+        barrier()
+        if rank == 0:
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                for cell in cells:
+                    pool.submit(cell)
+            pool.drain(); pool.sync()
+            n1_in_run = args.steps * len(cells) * args.slots / (time.perf_counter() - t1)
+        barrier()
     sink = [] if (rank == 0 and args.fuse) else None
     if sink is not None:
         for c_ in pool.ctxs:
@@ -444,6 +514,11 @@ def main():
     recs = np.array([d.make_record(cid, cell.last, dt) for cid, cell in zip(my_cells, cells)]).reshape(-1, d.RECORD_LEN)
     on_gpu = dist is not None and dist.get_backend() == "nccl"
     allr = d.gather_records(recs, dist, torch.device("cuda", local_rank) if on_gpu else None)
+    # per-rank timed-region durations (every record of a rank carries that rank's dt): the max defines `value`
+    per_rank_ms = {}
+    for r in allr:
+        rk = (int(r[0]) % world) if args.cells > 0 else (int(r[0]) // max(args.cells_per_gpu, 1))
+        per_rank_ms[rk] = round(1e3 * float(r[6]), 3)
     dt = float(np.nanmax(allr[:, 6])) if allr.size else dt
     n_cpi = args.steps * n_total_cells
     slots = n_cpi * args.slots
@@ -454,6 +529,10 @@ def main():
             "metric": "sensing slots/sec (CDL echo->2D-FFT->2D-CFAR)", "value": round(slots / dt, 2), "unit": "sensing slots/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "strong" if args.cells > 0 else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "per_rank_ms": [per_rank_ms.get(r) for r in range(world)],
+            "hw_queues": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "hip_streams": 2 * args.inflight,
+                          "note": "set by bench.py before the HIP runtime starts (the library loader does not touch the environment): one hardware queue per "
+                                  "HIP stream, two streams per in-flight CPI; INTEGRATION.md section 4"},
             "pipeline": {"cpis_in_flight": args.inflight, "blocking_cpi_ms": None if blocking_ms is None else round(blocking_ms, 3),
                          "note": "the timed region starts with an empty device and ends fully drained: its K steps include one pipeline fill and "
                                  "one drain (about one blocking CPI latency in total); steady-state rate = the same command with --steps 100"},
@@ -469,6 +548,14 @@ def main():
         res["cells"] = [{"cell": int(r[0]), "nRng": None if np.isnan(r[1]) else int(r[1]), "rngEst0": None if np.isnan(r[2]) else round(float(r[2]), 6),
                          "velEst0": None if np.isnan(r[3]) else round(float(r[3]), 6), "aziEst0": None if np.isnan(r[4]) else float(r[4])}
                         for r in allr[:64]]
+        if world > 1:
+            n1 = n1_in_run if n1_in_run is not None else args.n1_value
+            per_gpu = "the same per-GPU workload" if args.cells == 0 else "rank 0's share of the cells"
+            res["scaling_point"] = {"n1_value": None if n1 is None else round(n1, 2), "n1_source": "in-run leg (rank 0 alone, other GPUs idle)" if n1_in_run is not None
+                                    else ("--n1-value" if args.n1_value is not None else None),
+                                    "efficiency_vs_n1": None if n1 is None else round(res["value"] / (world * n1), 4),
+                                    "note": f"efficiency = value / (N x N=1 value of {per_gpu}); no multi-GPU scaling curve has been measured on hardware yet "
+                                            "(DESIGN.md section 6) -- the driver computes its own from the per-N lines"}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(cells[0])
             res["gpu_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
