@@ -836,15 +836,17 @@ extern "C" int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_TRY(eig_status(ctx, A));
   if (ctl[0] == 1 && n_top < A) {                                   // the subspace kernel delivered the vectors, descending eigenvalue order
-    ISAC_HIP(hipMemcpy(U, ctx->eig_v.p, sizeof(c64) * (size_t)A * n_top, hipMemcpyDeviceToHost));
+    ISAC_HIP(hipMemcpyAsync(U, ctx->eig_v.p, sizeof(c64) * (size_t)A * n_top, hipMemcpyDeviceToHost, ctx->stream));
+    ISAC_HIP(hipStreamSynchronize(ctx->stream));
     return ISAC_OK;
   }
   // n_top beyond the subspace kernel's capacity (or the whole basis): the QL pipeline ran; pick the columns of the n_top largest
   std::vector<double> wv((size_t)A);
   std::vector<c64> vv((size_t)A * A);
   if (n_top == A) ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));
-  ISAC_HIP(hipMemcpy(wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost));
-  ISAC_HIP(hipMemcpy(vv.data(), ctx->eig_v.p, sizeof(c64) * (size_t)A * A, hipMemcpyDeviceToHost));
+  ISAC_HIP(hipMemcpyAsync(wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));   // (the context's streams are
+  ISAC_HIP(hipMemcpyAsync(vv.data(), ctx->eig_v.p, sizeof(c64) * (size_t)A * A, hipMemcpyDeviceToHost, ctx->stream));  //  non-blocking: stay on them)
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_TRY(eig_status(ctx, A));
   std::vector<int> order((size_t)A);
   std::iota(order.begin(), order.end(), 0);

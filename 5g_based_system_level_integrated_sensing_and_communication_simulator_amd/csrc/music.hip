@@ -1314,7 +1314,9 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
   __syncthreads();
   tn = 0.0;
   for (int w = 0; w < 16; ++w) tn = fmax(tn, s_red[w]);
-  const double tiny = 2.220446049250313e-16 * fmax(tn, 2.2250738585072014e-308);
+  // pivot floor of the elimination: eps ||T||.  The matrix is safe-scaled (entries inside [2^-400, 2^400], or exactly zero): the 2^-400
+  // floor keeps 1 / tiny and the squared norms of the solutions finite for the zero matrix too (any orthonormal basis is right there)
+  const double tiny = 2.220446049250313e-16 * fmax(tn, 0x1.0p-400);
   const bool solver = wid == 0 && lane < L;                          // one lane per vector, descending eigenvalue order
   const double lam = solver ? S.wsc[n - 1 - lane] : 0.0;
   if (solver) {                                                      // deterministic pseudo-random start vectors (same LCG as the restatement)

@@ -151,7 +151,7 @@ def signal_vectors_tridiag(d, e, w, n_sig, rounds=3):
     """Orthonormal basis Z [n x n_sig] (real) of the invariant subspace of the n_sig largest eigenvalues of tridiag(d, e)."""
     n = d.size
     lam = w[::-1][:n_sig]                                     # descending
-    tnorm = max(np.abs(d).max(), np.abs(e).max() if e.size else 0.0, np.finfo(float).tiny)
+    tnorm = max(np.abs(d).max(), np.abs(e).max() if e.size else 0.0, 2.0 ** -400)   # (the device works on the safe-scaled matrix)
     tiny = EPS * tnorm
     z = np.stack([start_vector(n, j) for j in range(n_sig)], axis=1)
     for r in range(rounds):
