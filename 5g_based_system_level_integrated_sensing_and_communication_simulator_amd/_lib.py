@@ -90,7 +90,7 @@ EXPORTS = [
     "isac_mono_static_sensing", "isac_mono_static_sensing_fused_dev", "isac_ofdm_symbol_count", "isac_ofdm_demodulate_dev", "isac_ofdm_modulate_dev", "isac_ofdm_modulate_windowed_dev", "isac_sentx_append_dev",
     "isac_ofdm_waveform_length", "isac_cfar2d_ca", "isac_fft2d_dev", "isac_fft2d", "isac_fft2d_submit_dev", "isac_fft2d_submit_cached_dev", "isac_fft2d_collect", "isac_fft2d_range_stage_dev", "isac_fft2d_get_detections",
     "isac_fft2d_get_power_window", "isac_fft2d_get_covariance", "isac_fft2d_get_music_spectrum",
-    "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_music_set_route", "isac_eigh_top", "isac_beamscan_doa", "isac_music2d_dev", "isac_eigh", "isac_cdl_apply_dev", "isac_precoded_sinr_cqi_dev", "isac_type1sp_codebook", "isac_csi_report_dev", "isac_los_check_dev", "isac_winding_number_dev", "isac_synth_qpsk_grid_dev",
+    "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_ctx_set_option", "isac_eigh_top", "isac_beamscan_doa", "isac_music2d_dev", "isac_eigh", "isac_cdl_apply_dev", "isac_precoded_sinr_cqi_dev", "isac_type1sp_codebook", "isac_csi_report_dev", "isac_los_check_dev", "isac_winding_number_dev", "isac_synth_qpsk_grid_dev",
 ]
 
 
@@ -222,8 +222,12 @@ class Context:
         return d
 
     def set_music_route(self, route: int):
-        """0 = MUSIC through the signal-subspace eigensolver (default), 1 = always the full eigendecomposition (isac_music_set_route)."""
-        self.check(self.lib.isac_music_set_route(self.handle, C.c_int32(int(route))))
+        """0 = MUSIC through the signal-subspace eigensolver (default), 1 = always the full eigendecomposition (ISAC_OPT_MUSIC_ROUTE)."""
+        self.check(self.lib.isac_ctx_set_option(self.handle, C.c_int32(0), C.c_int32(int(route))))
+
+    def set_tail_fusion(self, on: bool):
+        """True (default) = Doppler FFT + CFAR + merge + numDets in one launch where applicable, False = separate kernels (ISAC_OPT_TAIL_FUSION)."""
+        self.check(self.lib.isac_ctx_set_option(self.handle, C.c_int32(1), C.c_int32(1 if on else 0)))
 
     def eigh_top(self, h, n_top: int):
         """(w, U): all eigenvalues ascending + the eigenvectors of the n_top largest (descending order) -- isac_eigh_top."""

@@ -12,7 +12,7 @@ using namespace isac;
 // kernels / stages implemented in the other translation units
 int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, const c64* d_rx, const c64* d_tx,
                           int K, int L, int A, int* nr_out, int* nc_out, bool use_cached_range);
-int isac_cfar_window(isac_ctx* ctx, const isac_cfar_config* cf, int nr, int nc, int A, int cap);
+int isac_cfar_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, int nr, int nc, int A, int cap);
 int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st);
 // status word the device eigensolver leaves behind the eigenvalues (ctx->eig_w [A] | info[0..5]): negative = the QL
 // recurrence ran out of rotation storage (-1) or a replay block gave up waiting (-2).  Call after the stream is idle.
@@ -289,6 +289,9 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
   const int p1 = 0, p2 = prio_hi;
   if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, p1) != hipSuccess ||
       hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, p2) != hipSuccess ||
+      hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, p2) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_range, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_cfar, hipEventDisableTiming) != hipSuccess ||
@@ -298,6 +301,8 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
     delete ctx;
     return ISAC_ERR_HIP;
   }
+  ctx->tail_st = ctx->stream;
+  if (const char* e = std::getenv("ISAC_TAIL_STREAM")) ctx->tail_stream_on = std::atoi(e) != 0;   // development override of ISAC_OPT_TAIL_STREAM's default
   *out = ctx;
   return ISAC_OK;
 }
@@ -307,12 +312,13 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream2);
+  (void)hipStreamSynchronize(ctx->stream3);
   for (auto& kv : ctx->twiddles) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->kaiser3) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->sind) (void)hipFree(kv.second.p);
   DevBuf* bufs[] = {&ctx->beam, &ctx->coef, &ctx->phase_rx, &ctx->steer, &ctx->dgrid,
                     &ctx->ymid, &ctx->pwin, &ctx->flags, &ctx->det_cut, &ctx->det_pow, &ctx->det_cnt, &ctx->cov_part,
-                    &ctx->cov, &ctx->eig_w, &ctx->eig_v, &ctx->eig_scratch, &ctx->spec, &ctx->misc, &ctx->stage_a, &ctx->stage_b,
+                    &ctx->cov, &ctx->eig_w, &ctx->eig_v, &ctx->eig_scratch, &ctx->spec, &ctx->misc, &ctx->stage_a, &ctx->stage_b, &ctx->seg, &ctx->tail_ctr,
                     &ctx->stage_c, &ctx->sind_tab};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -328,6 +334,9 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   (void)hipEventDestroy(ctx->ev_k1);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->stream2);
+  (void)hipStreamDestroy(ctx->stream3);
+  (void)hipEventDestroy(ctx->ev_range);
+  (void)hipEventDestroy(ctx->ev_tail);
   delete ctx;
   return ISAC_OK;
 }
@@ -532,15 +541,22 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   // per-antenna detection capacity: every CUT of the zone, bounded only by a 256 MB scratch budget (A x cap x 12 B) -- at the default
   // zone (8 510 CUTs) and any A <= 2500 an antenna can report every CUT, as phased.CFARDetector2D would
   const int cap = (int)std::min<long long>(n_cut, std::max<long long>(4096, (256ll << 20) / 12 / A));
-  ISAC_TRY(isac_cfar_window(ctx, cfar, nr, nc, A, cap));                                 // fft2D.m:62 (+ numDets on device)
-  ISAC_HIP(hipEventRecord(ctx->ev_cfar, ctx->stream));
+  // The small-grid tail (fused Doppler + CFAR, pack, result copy) may run on its own high-priority stream: in a pipelined run its few
+  // hundred workgroups otherwise queue behind the wide kernels of the other CPIs in flight (ISAC_OPT_TAIL_STREAM)
+  ctx->tail_st = (ctx->tail_deferred && ctx->tail_stream_on && !single_stream) ? ctx->stream3 : ctx->stream;
+  if (ctx->tail_st != ctx->stream) {
+    ISAC_HIP(hipEventRecord(ctx->ev_range, ctx->stream));
+    ISAC_HIP(hipStreamWaitEvent(ctx->tail_st, ctx->ev_range, 0));
+  }
+  ISAC_TRY(isac_cfar_window(ctx, ep, cfar, nr, nc, A, cap));                                 // fft2D.m:62 (+ numDets on device)
+  ISAC_HIP(hipEventRecord(ctx->ev_cfar, ctx->tail_st));
   ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_cfar, 0));
   if (!upa) {   // numDets comes from the CFAR branch, still on the device                   music.m:12,82-91
     if (sub) ISAC_TRY(isac_music_subspace_dev(ctx, A, (const int*)ctx->misc.p, 0, s2));          // the numDets signal vectors (or the QL fallback)
     ISAC_TRY(isac_music_scan_dev(ctx, A, (const int*)ctx->misc.p, 0, d_sind, n_steps, 0.5, (double*)ctx->spec.p, s2, 0, sub ? isac_music_ctl(ctx) : nullptr));
   }
   ISAC_HIP(hipEventRecord(ctx->ev_join, s2));
-  ISAC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  ISAC_HIP(hipStreamWaitEvent(ctx->tail_st, ctx->ev_join, 0));
   // pack + one device->host copy
   const int pack_first = 4096;
   const size_t hdr_ints = 3 + (size_t)A + 1;
@@ -559,13 +575,17 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   ISAC_TRY(ensure(ctx, ctx->stage_b, (sizeof(double) + sizeof(int)) * pack_cap + 64));
   double* d_ppow_full = (double*)ctx->stage_b.p;
   int* d_pcut_full = (int*)((char*)ctx->stage_b.p + sizeof(double) * pack_cap);
-  hipLaunchKernelGGL(pack_kernel, dim3(1), dim3(256), 0, ctx->stream, (const int*)ctx->det_cnt.p, (const int*)ctx->det_cut.p,
+  hipLaunchKernelGGL(pack_kernel, dim3(1), dim3(256), 0, ctx->tail_st, (const int*)ctx->det_cnt.p, (const int*)ctx->det_cut.p,
                      (const double*)ctx->det_pow.p, (const int*)ctx->misc.p, A, cap, (int*)dbase, d_pcut_full, d_ppow_full,
                      pack_first, d_pcut_first, d_ppow_first, (const double*)ctx->spec.p, n_steps, (double*)(dbase + off_spec),
                      upa ? nullptr : (const int*)((const char*)ctx->eig_w.p + sizeof(double) * (size_t)A));
   ISAC_HIP(hipGetLastError());
   char* h = (char*)ctx->pinned;
-  ISAC_HIP(hipMemcpyAsync(h, dbase, first_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipMemcpyAsync(h, dbase, first_bytes, hipMemcpyDeviceToHost, ctx->tail_st));
+  if (ctx->tail_st != ctx->stream) {                 // the context's main stream is "done" only when the tail is: collect and every later call order behind it
+    ISAC_HIP(hipEventRecord(ctx->ev_tail, ctx->tail_st));
+    ISAC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail, 0));
+  }
   // everything the host half needs later
   Fft2dPending& pd = ctx->pending;
   pd.ep = *ep; pd.cfar = *cfar;
@@ -855,11 +875,15 @@ extern "C" int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_
   return ISAC_OK;
 }
 
-extern "C" int isac_music_set_route(isac_ctx* ctx, int32_t route) {
+extern "C" int isac_ctx_set_option(isac_ctx* ctx, int32_t option, int32_t value) {
   ISAC_ENTER(ctx);
-  if (route != 0 && route != 1) return fail(ctx, ISAC_ERR_INVALID_ARG, "route: 0 = signal-subspace eigensolver (default), 1 = full eigendecomposition");
-  ctx->music_route = route;
-  return ISAC_OK;
+  if (value != 0 && value != 1) return fail(ctx, ISAC_ERR_INVALID_ARG, "option values are 0 or 1");
+  switch (option) {
+    case ISAC_OPT_MUSIC_ROUTE: ctx->music_route = value; return ISAC_OK;          // 0 = signal-subspace eigensolver (default), 1 = full eig
+    case ISAC_OPT_TAIL_FUSION: ctx->tail_fusion = value; return ISAC_OK;          // 1 = one Doppler + CFAR launch (default), 0 = separate kernels
+    case ISAC_OPT_TAIL_STREAM: ctx->tail_stream_on = value; return ISAC_OK;       // 1 = the fused tail on its own high-priority stream
+    default: return fail(ctx, ISAC_ERR_INVALID_ARG, "unknown option");
+  }
 }
 
 extern "C" int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_params* ep, const isac_c64* Ra, int32_t A,

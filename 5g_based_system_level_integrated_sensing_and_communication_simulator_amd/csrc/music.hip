@@ -1223,15 +1223,17 @@ __device__ __forceinline__ double wave_sum(double x) { for (int o = 32; o > 0; o
 __device__ __forceinline__ double wave_max(double x) { for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o)); return x; }
 __device__ __forceinline__ double wave_min(double x) { for (int o = 32; o > 0; o >>= 1) x = fmin(x, __shfl_xor(x, o)); return x; }
 
-constexpr int kBisectWaves = 16;                         // eigenvalues per workgroup (one wavefront each)
-__global__ __launch_bounds__(1024) void eigh_bisect_kernel(int n, void* scratch, double* __restrict__ w_out /* [n] ascending */) {
+// Four wavefronts per workgroup = one per SIMD: the count recurrence is a dependent chain of ~12 fp64 instructions per matrix row, and
+// a SIMD shared by four such chains runs each at a quarter of the rate (16 waves per workgroup: 70 us at n = 64) while the other CUs idle.
+constexpr int kBisectWaves = 4;                          // eigenvalues per workgroup (one wavefront each)
+__global__ __launch_bounds__(64 * kBisectWaves) void eigh_bisect_kernel(int n, void* scratch, double* __restrict__ w_out /* [n] ascending */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   EighScratch S(scratch, n);
   c64* de = reinterpret_cast<c64*>(smem_raw);            // [n]  (.re = d_i, .im = e_{i-1}^2 with e_{-1} = 0)
   double* sred = reinterpret_cast<double*>(de + n);      // [3][16]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   double gl = 1.7976931348623157e308, gu = -1.7976931348623157e308, e2m = 0.0;
-  for (int i = tid; i < n; i += 1024) {                  // Gershgorin interval
+  for (int i = tid; i < n; i += 64 * kBisectWaves) {     // Gershgorin interval
     const double d = S.d[i];
     const double el = i > 0 ? S.e[i - 1] : 0.0, er = i < n - 1 ? S.e[i] : 0.0;
     de[i] = mk(d, el * el);
@@ -1241,7 +1243,7 @@ __global__ __launch_bounds__(1024) void eigh_bisect_kernel(int n, void* scratch,
   gl = wave_min(gl); gu = wave_max(gu); e2m = wave_max(e2m);
   if (lane == 0) { sred[wid] = gl; sred[16 + wid] = gu; sred[32 + wid] = e2m; }
   __syncthreads();
-  for (int w = 0; w < 16; ++w) { gl = fmin(gl, sred[w]); gu = fmax(gu, sred[16 + w]); e2m = fmax(e2m, sred[32 + w]); }
+  for (int w = 0; w < kBisectWaves; ++w) { gl = fmin(gl, sred[w]); gu = fmax(gu, sred[16 + w]); e2m = fmax(e2m, sred[32 + w]); }
   const double bnorm = fmax(fabs(gl), fabs(gu));
   const double pivmin = 2.2250738585072014e-308 * fmax(1.0, e2m);
   const double eps = 2.220446049250313e-16;
@@ -1302,10 +1304,12 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
   double* y = u2 + plane;                                            // right-hand sides / solutions = the vectors, [row][vector]
   double* sd = y + plane;                                            // [n] d
   double* se = sd + n;                                               // [n] e (e[n-1] = 0)
+  c64* s_tau = reinterpret_cast<c64*>(se + n);                       // [n] reflector scalars
   double tn = 0.0;
   for (int i = tid; i < n; i += 1024) {
     const double d = S.d[i], e = i < n - 1 ? S.e[i] : 0.0;
     sd[i] = d; se[i] = e;
+    s_tau[i] = i < n - 1 ? S.tau[i] : mk(0.0, 0.0);
     tn = fmax(tn, fmax(fabs(d), fabs(e)));
   }
   tn = wave_max(tn);
@@ -1336,7 +1340,8 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
         const double c = se[i], dn = sd[i + 1] - lam, en = se[i + 1];
         const double ynext = y[(size_t)(i + 1) * lv + lane];
         const bool swap = fabs(a) < fabs(c);
-        const double piv = swap ? c : (a == 0.0 ? tiny : a);
+        double piv = swap ? c : a;
+        piv = fabs(piv) < tiny ? (piv < 0.0 ? -tiny : tiny) : piv;   // singular to working precision: dlagts' pivot perturbation (also keeps 1 / piv finite)
         const double inv = rcp_fast(piv);
         const double m = (swap ? a : c) * inv;
         const size_t o = (size_t)i * lv + lane;
@@ -1394,42 +1399,78 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
     }
     __syncthreads();
   }
-  // ---- U = Q Z, Q = H_0 ... H_{n-2} (zungtr's product, applied to L vectors instead of formed): one wavefront per vector; the
-  // reflector of the next step is fetched under the current one
+  // ---- U = Q Z, Q = H_0 ... H_{n-2} (zungtr's product, applied to L vectors instead of formed): one wavefront per vector (two when
+  // L > 16).  The reflectors come through LDS in chunks of 16 columns fetched by the whole workgroup (the dead elimination planes; the
+  // next chunk's global loads fly under the current chunk's arithmetic): a wavefront that fetched its own columns from L2 step by step
+  // waited a round trip per reflector (85 us at n = 64, most of it here).
+  constexpr int CH = 16;
   const c64* M = S.M;
-  auto load_col = [&](c64 (&dst)[R], int k) {
+  c64* s_ref = reinterpret_cast<c64*>(u0);                           // [CH][n]  (3 n lv doubles >= 16 n complex for every supported n)
+  const int n_chunks = (n - 1 + CH - 1) / CH;
+  c64 pre[R];
+  auto fetch_chunk = [&](int c) {
+    const int k_hi = n - 2 - CH * c;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int i = lane + 64 * r;
-      const c64 raw = M[(size_t)(i < n ? i : n - 1) + (size_t)n * k];                 // (unconditional, clamped)
-      dst[r] = (i > k + 1 && i < n) ? raw : mk(i == k + 1 ? 1.0 : 0.0, 0.0);
+      const int e = tid + 1024 * r;                                  // (kl, i) = (e / n, e % n); CH n = 1024 R elements exactly when n = 64 R
+      const int kl = e / n, i = e - kl * n;
+      const int k = k_hi - kl;
+      const bool in = kl < CH && k >= 0;
+      const c64 raw = M[(size_t)i + (size_t)n * (in ? k : 0)];       // (unconditional, clamped)
+      pre[r] = !in ? mk(0.0, 0.0) : (i > k + 1 ? raw : mk(i == k + 1 ? 1.0 : 0.0, 0.0));
     }
   };
-  bool bad = false;
-  for (int v = wid; v < L; v += 16) {
-    c64 u[R], vk[R];
+  c64 u[2][R];
+  const bool has0 = wid < L, has1 = R <= 2 && wid + 16 < L;          // (orders above 128: at most 16 vectors, one per wavefront -- host side)
 #pragma unroll
-    for (int r = 0; r < R; ++r) { const int i = lane + 64 * r; u[r] = mk(i < n ? y[(size_t)i * lv + v] : 0.0, 0.0); }
-    load_col(vk, n - 2);
-    for (int k = n - 2; k >= 0; --k) {
-      c64 vn[R];
-      load_col(vn, k > 0 ? k - 1 : 0);
-      const c64 tau = S.tau[k];
-      c64 sacc = mk(0.0, 0.0);
+  for (int r = 0; r < R; ++r) {
+    const int i = lane + 64 * r;
+    u[0][r] = mk((has0 && i < n) ? y[(size_t)i * lv + wid] : 0.0, 0.0);
+    u[1][r] = mk((has1 && i < n) ? y[(size_t)i * lv + wid + 16] : 0.0, 0.0);
+  }
+  fetch_chunk(0);
+  __syncthreads();                                                   // the vectors are in registers: the planes are free
+  for (int c = 0; c < n_chunks; ++c) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) sacc = fma(conj(vk[r]), u[r], sacc);
-      sacc.re = wave_sum(sacc.re); sacc.im = wave_sum(sacc.im);
-      const c64 t = tau * sacc;
+    for (int r = 0; r < R; ++r) { const int e = tid + 1024 * r; if (e < CH * n) s_ref[e] = pre[r]; }
+    __syncthreads();
+    if (c + 1 < n_chunks) fetch_chunk(c + 1);
+    const int k_hi = n - 2 - CH * c;
+    if (has0) {                                                      // (wave-uniform)
 #pragma unroll
-      for (int r = 0; r < R; ++r) { u[r] = u[r] - t * vk[r]; vk[r] = vn[r]; }
-    }
+      for (int kl = 0; kl < CH; ++kl) {
+        const int k = k_hi - kl;
+        if (k < 0) break;
+        const c64 tau = s_tau[k];
+        c64 vk[R], s0 = mk(0.0, 0.0), s1 = mk(0.0, 0.0);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const int i = lane + 64 * r;
-      if (i < n) {
-        U_out[(size_t)i + (size_t)n * v] = u[r];
-        bad = bad || !(fabs(u[r].re) <= 2.0 && fabs(u[r].im) <= 2.0);               // unit vectors; catches NaN / Inf input
+        for (int r = 0; r < R; ++r) {
+          const int i = lane + 64 * r;
+          vk[r] = i < n ? s_ref[kl * n + i] : mk(0.0, 0.0);
+          s0 = fma(conj(vk[r]), u[0][r], s0);
+          if (has1) s1 = fma(conj(vk[r]), u[1][r], s1);
+        }
+        s0.re = wave_sum(s0.re); s0.im = wave_sum(s0.im);
+        const c64 t0 = tau * s0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) u[0][r] = u[0][r] - t0 * vk[r];
+        if (has1) {
+          s1.re = wave_sum(s1.re); s1.im = wave_sum(s1.im);
+          const c64 t1 = tau * s1;
+#pragma unroll
+          for (int r = 0; r < R; ++r) u[1][r] = u[1][r] - t1 * vk[r];
+        }
       }
+    }
+    __syncthreads();
+  }
+  bool bad = false;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int i = lane + 64 * r;
+    if (i < n) {
+      if (has0) { U_out[(size_t)i + (size_t)n * wid] = u[0][r]; bad = bad || !(fabs(u[0][r].re) <= 2.0 && fabs(u[0][r].im) <= 2.0); }   // unit vectors; catches NaN / Inf input
+      if (has1) { U_out[(size_t)i + (size_t)n * (wid + 16)] = u[1][r]; bad = bad || !(fabs(u[1][r].re) <= 2.0 && fabs(u[1][r].im) <= 2.0); }
     }
   }
   if (__any(bad) && lane == 0) s_bad = 1;
@@ -1702,7 +1743,7 @@ int isac_music_tridiag_bisect_dev(isac_ctx* ctx, const c64* d_H, int A, hipStrea
   int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)A);
   ISAC_TRY(launch_tridiag(ctx, d_H, n, st, info));
   const size_t lds = sizeof(c64) * (size_t)n + sizeof(double) * 48 + 64;
-  hipLaunchKernelGGL(eigh_bisect_kernel, dim3((unsigned)((n + kBisectWaves - 1) / kBisectWaves)), dim3(1024), lds, st, n, ctx->eig_scratch.p,
+  hipLaunchKernelGGL(eigh_bisect_kernel, dim3((unsigned)((n + kBisectWaves - 1) / kBisectWaves)), dim3(64 * kBisectWaves), lds, st, n, ctx->eig_scratch.p,
                      (double*)ctx->eig_w.p);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
@@ -1717,7 +1758,8 @@ int isac_music_subspace_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num
   int lmax = (int)(122880 / (32 * (size_t)n));
   lmax = lmax > 32 ? 32 : (lmax < 1 ? 1 : lmax);
   const int lv = lmax | 1;                           // odd pitch
-  const size_t lds = sizeof(double) * ((size_t)4 * n * lv + 2 * (size_t)n) + 64;
+  if (n > 128 && lmax > 16) lmax = 16;               // one vector per wavefront in the back-transformation of the R = 4 instantiation
+  const size_t lds = sizeof(double) * ((size_t)4 * n * lv + 4 * (size_t)n) + 64;
 #define ISAC_SUBSPACE(RR)                                                                                                         \
   do {                                                                                                                            \
     ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(music_subspace_kernel<RR>), (size_t)(150 * 1024)));                     \

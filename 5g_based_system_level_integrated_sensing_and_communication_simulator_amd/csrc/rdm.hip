@@ -312,6 +312,217 @@ __global__ void count_rows_kernel(const unsigned* __restrict__ row_seen, int n, 
   if (threadIdx.x == 0) *num_dets = s_cnt;
 }
 
+// ---------------------------------------------------------------- Doppler FFT + |.|^2 + CA-CFAR + row flags in ONE launch (nFFT = 256)
+// fft2D.m:44-46,59-99 after the range stage.  The two kernels above run back to back on grids of 1 536 and 64 workgroups, followed by a
+// one-workgroup row count and preceded by a memset: four dependent launches whose small grids wait behind other CPIs' wide kernels in a
+// pipelined run.  Here a workgroup owns (antenna a, panel p of kTailPR CUT rows): it transforms the panel's kTailRows = kTailPR + 2 hr window
+// rows (three passes of 16 rows through the same 256-point FFT as doppler_fft256_kernel: bit-identical powers), keeps their |rdm|^2 window
+// columns in LDS (written to pwin once, for the debug accessors), and evaluates its CUTs with the same oracle-order sums as
+// cfar_window_kernel.  Detections leave the workgroup as a list in (column, row) order plus per-column counts; the LAST workgroup of an
+// antenna to finish (atomic ticket; agent-scope fences) merges the panels' lists into the antenna's list in CUT order (rows fastest,
+// cfar2D.m:23-24 -- the order phased.CFARDetector2D reports), and the last antenna to finish counts the detected rows (numDets,
+// fft2D.m:99,110) and clears the tickets / flags for the next call: no memset, no count kernel.
+constexpr int kTailPasses = 3;
+constexpr int kTailRows = 16 * kTailPasses;                     // window rows per workgroup
+
+struct TailGeom {
+  int nr, nc;            // power window dims (rows, columns)
+  int hr, hc, gr, gc;    // guard+training / guard half sizes
+  int n_cut_rows, n_cut_cols;
+  int pr;                // CUT rows per panel = kTailRows - 2 hr
+  int n_panels;
+  int cap;               // per-antenna list capacity
+  int col_lo;            // first rdm column of the window (0-based)
+  double alpha, n_train, sqrt_nfft;
+};
+
+__global__ __launch_bounds__(256, 2) void doppler_cfar_kernel(const c64* __restrict__ ymid, int L, int A, const c64* __restrict__ tw_d, TailGeom g,
+                                                              double* __restrict__ pwin, int* __restrict__ seg_cut /* [A][n_panels][pr * n_cut_cols] */,
+                                                              double* __restrict__ seg_pow, int* __restrict__ seg_colcnt /* [A][n_panels][n_cut_cols] */,
+                                                              int* __restrict__ det_cut /* [A x cap] */, double* __restrict__ det_pow,
+                                                              int* __restrict__ det_cnt /* [A] */, unsigned* __restrict__ row_seen /* [n_cut_rows] */,
+                                                              unsigned* __restrict__ tickets /* [A + 1] */, int* __restrict__ num_dets) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int NF = 256, RT = 16, RH = 8;
+  // LDS: W256 table (4 KB), the exchange image of HALF a pass (8 rows x 16 x 16 points, rows fastest: 32 KB), the panel's power window.
+  // No staging slab: thread (j = tid >> 4, rr = tid & 15) loads its 14 slow-time samples l = j + 16 q of window row rr straight into
+  // registers -- 16 consecutive lanes read the 256 contiguous bytes of 16 consecutive rows, 14 independent loads in flight per thread.
+  c64* s_tw = reinterpret_cast<c64*>(smem_raw);                 // [256]
+  c64* s_z = s_tw + NF;                                         // [16 k1][16 j][RH rows]
+  double* s_pw = reinterpret_cast<double*>(s_z + 16 * 16 * RH); // [nc][kTailRows] the panel's power window, rows fastest
+  int* s_cnt = reinterpret_cast<int*>(s_pw + (size_t)g.nc * kTailRows);   // [8 iterations][4 waves] detections
+  int* s_col = s_cnt + 32;                                      // [n_cut_cols] per-column detection counts
+  int* s_misc = s_col + g.n_cut_cols;                           // [0] last-of-antenna flag, [1] last-overall flag, [2] total
+  int* s_off = s_misc + 4;                                      // [n_cut_cols][n_panels] destination offsets (merge)
+  int* s_src = s_off + g.n_cut_cols * g.n_panels;               // [n_cut_cols][n_panels] source offsets (merge)
+  unsigned char* s_rank = reinterpret_cast<unsigned char*>(s_src + g.n_cut_cols * g.n_panels);   // [pr * n_cut_cols]
+  const int p = blockIdx.x, a = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r0 = p * g.pr;                                      // first window row of the panel (= its first CUT row, 0-based)
+  const int Lu = L < NF ? L : NF;                               // fft(., nFFT, 2) truncates when L > nFFT
+  const int half = L / 2;
+  s_tw[tid] = tw_d[tid];
+  for (int q = tid; q < 32 + g.n_cut_cols; q += 256) s_cnt[q] = 0;
+  const int j = tid >> 4, rr = tid & 15;
+  // ---- Doppler: kTailPasses passes of 16 rows through the two-pass radix-16 transform of doppler_fft256_kernel (same arithmetic)
+  for (int ps = 0; ps < kTailPasses; ++ps) {
+    const int rbase = r0 + RT * ps;
+    const int row = rbase + rr;                                 // window row
+    const int rowc = min(row, g.nr - 1);
+    const c64* src = ymid + (long long)rowc + (long long)g.nr * (long long)L * a;
+    c64 x[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = j + 16 * q;
+      int lsrc = (i < Lu ? i : 0) + half;                       // ifftshift over the slow-time axis (unconditional load, select afterwards)
+      if (lsrc >= L) lsrc -= L;
+      const c64 v = src[(long long)g.nr * lsrc];
+      x[q] = i < Lu ? v : mk(0.0, 0.0);                         // zero-pad L -> 256
+    }
+    dft16<-1>(x);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                               // the exchange, one half of the rows at a time (a thread writes, then reads, in ITS half)
+      __syncthreads();                                          // image free (first trip: tables written)
+      if ((rr >> 3) == h) {
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) s_z[(k1 * 16 + j) * RH + (rr & 7)] = k1 ? x[k1] * s_tw[j * k1] : x[0];
+      }
+      __syncthreads();
+      if ((rr >> 3) == h) {
+#pragma unroll
+        for (int d = 0; d < 16; ++d) x[d] = s_z[(j * 16 + d) * RH + (rr & 7)];      // thread (rr, k1 = j)
+      }
+    }
+    dft16<-1>(x);                                               // x[k2] = X[k1 + 16 k2]
+    const int prow = RT * ps + rr;                              // row inside the panel
+    const bool own = row < g.nr && (row < r0 + g.pr || p == g.n_panels - 1);   // halo rows belong to the next panel
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) {
+      const int kbin = j + 16 * k2;
+      const int c = (kbin + NF / 2) & (NF - 1);                 // fftshift: column c <-> bin (c + 128) mod 256
+      const int cc = c - g.col_lo;
+      if (cc >= 0 && cc < g.nc) {
+        const double re = x[k2].re / g.sqrt_nfft, im = x[k2].im / g.sqrt_nfft;   // fft(.)/sqrt(nFFT)  fft2D.m:46
+        const double hh = hypot(re, im);                        // abs(rdm)            fft2D.m:61
+        const double pw = hh * hh;                              // .^2
+        s_pw[cc * kTailRows + prow] = pw;
+        if (own) pwin[(long long)row + (long long)g.nr * ((long long)cc + (long long)g.nc * a)] = pw;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- CA-CFAR on the panel's CUTs, i = (column, row-in-panel) with rows fastest
+  const int prp = min(g.pr, g.n_cut_rows - r0);                 // CUT rows of this panel
+  const int n_cut = prp > 0 ? prp * g.n_cut_cols : 0;
+  const int n_iter = (n_cut + 255) / 256;                       // <= 8 (host checks pr * n_cut_cols <= 2048)
+  unsigned det_bits = 0u;
+  for (int k = 0; k < n_iter; ++k) {
+    const int i = k * 256 + tid;
+    bool det = false;
+    if (i < n_cut) {
+      const int crl = i % prp, cc = i / prp;
+      const int r = crl + g.hr, c = cc + g.hc;                  // position inside the panel window
+      double acc = 0.0;
+      for (int dc = -g.hc; dc <= g.hc; ++dc) {                  // ORACLE-DEFINED order: column offset slowest, row offset fastest, guard block skipped
+        const bool guard_col = (dc >= -g.gc && dc <= g.gc);
+        const double* colp = s_pw + (c + dc) * kTailRows + r;
+        for (int dr = -g.hr; dr <= g.hr; ++dr) {
+          if (guard_col && dr >= -g.gr && dr <= g.gr) continue;
+          acc = __dadd_rn(acc, colp[dr]);
+        }
+      }
+      const double thr = __dmul_rn(g.alpha, __ddiv_rn(acc, g.n_train));
+      det = s_pw[c * kTailRows + r] > thr;                      // strict
+      if (det) { atomicAdd(&s_col[cc], 1); row_seen[r0 + crl] = 1u; }
+    }
+    const unsigned long long mask = __ballot(det);
+    if (det) det_bits |= 1u << k;
+    if (lane == 0) s_cnt[k * 4 + wid] = __popcll(mask);
+    if (det) s_rank[i] = (unsigned char)__popcll(mask & ((1ull << lane) - 1ull));
+  }
+  __syncthreads();
+  const long long seg = ((long long)a * g.n_panels + p) * ((long long)g.pr * g.n_cut_cols);
+  if (det_bits) {
+    for (int k = 0; k < n_iter; ++k) {
+      if (!(det_bits & (1u << k))) continue;
+      int off = 0;
+      for (int q = 0; q < k * 4 + wid; ++q) off += s_cnt[q];
+      const int i = k * 256 + tid;
+      const int pos = off + s_rank[i];
+      const int crl = i % prp, cc = i / prp;
+      seg_cut[seg + pos] = (r0 + crl) + g.n_cut_rows * cc;      // CUT ordinal of the antenna
+      seg_pow[seg + pos] = s_pw[(cc + g.hc) * kTailRows + crl + g.hr];
+    }
+  }
+  int* my_colcnt = seg_colcnt + ((long long)a * g.n_panels + p) * g.n_cut_cols;
+  for (int cc = tid; cc < g.n_cut_cols; cc += 256) my_colcnt[cc] = s_col[cc];
+  // ---- ticket: the last panel of this antenna merges
+  __threadfence();                                              // this workgroup's lists / counts / flags before its ticket
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = atomicAdd(&tickets[a], 1u);
+    s_misc[0] = (t == (unsigned)g.n_panels - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_misc[0]) return;                                       // (uniform)
+  __threadfence();                                              // acquire: the other panels' writes
+  // per-(column, panel) destination offsets in CUT order: column slowest, panel (= row block) next
+  const int* colcnt_a = seg_colcnt + (long long)a * g.n_panels * g.n_cut_cols;
+  if (tid == 0) {
+    int acc = 0;
+    for (int cc = 0; cc < g.n_cut_cols; ++cc)
+      for (int q = 0; q < g.n_panels; ++q) {
+        s_off[cc * g.n_panels + q] = acc;
+        acc += __hip_atomic_load(&colcnt_a[q * g.n_cut_cols + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    s_misc[2] = acc;
+    det_cnt[a] = acc;                                           // (may exceed cap only if cap < every CUT: the host reports ISAC_ERR_CAPACITY)
+    tickets[a] = 0u;                                            // ready for the next call on this context
+  }
+  if (tid < g.n_panels) {                                       // source offset of column cc inside panel tid's list
+    int acc = 0;
+    for (int cc = 0; cc < g.n_cut_cols; ++cc) {
+      s_src[cc * g.n_panels + tid] = acc;
+      acc += __hip_atomic_load(&colcnt_a[tid * g.n_cut_cols + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  for (int sgm = wid; sgm < g.n_cut_cols * g.n_panels; sgm += 4) {    // one wavefront per (column, panel) segment
+    const int cc = sgm / g.n_panels, q = sgm % g.n_panels;
+    const int cnt = __hip_atomic_load(&colcnt_a[q * g.n_cut_cols + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long sbase = ((long long)a * g.n_panels + q) * ((long long)g.pr * g.n_cut_cols) + s_src[sgm];
+    const int dbase = s_off[sgm];
+    for (int jj = lane; jj < cnt; jj += 64) {
+      const int dst = dbase + jj;
+      if (dst < g.cap) {
+        det_cut[(long long)a * g.cap + dst] = __hip_atomic_load(&seg_cut[sbase + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        det_pow[(long long)a * g.cap + dst] = __hip_atomic_load(&seg_pow[sbase + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  // ---- ticket 2: the last antenna counts the detected rows
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = atomicAdd(&tickets[A], 1u);
+    s_misc[1] = (t == (unsigned)A - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_misc[1]) return;
+  __threadfence();
+  __shared__ int s_rows;
+  if (tid == 0) s_rows = 0;
+  __syncthreads();
+  int local = 0;
+  for (int i = tid; i < g.n_cut_rows; i += 256) {
+    local += __hip_atomic_load(&row_seen[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+    row_seen[i] = 0u;                                           // clean for the next call
+  }
+  atomicAdd(&s_rows, local);
+  __syncthreads();
+  if (tid == 0) { *num_dets = s_rows; tickets[A] = 0u; }        // numDets = numel(unique(allRngEst))  fft2D.m:99,110
+}
+
 // ---------------------------------------------------------------- generic detector: arbitrary CUT list on an arbitrary map
 __global__ __launch_bounds__(256) void cfar_list_kernel(const double* __restrict__ P, int n_rows, int n_cols,
                                                         const int* __restrict__ cut /* [2 x n_cut] 1-based */, int n_cut,
@@ -381,6 +592,31 @@ static int launch_range(isac_ctx* ctx, hipStream_t st, const c64* rx, const c64*
 }
 
 // Range + Doppler + power window for the CUT rectangle.  Leaves pwin [nr x nc x A] in ctx->pwin.
+// The fused Doppler + CFAR launch (doppler_cfar_kernel) applies when nFFT = 256, the CUT half-window fits a 48-row panel and the panel's
+// bookkeeping fits its LDS carve; anything else -- or ISAC_OPT_TAIL_FUSION = 0 -- takes the separate Doppler / CFAR / count kernels.
+static bool tail_fusable(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, TailGeom* out) {
+  static const bool off = std::getenv("ISAC_TAIL_UNFUSED") != nullptr;
+  if (off || !ctx->tail_fusion || ep->n_fft != 256 || std::getenv("ISAC_DOPPLER_DIRECT")) return false;
+  TailGeom g{};
+  g.gr = cf->guard[0]; g.gc = cf->guard[1];
+  g.hr = cf->guard[0] + cf->train[0]; g.hc = cf->guard[1] + cf->train[1];
+  g.n_cut_rows = cf->row1 - cf->row0 + 1;
+  g.n_cut_cols = cf->col1 - cf->col0 + 1;
+  g.nr = g.n_cut_rows + 2 * g.hr; g.nc = g.n_cut_cols + 2 * g.hc;
+  g.pr = kTailRows - 2 * g.hr;
+  if (g.pr < 8 || g.n_cut_rows < 1 || g.n_cut_cols < 1) return false;
+  g.n_panels = (g.n_cut_rows + g.pr - 1) / g.pr;
+  if ((long long)g.pr * g.n_cut_cols > 2048 || g.n_panels > 256 || (long long)g.n_cut_cols * g.n_panels > 4096 || g.nc > 96) return false;
+  const int n_train = (2 * g.hr + 1) * (2 * g.hc + 1) - (2 * g.gr + 1) * (2 * g.gc + 1);
+  if (n_train <= 0) return false;
+  g.alpha = cfar_alpha(n_train, cf->pfa);
+  g.n_train = (double)n_train;
+  g.sqrt_nfft = std::sqrt((double)ep->n_fft);
+  g.col_lo = cf->col0 - 1 - g.hc;
+  *out = g;
+  return true;
+}
+
 int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, const c64* d_rx,
                           const c64* d_tx, int K, int L, int A, int* nr_out, int* nc_out, bool use_cached_range) {
   const int n_ifft = ep->n_ifft, n_fft = ep->n_fft;
@@ -414,7 +650,11 @@ int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_c
                                                             (c64*)ctx->ymid.p))));
   }
   const int Lu = L < n_fft ? L : n_fft;
-  if (n_fft == 256 && !std::getenv("ISAC_DOPPLER_DIRECT")) {
+  TailGeom tg;
+  ctx->tail_deferred = tail_fusable(ctx, ep, cf, &tg);     // the Doppler stage runs inside the CFAR launch (isac_cfar_window, next call)
+  if (ctx->tail_deferred) {
+    ctx->tail_L = L;
+  } else if (n_fft == 256 && !std::getenv("ISAC_DOPPLER_DIRECT")) {
     size_t lds = sizeof(c64) * (256 + std::max((size_t)Lu * (kDopRows + 1), (size_t)kDopRows * 16 * 17));
     ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(doppler_fft256_kernel), lds));
     hipLaunchKernelGGL(doppler_fft256_kernel, dim3(cdiv(nr, kDopRows), A), dim3(256), lds, ctx->stream, (const c64*)ctx->ymid.p, nr, L,
@@ -433,7 +673,46 @@ int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_c
 }
 
 // CFAR over the window in ctx->pwin; leaves compact lists in ctx->det_* and numDets in ctx->misc[0].
-int isac_cfar_window(isac_ctx* ctx, const isac_cfar_config* cf, int nr, int nc, int A, int cap) {
+static int launch_tail_fused(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, int nr, int nc, int A, int cap) {
+  TailGeom g;
+  if (!tail_fusable(ctx, ep, cf, &g) || g.nr != nr || g.nc != nc) return fail(ctx, ISAC_ERR_HIP, "internal: fused tail geometry changed between its two halves");
+  g.cap = cap;
+  const c64* twd = nullptr;
+  ISAC_TRY(isac_get_twiddles2(ctx, 256, &twd));
+  const size_t seg_elems = (size_t)A * g.n_panels * (size_t)g.pr * g.n_cut_cols;
+  ISAC_TRY(ensure(ctx, ctx->det_cut, sizeof(int) * (size_t)A * cap));
+  ISAC_TRY(ensure(ctx, ctx->det_pow, sizeof(double) * (size_t)A * cap));
+  ISAC_TRY(ensure(ctx, ctx->det_cnt, sizeof(int) * (size_t)A));
+  ISAC_TRY(ensure(ctx, ctx->seg, (sizeof(double) + sizeof(int)) * seg_elems + sizeof(int) * (size_t)A * g.n_panels * g.n_cut_cols + 64));
+  double* seg_pow = (double*)ctx->seg.p;
+  int* seg_cut = (int*)(seg_pow + seg_elems);
+  int* seg_colcnt = seg_cut + seg_elems;
+  // row flags + tickets: zero once (allocation / geometry change); the kernel's last workgroups leave them zero again
+  const size_t ctr_bytes = sizeof(unsigned) * ((size_t)g.n_cut_rows + (size_t)A + 1);
+  const long long sig = ((long long)g.n_cut_rows << 20) ^ (long long)A;
+  const bool fresh = ctx->tail_ctr.cap < ctr_bytes || ctx->tail_ctr_sig != sig;
+  ISAC_TRY(ensure(ctx, ctx->tail_ctr, ctr_bytes));
+  if (fresh) {
+    ISAC_HIP(hipMemsetAsync(ctx->tail_ctr.p, 0, ctx->tail_ctr.cap, ctx->tail_st));
+    ctx->tail_ctr_sig = sig;
+  }
+  unsigned* row_seen = (unsigned*)ctx->tail_ctr.p;
+  unsigned* tickets = row_seen + g.n_cut_rows;
+  const size_t lds = sizeof(c64) * (256 + 16 * 16 * 8) + sizeof(double) * (size_t)g.nc * kTailRows +
+                     sizeof(int) * (32 + (size_t)g.n_cut_cols + 4 + 2 * (size_t)g.n_cut_cols * g.n_panels) + (size_t)g.pr * g.n_cut_cols + 64;
+  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(doppler_cfar_kernel), lds));
+  hipLaunchKernelGGL(doppler_cfar_kernel, dim3(g.n_panels, A), dim3(256), lds, ctx->tail_st, (const c64*)ctx->ymid.p, ctx->tail_L, A, twd, g,
+                     (double*)ctx->pwin.p, seg_cut, seg_pow, seg_colcnt, (int*)ctx->det_cut.p, (double*)ctx->det_pow.p, (int*)ctx->det_cnt.p,
+                     row_seen, tickets, (int*)ctx->misc.p);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+int isac_cfar_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, int nr, int nc, int A, int cap) {
+  if (ctx->tail_deferred) {
+    ctx->tail_deferred = false;
+    return launch_tail_fused(ctx, ep, cf, nr, nc, A, cap);
+  }
   CfarGeom g{};
   g.nr = nr; g.nc = nc;
   g.gr = cf->guard[0]; g.gc = cf->guard[1];

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 /* Bumped on EVERY change of a struct layout, enum value or entry-point signature below (1: round 1; 2: ISAC_MAX_EST 1024 -> 4096,
- * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_eig_* controls).  A host must
+ * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top).  A host must
  * compare isac_abi_version() with the ISAC_ABI_VERSION it was compiled against AND isac_abi_sizeof() with its own sizeof of every
  * struct it passes: the library writes whole structs (isac_est_result is 128 KB) into caller memory. */
 #define ISAC_ABI_VERSION 3
@@ -294,13 +294,21 @@ int isac_covariance_dev(isac_ctx* ctx, const isac_c64* d_grid, int64_t N, int32_
  * descending eigenvalue order (inverse iteration on the tridiagonal form, back-transformed).  3 <= A <= 256; n_top = 0: eigenvalues only. */
 int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_t n_top, double* w, isac_c64* U);
 
-/* How doaEstimation.music obtains Uan*Uan' (music.m:19-29), for fft2D and isac_music_doa on this context:
+/* Per-context algorithm switches (both settings of each give the same estimates; tests run both):
+ * ISAC_OPT_MUSIC_ROUTE  how doaEstimation.music obtains Uan*Uan' (music.m:19-29), for fft2D and isac_music_doa:
  *   0 (default)  the signal-subspace route: Householder tridiagonalisation, all eigenvalues by bisection, the L = numDets eigenvectors of
  *                the largest eigenvalues by inverse iteration, a' Uan Uan' a = || a - Us Us' a ||^2  (arrays of 3..256 elements; falls back
- *                to route 1 by itself when L exceeds what one workgroup's LDS holds: 32 vectors up to 64 antennas, 15 at 256);
+ *                to route 1 by itself when L exceeds what one workgroup holds: 32 vectors up to 64 antennas, 15-16 at 129..256);
  *   1            always the full eigendecomposition eig(Ra) (Jacobi / tridiagonal QL pipeline) and the explicit sum over the noise vectors.
- * Both give the same aziEst (tests/test_gpu_music_subspace.py); route 0 removes the longest kernel of a blocking CPI. */
-int isac_music_set_route(isac_ctx* ctx, int32_t route);
+ * ISAC_OPT_TAIL_FUSION  fft2D.m:44-46,59-99 after the range stage:
+ *   1 (default)  Doppler FFT, |.|^2, CA-CFAR, CUT-order merge and the numDets count in ONE launch (nFFT = 256, zones whose half-window
+ *                fits a 48-row panel; other shapes take setting 0 by themselves);
+ *   0            separate Doppler, CFAR and count kernels.
+ * ISAC_OPT_TAIL_STREAM  1: the fused tail, the result packing and the result copy of an fft2D call run on a third, high-priority HIP stream of
+ *                the context (a host that keeps several CPIs in flight: the small grids no longer queue behind the other CPIs' wide kernels;
+ *                give every stream a hardware queue -- GPU_MAX_HW_QUEUES >= 3 x contexts); 0 (default): on the main stream. */
+enum { ISAC_OPT_MUSIC_ROUTE = 0, ISAC_OPT_TAIL_FUSION = 1, ISAC_OPT_TAIL_STREAM = 2 };
+int isac_ctx_set_option(isac_ctx* ctx, int32_t option, int32_t value);
 
 /* sensing.estimation.doaEstimation.music(numDets, radarEstParams, Ra) (music.m:1), ULA branch.
  * num_dets < 0 means [] (model order from determineNumTargets, music.m:109-125). */

@@ -113,13 +113,15 @@ def _lu_solve_tridiag(d, e, lam, x, tiny):
         dn = d[i + 1] - lam
         en = e[i + 1] if i + 1 < n - 1 else 0.0
         if abs(a) >= abs(c):
-            if a == 0.0:
-                a = tiny
+            if abs(a) < tiny:
+                a = -tiny if a < 0.0 else tiny
             m = c / a
             u0[i], u1[i], u2[i] = a, b, 0.0
             a, b = dn - m * b, en
             y[i + 1] -= m * y[i]
         else:
+            if abs(c) < tiny:
+                c = -tiny if c < 0.0 else tiny
             m = a / c
             u0[i], u1[i], u2[i] = c, dn, en
             a, b = b - m * dn, -m * en

@@ -1,7 +1,7 @@
 """MUSIC's default eigensolver route on the device (csrc/music.hip, "eigensolver III"): Householder tridiagonalisation -> all eigenvalues by
 Sturm-count bisection -> the L = numDets signal eigenvectors by block inverse iteration -> a' Uan Uan' a = ||a - Us Us' a||^2
 (music.m:19-29,82-91), against (1) SciPy's eigh for the operator itself (isac_eigh_top), (2) the full-eigendecomposition route of the same
-library (isac_music_set_route(1)) and (3) the oracle's music_doa / fft2d for the estimates.  Tolerances: eigenvalues <= 1e-13 ||H||,
+library (isac_ctx_set_option(ISAC_OPT_MUSIC_ROUTE, 1)) and (3) the oracle's music_doa / fft2d for the estimates.  Tolerances: eigenvalues <= 1e-13 ||H||,
 orthonormality <= 1e-12, invariant-subspace residual <= 1e-11 ||H||; azimuth estimates exact."""
 from __future__ import annotations
 
@@ -27,7 +27,7 @@ def ctx(pkg):
 
 
 def _lmax(a):
-    return max(1, min(32, 122880 // (32 * a)))
+    return max(1, min(32 if a <= 128 else 16, 122880 // (32 * a)))
 
 
 def _sample_cov(rng, a, q, n, snr):

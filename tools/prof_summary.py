@@ -72,7 +72,51 @@ def overlap(path):
         print(f"  {a[:44]:44s} resident {1e-6 * self_t:8.2f} ms; with: " + ", ".join(f"{b[:28]} {100 * v / self_t:.0f}%" for b, v in tops))
 
 
+def gaps(path):
+    """Idle-gap attribution of a kernel trace (middle 60 %): every interval with NO kernel resident, which kernel ended last before it
+    and which started first after it."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    rows = list(cur.execute(f"select s.kernel_name, d.start, d.end from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
+    import re
+
+    def short(n):
+        m = re.search(r"\d+([a-z][a-z0-9_]*_kernel)", n.replace("isac", ""))
+        return (m.group(1) if m else n)[:28]
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    lo, hi = t0 + 0.2 * (t1 - t0), t0 + 0.8 * (t1 - t0)
+    rows = [(short(n), a, b) for n, a, b in rows if b > lo and a < hi]
+    cur_end, last_name, out = None, None, []
+    for n, a, b in rows:
+        if cur_end is not None and a > cur_end:
+            out.append((a - cur_end, last_name, n))
+        if cur_end is None or b > cur_end:
+            cur_end, last_name = b, n
+    tot = sum(g[0] for g in out)
+    print(f"window {1e-6 * (hi - lo):.2f} ms: {len(out)} idle gaps, {1e-6 * tot:.2f} ms idle ({100 * tot / (hi - lo):.1f} %), mean {1e-3 * tot / max(len(out), 1):.1f} us")
+    edges = [2e3, 5e3, 10e3, 20e3, 50e3, 100e3, 1e12]
+    acc = [[0, 0.0] for _ in edges]
+    for g, _, _ in out:
+        for i, e in enumerate(edges):
+            if g < e:
+                acc[i][0] += 1; acc[i][1] += g
+                break
+    print("gap length histogram (count, share of idle): " + "  ".join(f"<{int(e / 1e3) if e < 1e11 else 'inf'}us: {c} ({100 * t / max(tot, 1):.0f}%)" for e, (c, t) in zip(edges, acc)))
+    pairs = {}
+    for g, a, b in out:
+        k = (a, b)
+        pairs[k] = (pairs.get(k, (0, 0.0))[0] + 1, pairs.get(k, (0, 0.0))[1] + g)
+    for (a, b), (c, t) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:14]:
+        print(f"  after {a:28s} before {b:28s} n={c:4d} idle {1e-6 * t:7.2f} ms  mean {1e-3 * t / c:6.1f} us")
+
+
 if __name__ == "__main__":
+    if "--gaps" in sys.argv:
+        gaps(sys.argv[1])
+        sys.exit(0)
     if "--overlap" in sys.argv:
         overlap(sys.argv[1])
         sys.exit(0)
