@@ -289,7 +289,6 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
   const int p1 = 0, p2 = prio_hi;
   if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, p1) != hipSuccess ||
       hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, p2) != hipSuccess ||
-      hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, p2) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_range, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -312,7 +311,7 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream2);
-  (void)hipStreamSynchronize(ctx->stream3);
+  if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
   for (auto& kv : ctx->twiddles) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->kaiser3) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->sind) (void)hipFree(kv.second.p);
@@ -334,7 +333,7 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   (void)hipEventDestroy(ctx->ev_k1);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->stream2);
-  (void)hipStreamDestroy(ctx->stream3);
+  if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
   (void)hipEventDestroy(ctx->ev_range);
   (void)hipEventDestroy(ctx->ev_tail);
   delete ctx;
@@ -541,9 +540,14 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   // per-antenna detection capacity: every CUT of the zone, bounded only by a 256 MB scratch budget (A x cap x 12 B) -- at the default
   // zone (8 510 CUTs) and any A <= 2500 an antenna can report every CUT, as phased.CFARDetector2D would
   const int cap = (int)std::min<long long>(n_cut, std::max<long long>(4096, (256ll << 20) / 12 / A));
-  // The small-grid tail (fused Doppler + CFAR, pack, result copy) may run on its own high-priority stream: in a pipelined run its few
-  // hundred workgroups otherwise queue behind the wide kernels of the other CPIs in flight (ISAC_OPT_TAIL_STREAM)
-  ctx->tail_st = (ctx->tail_deferred && ctx->tail_stream_on && !single_stream) ? ctx->stream3 : ctx->stream;
+  // The small-grid tail (CFAR, pack, result copy) may run on its own high-priority stream: in a pipelined run its few hundred
+  // workgroups otherwise queue behind the wide kernels of the other CPIs in flight (ISAC_OPT_TAIL_STREAM)
+  if (ctx->tail_stream_on && !ctx->stream3) {        // created on first use only: every HIP stream takes a hardware queue from the other streams
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    ISAC_HIP(hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, prio_hi));
+  }
+  ctx->tail_st = (ctx->tail_stream_on && !single_stream) ? ctx->stream3 : ctx->stream;
   if (ctx->tail_st != ctx->stream) {
     ISAC_HIP(hipEventRecord(ctx->ev_range, ctx->stream));
     ISAC_HIP(hipStreamWaitEvent(ctx->tail_st, ctx->ev_range, 0));

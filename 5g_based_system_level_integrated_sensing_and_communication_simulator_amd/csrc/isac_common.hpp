@@ -88,7 +88,7 @@ struct isac_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // MUSIC branch (covariance/eig) overlaps the RDM branch
-  hipStream_t stream3 = nullptr;   // high-priority stream of the small-grid tail (fused Doppler + CFAR, pack, result copy): ISAC_OPT_TAIL_STREAM
+  hipStream_t stream3 = nullptr;   // high-priority stream of the small-grid tail (CFAR, pack, result copy): ISAC_OPT_TAIL_STREAM
   hipStream_t tail_st = nullptr;   // the stream the current fft2D call's tail goes to (stream or stream3)
   hipEvent_t ev_range = nullptr, ev_tail = nullptr;
   int tail_stream_on = 0;
@@ -96,7 +96,7 @@ struct isac_ctx {
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // isac_profile_*: around the dominant kernel of the last fused echo call
   bool profile = false, profile_recorded = false;
   int music_route = 0;             // ISAC_OPT_MUSIC_ROUTE: 0 = signal-subspace eigensolver for MUSIC (default), 1 = always the full eigendecomposition
-  int tail_fusion = 1;             // ISAC_OPT_TAIL_FUSION: 1 = one Doppler + CFAR launch where applicable (default), 0 = separate kernels
+  int tail_fusion = 1;             // ISAC_OPT_TAIL_FUSION: 1 = panel CFAR + merge + numDets in one launch where applicable (default), 0 = memset + per-antenna CFAR + count
   std::string err;
   // cached device tables
   std::map<const void*, size_t> lds_allowed;                        // kernel -> dynamic LDS bytes enabled on this context's device
@@ -106,8 +106,6 @@ struct isac_ctx {
   // scratch
   isac::DevBuf beam, coef, phase_rx, steer, dgrid, ymid, pwin, flags, det_cut, det_pow, det_cnt, cov_part, cov,
       eig_w, eig_v, eig_scratch, spec, misc, stage_a, stage_b, stage_c, sind_tab, seg, tail_ctr;
-  bool tail_deferred = false;      // isac_rdm_power_window left the Doppler stage to the fused Doppler + CFAR launch of the following isac_cfar_window
-  int tail_L = 0;
   long long tail_ctr_sig = -1;     // (CUT rows, antennas) the zero-initialised row flags / tickets in tail_ctr are laid out for
   void* pinned = nullptr; size_t pinned_cap = 0;
   isac::Fft2dLast last;

@@ -1333,12 +1333,17 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
   __syncthreads();
   for (int round = 0; round < 3; ++round) {
     if (solver) {
-      // ---- (T - lam I) y = x : elimination with row interchanges; the forward substitution rides along
+      // ---- (T - lam I) y = x : elimination with row interchanges; the forward substitution rides along.  A lone wavefront pays every
+      // LDS round trip in full, so the operands of step i + 1 are fetched before the dependent arithmetic of step i (they do not depend on it).
       double a = sd[0] - lam, b = se[0];
       double ycur = y[lane];
+      double c_n = se[0], dn_n = sd[1] - lam, en_n = se[1], yn_n = y[(size_t)lv + lane];
       for (int i = 0; i < n - 1; ++i) {
-        const double c = se[i], dn = sd[i + 1] - lam, en = se[i + 1];
-        const double ynext = y[(size_t)(i + 1) * lv + lane];
+        const double c = c_n, dn = dn_n, en = en_n, ynext = yn_n;
+        {
+          const int i1 = i + 1 < n - 1 ? i + 1 : i;                  // (clamped: the last trip's prefetch is unused)
+          c_n = se[i1]; dn_n = sd[i1 + 1] - lam; en_n = se[i1 + 1]; yn_n = y[(size_t)(i1 + 1) * lv + lane];
+        }
         const bool swap = fabs(a) < fabs(c);
         double piv = swap ? c : a;
         piv = fabs(piv) < tiny ? (piv < 0.0 ? -tiny : tiny) : piv;   // singular to working precision: dlagts' pivot perturbation (also keeps 1 / piv finite)
@@ -1355,18 +1360,24 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
         y[o] = yi;
         ycur = ::fma(-m, yi, yo);
       }
-      if (fabs(a) < tiny) a = a < 0.0 ? -tiny : tiny;               // singular to working precision: dlagts' pivot perturbation
+      if (fabs(a) < tiny) a = a < 0.0 ? -tiny : tiny;
       {
         const size_t o = (size_t)(n - 1) * lv + lane;
         u0[o] = rcp_fast(a); u1[o] = 0.0; u2[o] = 0.0;
         y[o] = ycur;
       }
       double y1 = 0.0, y2 = 0.0;
-      for (int i = n - 1; i >= 0; --i) {
-        const size_t o = (size_t)i * lv + lane;
-        const double v = ::fma(-u2[o], y2, ::fma(-u1[o], y1, y[o])) * u0[o];
-        y[o] = v;
-        y2 = y1; y1 = v;
+      {
+        size_t o = (size_t)(n - 1) * lv + lane;
+        double p0 = u0[o], p1 = u1[o], p2 = u2[o], py = y[o];
+        for (int i = n - 1; i >= 0; --i) {
+          const double q0 = p0, q1 = p1, q2 = p2, qy = py;
+          const size_t oc = o;
+          if (i > 0) { o -= lv; p0 = u0[o]; p1 = u1[o]; p2 = u2[o]; py = y[o]; }   // operands of the next step, under this step's arithmetic
+          const double v = ::fma(-q2, y2, ::fma(-q1, y1, qy)) * q0;
+          y[oc] = v;
+          y2 = y1; y1 = v;
+        }
       }
     }
     __syncthreads();

@@ -312,18 +312,17 @@ __global__ void count_rows_kernel(const unsigned* __restrict__ row_seen, int n, 
   if (threadIdx.x == 0) *num_dets = s_cnt;
 }
 
-// ---------------------------------------------------------------- Doppler FFT + |.|^2 + CA-CFAR + row flags in ONE launch (nFFT = 256)
-// fft2D.m:44-46,59-99 after the range stage.  The two kernels above run back to back on grids of 1 536 and 64 workgroups, followed by a
-// one-workgroup row count and preceded by a memset: four dependent launches whose small grids wait behind other CPIs' wide kernels in a
-// pipelined run.  Here a workgroup owns (antenna a, panel p of kTailPR CUT rows): it transforms the panel's kTailRows = kTailPR + 2 hr window
-// rows (three passes of 16 rows through the same 256-point FFT as doppler_fft256_kernel: bit-identical powers), keeps their |rdm|^2 window
-// columns in LDS (written to pwin once, for the debug accessors), and evaluates its CUTs with the same oracle-order sums as
-// cfar_window_kernel.  Detections leave the workgroup as a list in (column, row) order plus per-column counts; the LAST workgroup of an
-// antenna to finish (atomic ticket; agent-scope fences) merges the panels' lists into the antenna's list in CUT order (rows fastest,
-// cfar2D.m:23-24 -- the order phased.CFARDetector2D reports), and the last antenna to finish counts the detected rows (numDets,
-// fft2D.m:99,110) and clears the tickets / flags for the next call: no memset, no count kernel.
-constexpr int kTailPasses = 3;
-constexpr int kTailRows = 16 * kTailPasses;                     // window rows per workgroup
+// ---------------------------------------------------------------- CA-CFAR on row panels + CUT-order merge + numDets in ONE launch
+// fft2D.m:59-99 after the power window.  cfar_window_kernel above runs one workgroup per antenna (64 workgroups on 256 CUs: 53 us of a
+// blocking CPI) between a memset of the row flags and a one-workgroup row count: three dependent launches whose small grids also wait
+// behind other CPIs' wide kernels in a pipelined run.  Here a workgroup owns (antenna a, panel p of kTailPR CUT rows): it stages the panel's
+// kTailRows = kTailPR + 2 hr window rows of |rdm|^2 in LDS and evaluates its CUTs with the same oracle-order sums.  Detections leave the
+// workgroup as a list in (column, row) order plus per-column counts; the LAST workgroup of an antenna to finish (atomic ticket; agent-scope
+// fences) merges the panels' lists into the antenna's list in CUT order (rows fastest, cfar2D.m:23-24 -- the order phased.CFARDetector2D
+// reports), and the last antenna to finish counts the detected rows (numDets, fft2D.m:99,110) and clears the tickets / flags for the next
+// call: no memset, no count kernel.  (A version that also ran the Doppler FFT of its 48 rows in the same workgroup needed 228 VGPRs -- two
+// workgroups per CU, 576 workgroups on 512 slots: 153 us against 41 + 53 for the separate kernels; the Doppler stage stays its own launch.)
+constexpr int kTailRows = 48;                                   // window rows per workgroup
 
 struct TailGeom {
   int nr, nc;            // power window dims (rows, columns)
@@ -336,20 +335,14 @@ struct TailGeom {
   double alpha, n_train, sqrt_nfft;
 };
 
-__global__ __launch_bounds__(256, 2) void doppler_cfar_kernel(const c64* __restrict__ ymid, int L, int A, const c64* __restrict__ tw_d, TailGeom g,
-                                                              double* __restrict__ pwin, int* __restrict__ seg_cut /* [A][n_panels][pr * n_cut_cols] */,
+__global__ __launch_bounds__(256) void cfar_panel_kernel(const double* __restrict__ pwin /* [nr x nc x A] */, int A, TailGeom g,
+                                                         int* __restrict__ seg_cut /* [A][n_panels][pr * n_cut_cols] */,
                                                               double* __restrict__ seg_pow, int* __restrict__ seg_colcnt /* [A][n_panels][n_cut_cols] */,
                                                               int* __restrict__ det_cut /* [A x cap] */, double* __restrict__ det_pow,
                                                               int* __restrict__ det_cnt /* [A] */, unsigned* __restrict__ row_seen /* [n_cut_rows] */,
                                                               unsigned* __restrict__ tickets /* [A + 1] */, int* __restrict__ num_dets) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int NF = 256, RT = 16, RH = 8;
-  // LDS: W256 table (4 KB), the exchange image of HALF a pass (8 rows x 16 x 16 points, rows fastest: 32 KB), the panel's power window.
-  // No staging slab: thread (j = tid >> 4, rr = tid & 15) loads its 14 slow-time samples l = j + 16 q of window row rr straight into
-  // registers -- 16 consecutive lanes read the 256 contiguous bytes of 16 consecutive rows, 14 independent loads in flight per thread.
-  c64* s_tw = reinterpret_cast<c64*>(smem_raw);                 // [256]
-  c64* s_z = s_tw + NF;                                         // [16 k1][16 j][RH rows]
-  double* s_pw = reinterpret_cast<double*>(s_z + 16 * 16 * RH); // [nc][kTailRows] the panel's power window, rows fastest
+  double* s_pw = reinterpret_cast<double*>(smem_raw);           // [nc][kTailRows] the panel's power window, rows fastest
   int* s_cnt = reinterpret_cast<int*>(s_pw + (size_t)g.nc * kTailRows);   // [8 iterations][4 waves] detections
   int* s_col = s_cnt + 32;                                      // [n_cut_cols] per-column detection counts
   int* s_misc = s_col + g.n_cut_cols;                           // [0] last-of-antenna flag, [1] last-overall flag, [2] total
@@ -359,55 +352,20 @@ __global__ __launch_bounds__(256, 2) void doppler_cfar_kernel(const c64* __restr
   const int p = blockIdx.x, a = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r0 = p * g.pr;                                      // first window row of the panel (= its first CUT row, 0-based)
-  const int Lu = L < NF ? L : NF;                               // fft(., nFFT, 2) truncates when L > nFFT
-  const int half = L / 2;
-  s_tw[tid] = tw_d[tid];
   for (int q = tid; q < 32 + g.n_cut_cols; q += 256) s_cnt[q] = 0;
-  const int j = tid >> 4, rr = tid & 15;
-  // ---- Doppler: kTailPasses passes of 16 rows through the two-pass radix-16 transform of doppler_fft256_kernel (same arithmetic)
-  for (int ps = 0; ps < kTailPasses; ++ps) {
-    const int rbase = r0 + RT * ps;
-    const int row = rbase + rr;                                 // window row
-    const int rowc = min(row, g.nr - 1);
-    const c64* src = ymid + (long long)rowc + (long long)g.nr * (long long)L * a;
-    c64 x[16];
+  {   // the panel's rows of every window column; 8 independent loads in flight per thread (rows past the window: clamped, never used by a CUT)
+    const double* src = pwin + (long long)g.nr * g.nc * a;
+    const int n_el = g.nc * kTailRows;
+    for (int i0 = tid; i0 < n_el; i0 += 8 * 256) {
+      double v[8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int i = j + 16 * q;
-      int lsrc = (i < Lu ? i : 0) + half;                       // ifftshift over the slow-time axis (unconditional load, select afterwards)
-      if (lsrc >= L) lsrc -= L;
-      const c64 v = src[(long long)g.nr * lsrc];
-      x[q] = i < Lu ? v : mk(0.0, 0.0);                         // zero-pad L -> 256
-    }
-    dft16<-1>(x);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {                               // the exchange, one half of the rows at a time (a thread writes, then reads, in ITS half)
-      __syncthreads();                                          // image free (first trip: tables written)
-      if ((rr >> 3) == h) {
-#pragma unroll
-        for (int k1 = 0; k1 < 16; ++k1) s_z[(k1 * 16 + j) * RH + (rr & 7)] = k1 ? x[k1] * s_tw[j * k1] : x[0];
+      for (int u = 0; u < 8; ++u) {
+        const int i = min(i0 + u * 256, n_el - 1);
+        const int cc = i / kTailRows, prow = i - cc * kTailRows;
+        v[u] = src[(long long)min(r0 + prow, g.nr - 1) + (long long)g.nr * cc];
       }
-      __syncthreads();
-      if ((rr >> 3) == h) {
 #pragma unroll
-        for (int d = 0; d < 16; ++d) x[d] = s_z[(j * 16 + d) * RH + (rr & 7)];      // thread (rr, k1 = j)
-      }
-    }
-    dft16<-1>(x);                                               // x[k2] = X[k1 + 16 k2]
-    const int prow = RT * ps + rr;                              // row inside the panel
-    const bool own = row < g.nr && (row < r0 + g.pr || p == g.n_panels - 1);   // halo rows belong to the next panel
-#pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) {
-      const int kbin = j + 16 * k2;
-      const int c = (kbin + NF / 2) & (NF - 1);                 // fftshift: column c <-> bin (c + 128) mod 256
-      const int cc = c - g.col_lo;
-      if (cc >= 0 && cc < g.nc) {
-        const double re = x[k2].re / g.sqrt_nfft, im = x[k2].im / g.sqrt_nfft;   // fft(.)/sqrt(nFFT)  fft2D.m:46
-        const double hh = hypot(re, im);                        // abs(rdm)            fft2D.m:61
-        const double pw = hh * hh;                              // .^2
-        s_pw[cc * kTailRows + prow] = pw;
-        if (own) pwin[(long long)row + (long long)g.nr * ((long long)cc + (long long)g.nc * a)] = pw;
-      }
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * 256; if (i < n_el) s_pw[i] = v[u]; }
     }
   }
   __syncthreads();
@@ -592,11 +550,11 @@ static int launch_range(isac_ctx* ctx, hipStream_t st, const c64* rx, const c64*
 }
 
 // Range + Doppler + power window for the CUT rectangle.  Leaves pwin [nr x nc x A] in ctx->pwin.
-// The fused Doppler + CFAR launch (doppler_cfar_kernel) applies when nFFT = 256, the CUT half-window fits a 48-row panel and the panel's
-// bookkeeping fits its LDS carve; anything else -- or ISAC_OPT_TAIL_FUSION = 0 -- takes the separate Doppler / CFAR / count kernels.
+// The panel detector (cfar_panel_kernel: CFAR + CUT-order merge + numDets in one launch) applies when the CUT half-window fits a 48-row
+// panel and the panel's bookkeeping fits its LDS carve; anything else -- or ISAC_OPT_TAIL_FUSION = 0 -- takes memset + cfar_window_kernel + count.
 static bool tail_fusable(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, TailGeom* out) {
   static const bool off = std::getenv("ISAC_TAIL_UNFUSED") != nullptr;
-  if (off || !ctx->tail_fusion || ep->n_fft != 256 || std::getenv("ISAC_DOPPLER_DIRECT")) return false;
+  if (off || !ctx->tail_fusion) return false;
   TailGeom g{};
   g.gr = cf->guard[0]; g.gc = cf->guard[1];
   g.hr = cf->guard[0] + cf->train[0]; g.hc = cf->guard[1] + cf->train[1];
@@ -606,7 +564,7 @@ static bool tail_fusable(isac_ctx* ctx, const isac_est_params* ep, const isac_cf
   g.pr = kTailRows - 2 * g.hr;
   if (g.pr < 8 || g.n_cut_rows < 1 || g.n_cut_cols < 1) return false;
   g.n_panels = (g.n_cut_rows + g.pr - 1) / g.pr;
-  if ((long long)g.pr * g.n_cut_cols > 2048 || g.n_panels > 256 || (long long)g.n_cut_cols * g.n_panels > 4096 || g.nc > 96) return false;
+  if ((long long)g.pr * g.n_cut_cols > 2048 || g.n_panels > 256 || (long long)g.n_cut_cols * g.n_panels > 4096 || g.nc > 128) return false;
   const int n_train = (2 * g.hr + 1) * (2 * g.hc + 1) - (2 * g.gr + 1) * (2 * g.gc + 1);
   if (n_train <= 0) return false;
   g.alpha = cfar_alpha(n_train, cf->pfa);
@@ -650,11 +608,7 @@ int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_c
                                                             (c64*)ctx->ymid.p))));
   }
   const int Lu = L < n_fft ? L : n_fft;
-  TailGeom tg;
-  ctx->tail_deferred = tail_fusable(ctx, ep, cf, &tg);     // the Doppler stage runs inside the CFAR launch (isac_cfar_window, next call)
-  if (ctx->tail_deferred) {
-    ctx->tail_L = L;
-  } else if (n_fft == 256 && !std::getenv("ISAC_DOPPLER_DIRECT")) {
+  if (n_fft == 256 && !std::getenv("ISAC_DOPPLER_DIRECT")) {
     size_t lds = sizeof(c64) * (256 + std::max((size_t)Lu * (kDopRows + 1), (size_t)kDopRows * 16 * 17));
     ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(doppler_fft256_kernel), lds));
     hipLaunchKernelGGL(doppler_fft256_kernel, dim3(cdiv(nr, kDopRows), A), dim3(256), lds, ctx->stream, (const c64*)ctx->ymid.p, nr, L,
@@ -675,10 +629,8 @@ int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_c
 // CFAR over the window in ctx->pwin; leaves compact lists in ctx->det_* and numDets in ctx->misc[0].
 static int launch_tail_fused(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, int nr, int nc, int A, int cap) {
   TailGeom g;
-  if (!tail_fusable(ctx, ep, cf, &g) || g.nr != nr || g.nc != nc) return fail(ctx, ISAC_ERR_HIP, "internal: fused tail geometry changed between its two halves");
+  if (!tail_fusable(ctx, ep, cf, &g) || g.nr != nr || g.nc != nc) return fail(ctx, ISAC_ERR_HIP, "internal: panel detector geometry mismatch");
   g.cap = cap;
-  const c64* twd = nullptr;
-  ISAC_TRY(isac_get_twiddles2(ctx, 256, &twd));
   const size_t seg_elems = (size_t)A * g.n_panels * (size_t)g.pr * g.n_cut_cols;
   ISAC_TRY(ensure(ctx, ctx->det_cut, sizeof(int) * (size_t)A * cap));
   ISAC_TRY(ensure(ctx, ctx->det_pow, sizeof(double) * (size_t)A * cap));
@@ -698,20 +650,20 @@ static int launch_tail_fused(isac_ctx* ctx, const isac_est_params* ep, const isa
   }
   unsigned* row_seen = (unsigned*)ctx->tail_ctr.p;
   unsigned* tickets = row_seen + g.n_cut_rows;
-  const size_t lds = sizeof(c64) * (256 + 16 * 16 * 8) + sizeof(double) * (size_t)g.nc * kTailRows +
+  const size_t lds = sizeof(double) * (size_t)g.nc * kTailRows +
                      sizeof(int) * (32 + (size_t)g.n_cut_cols + 4 + 2 * (size_t)g.n_cut_cols * g.n_panels) + (size_t)g.pr * g.n_cut_cols + 64;
-  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(doppler_cfar_kernel), lds));
-  hipLaunchKernelGGL(doppler_cfar_kernel, dim3(g.n_panels, A), dim3(256), lds, ctx->tail_st, (const c64*)ctx->ymid.p, ctx->tail_L, A, twd, g,
-                     (double*)ctx->pwin.p, seg_cut, seg_pow, seg_colcnt, (int*)ctx->det_cut.p, (double*)ctx->det_pow.p, (int*)ctx->det_cnt.p,
+  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cfar_panel_kernel), lds));
+  hipLaunchKernelGGL(cfar_panel_kernel, dim3(g.n_panels, A), dim3(256), lds, ctx->tail_st, (const double*)ctx->pwin.p, A, g,
+                     seg_cut, seg_pow, seg_colcnt, (int*)ctx->det_cut.p, (double*)ctx->det_pow.p, (int*)ctx->det_cnt.p,
                      row_seen, tickets, (int*)ctx->misc.p);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }
 
 int isac_cfar_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, int nr, int nc, int A, int cap) {
-  if (ctx->tail_deferred) {
-    ctx->tail_deferred = false;
-    return launch_tail_fused(ctx, ep, cf, nr, nc, A, cap);
+  {
+    TailGeom tg;
+    if (tail_fusable(ctx, ep, cf, &tg)) return launch_tail_fused(ctx, ep, cf, nr, nc, A, cap);
   }
   CfarGeom g{};
   g.nr = nr; g.nc = nc;

@@ -103,7 +103,7 @@ def test_eigh_top_degenerate_spectra(ctx, kind, a):
     for n_top in (1, 2, 3, min(8, a - 1)):
         w, u = ctx.eigh_top(h, n_top)
         assert np.all(np.isfinite(w)) and np.all(np.isfinite(u))
-        assert np.abs(w - wr).max() < 1e-13 * scale, (kind, a, n_top)
+        assert np.abs(w - wr).max() < max(1e-13 * scale, 1e-300), (kind, a, n_top)      # (zero matrix: the bracket is a few pivmin wide)
         assert np.abs(u.conj().T @ u - np.eye(n_top)).max() < 1e-12, (kind, a, n_top)
         # invariant subspace: H U = U (U' H U) whenever the n_top-th and (n_top+1)-th eigenvalues are separated or the
         # whole cluster they share is flat to rounding

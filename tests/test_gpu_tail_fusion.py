@@ -1,5 +1,5 @@
-"""fft2D.m:44-46,59-99 after the range stage, one launch (doppler_cfar_kernel: Doppler FFT -> |.|^2 -> CA-CFAR -> CUT-order merge -> numDets)
-against the separate Doppler / CFAR / count kernels of the same library (ISAC_OPT_TAIL_FUSION = 0) bit for bit, and against the oracle:
+"""fft2D.m:44-46,59-99 after the range stage, one launch (cfar_panel_kernel: CA-CFAR on row panels -> CUT-order merge -> numDets)
+against the memset + per-antenna CFAR + count kernels of the same library (ISAC_OPT_TAIL_FUSION = 0) bit for bit, and against the oracle:
 zone shapes that give one panel, many panels, a ragged last panel, wide / narrow Doppler zones; thousands of detections per antenna
 (the merge); repeated and re-shaped calls on one context (the self-resetting tickets / row flags); the high-priority tail stream."""
 from __future__ import annotations
