@@ -289,8 +289,6 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
   const int p1 = 0, p2 = prio_hi;
   if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, p1) != hipSuccess ||
       hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, p2) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_range, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_tail, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_cfar, hipEventDisableTiming) != hipSuccess ||
@@ -300,8 +298,6 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
     delete ctx;
     return ISAC_ERR_HIP;
   }
-  ctx->tail_st = ctx->stream;
-  if (const char* e = std::getenv("ISAC_TAIL_STREAM")) ctx->tail_stream_on = std::atoi(e) != 0;   // development override of ISAC_OPT_TAIL_STREAM's default
   *out = ctx;
   return ISAC_OK;
 }
@@ -311,7 +307,6 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream2);
-  if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
   for (auto& kv : ctx->twiddles) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->kaiser3) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->sind) (void)hipFree(kv.second.p);
@@ -333,9 +328,6 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   (void)hipEventDestroy(ctx->ev_k1);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->stream2);
-  if (ctx->stream3) (void)hipStreamDestroy(ctx->stream3);
-  (void)hipEventDestroy(ctx->ev_range);
-  (void)hipEventDestroy(ctx->ev_tail);
   delete ctx;
   return ISAC_OK;
 }
@@ -540,27 +532,15 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   // per-antenna detection capacity: every CUT of the zone, bounded only by a 256 MB scratch budget (A x cap x 12 B) -- at the default
   // zone (8 510 CUTs) and any A <= 2500 an antenna can report every CUT, as phased.CFARDetector2D would
   const int cap = (int)std::min<long long>(n_cut, std::max<long long>(4096, (256ll << 20) / 12 / A));
-  // The small-grid tail (CFAR, pack, result copy) may run on its own high-priority stream: in a pipelined run its few hundred
-  // workgroups otherwise queue behind the wide kernels of the other CPIs in flight (ISAC_OPT_TAIL_STREAM)
-  if (ctx->tail_stream_on && !ctx->stream3) {        // created on first use only: every HIP stream takes a hardware queue from the other streams
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    ISAC_HIP(hipStreamCreateWithPriority(&ctx->stream3, hipStreamNonBlocking, prio_hi));
-  }
-  ctx->tail_st = (ctx->tail_stream_on && !single_stream) ? ctx->stream3 : ctx->stream;
-  if (ctx->tail_st != ctx->stream) {
-    ISAC_HIP(hipEventRecord(ctx->ev_range, ctx->stream));
-    ISAC_HIP(hipStreamWaitEvent(ctx->tail_st, ctx->ev_range, 0));
-  }
   ISAC_TRY(isac_cfar_window(ctx, ep, cfar, nr, nc, A, cap));                                 // fft2D.m:62 (+ numDets on device)
-  ISAC_HIP(hipEventRecord(ctx->ev_cfar, ctx->tail_st));
+  ISAC_HIP(hipEventRecord(ctx->ev_cfar, ctx->stream));
   ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_cfar, 0));
   if (!upa) {   // numDets comes from the CFAR branch, still on the device                   music.m:12,82-91
     if (sub) ISAC_TRY(isac_music_subspace_dev(ctx, A, (const int*)ctx->misc.p, 0, s2));          // the numDets signal vectors (or the QL fallback)
     ISAC_TRY(isac_music_scan_dev(ctx, A, (const int*)ctx->misc.p, 0, d_sind, n_steps, 0.5, (double*)ctx->spec.p, s2, 0, sub ? isac_music_ctl(ctx) : nullptr));
   }
   ISAC_HIP(hipEventRecord(ctx->ev_join, s2));
-  ISAC_HIP(hipStreamWaitEvent(ctx->tail_st, ctx->ev_join, 0));
+  ISAC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   // pack + one device->host copy
   const int pack_first = 4096;
   const size_t hdr_ints = 3 + (size_t)A + 1;
@@ -579,17 +559,13 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   ISAC_TRY(ensure(ctx, ctx->stage_b, (sizeof(double) + sizeof(int)) * pack_cap + 64));
   double* d_ppow_full = (double*)ctx->stage_b.p;
   int* d_pcut_full = (int*)((char*)ctx->stage_b.p + sizeof(double) * pack_cap);
-  hipLaunchKernelGGL(pack_kernel, dim3(1), dim3(256), 0, ctx->tail_st, (const int*)ctx->det_cnt.p, (const int*)ctx->det_cut.p,
+  hipLaunchKernelGGL(pack_kernel, dim3(1), dim3(256), 0, ctx->stream, (const int*)ctx->det_cnt.p, (const int*)ctx->det_cut.p,
                      (const double*)ctx->det_pow.p, (const int*)ctx->misc.p, A, cap, (int*)dbase, d_pcut_full, d_ppow_full,
                      pack_first, d_pcut_first, d_ppow_first, (const double*)ctx->spec.p, n_steps, (double*)(dbase + off_spec),
                      upa ? nullptr : (const int*)((const char*)ctx->eig_w.p + sizeof(double) * (size_t)A));
   ISAC_HIP(hipGetLastError());
   char* h = (char*)ctx->pinned;
-  ISAC_HIP(hipMemcpyAsync(h, dbase, first_bytes, hipMemcpyDeviceToHost, ctx->tail_st));
-  if (ctx->tail_st != ctx->stream) {                 // the context's main stream is "done" only when the tail is: collect and every later call order behind it
-    ISAC_HIP(hipEventRecord(ctx->ev_tail, ctx->tail_st));
-    ISAC_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail, 0));
-  }
+  ISAC_HIP(hipMemcpyAsync(h, dbase, first_bytes, hipMemcpyDeviceToHost, ctx->stream));
   // everything the host half needs later
   Fft2dPending& pd = ctx->pending;
   pd.ep = *ep; pd.cfar = *cfar;
@@ -885,7 +861,6 @@ extern "C" int isac_ctx_set_option(isac_ctx* ctx, int32_t option, int32_t value)
   switch (option) {
     case ISAC_OPT_MUSIC_ROUTE: ctx->music_route = value; return ISAC_OK;          // 0 = signal-subspace eigensolver (default), 1 = full eig
     case ISAC_OPT_TAIL_FUSION: ctx->tail_fusion = value; return ISAC_OK;          // 1 = one Doppler + CFAR launch (default), 0 = separate kernels
-    case ISAC_OPT_TAIL_STREAM: ctx->tail_stream_on = value; return ISAC_OK;       // 1 = the fused tail on its own high-priority stream
     default: return fail(ctx, ISAC_ERR_INVALID_ARG, "unknown option");
   }
 }

@@ -88,10 +88,6 @@ struct isac_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // MUSIC branch (covariance/eig) overlaps the RDM branch
-  hipStream_t stream3 = nullptr;   // high-priority stream of the small-grid tail (CFAR, pack, result copy): ISAC_OPT_TAIL_STREAM
-  hipStream_t tail_st = nullptr;   // the stream the current fft2D call's tail goes to (stream or stream3)
-  hipEvent_t ev_range = nullptr, ev_tail = nullptr;
-  int tail_stream_on = 0;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cfar = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // isac_profile_*: around the dominant kernel of the last fused echo call
   bool profile = false, profile_recorded = false;

@@ -31,6 +31,27 @@ __device__ __forceinline__ void tile_ij(int t, int nb, int& I, int& J) {
   J = i + rem;
 }
 
+// Sum over the 64 lanes of a wavefront through DPP row operations (quad_perm, row_ror, row_bcast15 / 31 + one readlane): six short VALU
+// steps.  The __shfl_xor butterfly goes through the LDS crossbar (ds_bpermute: ~100 cycles per step, six dependent steps) -- for the
+// one-reduction-per-Householder-step kernels below that latency WAS the kernel (two of them per reflector: 37 of the 83 us of the subspace
+// kernel at n = 64).  Returns the total in every lane (wave-uniform).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double x) {
+  const int lo = __double2loint(x), hi = __double2hiint(x);
+  const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);    // rows outside ROW_MASK receive 0: the add leaves them unchanged
+  const int h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(h2, l2);
+}
+__device__ __forceinline__ double wave_sum_dpp(double x) {
+  x += dpp_move<0xB1, 0xf>(x);                       // quad_perm [1,0,3,2]
+  x += dpp_move<0x4E, 0xf>(x);                       // quad_perm [2,3,0,1]
+  x += dpp_move<0x124, 0xf>(x);                      // row_ror:4
+  x += dpp_move<0x128, 0xf>(x);                      // row_ror:8   -> every lane: the sum of its row of 16
+  x += dpp_move<0x142, 0xa>(x);                      // row_bcast15 -> rows 1, 3 += rows 0, 2
+  x += dpp_move<0x143, 0xc>(x);                      // row_bcast31 -> rows 2, 3 += rows 0 + 1: lane 63 holds the total
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+
 // ---- specialised schedule for A <= 64 (NB = ceil(A/16) <= 4 antenna blocks): every wave keeps ALL blocks'
 // operands of its samples in registers and owns a static group of <= 5 output tiles, so the four waves of a
 // workgroup issue exactly the same number of MFMAs (balanced SIMDs), and the next slab is prefetched under the
@@ -785,7 +806,7 @@ __global__ __launch_bounds__(256) void eigh_tridiag_small_kernel(const c64* __re
   if (tid == 0) *S.scale = scl;
   if (tid < 8) S.cnt[tid] = 0;                                    // publication counters of the next two stages
   __syncthreads();
-  auto wave_sum = [](double x) { for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o); return x; };
+  auto wave_sum = [](double x) { return wave_sum_dpp(x); };
   for (int k = 0; k < n - 1; ++k) {                               // zhetd2, lower
     const bool below = lane > k + 1 && lane < n;
     const c64 xi = below ? M[lane + n * k] : mk(0.0, 0.0);
@@ -1393,14 +1414,14 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
             double zi[R], dot = 0.0;
 #pragma unroll
             for (int r = 0; r < R; ++r) { const int i = lane + 64 * r; zi[r] = i < n ? y[(size_t)i * lv + i2] : 0.0; dot = ::fma(zi[r], zj[r], dot); }
-            dot = wave_sum(dot);
+            dot = wave_sum_dpp(dot);
 #pragma unroll
             for (int r = 0; r < R; ++r) zj[r] = ::fma(-dot, zi[r], zj[r]);
           }
           double nrm = 0.0;
 #pragma unroll
           for (int r = 0; r < R; ++r) nrm = ::fma(zj[r], zj[r], nrm);
-          nrm = wave_sum(nrm);
+          nrm = wave_sum_dpp(nrm);
           const bool ok = nrm > 0.0 && nrm < 1.7976931348623157e308;
           const double inv = ok ? 1.0 / sqrt(nrm) : 0.0;
           if (!ok && lane == 0) s_bad = 1;
@@ -1461,12 +1482,12 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
           s0 = fma(conj(vk[r]), u[0][r], s0);
           if (has1) s1 = fma(conj(vk[r]), u[1][r], s1);
         }
-        s0.re = wave_sum(s0.re); s0.im = wave_sum(s0.im);
+        s0.re = wave_sum_dpp(s0.re); s0.im = wave_sum_dpp(s0.im);
         const c64 t0 = tau * s0;
 #pragma unroll
         for (int r = 0; r < R; ++r) u[0][r] = u[0][r] - t0 * vk[r];
         if (has1) {
-          s1.re = wave_sum(s1.re); s1.im = wave_sum(s1.im);
+          s1.re = wave_sum_dpp(s1.re); s1.im = wave_sum_dpp(s1.im);
           const c64 t1 = tau * s1;
 #pragma unroll
           for (int r = 0; r < R; ++r) u[1][r] = u[1][r] - t1 * vk[r];

@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256) void cfar_panel_kernel(const double* __restric
   int* s_misc = s_col + g.n_cut_cols;                           // [0] last-of-antenna flag, [1] last-overall flag, [2] total
   int* s_off = s_misc + 4;                                      // [n_cut_cols][n_panels] destination offsets (merge)
   int* s_src = s_off + g.n_cut_cols * g.n_panels;               // [n_cut_cols][n_panels] source offsets (merge)
-  unsigned char* s_rank = reinterpret_cast<unsigned char*>(s_src + g.n_cut_cols * g.n_panels);   // [pr * n_cut_cols]
+  int* s_cc = s_src + g.n_cut_cols * g.n_panels;                // [n_cut_cols][n_panels] the antenna's per-(column, panel) counts (merge)
+  unsigned char* s_rank = reinterpret_cast<unsigned char*>(s_cc + g.n_cut_cols * g.n_panels);   // [pr * n_cut_cols]
   const int p = blockIdx.x, a = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r0 = p * g.pr;                                      // first window row of the panel (= its first CUT row, 0-based)
@@ -424,30 +425,37 @@ __global__ __launch_bounds__(256) void cfar_panel_kernel(const double* __restric
   __syncthreads();
   if (!s_misc[0]) return;                                       // (uniform)
   __threadfence();                                              // acquire: the other panels' writes
-  // per-(column, panel) destination offsets in CUT order: column slowest, panel (= row block) next
+  // per-(column, panel) destination offsets in CUT order: column slowest, panel (= row block) next.  The counts come into LDS with one
+  // parallel sweep (a thread that walked them one dependent L2 round trip at a time made this kernel 110 us), the prefix is a wavefront scan.
   const int* colcnt_a = seg_colcnt + (long long)a * g.n_panels * g.n_cut_cols;
-  if (tid == 0) {
-    int acc = 0;
-    for (int cc = 0; cc < g.n_cut_cols; ++cc)
-      for (int q = 0; q < g.n_panels; ++q) {
-        s_off[cc * g.n_panels + q] = acc;
-        acc += __hip_atomic_load(&colcnt_a[q * g.n_cut_cols + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    s_misc[2] = acc;
-    det_cnt[a] = acc;                                           // (may exceed cap only if cap < every CUT: the host reports ISAC_ERR_CAPACITY)
-    tickets[a] = 0u;                                            // ready for the next call on this context
+  const int n_seg = g.n_cut_cols * g.n_panels;
+  for (int sgm = tid; sgm < n_seg; sgm += 256) {
+    const int cc = sgm / g.n_panels, q = sgm - cc * g.n_panels;
+    s_cc[sgm] = __hip_atomic_load(&colcnt_a[q * g.n_cut_cols + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (wid == 0) {
+    const int per = (n_seg + 63) / 64;
+    int loc = 0;
+    for (int u = 0; u < per; ++u) { const int idx = lane * per + u; if (idx < n_seg) loc += s_cc[idx]; }
+    int incl = loc;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    int run = incl - loc;
+    for (int u = 0; u < per; ++u) { const int idx = lane * per + u; if (idx < n_seg) { s_off[idx] = run; run += s_cc[idx]; } }
+    if (lane == 63) {
+      det_cnt[a] = incl;                                        // (may exceed cap only if cap < every CUT: the host reports ISAC_ERR_CAPACITY)
+      tickets[a] = 0u;                                          // ready for the next call on this context
+    }
   }
   if (tid < g.n_panels) {                                       // source offset of column cc inside panel tid's list
     int acc = 0;
-    for (int cc = 0; cc < g.n_cut_cols; ++cc) {
-      s_src[cc * g.n_panels + tid] = acc;
-      acc += __hip_atomic_load(&colcnt_a[tid * g.n_cut_cols + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    for (int cc = 0; cc < g.n_cut_cols; ++cc) { s_src[cc * g.n_panels + tid] = acc; acc += s_cc[cc * g.n_panels + tid]; }
   }
   __syncthreads();
-  for (int sgm = wid; sgm < g.n_cut_cols * g.n_panels; sgm += 4) {    // one wavefront per (column, panel) segment
-    const int cc = sgm / g.n_panels, q = sgm % g.n_panels;
-    const int cnt = __hip_atomic_load(&colcnt_a[q * g.n_cut_cols + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int sgm = wid; sgm < n_seg; sgm += 4) {                  // one wavefront per (column, panel) segment
+    const int cnt = s_cc[sgm];
+    if (cnt == 0) continue;                                     // (wave-uniform)
+    const int q = sgm % g.n_panels;
     const long long sbase = ((long long)a * g.n_panels + q) * ((long long)g.pr * g.n_cut_cols) + s_src[sgm];
     const int dbase = s_off[sgm];
     for (int jj = lane; jj < cnt; jj += 64) {
@@ -645,15 +653,15 @@ static int launch_tail_fused(isac_ctx* ctx, const isac_est_params* ep, const isa
   const bool fresh = ctx->tail_ctr.cap < ctr_bytes || ctx->tail_ctr_sig != sig;
   ISAC_TRY(ensure(ctx, ctx->tail_ctr, ctr_bytes));
   if (fresh) {
-    ISAC_HIP(hipMemsetAsync(ctx->tail_ctr.p, 0, ctx->tail_ctr.cap, ctx->tail_st));
+    ISAC_HIP(hipMemsetAsync(ctx->tail_ctr.p, 0, ctx->tail_ctr.cap, ctx->stream));
     ctx->tail_ctr_sig = sig;
   }
   unsigned* row_seen = (unsigned*)ctx->tail_ctr.p;
   unsigned* tickets = row_seen + g.n_cut_rows;
   const size_t lds = sizeof(double) * (size_t)g.nc * kTailRows +
-                     sizeof(int) * (32 + (size_t)g.n_cut_cols + 4 + 2 * (size_t)g.n_cut_cols * g.n_panels) + (size_t)g.pr * g.n_cut_cols + 64;
+                     sizeof(int) * (32 + (size_t)g.n_cut_cols + 4 + 3 * (size_t)g.n_cut_cols * g.n_panels) + (size_t)g.pr * g.n_cut_cols + 64;
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cfar_panel_kernel), lds));
-  hipLaunchKernelGGL(cfar_panel_kernel, dim3(g.n_panels, A), dim3(256), lds, ctx->tail_st, (const double*)ctx->pwin.p, A, g,
+  hipLaunchKernelGGL(cfar_panel_kernel, dim3(g.n_panels, A), dim3(256), lds, ctx->stream, (const double*)ctx->pwin.p, A, g,
                      seg_cut, seg_pow, seg_colcnt, (int*)ctx->det_cut.p, (double*)ctx->det_pow.p, (int*)ctx->det_cnt.p,
                      row_seen, tickets, (int*)ctx->misc.p);
   ISAC_HIP(hipGetLastError());

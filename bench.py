@@ -414,6 +414,8 @@ def main():
                     help="Philox AWGN drawn on the demodulated grid (default; same distribution, include/isac.h isac_noise_mode) or per time sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prime-ms", type=float, default=300.0, help="untimed device priming (hot-path steps) before the warm-up steps; 0 = none")
+    ap.add_argument("--trace-only", action="store_true", help="profiling aid: nothing after the timed region (no isolated-kernel / blocking-CPI / stage / CPU legs), "
+                                                              "so that a rocprofv3 trace holds priming + warm-up + the timed steps only")
     ap.add_argument("--n1-value", type=float, default=None, help="N > 1: the N = 1 value of the same per-GPU workload (slots/s) -> `efficiency_vs_n1` in the line")
     ap.add_argument("--n1-leg", action="store_true", help="N > 1: before the timed region rank 0 times the same per-GPU workload ALONE (the other ranks idle at a "
                                                           "barrier) and the line carries `n1_in_run` + `efficiency_vs_n1`: the whole scaling point in one command")
@@ -501,15 +503,15 @@ def main():
     for cell in cells:
         cell.profile_sink = None
     dom_ms_timed = float(np.mean(sink)) if sink else None                       # fused kernel, launches of the timed region (other CPIs co-running)
-    dom_ms_iso = cells[0].time_dominant_kernel_isolated() if (rank == 0 and args.fuse) else None
+    dom_ms_iso = cells[0].time_dominant_kernel_isolated() if (rank == 0 and args.fuse and not args.trace_only) else None
     blocking_ms = None
-    if rank == 0:                                            # latency of one blocking CPI (submit + collect, nothing else in flight)
+    if rank == 0 and not args.trace_only:                    # latency of one blocking CPI (submit + collect, nothing else in flight)
         cells[0].step()
         tb = time.perf_counter()
         for _ in range(3):
             cells[0].step()
         blocking_ms = 1e3 * (time.perf_counter() - tb) / 3
-    stages = stage_table(cells[0]) if rank == 0 else []
+    stages = stage_table(cells[0]) if (rank == 0 and not args.trace_only) else []
     # per-cell result record gather -- the only collective (KB-scale, RCCL over xGMI); max over ranks of the timed region
     recs = np.array([d.make_record(cid, cell.last, dt) for cid, cell in zip(my_cells, cells)]).reshape(-1, d.RECORD_LEN)
     on_gpu = dist is not None and dist.get_backend() == "nccl"
@@ -556,7 +558,7 @@ def main():
                                     "efficiency_vs_n1": None if n1 is None else round(res["value"] / (world * n1), 4),
                                     "note": f"efficiency = value / (N x N=1 value of {per_gpu}); no multi-GPU scaling curve has been measured on hardware yet "
                                             "(DESIGN.md section 6) -- the driver computes its own from the per-N lines"}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.trace_only:
             res["cpu_baseline"] = cpu_baseline(cells[0])
             res["gpu_vs_cpu_baseline"] = round(res["value"] / res["cpu_baseline"]["value"], 1)
         print(json.dumps(res))

@@ -303,11 +303,8 @@ int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_t n_top, do
  * ISAC_OPT_TAIL_FUSION  fft2D.m:59-99 after the power window:
  *   1 (default)  CA-CFAR on (antenna, 42-CUT-row panel) workgroups with the CUT-order merge and the numDets count inside the same launch
  *                (zones whose half-window fits a 48-row panel; other shapes take setting 0 by themselves);
- *   0            memset of the row flags, one CFAR workgroup per antenna, a separate count kernel.
- * ISAC_OPT_TAIL_STREAM  1: the CFAR stage, the result packing and the result copy of an fft2D call run on a third, high-priority HIP stream of
- *                the context (a host that keeps several CPIs in flight: the small grids no longer queue behind the other CPIs' wide kernels;
- *                give every stream a hardware queue -- GPU_MAX_HW_QUEUES >= 3 x contexts); 0 (default): on the main stream. */
-enum { ISAC_OPT_MUSIC_ROUTE = 0, ISAC_OPT_TAIL_FUSION = 1, ISAC_OPT_TAIL_STREAM = 2 };
+ *   0            memset of the row flags, one CFAR workgroup per antenna, a separate count kernel. */
+enum { ISAC_OPT_MUSIC_ROUTE = 0, ISAC_OPT_TAIL_FUSION = 1 };
 int isac_ctx_set_option(isac_ctx* ctx, int32_t option, int32_t value);
 
 /* sensing.estimation.doaEstimation.music(numDets, radarEstParams, Ra) (music.m:1), ULA branch.

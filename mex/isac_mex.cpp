@@ -392,8 +392,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     plhs[3] = vec(rep.subband_cqi, rep.n_cqi, true);
     plhs[4] = vec(rep.sinr_per_subband_cw, rep.n_cqi, true);
   } else if (fn == "senTxAppend") {
-    // [senTxGrid_h, senTxWave_h] state kept in handles: (gridHandle, waveHandle, txGrid [K x 14 x A], currSlot, isDLslot, carrierInfo, signalAmp, windowing,
-    //  slotsAlready)                                                                           gNBPhy.m:591-612
+    // tLen = isac_mex('senTxAppend', gridHandle, waveHandle, txGrid [K x 14 x A], currSlot, isDLslot, carrierInfo, signalAmp, windowing,
+    //                   slotsAlready, samplesAlready)                                          gNBPhy.m:591-612
+    // The slot lands at grid column 14 slotsAlready and waveform row samplesAlready; tLen = the slot's own sample count.  At 60 / 120 kHz
+    // the slots of a subframe differ in length (the long cyclic prefix sits at symbols 0 and 7 * 2^mu only): the caller accumulates tLen
+    // (SenTx.m) -- a fixed slot pitch would leave zero gaps that the reference's cat(1, senTxWave, txWaveform) (gNBPhy.m:608) does not have.
     DevArray& sg = lookup(prhs[1]);
     DevArray& sw = lookup(prhs[2]);
     DevIn d_g(prhs[3]);
@@ -401,9 +404,29 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const int done = (int)mxGetScalar(prhs[9]);
     int64_t t_len = 0, t_slot = 0;
     check(isac_ofdm_waveform_length(&c, 14, &t_slot));
+    const int64_t t_off = nrhs > 10 ? (int64_t)mxGetScalar(prhs[10]) : t_slot * done;   // (9-argument form: equal-length slots, 15 / 30 kHz)
     check(isac_sentx_append_dev(ctx(), &c, (int)sg.dims[2], (int)mxGetScalar(prhs[4]), mxGetScalar(prhs[5]) != 0, d_g.p, mxGetScalar(prhs[7]), (int)mxGetScalar(prhs[8]),
-                                (isac_c64*)sg.p, (int)sg.dims[1], 14 * done, (isac_c64*)sw.p, (int64_t)sw.dims[0], t_slot * done, &t_len));
+                                (isac_c64*)sg.p, (int)sg.dims[1], 14 * done, (isac_c64*)sw.p, (int64_t)sw.dims[0], t_off, &t_len));
     check(isac_sync(ctx()));
+    if (nlhs > 0) plhs[0] = mxCreateDoubleScalar((double)t_len);
+  } else if (fn == "trim") {                                // h2 = isac_mex('trim', h, keep0, keep1): the leading [keep0 x keep1 x d2] block as a new array
+    DevArray& a = lookup(prhs[1]);
+    const mwSize k0 = (mwSize)mxGetScalar(prhs[2]), k1 = (mwSize)mxGetScalar(prhs[3]);
+    if (k0 < 1 || k1 < 1 || k0 > a.dims[0] || k1 > a.dims[1]) mexErrMsgIdAndTxt("isac:INVALID_ARG", "trim: block larger than the array");
+    void* p = nullptr;
+    check(isac_dev_alloc(ctx(), sizeof(isac_c64) * k0 * k1 * a.dims[2], &p));
+    const isac_c64* src = (const isac_c64*)a.p;
+    isac_c64* dst = (isac_c64*)p;
+    for (mwSize z = 0; z < a.dims[2]; ++z) {
+      if (k0 == a.dims[0]) {                                // whole columns: one contiguous run per plane
+        check(isac_memcpy_d2d(ctx(), dst + k0 * k1 * z, src + a.dims[0] * a.dims[1] * z, sizeof(isac_c64) * k0 * k1));
+      } else {
+        for (mwSize j = 0; j < k1; ++j)
+          check(isac_memcpy_d2d(ctx(), dst + k0 * (j + k1 * z), src + a.dims[0] * (j + a.dims[1] * z), sizeof(isac_c64) * k0));
+      }
+    }
+    check(isac_sync(ctx()));
+    plhs[0] = make_handle(p, k0, k1, a.dims[2], true);
   } else if (fn == "allocDevice") {                         // h = isac_mex('allocDevice', [d0 d1 d2]) zero-filled complex array (senTx accumulators)
     const double* d = mxGetDoubles(prhs[1]);
     const mwSize n = mxGetNumberOfElements(prhs[1]);

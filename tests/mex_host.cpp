@@ -308,6 +308,31 @@ int comm(const char* in, const char* out) {
     write_cplx(o, call("gather", {hw})[0]);
     call("free", {hg}); call("free", {hw});
   }
+  {   // ---- senTx accumulation at 60 kHz, SenTx.m's call sequence: the slots of a subframe differ in length, the waveform offset is the
+      //      running sample count returned by senTxAppend, the accumulators are over-sized and trimmed to what was appended     gNBPhy.m:604-612
+    int32_t d[6]; double amp;
+    rd(d, sizeof(d), f); rd(&amp, sizeof(amp), f);
+    const int nrb = d[0], A = d[1], n_slots = d[2], scs = d[3], win = d[4];
+    const int64_t t_cap = d[5];                                // longest slot of the subframe
+    const int K = 12 * nrb, cap_slots = n_slots + 2;
+    mxArray* car = make_struct({{"NRBsDL", scalar(nrb)}, {"SubcarrierSpacing", scalar(scs)}});
+    const double gdim[3] = {(double)K, 14.0 * cap_slots, (double)A}, wdim[2] = {(double)t_cap * cap_slots, (double)A};
+    mxArray* hg = call("allocDevice", {real_row(gdim, 3)})[0];
+    mxArray* hw = call("allocDevice", {real_row(wdim, 2)})[0];
+    double n_samples = 0.0;
+    for (int i = 0; i < n_slots; ++i) {
+      int32_t sl[2];
+      rd(sl, sizeof(sl), f);
+      auto g = rdv<isac_c64>(f, (size_t)K * 14 * A);
+      mxArray* tl = call("senTxAppend", {hg, hw, cplx_array(g.data(), K, 14, A), scalar(sl[0]), scalar(sl[1]), car, scalar(amp), scalar(win), scalar(i), scalar(n_samples)}, 1)[0];
+      n_samples += mxGetScalar(tl);
+    }
+    mxArray* tg = call("trim", {hg, scalar(K), scalar(14.0 * n_slots)})[0];
+    mxArray* tw = call("trim", {hw, scalar(n_samples), scalar(A)})[0];
+    write_cplx(o, call("gather", {tg})[0]);
+    write_cplx(o, call("gather", {tw})[0]);
+    call("free", {hg}); call("free", {hw}); call("free", {tg}); call("free", {tw});
+  }
   {   // ---- checkLoS(wallTable, uePos, antPos)                                                          openStreetMapCity.m:67-93
     int32_t d[3];
     rd(d, sizeof(d), f);

@@ -160,6 +160,20 @@ def test_mex_gateway_communication_and_topology_entries(tmp_path):
             g = qpsk((12 * nrb2, 14, A2), 200 + s)
             ref.append(g, s)
             f.write(struct.pack("<2i", s, 1 if tdd[s % 5] == "D" else 0)); f.write(g.tobytes(order="F"))
+        # ---- senTx accumulation at 60 kHz: 24 PRB, 2 antennas, slots 0..5 of DDDSU -- slots 0 / 2 / 4 carry the long cyclic prefix,
+        # the accumulators are over-sized by two slots and trimmed (SenTx.m: running sample count + 'trim')
+        nrb3, A3, win3, nfft3, scs3 = 24, 2, 9, 512, 60
+        slots3 = [s for s in range(6) if tdd[s % 5] != "U"]
+        ref3 = O.sentx.SenTx(nfft3, scs3, tdd, 46.0, windowing=win3)
+        amp3 = O.sentx.signal_amp(46.0, nfft3, 12 * nrb3, A3)
+        t_cap3 = max(O.ofdm_modulate(np.zeros((12 * nrb3, 14, 1), dtype=complex), nfft3, scs3, 0, 14 * q).shape[0] for q in range(4))
+        f.write(struct.pack("<6i d", nrb3, A3, len(slots3), scs3, win3, t_cap3, amp3))
+        for s in slots3:
+            g = qpsk((12 * nrb3, 14, A3), 300 + s)
+            ref3.append(g, s)
+            f.write(struct.pack("<2i", s, 1 if tdd[s % 5] == "D" else 0)); f.write(g.tobytes(order="F"))
+        lens3 = {O.ofdm_modulate(np.zeros((12 * nrb3, 14, 1), dtype=complex), nfft3, scs3, 0, 14 * q).shape[0] for q in range(4)}
+        assert len(lens3) == 2                                   # the slots of a 60 kHz subframe really differ in length
         # ---- checkLoS
         plans, heights = _random_city(np.random.default_rng(4), 20)
         B = pkg.networkTopology.blockages
@@ -205,6 +219,14 @@ def test_mex_gateway_communication_and_topology_entries(tmp_path):
     (n,) = struct.unpack_from("<Q", buf, off_b); off_b += 8
     wave = np.frombuffer(buf, dtype=np.complex128, count=n, offset=off_b).reshape(ref.wave.shape, order="F"); off_b += 16 * n
     assert np.array_equal(grid, ref.grid) and np.abs(wave - ref.wave).max() <= 1e-10 * np.abs(ref.wave).max()
+    # senTx accumulators at 60 kHz: exactly the reference's cat() results (no gaps between slots of different length, no zero tail)
+    (n,) = struct.unpack_from("<Q", buf, off_b); off_b += 8
+    assert n == ref3.grid.size
+    grid3 = np.frombuffer(buf, dtype=np.complex128, count=n, offset=off_b).reshape(ref3.grid.shape, order="F"); off_b += 16 * n
+    (n,) = struct.unpack_from("<Q", buf, off_b); off_b += 8
+    assert n == ref3.wave.size
+    wave3 = np.frombuffer(buf, dtype=np.complex128, count=n, offset=off_b).reshape(ref3.wave.shape, order="F"); off_b += 16 * n
+    assert np.array_equal(grid3, ref3.grid) and np.abs(wave3 - ref3.wave).max() <= 1e-10 * np.abs(ref3.wave).max()
     # checkLoS
     los = np.frombuffer(buf, dtype=np.uint8, count=n_links, offset=off_b).astype(bool); off_b += n_links
     want_los = OL.check_los(list(zip(plans, heights)), ue.T, ant.T)

@@ -1,7 +1,7 @@
 """fft2D.m:44-46,59-99 after the range stage, one launch (cfar_panel_kernel: CA-CFAR on row panels -> CUT-order merge -> numDets)
 against the memset + per-antenna CFAR + count kernels of the same library (ISAC_OPT_TAIL_FUSION = 0) bit for bit, and against the oracle:
 zone shapes that give one panel, many panels, a ragged last panel, wide / narrow Doppler zones; thousands of detections per antenna
-(the merge); repeated and re-shaped calls on one context (the self-resetting tickets / row flags); the high-priority tail stream."""
+(the merge); repeated and re-shaped calls on one context (the self-resetting tickets / row flags)."""
 from __future__ import annotations
 
 import numpy as np
@@ -18,7 +18,7 @@ def pkg():
     return load_pkg()
 
 
-def _both(pkg, sc, pfa=None, tail_stream=False, ctxs=None):
+def _both(pkg, sc, pfa=None, ctxs=None):
     if pfa is not None:
         sc.rp.Pfa = pfa
     rx = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, sc.noise, nfft=sc.wave.Nfft)
@@ -31,8 +31,6 @@ def _both(pkg, sc, pfa=None, tail_stream=False, ctxs=None):
     for k, fused in enumerate((True, False)):
         c = ctxs[k] if ctxs else pkg.Context()
         c.set_tail_fusion(fused)
-        if tail_stream:
-            c.check(c.lib.isac_ctx_set_option(c.handle, 2, 1))
         rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
         if pfa is not None:
             rp.Pfa = pfa
@@ -100,10 +98,3 @@ def test_fused_tail_repeated_and_reshaped_calls_on_one_context(pkg):
         got = _both(pkg, sc, ctxs=ctxs)
         if sc is a:
             assert np.array_equal(got[0].rngEst, first[0].rngEst) and np.array_equal(got[1].power_window, first[1].power_window)
-
-
-def test_tail_stream_gives_the_same_results(pkg):
-    sc = make_scene(n_ants=4, n_slots=4, nrb=273, targets=((100.0, 20.0, 1.5), (250.0, -120.0, 1.5)), velocity=(7.0, -4.0), seed=51)
-    ctxs = [pkg.Context(), pkg.Context()]
-    for _ in range(4):
-        _both(pkg, sc, tail_stream=True, ctxs=ctxs)
