@@ -312,7 +312,7 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   for (auto& kv : ctx->sind) (void)hipFree(kv.second.p);
   DevBuf* bufs[] = {&ctx->beam, &ctx->coef, &ctx->phase_rx, &ctx->steer, &ctx->dgrid,
                     &ctx->ymid, &ctx->pwin, &ctx->flags, &ctx->det_cut, &ctx->det_pow, &ctx->det_cnt, &ctx->cov_part,
-                    &ctx->cov, &ctx->eig_w, &ctx->eig_v, &ctx->eig_scratch, &ctx->spec, &ctx->misc, &ctx->stage_a, &ctx->stage_b, &ctx->seg, &ctx->tail_ctr,
+                    &ctx->cov, &ctx->eig_w, &ctx->eig_v, &ctx->eig_scratch, &ctx->spec, &ctx->misc, &ctx->stage_a, &ctx->stage_b, &ctx->seg,
                     &ctx->stage_c, &ctx->sind_tab};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);

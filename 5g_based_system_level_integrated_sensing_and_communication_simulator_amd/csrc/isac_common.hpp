@@ -92,7 +92,7 @@ struct isac_ctx {
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // isac_profile_*: around the dominant kernel of the last fused echo call
   bool profile = false, profile_recorded = false;
   int music_route = 0;             // ISAC_OPT_MUSIC_ROUTE: 0 = signal-subspace eigensolver for MUSIC (default), 1 = always the full eigendecomposition
-  int tail_fusion = 1;             // ISAC_OPT_TAIL_FUSION: 1 = panel CFAR + merge + numDets in one launch where applicable (default), 0 = memset + per-antenna CFAR + count
+  int tail_fusion = 1;             // ISAC_OPT_TAIL_FUSION: 1 = panel CFAR + per-antenna merge / numDets where applicable (default), 0 = memset + per-antenna CFAR + count
   std::string err;
   // cached device tables
   std::map<const void*, size_t> lds_allowed;                        // kernel -> dynamic LDS bytes enabled on this context's device
@@ -101,8 +101,7 @@ struct isac_ctx {
   std::map<std::pair<long long, long long>, isac::DevBuf> sind;     // (scale, granularity) -> sind(scan angles)
   // scratch
   isac::DevBuf beam, coef, phase_rx, steer, dgrid, ymid, pwin, flags, det_cut, det_pow, det_cnt, cov_part, cov,
-      eig_w, eig_v, eig_scratch, spec, misc, stage_a, stage_b, stage_c, sind_tab, seg, tail_ctr;
-  long long tail_ctr_sig = -1;     // (CUT rows, antennas) the zero-initialised row flags / tickets in tail_ctr are laid out for
+      eig_w, eig_v, eig_scratch, spec, misc, stage_a, stage_b, stage_c, sind_tab, seg;
   void* pinned = nullptr; size_t pinned_cap = 0;
   isac::Fft2dLast last;
   isac::Fft2dPending pending;

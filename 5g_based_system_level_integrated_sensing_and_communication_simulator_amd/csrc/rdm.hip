@@ -312,16 +312,18 @@ __global__ void count_rows_kernel(const unsigned* __restrict__ row_seen, int n, 
   if (threadIdx.x == 0) *num_dets = s_cnt;
 }
 
-// ---------------------------------------------------------------- CA-CFAR on row panels + CUT-order merge + numDets in ONE launch
+// ---------------------------------------------------------------- CA-CFAR on row panels, then a per-antenna CUT-order merge + numDets
 // fft2D.m:59-99 after the power window.  cfar_window_kernel above runs one workgroup per antenna (64 workgroups on 256 CUs: 53 us of a
-// blocking CPI) between a memset of the row flags and a one-workgroup row count: three dependent launches whose small grids also wait
-// behind other CPIs' wide kernels in a pipelined run.  Here a workgroup owns (antenna a, panel p of kTailPR CUT rows): it stages the panel's
-// kTailRows = kTailPR + 2 hr window rows of |rdm|^2 in LDS and evaluates its CUTs with the same oracle-order sums.  Detections leave the
-// workgroup as a list in (column, row) order plus per-column counts; the LAST workgroup of an antenna to finish (atomic ticket; agent-scope
-// fences) merges the panels' lists into the antenna's list in CUT order (rows fastest, cfar2D.m:23-24 -- the order phased.CFARDetector2D
-// reports), and the last antenna to finish counts the detected rows (numDets, fft2D.m:99,110) and clears the tickets / flags for the next
-// call: no memset, no count kernel.  (A version that also ran the Doppler FFT of its 48 rows in the same workgroup needed 228 VGPRs -- two
-// workgroups per CU, 576 workgroups on 512 slots: 153 us against 41 + 53 for the separate kernels; the Doppler stage stays its own launch.)
+// blocking CPI) between a memset of the row flags and a one-workgroup row count.  Here
+//   K1  cfar_panel_kernel   workgroup = (antenna a, panel p of kTailPR CUT rows): stages the panel's kTailRows = kTailPR + 2 hr window rows of
+//       |rdm|^2 in LDS and evaluates its CUTs with the same oracle-order sums; leaves a detection list in (column, row) order, per-column
+//       counts and a 64-bit mask of the panel's detected rows -- every workgroup writes only its own slots, nothing needs zeroing;
+//   K2  cfar_merge_kernel   workgroup = antenna: merges its panels' lists into the antenna's list in CUT order (rows fastest, cfar2D.m:23-24 --
+//       the order phased.CFARDetector2D reports); workgroup 0 also ORs the row masks of all antennas: numDets (fft2D.m:99,110).
+// Two launches instead of four (memset, CFAR, count; the memset is two fill kernels), 576 + 64 workgroups.  (One-launch variants measured
+// and rejected: the Doppler FFT inside K1 needs 228 VGPRs -- 153 us; "last workgroup merges" tickets need agent-scope fences, i.e. an
+// L2 write-back + invalidate per workgroup on this multi-XCD part -- 83 us alone, and 12 % off the pipelined rate because the other
+// CPIs' kernels lose their L2 contents.)
 constexpr int kTailRows = 48;                                   // window rows per workgroup
 
 struct TailGeom {
@@ -335,25 +337,21 @@ struct TailGeom {
   double alpha, n_train, sqrt_nfft;
 };
 
-__global__ __launch_bounds__(256) void cfar_panel_kernel(const double* __restrict__ pwin /* [nr x nc x A] */, int A, TailGeom g,
+__global__ __launch_bounds__(256) void cfar_panel_kernel(const double* __restrict__ pwin /* [nr x nc x A] */, TailGeom g,
                                                          int* __restrict__ seg_cut /* [A][n_panels][pr * n_cut_cols] */,
-                                                              double* __restrict__ seg_pow, int* __restrict__ seg_colcnt /* [A][n_panels][n_cut_cols] */,
-                                                              int* __restrict__ det_cut /* [A x cap] */, double* __restrict__ det_pow,
-                                                              int* __restrict__ det_cnt /* [A] */, unsigned* __restrict__ row_seen /* [n_cut_rows] */,
-                                                              unsigned* __restrict__ tickets /* [A + 1] */, int* __restrict__ num_dets) {
+                                                         double* __restrict__ seg_pow, int* __restrict__ seg_colcnt /* [A][n_panels][n_cut_cols] */,
+                                                         unsigned long long* __restrict__ rowmask /* [A][n_panels] */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* s_pw = reinterpret_cast<double*>(smem_raw);           // [nc][kTailRows] the panel's power window, rows fastest
   int* s_cnt = reinterpret_cast<int*>(s_pw + (size_t)g.nc * kTailRows);   // [8 iterations][4 waves] detections
   int* s_col = s_cnt + 32;                                      // [n_cut_cols] per-column detection counts
-  int* s_misc = s_col + g.n_cut_cols;                           // [0] last-of-antenna flag, [1] last-overall flag, [2] total
-  int* s_off = s_misc + 4;                                      // [n_cut_cols][n_panels] destination offsets (merge)
-  int* s_src = s_off + g.n_cut_cols * g.n_panels;               // [n_cut_cols][n_panels] source offsets (merge)
-  int* s_cc = s_src + g.n_cut_cols * g.n_panels;                // [n_cut_cols][n_panels] the antenna's per-(column, panel) counts (merge)
-  unsigned char* s_rank = reinterpret_cast<unsigned char*>(s_cc + g.n_cut_cols * g.n_panels);   // [pr * n_cut_cols]
+  unsigned char* s_rank = reinterpret_cast<unsigned char*>(s_col + g.n_cut_cols);   // [pr * n_cut_cols]
+  __shared__ unsigned long long s_rows;
   const int p = blockIdx.x, a = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r0 = p * g.pr;                                      // first window row of the panel (= its first CUT row, 0-based)
   for (int q = tid; q < 32 + g.n_cut_cols; q += 256) s_cnt[q] = 0;
+  if (tid == 0) s_rows = 0ull;
   {   // the panel's rows of every window column; 8 independent loads in flight per thread (rows past the window: clamped, never used by a CUT)
     const double* src = pwin + (long long)g.nr * g.nc * a;
     const int n_el = g.nc * kTailRows;
@@ -392,7 +390,7 @@ __global__ __launch_bounds__(256) void cfar_panel_kernel(const double* __restric
       }
       const double thr = __dmul_rn(g.alpha, __ddiv_rn(acc, g.n_train));
       det = s_pw[c * kTailRows + r] > thr;                      // strict
-      if (det) { atomicAdd(&s_col[cc], 1); row_seen[r0 + crl] = 1u; }
+      if (det) { atomicAdd(&s_col[cc], 1); atomicOr(&s_rows, 1ull << crl); }
     }
     const unsigned long long mask = __ballot(det);
     if (det) det_bits |= 1u << k;
@@ -415,24 +413,28 @@ __global__ __launch_bounds__(256) void cfar_panel_kernel(const double* __restric
   }
   int* my_colcnt = seg_colcnt + ((long long)a * g.n_panels + p) * g.n_cut_cols;
   for (int cc = tid; cc < g.n_cut_cols; cc += 256) my_colcnt[cc] = s_col[cc];
-  // ---- ticket: the last panel of this antenna merges
-  __threadfence();                                              // this workgroup's lists / counts / flags before its ticket
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned t = atomicAdd(&tickets[a], 1u);
-    s_misc[0] = (t == (unsigned)g.n_panels - 1u) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_misc[0]) return;                                       // (uniform)
-  __threadfence();                                              // acquire: the other panels' writes
-  // per-(column, panel) destination offsets in CUT order: column slowest, panel (= row block) next.  The counts come into LDS with one
-  // parallel sweep (a thread that walked them one dependent L2 round trip at a time made this kernel 110 us), the prefix is a wavefront scan.
-  const int* colcnt_a = seg_colcnt + (long long)a * g.n_panels * g.n_cut_cols;
+  if (tid == 0) rowmask[(long long)a * g.n_panels + p] = s_rows;
+}
+
+__global__ __launch_bounds__(256) void cfar_merge_kernel(TailGeom g, int A, const int* __restrict__ seg_cut, const double* __restrict__ seg_pow,
+                                                         const int* __restrict__ seg_colcnt, const unsigned long long* __restrict__ rowmask,
+                                                         int* __restrict__ det_cut /* [A x cap] */, double* __restrict__ det_pow,
+                                                         int* __restrict__ det_cnt /* [A] */, int* __restrict__ num_dets) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int n_seg = g.n_cut_cols * g.n_panels;
+  int* s_off = reinterpret_cast<int*>(smem_raw);                // [n_cut_cols][n_panels] destination offsets
+  int* s_src = s_off + n_seg;                                   // [n_cut_cols][n_panels] source offsets
+  int* s_cc = s_src + n_seg;                                    // [n_cut_cols][n_panels] the antenna's per-(column, panel) counts
+  __shared__ int s_rows;
+  const int a = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // per-(column, panel) destination offsets in CUT order: column slowest, panel (= row block) next
+  const int* colcnt_a = seg_colcnt + (long long)a * g.n_panels * g.n_cut_cols;
   for (int sgm = tid; sgm < n_seg; sgm += 256) {
     const int cc = sgm / g.n_panels, q = sgm - cc * g.n_panels;
-    s_cc[sgm] = __hip_atomic_load(&colcnt_a[q * g.n_cut_cols + cc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_cc[sgm] = colcnt_a[q * g.n_cut_cols + cc];
   }
+  if (tid == 0) s_rows = 0;
   __syncthreads();
   if (wid == 0) {
     const int per = (n_seg + 63) / 64;
@@ -442,10 +444,7 @@ __global__ __launch_bounds__(256) void cfar_panel_kernel(const double* __restric
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
     int run = incl - loc;
     for (int u = 0; u < per; ++u) { const int idx = lane * per + u; if (idx < n_seg) { s_off[idx] = run; run += s_cc[idx]; } }
-    if (lane == 63) {
-      det_cnt[a] = incl;                                        // (may exceed cap only if cap < every CUT: the host reports ISAC_ERR_CAPACITY)
-      tickets[a] = 0u;                                          // ready for the next call on this context
-    }
+    if (lane == 63) det_cnt[a] = incl;                          // (may exceed cap only if cap < every CUT: the host reports ISAC_ERR_CAPACITY)
   }
   if (tid < g.n_panels) {                                       // source offset of column cc inside panel tid's list
     int acc = 0;
@@ -461,32 +460,22 @@ __global__ __launch_bounds__(256) void cfar_panel_kernel(const double* __restric
     for (int jj = lane; jj < cnt; jj += 64) {
       const int dst = dbase + jj;
       if (dst < g.cap) {
-        det_cut[(long long)a * g.cap + dst] = __hip_atomic_load(&seg_cut[sbase + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        det_pow[(long long)a * g.cap + dst] = __hip_atomic_load(&seg_pow[sbase + jj], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        det_cut[(long long)a * g.cap + dst] = seg_cut[sbase + jj];
+        det_pow[(long long)a * g.cap + dst] = seg_pow[sbase + jj];
       }
     }
   }
-  // ---- ticket 2: the last antenna counts the detected rows
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned t = atomicAdd(&tickets[A], 1u);
-    s_misc[1] = (t == (unsigned)A - 1u) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_misc[1]) return;
-  __threadfence();
-  __shared__ int s_rows;
-  if (tid == 0) s_rows = 0;
-  __syncthreads();
+  if (a != 0) return;                                           // (workgroup-uniform)
+  // numDets = numel(unique(allRngEst)) = number of distinct detected rows over all antennas (fft2D.m:99,110)
   int local = 0;
-  for (int i = tid; i < g.n_cut_rows; i += 256) {
-    local += __hip_atomic_load(&row_seen[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
-    row_seen[i] = 0u;                                           // clean for the next call
+  for (int q = tid; q < g.n_panels; q += 256) {
+    unsigned long long m = 0ull;
+    for (int aa = 0; aa < A; ++aa) m |= rowmask[(long long)aa * g.n_panels + q];
+    local += __popcll(m);
   }
   atomicAdd(&s_rows, local);
   __syncthreads();
-  if (tid == 0) { *num_dets = s_rows; tickets[A] = 0u; }        // numDets = numel(unique(allRngEst))  fft2D.m:99,110
+  if (tid == 0) *num_dets = s_rows;
 }
 
 // ---------------------------------------------------------------- generic detector: arbitrary CUT list on an arbitrary map
@@ -558,8 +547,8 @@ static int launch_range(isac_ctx* ctx, hipStream_t st, const c64* rx, const c64*
 }
 
 // Range + Doppler + power window for the CUT rectangle.  Leaves pwin [nr x nc x A] in ctx->pwin.
-// The panel detector (cfar_panel_kernel: CFAR + CUT-order merge + numDets in one launch) applies when the CUT half-window fits a 48-row
-// panel and the panel's bookkeeping fits its LDS carve; anything else -- or ISAC_OPT_TAIL_FUSION = 0 -- takes memset + cfar_window_kernel + count.
+// The panel detector (cfar_panel_kernel + cfar_merge_kernel) applies when the CUT half-window fits a 48-row panel and the bookkeeping fits
+// the LDS carves; anything else -- or ISAC_OPT_TAIL_FUSION = 0 -- takes memset + cfar_window_kernel + count.
 static bool tail_fusable(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, TailGeom* out) {
   static const bool off = std::getenv("ISAC_TAIL_UNFUSED") != nullptr;
   if (off || !ctx->tail_fusion) return false;
@@ -640,30 +629,23 @@ static int launch_tail_fused(isac_ctx* ctx, const isac_est_params* ep, const isa
   if (!tail_fusable(ctx, ep, cf, &g) || g.nr != nr || g.nc != nc) return fail(ctx, ISAC_ERR_HIP, "internal: panel detector geometry mismatch");
   g.cap = cap;
   const size_t seg_elems = (size_t)A * g.n_panels * (size_t)g.pr * g.n_cut_cols;
+  const size_t n_slots = (size_t)A * g.n_panels;
   ISAC_TRY(ensure(ctx, ctx->det_cut, sizeof(int) * (size_t)A * cap));
   ISAC_TRY(ensure(ctx, ctx->det_pow, sizeof(double) * (size_t)A * cap));
   ISAC_TRY(ensure(ctx, ctx->det_cnt, sizeof(int) * (size_t)A));
-  ISAC_TRY(ensure(ctx, ctx->seg, (sizeof(double) + sizeof(int)) * seg_elems + sizeof(int) * (size_t)A * g.n_panels * g.n_cut_cols + 64));
+  ISAC_TRY(ensure(ctx, ctx->seg, (sizeof(double) + sizeof(int)) * seg_elems + sizeof(unsigned long long) * n_slots + sizeof(int) * n_slots * g.n_cut_cols + 64));
   double* seg_pow = (double*)ctx->seg.p;
-  int* seg_cut = (int*)(seg_pow + seg_elems);
+  unsigned long long* rowmask = (unsigned long long*)(seg_pow + seg_elems);
+  int* seg_cut = (int*)(rowmask + n_slots);
   int* seg_colcnt = seg_cut + seg_elems;
-  // row flags + tickets: zero once (allocation / geometry change); the kernel's last workgroups leave them zero again
-  const size_t ctr_bytes = sizeof(unsigned) * ((size_t)g.n_cut_rows + (size_t)A + 1);
-  const long long sig = ((long long)g.n_cut_rows << 20) ^ (long long)A;
-  const bool fresh = ctx->tail_ctr.cap < ctr_bytes || ctx->tail_ctr_sig != sig;
-  ISAC_TRY(ensure(ctx, ctx->tail_ctr, ctr_bytes));
-  if (fresh) {
-    ISAC_HIP(hipMemsetAsync(ctx->tail_ctr.p, 0, ctx->tail_ctr.cap, ctx->stream));
-    ctx->tail_ctr_sig = sig;
-  }
-  unsigned* row_seen = (unsigned*)ctx->tail_ctr.p;
-  unsigned* tickets = row_seen + g.n_cut_rows;
-  const size_t lds = sizeof(double) * (size_t)g.nc * kTailRows +
-                     sizeof(int) * (32 + (size_t)g.n_cut_cols + 4 + 3 * (size_t)g.n_cut_cols * g.n_panels) + (size_t)g.pr * g.n_cut_cols + 64;
-  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cfar_panel_kernel), lds));
-  hipLaunchKernelGGL(cfar_panel_kernel, dim3(g.n_panels, A), dim3(256), lds, ctx->stream, (const double*)ctx->pwin.p, A, g,
-                     seg_cut, seg_pow, seg_colcnt, (int*)ctx->det_cut.p, (double*)ctx->det_pow.p, (int*)ctx->det_cnt.p,
-                     row_seen, tickets, (int*)ctx->misc.p);
+  const size_t lds1 = sizeof(double) * (size_t)g.nc * kTailRows + sizeof(int) * (32 + (size_t)g.n_cut_cols) + (size_t)g.pr * g.n_cut_cols + 64;
+  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cfar_panel_kernel), lds1));
+  hipLaunchKernelGGL(cfar_panel_kernel, dim3(g.n_panels, A), dim3(256), lds1, ctx->stream, (const double*)ctx->pwin.p, g, seg_cut, seg_pow, seg_colcnt, rowmask);
+  ISAC_HIP(hipGetLastError());
+  const size_t lds2 = sizeof(int) * 3 * (size_t)g.n_cut_cols * g.n_panels + 64;
+  ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cfar_merge_kernel), lds2));
+  hipLaunchKernelGGL(cfar_merge_kernel, dim3(A), dim3(256), lds2, ctx->stream, g, A, (const int*)seg_cut, (const double*)seg_pow, (const int*)seg_colcnt,
+                     (const unsigned long long*)rowmask, (int*)ctx->det_cut.p, (double*)ctx->det_pow.p, (int*)ctx->det_cnt.p, (int*)ctx->misc.p);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }

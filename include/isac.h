@@ -301,7 +301,7 @@ int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_t n_top, do
  *                to route 1 by itself when L exceeds what one workgroup holds: 32 vectors up to 64 antennas, 15-16 at 129..256);
  *   1            always the full eigendecomposition eig(Ra) (Jacobi / tridiagonal QL pipeline) and the explicit sum over the noise vectors.
  * ISAC_OPT_TAIL_FUSION  fft2D.m:59-99 after the power window:
- *   1 (default)  CA-CFAR on (antenna, 42-CUT-row panel) workgroups with the CUT-order merge and the numDets count inside the same launch
+ *   1 (default)  CA-CFAR on (antenna, 42-CUT-row panel) workgroups, then one merge workgroup per antenna (CUT order) that also forms numDets
  *                (zones whose half-window fits a 48-row panel; other shapes take setting 0 by themselves);
  *   0            memset of the row flags, one CFAR workgroup per antenna, a separate count kernel. */
 enum { ISAC_OPT_MUSIC_ROUTE = 0, ISAC_OPT_TAIL_FUSION = 1 };

@@ -1,7 +1,7 @@
-"""fft2D.m:44-46,59-99 after the range stage, one launch (cfar_panel_kernel: CA-CFAR on row panels -> CUT-order merge -> numDets)
+"""fft2D.m:59-99 after the power window: cfar_panel_kernel (CA-CFAR on row panels) + cfar_merge_kernel (CUT-order merge, numDets)
 against the memset + per-antenna CFAR + count kernels of the same library (ISAC_OPT_TAIL_FUSION = 0) bit for bit, and against the oracle:
 zone shapes that give one panel, many panels, a ragged last panel, wide / narrow Doppler zones; thousands of detections per antenna
-(the merge); repeated and re-shaped calls on one context (the self-resetting tickets / row flags)."""
+(the merge); repeated and re-shaped calls on one context (nothing carries over between calls: every workgroup writes only its own slots)."""
 from __future__ import annotations
 
 import numpy as np
@@ -87,8 +87,8 @@ def test_fused_tail_merge_with_thousands_of_detections(pkg):
 
 
 def test_fused_tail_repeated_and_reshaped_calls_on_one_context(pkg):
-    """The tickets and row flags are cleared by the kernel's own last workgroups: ten calls in a row, a zone change, an antenna-count change
-    and a call with no detection at all in between must each give the right answer on the same context."""
+    """No state carries over between calls (lists, counts and row masks are rewritten in full): calls in a row, a zone change, an
+    antenna-count change and a call with no detection at all in between must each give the right answer on the same context."""
     ctxs = [pkg.Context(), pkg.Context()]
     a = make_scene(n_ants=4, n_slots=4, nrb=273, targets=((100.0, 20.0, 1.5),), velocity=(7.0,), seed=41)
     b = make_scene(n_ants=2, n_slots=4, nrb=273, targets=((300.0, 50.0, 1.5),), velocity=(-3.0,), seed=42, detection_area=((200.0, 400.0), (-30.0, 30.0)))
