@@ -254,22 +254,16 @@ __constant__ unsigned char kCovDiagTiles[4][4] = {              // 16*I + J per 
     {0x00, 0x01, 0x02, 255}, {0x03, 0x11, 0x12, 255}, {0x13, 0x22, 255, 255}, {0x23, 0x33, 255, 255}};
 
 __global__ __launch_bounds__(256, 2) void cov_mfma_block_kernel(const c64* __restrict__ G, long long N, int A, int n_blk,
-                                                                int n_pairs, long long slabs_per_wg, int n_chunks, int xcd_map,
+                                                                int n_pairs, long long slabs_per_wg,
                                                                 double* __restrict__ part /* [chunk][pair][16][2][256] */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);      // [2][kCovBufElems]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
-  // xcd_map: the block pairs of one sample chunk share an XCD (the dispatcher places workgroup b on XCD b % 8 -- a speed assumption only):
-  // the chunk's slabs are then fetched into ONE L2 instead of up to eight
-  int pair = blockIdx.x % n_pairs, chunk = blockIdx.x / n_pairs;
-  if (xcd_map) {
-    const int x = blockIdx.x & 7, sq = blockIdx.x >> 3;
-    pair = sq % n_pairs;
-    chunk = (sq / n_pairs) * 8 + x;
-    if (chunk >= n_chunks) return;                  // padding workgroup (before any barrier)
-  }
+  // (pinning the block pairs of one sample chunk to one XCD -- workgroup b runs on XCD b % 8 -- so that a chunk's slabs enter ONE L2: 3.71 ->
+  // 4.11 ms at A = 256, no change at A = 128: the diagonal pairs run 1.6x faster than the off-diagonal ones and drift out of the L2 window)
+  const int pair = blockIdx.x % n_pairs, chunk = blockIdx.x / n_pairs;
   int BI = 0, BJ = 0;
   {
     int rem = pair;                                 // pair-th (BI <= BJ) in row-major order
@@ -1709,10 +1703,8 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
     ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * (size_t)n_chunks * n_pairs * 16 * 2 * 256));
     const size_t lds = sizeof(c64) * 2 * kCovBufElems;
     ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cov_mfma_block_kernel), (size_t)(lds)));
-    static const int xcd_map = std::getenv("ISAC_COV_XCD") ? std::atoi(std::getenv("ISAC_COV_XCD")) : 0;   // (A/B switch while being measured)
-    const unsigned grid = xcd_map ? (unsigned)(((n_chunks + 7) / 8) * 8 * n_pairs) : (unsigned)(n_chunks * n_pairs);
-    hipLaunchKernelGGL(cov_mfma_block_kernel, dim3(grid), dim3(256), lds, st, (const c64*)d_grid, (long long)N, A,
-                       n_blk, n_pairs, per, (int)n_chunks, xcd_map, (double*)ctx->cov_part.p);
+    hipLaunchKernelGGL(cov_mfma_block_kernel, dim3((unsigned)(n_chunks * n_pairs)), dim3(256), lds, st, (const c64*)d_grid, (long long)N, A,
+                       n_blk, n_pairs, per, (double*)ctx->cov_part.p);
     ISAC_HIP(hipGetLastError());
     hipLaunchKernelGGL(cov_block_reduce_kernel, dim3(16, n_pairs), dim3(256, 4), 0, st, (const double*)ctx->cov_part.p, (int)n_chunks,
                        n_blk, n_pairs, A, 1.0 / (double)N, (c64*)d_Ra);

@@ -131,6 +131,7 @@ class SlotPool:
         self.ctxs = [pkg.Context(device) for _ in range(max(1, n))]
         self.owner = [None] * len(self.ctxs)
         self.k = 0
+        self.timeline = None          # list of (collect_s, enqueue_s) per submit while recording (host-side stalls show up here)
 
     def collect(self, slot):
         cell, self.owner[slot] = self.owner[slot], None
@@ -138,8 +139,12 @@ class SlotPool:
 
     def submit(self, cell):
         slot = self.k % len(self.ctxs)
+        t0 = time.perf_counter()
         self.collect(slot)
+        t1 = time.perf_counter()
         cell.enqueue(self.ctxs[slot])
+        if self.timeline is not None:
+            self.timeline.append((t1 - t0, time.perf_counter() - t1))
         self.owner[slot] = cell
         self.k += 1
 
@@ -490,6 +495,7 @@ def main():
         for cell in cells:
             cell.profile_sink = sink
     barrier()
+    pool.timeline = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for cell in cells:
@@ -500,6 +506,7 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    tl, pool.timeline = np.array(pool.timeline).reshape(-1, 2), None
     for cell in cells:
         cell.profile_sink = None
     dom_ms_timed = float(np.mean(sink)) if sink else None                       # fused kernel, launches of the timed region (other CPIs co-running)
@@ -535,6 +542,11 @@ def main():
             "hw_queues": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "hip_streams": 2 * args.inflight,
                           "note": "set by bench.py before the HIP runtime starts (the library loader does not touch the environment): one hardware queue per "
                                   "HIP stream, two streams per in-flight CPI; INTEGRATION.md section 4"},
+            "host_timeline": None if not tl.size else {
+                "collect_wait_ms": {"p50": round(1e3 * float(np.median(tl[:, 0])), 3), "p99": round(1e3 * float(np.percentile(tl[:, 0], 99)), 3), "max": round(1e3 * float(tl[:, 0].max()), 3)},
+                "enqueue_ms": {"p50": round(1e3 * float(np.median(tl[:, 1])), 3), "p99": round(1e3 * float(np.percentile(tl[:, 1], 99)), 3), "max": round(1e3 * float(tl[:, 1].max()), 3)},
+                "enqueue_over_1ms": int((tl[:, 1] > 1e-3).sum()), "enqueue_total_ms": round(1e3 * float(tl[:, 1].sum()), 2), "collect_total_ms": round(1e3 * float(tl[:, 0].sum()), 2),
+                "note": "host wall time per submitted CPI in the timed region: waiting for + post-processing the oldest CPI of the slot (collect), then the launches of the new one (enqueue)"},
             "pipeline": {"cpis_in_flight": args.inflight, "blocking_cpi_ms": None if blocking_ms is None else round(blocking_ms, 3),
                          "note": "the timed region starts with an empty device and ends fully drained: its K steps include one pipeline fill and "
                                  "one drain (about one blocking CPI latency in total); steady-state rate = the same command with --steps 100"},

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Prints the "headline readings" block of profiles/README.md for a round tag FROM the committed CSV / JSON files (the prose
+must not drift from the data):   python tools/profiles_readme.py r03 > /tmp/block.md"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+
+
+def rows(name):
+    f = os.path.join(P, f"{tag}_{name}")
+    return list(csv.DictReader(open(f))) if os.path.exists(f) else []
+
+
+def jline(name):
+    f = os.path.join(P, f"{tag}_{name}")
+    if not os.path.exists(f):
+        return None
+    for ln in reversed(open(f).read().splitlines()):
+        if ln.startswith("{"):
+            return json.loads(ln)
+    return None
+
+
+def short(k):
+    import re
+    m = re.search(r"\d+([a-z][a-z0-9_]*_kernel)", k.replace("isac", ""))
+    return m.group(1) if m else k.strip('"')[:40]
+
+
+def kern(rs, name):
+    for r in rs:
+        if name in r["kernel"]:
+            return r
+    return None
+
+
+out = []
+ss = rows("kernel_stats_single_stream.csv")
+if ss:
+    out.append(f"* Single-stream kernel trace (`{tag}_kernel_stats_single_stream.csv`, blocking call order): " +
+               "; ".join(f"`{short(r['kernel'])}` {float(r['avg_us']):.1f} us x {r['calls']} ({float(r['pct']):.1f} %)" for r in ss[:9]) + ".")
+    top = max(ss, key=lambda r: float(r["total_us"]))
+    out.append(f"* Largest share of GPU time: `{short(top['kernel'])}` ({float(top['pct']):.1f} %, {float(top['avg_us']):.1f} us avg).")
+fe, wr = rows("pmc_fetch_size.csv"), rows("pmc_write_size.csv")
+for name, alg in (("echo_range_kernel", 1.5029), ("cov_mfma_small_kernel", 0.7514), ("beamsum_kernel", 1.0066)):
+    a, b = kern(fe, name), kern(wr, name)
+    if a and b:
+        f_kb, w_kb = float(a["avg_value"]), float(b["avg_value"])
+        out.append(f"* `{name}`: FETCH_SIZE 2 x {f_kb:,.0f} KB + WRITE_SIZE {w_kb:,.0f} KB = {(2 * f_kb + w_kb) * 1024 / 1e9:.3f} GB per launch "
+                   f"(algorithmic {alg:.3f} GB); {float(a['avg_duration_us']):.1f} us in the FETCH pass.")
+mf = rows("pmc_mfma_busy.csv")
+cov = [r for r in mf if "cov_mfma_small" in r["kernel"]]
+if cov:
+    d = {r["counter"]: float(r["avg_value"]) for r in cov}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
+        out.append(f"* `cov_mfma_small_kernel`: SQ_VALU_MFMA_BUSY_CYCLES {d['SQ_VALU_MFMA_BUSY_CYCLES']:,.0f} (per counter instance, x 32 instances) over GRBM_GUI_ACTIVE "
+                   f"{d['GRBM_GUI_ACTIVE']:,.0f} cycles x 1024 SIMDs -> MfmaUtil {32 * d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] * 1024):.2f}.")
+wl = [r for r in rows("pmc_wait_lds.csv") if "echo_range_kernel" in r["kernel"]]
+if wl:
+    d = {r["counter"]: float(r["avg_value"]) for r in wl}
+    if "SQ_WAIT_ANY" in d and "SQ_WAVE_CYCLES" in d:
+        s = f"* `echo_range_kernel` (final kernel of the round): SQ_WAIT_ANY / SQ_WAVE_CYCLES = {d['SQ_WAIT_ANY'] / d['SQ_WAVE_CYCLES']:.2f}"
+        if "SQ_LDS_BANK_CONFLICT" in d and "SQ_LDS_IDX_ACTIVE" in d:
+            s += f"; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = {d['SQ_LDS_BANK_CONFLICT']:,.0f} / {d['SQ_LDS_IDX_ACTIVE']:,.0f} = {d['SQ_LDS_BANK_CONFLICT'] / d['SQ_LDS_IDX_ACTIVE']:.2f}"
+        out.append(s + f" (`{tag}_pmc_wait_lds.csv`).")
+for name, label in (("bench_driver_invocation.json", "driver invocation (`--gpus 1 --steps 20 --warmup 5`)"), ("bench_driver_invocation_2.json", "the same again"),
+                    ("bench_default_100steps.json", "100 steps"), ("bench_blocking.json", "`--inflight 1` (blocking CPIs)"),
+                    ("bench_blocking_full_eig.json", "`--inflight 1`, full eigendecomposition route (`ISAC_MUSIC_FULL_EIG=1`: the round-2 eigensolver)"),
+                    ("bench_default_100steps_old_cfar.json", "100 steps, per-antenna CFAR + memset + count (`ISAC_TAIL_UNFUSED=1`)"),
+                    ("bench_7cells_per_gpu.json", "7 cells per GPU"), ("bench_a256.json", "`--ants 256 --inflight 3`"),
+                    ("bench_a256_blocking.json", "`--ants 256 --inflight 1`"), ("bench_a16.json", "`--ants 16`"), ("bench_traced_pipelined.json", "under rocprofv3, 300 steps, `--trace-only`")):
+    d = jline(name)
+    if d:
+        rf = d.get("roofline", {})
+        out.append(f"* bench, {label}: **{d['value']:,.0f} slots/s**, {d['ms_per_step']:.3f} ms per step" +
+                   (f", blocking CPI {d['pipeline']['blocking_cpi_ms']} ms" if d.get("pipeline", {}).get("blocking_cpi_ms") else "") +
+                   (f", `roofline.frac` {rf.get('frac')} ({rf.get('avg_launch_ms')} ms per launch), whole-CPI frac {rf.get('whole_cpi', {}).get('frac')}" if rf.get("frac") else "") + ".")
+for name in ("pipeline_overlap.txt", "pipeline_gaps.txt"):
+    f = os.path.join(P, f"{tag}_{name}")
+    if os.path.exists(f):
+        lines = open(f).read().splitlines()
+        out.append(f"* `{tag}_{name}`: " + " | ".join(lines[:2]))
+print("\n".join(out))
