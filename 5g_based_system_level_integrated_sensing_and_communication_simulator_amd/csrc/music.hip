@@ -310,8 +310,10 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_block_kernel(const c64* __res
   const long long s_begin = (long long)chunk * slabs_per_wg;
   long long s_end = s_begin + slabs_per_wg;
   if (s_end > total) s_end = total;
-  c64 g[8];
-  auto fetch = [&](long long slab) {
+  // Two slabs of global loads in flight (register sets gA / gB in rotation): one slab of MFMAs is ~1.3 us, less than a loaded HBM round
+  // trip -- with a single prefetched slab (round 2) the stash of slab s + 1 still waited for its loads (0.52 of the MFMA peak at A = 256).
+  c64 gA[8], gB[8];
+  auto fetch = [&](c64 (&g)[8], long long slab) {
     long long n = slab * 16 + s_smp;
     const bool in = n < N;
     if (!in) n = N - 1;
@@ -323,18 +325,13 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_block_kernel(const c64* __res
       }
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](const c64 (&g)[8], int buf) {
     c64* d = lds + buf * kCovBufElems;
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (j < n_stage) d[s_lds[j]] = g[j];
   };
-  if (s_begin < s_end) { fetch(s_begin); stash(0); }
-  __syncthreads();
-  for (long long slab = s_begin; slab < s_end; ++slab) {
-    const int buf = (int)((slab - s_begin) & 1);
-    const bool more = slab + 1 < s_end;
-    if (more) fetch(slab + 1);                      // in flight under the MFMAs below
+  auto mfmas = [&](int buf) {
     const c64* cur = lds + buf * kCovBufElems;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -349,7 +346,26 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_block_kernel(const c64* __res
         s3[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(td[u] ? xa.im : xa.re - xa.im, td[u] ? xb.im : xb.re + xb.im, s3[u], 0, 0, 0);
       }
     }
-    if (more) stash(buf ^ 1);
+  };
+  const long long last = s_end - 1;                 // (loads past the chunk re-read its last slab: unconditional, never consumed)
+  if (s_begin < s_end) {
+    fetch(gA, s_begin);
+    stash(gA, 0);
+    fetch(gA, s_begin + 1 < s_end ? s_begin + 1 : last);
+    fetch(gB, s_begin + 2 < s_end ? s_begin + 2 : last);
+  }
+  __syncthreads();
+  for (long long slab = s_begin; slab < s_end; slab += 2) {
+    // even trip: slab from buffer 0; gA holds slab + 1 (issued two trips ago), gB slab + 2 (in flight)
+    mfmas(0);
+    if (slab + 1 < s_end) stash(gA, 1);
+    fetch(gA, slab + 3 < s_end ? slab + 3 : last);
+    __syncthreads();
+    if (slab + 1 >= s_end) break;
+    // odd trip: slab + 1 from buffer 1; gB holds slab + 2
+    mfmas(1);
+    if (slab + 2 < s_end) stash(gB, 0);
+    fetch(gB, slab + 4 < s_end ? slab + 4 : last);
     __syncthreads();
   }
 #pragma unroll

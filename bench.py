@@ -132,6 +132,8 @@ class SlotPool:
         self.owner = [None] * len(self.ctxs)
         self.k = 0
         self.timeline = None          # list of (collect_s, enqueue_s) per submit while recording (host-side stalls show up here)
+        self.pace_s = 0.0             # minimum spacing of consecutive submissions (0 = none): see --pace-ms
+        self.next_t = 0.0
 
     def collect(self, slot):
         cell, self.owner[slot] = self.owner[slot], None
@@ -142,6 +144,10 @@ class SlotPool:
         t0 = time.perf_counter()
         self.collect(slot)
         t1 = time.perf_counter()
+        if self.pace_s > 0.0:
+            while t1 < self.next_t:
+                t1 = time.perf_counter()
+            self.next_t = max(t1, self.next_t) + self.pace_s
         cell.enqueue(self.ctxs[slot])
         if self.timeline is not None:
             self.timeline.append((t1 - t0, time.perf_counter() - t1))
@@ -419,6 +425,10 @@ def main():
                     help="Philox AWGN drawn on the demodulated grid (default; same distribution, include/isac.h isac_noise_mode) or per time sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prime-ms", type=float, default=300.0, help="untimed device priming (hot-path steps) before the warm-up steps; 0 = none")
+    ap.add_argument("--pace-ms", type=float, default=-1.0, help="minimum host-side spacing of consecutive CPI submissions; 0 = none, < 0 (default) = 0.93 x the "
+                                                                 "un-paced time per CPI measured during the priming phase.  CPIs submitted in a burst advance in lockstep on the GPU "
+                                                                 "(round-robin dispatch among their queues) and finish together, so their narrow MUSIC tails leave the GPU nearly idle "
+                                                                 "once per batch; staggered arrivals keep the in-flight CPIs at different phases (profiles/r03_pacing_sweep.txt)")
     ap.add_argument("--trace-only", action="store_true", help="profiling aid: nothing after the timed region (no isolated-kernel / blocking-CPI / stage / CPU legs), "
                                                               "so that a rocprofv3 trace holds priming + warm-up + the timed steps only")
     ap.add_argument("--n1-value", type=float, default=None, help="N > 1: the N = 1 value of the same per-GPU workload (slots/s) -> `efficiency_vs_n1` in the line")
@@ -448,6 +458,7 @@ def main():
             dist.init_process_group(backend)
     pkg = importlib.import_module(PKG)
     pool = SlotPool(pkg, local_rank, args.inflight)          # the GPU's execution slots, shared by all its cells
+    pool.pace_s = 1e-3 * max(args.pace_ms, 0.0)
     d = importlib.import_module(PKG + "._dist")
     my_cells = d.shard_cells(args.cells, rank, world) if args.cells > 0 else [rank * args.cells_per_gpu + c for c in range(args.cells_per_gpu)]
     n_total_cells = args.cells if args.cells > 0 else args.cells_per_gpu * world
@@ -466,10 +477,18 @@ def main():
     # steady-state rate, behind 100 warm-up steps they measure the steady state (profiles/r02_warmup_sensitivity.txt).  The
     # timed region below is still exactly K steps of the full hot path between two barriers.
     prime_steps, t_prime = 0, time.perf_counter()
+    mark, unpaced_ms = None, None                            # auto pacing: un-paced period from the first 40 % of the priming phase
     while 1e3 * (time.perf_counter() - t_prime) < args.prime_ms:
         for cell in cells:
             pool.submit(cell)
         prime_steps += 1
+        if args.pace_ms < 0 and unpaced_ms is None and args.inflight > 1:
+            now = time.perf_counter()
+            if mark is None and pool.k >= 2 * args.inflight:
+                mark = (now, pool.k)
+            elif mark is not None and 1e3 * (now - t_prime) >= 0.4 * args.prime_ms and pool.k - mark[1] >= 2 * args.inflight:
+                unpaced_ms = 1e3 * (now - mark[0]) / (pool.k - mark[1])
+                pool.pace_s = 0.93e-3 * unpaced_ms           # the rest of the priming phase, the warm-up and the timed steps run paced
     pool.drain()
     prime_ms = 1e3 * (time.perf_counter() - t_prime)
     for _ in range(args.warmup):
@@ -496,6 +515,7 @@ def main():
             cell.profile_sink = sink
     barrier()
     pool.timeline = []
+    pool.next_t = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for cell in cells:
@@ -547,6 +567,9 @@ def main():
                 "enqueue_ms": {"p50": round(1e3 * float(np.median(tl[:, 1])), 3), "p99": round(1e3 * float(np.percentile(tl[:, 1], 99)), 3), "max": round(1e3 * float(tl[:, 1].max()), 3)},
                 "enqueue_over_1ms": int((tl[:, 1] > 1e-3).sum()), "enqueue_total_ms": round(1e3 * float(tl[:, 1].sum()), 2), "collect_total_ms": round(1e3 * float(tl[:, 0].sum()), 2),
                 "note": "host wall time per submitted CPI in the timed region: waiting for + post-processing the oldest CPI of the slot (collect), then the launches of the new one (enqueue)"},
+            "pacing": {"mode": "off" if pool.pace_s == 0.0 else ("auto" if args.pace_ms < 0 else "fixed"), "pace_ms": round(1e3 * pool.pace_s, 4),
+                       "unpaced_ms_per_cpi_during_priming": None if unpaced_ms is None else round(unpaced_ms, 4),
+                       "note": "host-side minimum spacing of consecutive CPI submissions (staggered arrivals; 0.93 x the un-paced period measured while priming)"},
             "pipeline": {"cpis_in_flight": args.inflight, "blocking_cpi_ms": None if blocking_ms is None else round(blocking_ms, 3),
                          "note": "the timed region starts with an empty device and ends fully drained: its K steps include one pipeline fill and "
                                  "one drain (about one blocking CPI latency in total); steady-state rate = the same command with --steps 100"},
