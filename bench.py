@@ -477,18 +477,24 @@ def main():
     # steady-state rate, behind 100 warm-up steps they measure the steady state (profiles/r02_warmup_sensitivity.txt).  The
     # timed region below is still exactly K steps of the full hot path between two barriers.
     prime_steps, t_prime = 0, time.perf_counter()
-    mark, unpaced_ms = None, None                            # auto pacing: un-paced period from the first 40 % of the priming phase
+    stamps, unpaced_ms = [], None                            # auto pacing: un-paced period over the last CPIs before 80 % of the priming phase
+    n_win = max(3 * args.inflight, 16)                       # (the first tens of ms run at low clocks and hold the first-call allocations)
     while 1e3 * (time.perf_counter() - t_prime) < args.prime_ms:
         for cell in cells:
             pool.submit(cell)
         prime_steps += 1
         if args.pace_ms < 0 and unpaced_ms is None and args.inflight > 1:
             now = time.perf_counter()
-            if mark is None and pool.k >= 2 * args.inflight:
-                mark = (now, pool.k)
-            elif mark is not None and 1e3 * (now - t_prime) >= 0.4 * args.prime_ms and pool.k - mark[1] >= 2 * args.inflight:
-                unpaced_ms = 1e3 * (now - mark[0]) / (pool.k - mark[1])
-                pool.pace_s = 0.93e-3 * unpaced_ms           # the rest of the priming phase, the warm-up and the timed steps run paced
+            stamps.append((now, pool.k))
+            if 1e3 * (now - t_prime) >= 0.8 * args.prime_ms:
+                est = []                                     # the fastest of the last few windows of n_win CPIs (a hiccup must not become the pace)
+                for j in range(len(stamps) - 1, max(len(stamps) - 1 - 4 * n_win, 0), -max(n_win // 2, 1)):
+                    old = [st for st in stamps[:j] if stamps[j][1] - st[1] >= n_win]
+                    if old:
+                        est.append(1e3 * (stamps[j][0] - old[-1][0]) / (stamps[j][1] - old[-1][1]))
+                if est:
+                    unpaced_ms = min(est)
+                    pool.pace_s = 0.93e-3 * unpaced_ms       # the rest of the priming phase, the warm-up and the timed steps run paced
     pool.drain()
     prime_ms = 1e3 * (time.perf_counter() - t_prime)
     for _ in range(args.warmup):

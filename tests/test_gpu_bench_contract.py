@@ -38,3 +38,11 @@ def test_bench_line_carries_the_contract_fields():
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
     assert d["value"] > 10 * cb["value"]                           # north_star: >= 10x the CPU path on the same host
+    assert "un-tuned" in cb["tuning"] and cb["cpi_s"]["min"] <= cb["cpi_s"]["median"] <= cb["cpi_s"]["max"]
+    # what the committed profiles say, read from the CSVs (not typed into bench.py)
+    top = rf["top_by_time"]
+    assert top and top["source"].startswith("profiles/r") and 0 < top["share"] < 1 and top["kernel"].endswith("_kernel")
+    assert rf["traffic_source"] is None or "profiles/r" in rf["traffic_source"]
+    # host-side bookkeeping of the pipelined run
+    assert d["pacing"]["mode"] in ("auto", "fixed", "off") and d["hw_queues"]["GPU_MAX_HW_QUEUES"] == "16" and d["host_timeline"]["enqueue_ms"]["p50"] > 0
+    assert d["per_rank_ms"] and abs(d["per_rank_ms"][0] - d["ms_per_step"] * d["steps"]) <= 1e-2 * d["per_rank_ms"][0]
