@@ -134,6 +134,7 @@ class SlotPool:
         self.timeline = None          # list of (collect_s, enqueue_s) per submit while recording (host-side stalls show up here)
         self.pace_s = 0.0             # minimum spacing of consecutive submissions (0 = none): see --pace-ms
         self.next_t = 0.0
+        self.spin_run = 0             # consecutive submissions that had to wait for their pace slot (beyond a pipeline fill: the pace throttles)
 
     def collect(self, slot):
         cell, self.owner[slot] = self.owner[slot], None
@@ -145,9 +146,16 @@ class SlotPool:
         self.collect(slot)
         t1 = time.perf_counter()
         if self.pace_s > 0.0:
+            spun = t1 < self.next_t
             while t1 < self.next_t:
                 t1 = time.perf_counter()
             self.next_t = max(t1, self.next_t) + self.pace_s
+            # A pace just below the GPU-bound period never makes the host wait here (the wait for the oldest CPI above is longer); waiting on
+            # every submission well past a pipeline fill means the pace itself has become the bottleneck: back off
+            self.spin_run = self.spin_run + 1 if spun else 0
+            if self.spin_run >= len(self.ctxs) + 6:
+                self.pace_s *= 0.85
+                self.spin_run = len(self.ctxs) // 2
         cell.enqueue(self.ctxs[slot])
         if self.timeline is not None:
             self.timeline.append((t1 - t0, time.perf_counter() - t1))
@@ -477,7 +485,7 @@ def main():
     # steady-state rate, behind 100 warm-up steps they measure the steady state (profiles/r02_warmup_sensitivity.txt).  The
     # timed region below is still exactly K steps of the full hot path between two barriers.
     prime_steps, t_prime = 0, time.perf_counter()
-    stamps, unpaced_ms = [], None                            # auto pacing: un-paced period over the last CPIs before 80 % of the priming phase
+    stamps, unpaced_ms = [], None                            # auto pacing: un-paced period over the last CPIs before 60 % of the priming phase
     n_win = max(3 * args.inflight, 16)                       # (the first tens of ms run at low clocks and hold the first-call allocations)
     while 1e3 * (time.perf_counter() - t_prime) < args.prime_ms:
         for cell in cells:
@@ -486,7 +494,7 @@ def main():
         if args.pace_ms < 0 and unpaced_ms is None and args.inflight > 1:
             now = time.perf_counter()
             stamps.append((now, pool.k))
-            if 1e3 * (now - t_prime) >= 0.8 * args.prime_ms:
+            if 1e3 * (now - t_prime) >= 0.6 * args.prime_ms:
                 est = []                                     # the fastest of the last few windows of n_win CPIs (a hiccup must not become the pace)
                 for j in range(len(stamps) - 1, max(len(stamps) - 1 - 4 * n_win, 0), -max(n_win // 2, 1)):
                     old = [st for st in stamps[:j] if stamps[j][1] - st[1] >= n_win]
@@ -521,7 +529,7 @@ def main():
             cell.profile_sink = sink
     barrier()
     pool.timeline = []
-    pool.next_t = 0.0
+    pool.next_t, pool.spin_run = 0.0, 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for cell in cells:
