@@ -759,6 +759,13 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
           c64 a0 = mk(0.0, 0.0), a1 = a0, a2 = a0, a3 = a0;
           if (i < n) {
             int j = j0;
+            for (; j + 8 <= j1; j += 8) {                    // eight independent loads in flight
+              c64 m[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) m[u] = M[i + n * (j + u)];
+              a0 = fma(m[0], sv[j], a0); a1 = fma(m[1], sv[j + 1], a1); a2 = fma(m[2], sv[j + 2], a2); a3 = fma(m[3], sv[j + 3], a3);
+              a0 = fma(m[4], sv[j + 4], a0); a1 = fma(m[5], sv[j + 5], a1); a2 = fma(m[6], sv[j + 6], a2); a3 = fma(m[7], sv[j + 7], a3);
+            }
             for (; j + 4 <= j1; j += 4) {
               const c64 m0 = M[i + n * j], m1 = M[i + n * (j + 1)], m2 = M[i + n * (j + 2)], m3 = M[i + n * (j + 3)];
               a0 = fma(m0, sv[j], a0); a1 = fma(m1, sv[j + 1], a1); a2 = fma(m2, sv[j + 2], a2); a3 = fma(m3, sv[j + 3], a3);
@@ -784,11 +791,21 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
       __syncthreads();
       for (int i = k + 1 + tid; i < n; i += nt) sp[i] = sp[i] + a2 * sv[i];
       __syncthreads();
-      // A22 -= v w^H + w v^H   (thread = row slot x column phase: rows coalesced, no per-element division)
+      // A22 -= v w^H + w v^H   (thread = row slot x column phase: rows coalesced, no per-element division).  Four columns per trip with
+      // their loads issued together: the one-element loop waited an L2 round trip per element (the stores to M keep the compiler from
+      // overlapping trips by itself) -- with the matrix in L2 (n > 64) that latency was most of the kernel.
       for (int i = k + 1 + (tid & (RWU - 1)); i < n; i += RWU) {
         const c64 vi = sv[i], wi = sp[i];
-        for (int j = k + 1 + tid / RWU; j < n; j += nt / RWU)
-          M[i + n * j] = M[i + n * j] - mul_conj(vi, sp[j]) - mul_conj(wi, sv[j]);
+        const int js = nt / RWU;
+        int j = k + 1 + tid / RWU;
+        for (; j + 3 * js < n; j += 4 * js) {
+          c64 m[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) m[u] = M[i + n * (j + u * js)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) M[i + n * (j + u * js)] = m[u] - mul_conj(vi, sp[j + u * js]) - mul_conj(wi, sv[j + u * js]);
+        }
+        for (; j < n; j += js) M[i + n * j] = M[i + n * j] - mul_conj(vi, sp[j]) - mul_conj(wi, sv[j]);
       }
     }
     __syncthreads();

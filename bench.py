@@ -153,7 +153,7 @@ class SlotPool:
             # A pace just below the GPU-bound period never makes the host wait here (the wait for the oldest CPI above is longer); waiting on
             # every submission well past a pipeline fill means the pace itself has become the bottleneck: back off
             self.spin_run = self.spin_run + 1 if spun else 0
-            if self.spin_run >= len(self.ctxs) + 6:
+            if self.spin_run >= 2 * len(self.ctxs) + 4:
                 self.pace_s *= 0.85
                 self.spin_run = len(self.ctxs) // 2
         cell.enqueue(self.ctxs[slot])
