@@ -835,6 +835,12 @@ extern "C" int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_
   ISAC_HIP(hipMemcpyAsync(ctl, isac_music_ctl(ctx), sizeof(ctl), hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_TRY(eig_status(ctx, A));
+  if (std::getenv("ISAC_DEBUG")) {
+    int inf[15] = {0};
+    ISAC_HIP(hipMemcpy(inf, (char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(inf), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "[isac] eigh_top A=%d n_top=%d phases(x64 clk): tridiag=%d (n <= 64: reflector=%d matvec=%d matvec+update=%d) | subspace: set-up=%d solves=%d "
+                 "gram-schmidt=%d back-transform=%d\n", A, n_top, inf[1], inf[12], inf[13], inf[14], inf[8], inf[9], inf[10], inf[11]);
+  }
   if (ctl[0] == 1 && n_top < A) {                                   // the subspace kernel delivered the vectors, descending eigenvalue order
     ISAC_HIP(hipMemcpyAsync(U, ctx->eig_v.p, sizeof(c64) * (size_t)A * n_top, hipMemcpyDeviceToHost, ctx->stream));
     ISAC_HIP(hipStreamSynchronize(ctx->stream));

@@ -825,24 +825,28 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
 // matrix-vector product (partials exchanged through LDS: barrier 1) and of the rank-2 update (barrier 2 before the next step reads the
 // updated column).  The matrix lives in LDS, the reflectors go straight to the scratch zungtr reads.  222 -> ~120 us at n = 64
 // (host-call time of the whole eigensolver 0.905 -> 0.807 ms).
-__global__ __launch_bounds__(256) void eigh_tridiag_small_kernel(const c64* __restrict__ Hin, int n, void* scratch, int* __restrict__ info) {
+constexpr int kTriWaves = 8;       // wavefronts of eigh_tridiag_small_kernel (four: 124 us at n = 64, 46 % of it the rank-2 update of 16 columns per wave)
+__global__ __launch_bounds__(64 * kTriWaves) void eigh_tridiag_small_kernel(const c64* __restrict__ Hin, int n, void* scratch, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int NW = kTriWaves;
   EighScratch S(scratch, n);
   c64* M = reinterpret_cast<c64*>(smem_raw);                     // [n x n] column-major working matrix
-  c64* spart = M + (size_t)n * n;                                 // [4][64] partial matrix-vector products
-  c64* svw = spart + 4 * 64;                                      // [4 waves][2][64]: each wave's own copy of v and w
-  double* sred = reinterpret_cast<double*>(svw + 4 * 2 * 64);     // [32] scratch of eigh_safe_scale
+  c64* spart = M + (size_t)n * n;                                 // [NW][64] partial matrix-vector products
+  c64* svw = spart + NW * 64;                                     // [NW waves][2][64]: each wave's own copy of v and w
+  double* sred = reinterpret_cast<double*>(svw + NW * 2 * 64);    // [32] scratch of eigh_safe_scale
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   c64* my_v = svw + (size_t)wid * 128;
   c64* my_w = my_v + 64;
   const long long t_start = clock64();
   const double scl = eigh_safe_scale(Hin, n * n, sred);
-  for (int i = tid; i < n * n; i += 256) M[i] = Hin[i] * scl;
+  for (int i = tid; i < n * n; i += 64 * NW) M[i] = Hin[i] * scl;
   if (tid == 0) *S.scale = scl;
   if (tid < 8) S.cnt[tid] = 0;                                    // publication counters of the next two stages
   __syncthreads();
   auto wave_sum = [](double x) { return wave_sum_dpp(x); };
+  long long c_refl = 0, c_mv = 0, c_upd = 0;                      // phase instrumentation (ISAC_DEBUG): cycles of thread 0
   for (int k = 0; k < n - 1; ++k) {                               // zhetd2, lower
+    const long long c0 = clock64();
     const bool below = lane > k + 1 && lane < n;
     const c64 xi = below ? M[lane + n * k] : mk(0.0, 0.0);
     const c64 alpha = M[k + 1 + n * k];                           // (broadcast read)
@@ -862,6 +866,8 @@ __global__ __launch_bounds__(256) void eigh_tridiag_small_kernel(const c64* __re
       if (below) S.M[lane + n * k] = vi;                          // the reflector, where zungtr expects it
       if (lane == 0) { S.d[k] = M[k + n * k].re; S.e[k] = beta; S.tau[k] = tau; }
     }
+    const long long c1 = clock64();
+    c_refl += c1 - c0;
     if (tau.re != 0.0 || tau.im != 0.0) {                         // (uniform)
       // p = tau A22 v: my columns' share of row `lane`
       // (four columns per trip, their LDS reads issued together: a single dependent chain waits ~130 cycles per column)
@@ -869,17 +875,21 @@ __global__ __launch_bounds__(256) void eigh_tridiag_small_kernel(const c64* __re
       if (lane < n) {
         c64 a0 = mk(0.0, 0.0), a1 = a0, a2_ = a0, a3 = a0;
         int j = k + 1 + wid;
-        for (; j + 12 < n; j += 16) {
-          const c64 m0 = M[lane + n * j], m1 = M[lane + n * (j + 4)], m2 = M[lane + n * (j + 8)], m3 = M[lane + n * (j + 12)];
-          const c64 v0 = my_v[j], v1 = my_v[j + 4], v2 = my_v[j + 8], v3 = my_v[j + 12];
+        for (; j + 3 * NW < n; j += 4 * NW) {
+          const c64 m0 = M[lane + n * j], m1 = M[lane + n * (j + NW)], m2 = M[lane + n * (j + 2 * NW)], m3 = M[lane + n * (j + 3 * NW)];
+          const c64 v0 = my_v[j], v1 = my_v[j + NW], v2 = my_v[j + 2 * NW], v3 = my_v[j + 3 * NW];
           a0 = fma(m0, v0, a0); a1 = fma(m1, v1, a1); a2_ = fma(m2, v2, a2_); a3 = fma(m3, v3, a3);
         }
-        for (; j < n; j += 4) a0 = fma(M[lane + n * j], my_v[j], a0);
+        for (; j < n; j += NW) a0 = fma(M[lane + n * j], my_v[j], a0);
         acc = (a0 + a1) + (a2_ + a3);
       }
       spart[wid * 64 + lane] = acc;
       __syncthreads();
-      const c64 pi = lane > k && lane < n ? tau * (((spart[lane] + spart[64 + lane]) + spart[128 + lane]) + spart[192 + lane]) : mk(0.0, 0.0);
+      c_mv += clock64() - c1;
+      c64 psum = mk(0.0, 0.0);
+#pragma unroll
+      for (int g = 0; g < NW; ++g) psum = psum + spart[g * 64 + lane];                    // fixed order: every wave forms the same p
+      const c64 pi = lane > k && lane < n ? tau * psum : mk(0.0, 0.0);
       const c64 t = mul_conj(vi, pi);                             // conj(p_i) v_i
       const c64 a2 = mk(-0.5, 0.0) * (tau * mk(wave_sum(t.re), wave_sum(t.im)));   // -1/2 tau (p^H v)   (zhetd2: zdotc(tau-scaled p, v))
       const c64 wi = pi + a2 * vi;
@@ -887,21 +897,28 @@ __global__ __launch_bounds__(256) void eigh_tridiag_small_kernel(const c64* __re
       // A22 -= v w^H + w v^H on my columns
       if (lane > k && lane < n) {
         int j = k + 1 + wid;
-        for (; j + 12 < n; j += 16) {
+        for (; j + 3 * NW < n; j += 4 * NW) {
           c64 m[4], wj[4], vj[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { m[u] = M[lane + n * (j + 4 * u)]; wj[u] = my_w[j + 4 * u]; vj[u] = my_v[j + 4 * u]; }
+          for (int u = 0; u < 4; ++u) { m[u] = M[lane + n * (j + NW * u)]; wj[u] = my_w[j + NW * u]; vj[u] = my_v[j + NW * u]; }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) M[lane + n * (j + 4 * u)] = m[u] - mul_conj(vi, wj[u]) - mul_conj(wi, vj[u]);
+          for (int u = 0; u < 4; ++u) M[lane + n * (j + NW * u)] = m[u] - mul_conj(vi, wj[u]) - mul_conj(wi, vj[u]);
         }
-        for (; j < n; j += 4) M[lane + n * j] = M[lane + n * j] - mul_conj(vi, my_w[j]) - mul_conj(wi, my_v[j]);
+        for (; j + NW < n; j += 2 * NW) {                          // (two columns per trip for the short tails)
+          const c64 m0 = M[lane + n * j], m1 = M[lane + n * (j + NW)];
+          const c64 w0 = my_w[j], w1 = my_w[j + NW], v0 = my_v[j], v1 = my_v[j + NW];
+          M[lane + n * j] = m0 - mul_conj(vi, w0) - mul_conj(wi, v0);
+          M[lane + n * (j + NW)] = m1 - mul_conj(vi, w1) - mul_conj(wi, v1);
+        }
+        for (; j < n; j += NW) M[lane + n * j] = M[lane + n * j] - mul_conj(vi, my_w[j]) - mul_conj(wi, my_v[j]);
       }
     }
     __syncthreads();
+    c_upd += clock64() - c1;
   }
   if (tid == 0) {
     S.d[n - 1] = M[n - 1 + n * (n - 1)].re; S.e[n - 1] = 0.0;
-    if (info) info[1] = (int)((clock64() - t_start) >> 6);
+    if (info) { info[1] = (int)((clock64() - t_start) >> 6); info[12] = (int)(c_refl >> 6); info[13] = (int)(c_mv >> 6); info[14] = (int)(c_upd >> 6); }
   }
 }
 
@@ -1261,7 +1278,7 @@ __global__ __launch_bounds__(256) void eigh_replay_kernel(int n, void* scratch, 
 //   K2  eigh_bisect_kernel       ALL eigenvalues by Sturm counts (negative pivots of T - x I, dstebz-style pivmin clamp): one wavefront per
 //                                eigenvalue, its 64 lanes cut the bracket into 65 parts per round (6 bits; ~9 rounds to eps ||T||)
 //   K3  music_subspace_kernel    after numDets is known (CFAR branch): block inverse iteration on T for the L largest eigenvalues -- one lane
-//                                per vector, Gaussian elimination with partial pivoting (dlagtf / dlagts), three rounds from pseudo-random
+//                                per vector, Gaussian elimination with partial pivoting (dlagtf / dlagts), two rounds from pseudo-random
 //                                start vectors with modified Gram-Schmidt in descending-eigenvalue order in between (exactly degenerate
 //                                clusters end up with an orthonormal basis of their eigenspace, like dstein) -- then U = Q Z through the
 //                                reflectors, one wavefront per vector
@@ -1353,6 +1370,8 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
     }
     return;
   }
+  const long long t_k0 = clock64();
+  long long t_solve = 0, t_mgs = 0;                                  // phase instrumentation (ISAC_DEBUG): cycles of thread 0
   const size_t plane = (size_t)n * lv;
   double* u0 = reinterpret_cast<double*>(smem_raw);                  // 1 / pivot
   double* u1 = u0 + plane;
@@ -1387,7 +1406,13 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
     }
   }
   __syncthreads();
-  for (int round = 0; round < 3; ++round) {
+  const long long t_k1 = clock64();
+  // Two rounds: with eigenvalues good to 2 eps ||T|| the first solve already leaves an error of ~1e-14, the second reaches working precision
+  // (oracle/subspace_music.py, ROUNDS: orthonormality and invariant-subspace residuals at 1e-16 after two rounds on every test spectrum,
+  // the exactly degenerate ones included -- dstein's own loop typically stops after two or three)
+  constexpr int kRounds = 2;
+  for (int round = 0; round < kRounds; ++round) {
+    const long long t_r0 = clock64();
     if (solver) {
       // ---- (T - lam I) y = x : elimination with row interchanges; the forward substitution rides along.  A lone wavefront pays every
       // LDS round trip in full, so the operands of step i + 1 are fetched before the dependent arithmetic of step i (they do not depend on it).
@@ -1437,9 +1462,11 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
       }
     }
     __syncthreads();
+    const long long t_r1 = clock64();
+    t_solve += t_r1 - t_r0;
     if (wid == 0) {
       // ---- modified Gram-Schmidt, descending-eigenvalue order (lanes = rows); twice after the last round
-      const int passes = round == 2 ? 2 : 1;
+      const int passes = round == kRounds - 1 ? 2 : 1;
       for (int p = 0; p < passes; ++p)
         for (int j = 0; j < L; ++j) {
           double zj[R];
@@ -1465,7 +1492,9 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
         }
     }
     __syncthreads();
+    t_mgs += clock64() - t_r1;
   }
+  const long long t_k2 = clock64();
   // ---- U = Q Z, Q = H_0 ... H_{n-2} (zungtr's product, applied to L vectors instead of formed): one wavefront per vector (two when
   // L > 16).  The reflectors come through LDS in chunks of 16 columns fetched by the whole workgroup (the dead elimination planes; the
   // next chunk's global loads fly under the current chunk's arithmetic): a wavefront that fetched its own columns from L2 step by step
@@ -1545,7 +1574,10 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
   if (tid == 0) {                                  // (no fence: the consumers are later kernels of the same stream)
     ctl[MusicCtl::kRoute] = 1;
     ctl[MusicCtl::kLsub] = L;
-    if (info) { info[0] = s_bad ? -3 : 0; info[5] = -3; }
+    if (info) {
+      info[0] = s_bad ? -3 : 0; info[5] = -3;
+      info[8] = (int)((t_k1 - t_k0) >> 6); info[9] = (int)(t_solve >> 6); info[10] = (int)(t_mgs >> 6); info[11] = (int)((clock64() - t_k2) >> 6);
+    }
   }
 }
 
@@ -1752,9 +1784,9 @@ static int launch_tridiag(isac_ctx* ctx, const c64* d_H, int n, hipStream_t st, 
   void* gs = ctx->eig_scratch.p;
   const size_t lds1 = sizeof(c64) * 6 * (size_t)n + sizeof(double) * 32 + 64;
   if (n <= 64) {       // four waves, two barriers per step, matrix in LDS (the general kernel with its matrix in LDS: 222 us at n = 64; this one ~120)
-    const size_t ldss = sizeof(c64) * ((size_t)n * n + 4 * 64 + 4 * 2 * 64) + sizeof(double) * 32 + 64;
-    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_tridiag_small_kernel), (size_t)(100 * 1024)));
-    hipLaunchKernelGGL(eigh_tridiag_small_kernel, dim3(1), dim3(256), ldss, st, d_H, n, gs, info);
+    const size_t ldss = sizeof(c64) * ((size_t)n * n + kTriWaves * 64 + kTriWaves * 2 * 64) + sizeof(double) * 32 + 64;
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_tridiag_small_kernel), (size_t)(112 * 1024)));
+    hipLaunchKernelGGL(eigh_tridiag_small_kernel, dim3(1), dim3(64 * kTriWaves), ldss, st, d_H, n, gs, info);
   } else {
     hipLaunchKernelGGL(eigh_tridiag_kernel<false>, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
   }

@@ -17,6 +17,8 @@ import numpy as np
 from .matlab_compat import EPS, sind, mag2db, findpeaks
 from .music import ula_scan_angles
 
+ROUNDS = 2          # inverse-iteration rounds of the device kernel (music_subspace_kernel)
+
 
 def householder_tridiag(h):
     """zhetd2 (lower): A = Q T Q^H, Q = H_0 ... H_{n-2}, H_k = I - tau_k v_k v_k^H.  Returns d [n], e [n-1] (real), V (v_k in
@@ -149,7 +151,7 @@ def start_vector(n, j):
     return out
 
 
-def signal_vectors_tridiag(d, e, w, n_sig, rounds=3):
+def signal_vectors_tridiag(d, e, w, n_sig, rounds=ROUNDS):
     """Orthonormal basis Z [n x n_sig] (real) of the invariant subspace of the n_sig largest eigenvalues of tridiag(d, e)."""
     n = d.size
     lam = w[::-1][:n_sig]                                     # descending
