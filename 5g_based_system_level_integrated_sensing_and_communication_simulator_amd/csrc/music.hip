@@ -825,7 +825,7 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
 // matrix-vector product (partials exchanged through LDS: barrier 1) and of the rank-2 update (barrier 2 before the next step reads the
 // updated column).  The matrix lives in LDS, the reflectors go straight to the scratch zungtr reads.  222 -> ~120 us at n = 64
 // (host-call time of the whole eigensolver 0.905 -> 0.807 ms).
-constexpr int kTriWaves = 8;       // wavefronts of eigh_tridiag_small_kernel (four: 124 us at n = 64, 46 % of it the rank-2 update of 16 columns per wave)
+constexpr int kTriWaves = 4;       // wavefronts of eigh_tridiag_small_kernel (eight: the same 124 us at n = 64 -- every step is a chain of LDS round trips, DPP sums and two barriers, ~5 000 cycles whatever the column count per wave)
 __global__ __launch_bounds__(64 * kTriWaves) void eigh_tridiag_small_kernel(const c64* __restrict__ Hin, int n, void* scratch, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int NW = kTriWaves;
@@ -1807,7 +1807,10 @@ static int launch_ql(isac_ctx* ctx, int n, hipStream_t st, int* info, const int*
   const size_t lds3 = rows3 + stage3;
   const bool lds_replay = rows3 <= 150 * 1024 && n <= 8 * bt;
   static const bool no_overlap = std::getenv("ISAC_EIG_NO_OVERLAP") != nullptr;   // development switch
-  const bool live = lds_replay && !no_overlap;       // replay blocks ride along with zungtr and the recurrence
+  // Replay blocks ride along with zungtr and the recurrence (they spin on flags of the same launch: co-resident workgroups are a speed
+  // assumption, a bounded spin turns a violation into an error) -- except when this is the in-stream fallback of the subspace route
+  // (ctl != null): there the replay is its own launch behind the recurrence, so the rare large-numDets CPI cannot fail on a spin time-out
+  const bool live = lds_replay && !no_overlap && ctl == nullptr;
   const int n_replay = (2 * n + bt - 1) / bt;
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_formq_ql_kernel), (size_t)(160 * 1024)));
   hipLaunchKernelGGL(eigh_formq_ql_kernel, dim3(live ? 2 + n_replay : 2), dim3(1024), live ? std::max(lds2, lds3) : lds2, st, n, gs,

@@ -95,9 +95,10 @@ def main():
     t = {"setup": 0.0, "los": 0.0, "sensing": 0.0, "cdl": 0.0, "cqi": 0.0}
     recs, extra = [], []
     t_all = time.perf_counter()
+    pool = bench.SlotPool(pkg, local_rank, 1)               # one context for all cells of this rank (its scratch, tables and kernel attributes are set up once)
     for c in mine:
         t0 = time.perf_counter()
-        cell = bench.Cell(pkg, local_rank, c, args.ants, args.slots, args.targets, inflight=1)
+        cell = bench.Cell(pkg, local_rank, c, args.ants, args.slots, args.targets, pool=pool, n_buf=1)
         ctx = cell.ctx
         plans, heights, ue = cell_layout(c, args.ues, args.targets)
         town = B.city.from_floor_plans(plans, heights, ctx=ctx)
