@@ -296,6 +296,148 @@ __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_ran
   else fft.drain(put, tid);
 }
 
+// Straight-line form of the same kernel for QT = 1..4.  The column loop above branches on `j < n_el` (uniform) and on `k < K` (per lane,
+// around the echoGrid store); SIInsertWaitcnts merges the pending-memory state conservatively at every join, and the ISA of that
+// form waits with `s_waitcnt vmcnt(0)` in front of EVERY element -- for the next group's loads just issued and for the acknowledgement
+// of the previous element's store (gfx9: one in-order counter for loads and stores).  Here no vector-memory instruction sits inside a
+// conditional: all eight elements of a thread are processed (loads at a clamped index, as before), the store is a raw buffer store
+// whose descriptor ends at the column's K-th element (lanes with k >= K are dropped by the bounds check), and the waits come out as
+// exact `vmcnt(N)` counts that leave the younger loads and every store in flight.
+//   PRO:   the three table loads (log table, W512, W4096^0..7) and the first load group are issued together, one wait (the form
+//          above: three load -> wait -> ds_write round trips in a row, the column's first loads only after the barrier);
+//   SPLIT: the generator runs per load group (draw group g under its loads, issue group g + 1, consume g) instead of all up front.
+
+template <int QT, int NZ, int PRO, bool SPLIT, int GROUP = (QT <= 1 ? 4 : 2)>
+__global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_range_kernel_sl(int K, int L_whole, int L_out, int A, int Q_rt, const c64* D,
+                                                            const c64* __restrict__ steer_rq, double sig, uint64_t seed,
+                                                            const c64* noise, const c64* __restrict__ tw,
+                                                            const c64* __restrict__ logtab_g, c64* grid,
+                                                            const c64* txg, const double* win_k,
+                                                            const double* __restrict__ win_r, double inv_n, double sqrt_n,
+                                                            int row_lo, int n_rows, c64* __restrict__ ymid) {
+  static_assert(QT >= 1 && QT <= 4, "compile-time target count");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* lds = reinterpret_cast<c64*>(smem_raw);
+  using FFT = Fft4096W;
+  constexpr int NT = FFT::NT, PER = FFT::PER, NG = PER / GROUP, WS = FFT::kW256Stride;
+  const int tid = threadIdx.x;
+  FFT fft;
+  int l, r;
+  if (!spectral_tile_map(blockIdx.x, L_whole, A, l, r)) return;       // padding workgroup of the tile grid (before any barrier)
+  const long long colg = (long long)l + (long long)L_out * r;
+  c64* lt = lds + FFT::LDS_ELEMS;
+  const c64* w256 = lds + FFT::IMG;
+  const c64* Dl = D + (long long)K * l;
+  const long long d_stride = (long long)K * L_whole;
+  const c64* ptx = txg + (long long)K * colg;
+  const c64* nzc = NZ == 2 ? noise + (long long)K * colg : nullptr;
+  const __amdgpu_buffer_rsrc_t rs_dst = buffer_of(grid + (long long)K * colg, (unsigned)K * (unsigned)sizeof(c64));
+  c64 s[QT];
+#pragma unroll
+  for (int q = 0; q < QT; ++q) s[q] = steer_rq[(long long)r * QT + q];   // uniform: scalar registers
+  struct Ld { c64 tx; double w; c64 d[QT]; c64 nz; };
+  Ld ld[2][GROUP];
+  auto load_group = [&](int g, int b) {
+#pragma unroll
+    for (int u = 0; u < GROUP; ++u) {
+      const int k = tid + NT * (g * GROUP + u);
+      const int kc = k < K ? k : K - 1;                                 // unconditional loads, select afterwards
+      Ld& e = ld[b][u];
+      e.tx = ptx[kc];
+      e.w = win_k[kc];
+      if constexpr (NZ == 2) e.nz = nzc[kc];
+#pragma unroll
+      for (int q = 0; q < QT; ++q) e.d[q] = Dl[(long long)q * d_stride + kc];
+    }
+  };
+  // `asm volatile("" ::: "memory")`: a compiler-only fence.  The instruction selector is free to sink a load towards its first use
+  // (sched_barrier only binds the machine scheduler); nothing moves across a statement that may touch memory.
+#define ISAC_PIN_ORDER() asm volatile("" ::: "memory")
+  if constexpr (PRO != 0) {
+    c64 t_log = mk(0.0, 0.0);
+    if constexpr (NZ == 1) t_log = logtab_g[tid & (kLogTabSize - 1)];
+    const c64 t_w = tw[tid], t_w8 = tw[512 + (tid & 7)];
+    ISAC_PIN_ORDER();
+    if constexpr (PRO == 1) { load_group(0, 0); ISAC_PIN_ORDER(); }
+    if constexpr (NZ == 1) lt[tid & (kLogTabSize - 1)] = t_log;         // (four lanes write the same value to a slot)
+    lds[FFT::IMG + tid] = t_w;
+    lds[FFT::IMG + 512 + (tid & 7)] = t_w8;
+    __syncthreads();
+    if constexpr (PRO == 2) { load_group(0, 0); ISAC_PIN_ORDER(); }
+  } else {
+    if (NZ == 1 && tid < kLogTabSize) lt[tid] = logtab_g[tid];
+    fft.init_table(lds, tw, tid);
+    load_group(0, 0);
+    ISAC_PIN_ORDER();
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < PER; ++j) fft.x[j] = mk(0.0, 0.0);               // unit noise first, then the range-IFFT input
+  const int wave_k0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+  auto draw = [&](int c) {                                              // one Philox call: elements 2c, 2c + 1 (echo_dev.hpp pairing)
+    if constexpr (NZ == 1) {
+      const int j0 = 2 * c, j1 = j0 + 1;
+      if (wave_k0 + NT * j0 < K) {                                      // (wavefront-uniform; VALU only inside)
+        const uint64_t ctr = (uint64_t)(tid + NT * c) + (uint64_t)kSpectralSlotsPerColumn * (uint64_t)colg;
+        uint32_t o[4];
+        philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), kSpectralStream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+        fft.x[j0] = box_muller32_tab<WS>(o[0], o[1], w256, lt);
+        if (wave_k0 + NT * j1 < K) fft.x[j1] = box_muller32_tab<WS>(o[2], o[3], w256, lt);
+      }
+    }
+  };
+  bool live = false;
+  auto consume = [&](int g, int b) {
+#pragma unroll
+    for (int u = 0; u < GROUP; ++u) {
+      const int j = g * GROUP + u, k = tid + NT * j;
+      const Ld& e = ld[b][u];
+      c64 v = mk(0.0, 0.0);
+#pragma unroll
+      for (int q = 0; q < QT; ++q) v = fma(e.d[q], s[q], v);
+      if constexpr (NZ == 1) v = v + fft.x[j] * sig;
+      if constexpr (NZ == 2) v = v + e.nz * sig;
+      buffer_store_c64_nt(rs_dst, (unsigned)k * (unsigned)sizeof(c64), v);            // echoGrid(k, l, r); k >= K: dropped by the bounds check
+      c64 y = mul_conj(v, e.tx) * e.w;                                  // fft2D.m:37,:43 (same order as range_kernel)
+      y = k < K ? y : mk(0.0, 0.0);                                     // ifft(., nIFFT, 1) zero-pads at the end
+      live |= (y.re != 0.0) | (y.im != 0.0);
+      fft.x[j] = y;
+    }
+  };
+  if constexpr (!SPLIT) {
+#pragma unroll
+    for (int c = 0; c < PER / 2; ++c) draw(c);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int c = g * GROUP / 2; c < (g + 1) * GROUP / 2; ++c) draw(c);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (g + 1 < NG) { load_group(g + 1, (g + 1) & 1); ISAC_PIN_ORDER(); }
+    consume(g, g & 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef ISAC_PIN_ORDER
+  c64* yd = ymid + (long long)n_rows * colg;
+  if (!__syncthreads_or(live)) {                                        // zero-filled 'S' slot column (see echo_range_kernel)
+    for (int rr = tid; rr < n_rows; rr += NT) yd[rr] = mk(0.0, 0.0);
+    return;
+  }
+  fft.init_twiddles_lds(lds, tid);
+  const int blk = FFT::block_of_rows(row_lo, n_rows);
+  fft.template transform<+1>(lds, tw, tid, blk);
+  auto put = [&](int n, c64 v) {
+    const int rr = n - row_lo;
+    const double wr = win_r[n];
+    if (rr >= 0 && rr < n_rows) yd[rr] = ((v * inv_n) * sqrt_n) * wr;            // fft2D.m:44-45
+  };
+  if (blk >= 0) fft.drain_block(put, tid, blk);
+  else fft.drain(put, tid);
+}
+
 // ---------------------------------------------------------------- CP-OFDM modulator
 // Placement of one call's L symbols inside larger arrays (senTx accumulation, gNBPhy.m:604-612): the grid may be a column
 // range [l_off, l_off + L) of planes with `grid_cols` columns, the waveform a sample range starting at t_off of columns with
@@ -726,8 +868,20 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
                        logtab, (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, 1.0 / ep->n_ifft, std::sqrt((double)ep->n_ifft),   \
                        row_lo, nr, (c64*)ctx->ymid.p);                                                                               \
   } while (0)
-#define ISAC_SPEC_Q(QT) do { if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL) ISAC_SPEC(QT, 1); else ISAC_SPEC(QT, 2); } while (0)
-    switch (Q) { case 1: ISAC_SPEC_Q(1); break; case 2: ISAC_SPEC_Q(2); break; case 3: ISAC_SPEC_Q(3); break; case 4: ISAC_SPEC_Q(4); break; default: ISAC_SPEC_Q(0); break; }
+#define ISAC_SPEC_SL(QT, NZ, PRO, SPLIT)                                                                                              \
+  do {                                                                                                                               \
+    auto kern = echo_range_kernel_sl<QT, NZ, PRO, SPLIT>;                                                                            \
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));                                                              \
+    hipLaunchKernelGGL(kern, gr, bl, lds, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, (const c64*)d_noise_unit, tw,   \
+                       logtab, (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, 1.0 / ep->n_ifft, std::sqrt((double)ep->n_ifft),   \
+                       row_lo, nr, (c64*)ctx->ymid.p);                                                                               \
+  } while (0)
+    static const int er_variant = [] { const char* e = getenv("ISAC_ER_VARIANT"); return e ? atoi(e) : 0; }();
+#define ISAC_SPEC_V(QT, NZ) do { switch (er_variant) { case 1: ISAC_SPEC_SL(QT, NZ, 0, false); break; case 2: ISAC_SPEC_SL(QT, NZ, 1, false); break; \
+      case 3: ISAC_SPEC_SL(QT, NZ, 2, false); break; case 4: ISAC_SPEC_SL(QT, NZ, 0, true); break; case 5: ISAC_SPEC_SL(QT, NZ, 2, true); break; default: ISAC_SPEC(QT, NZ); } } while (0)
+#define ISAC_SPEC_Q(QT) do { if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL) ISAC_SPEC_V(QT, 1); else ISAC_SPEC_V(QT, 2); } while (0)
+    if (Q > 4) { if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL) ISAC_SPEC(0, 1); else ISAC_SPEC(0, 2); } else
+    switch (Q) { case 1: ISAC_SPEC_Q(1); break; case 2: ISAC_SPEC_Q(2); break; case 3: ISAC_SPEC_Q(3); break; case 4: ISAC_SPEC_Q(4); break; default: break; }
 #undef ISAC_SPEC_Q
 #undef ISAC_SPEC
     ISAC_HIP(hipGetLastError());

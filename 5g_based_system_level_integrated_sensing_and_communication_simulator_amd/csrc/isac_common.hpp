@@ -41,6 +41,27 @@ __host__ __device__ inline c64 fma(c64 a, c64 b, c64 c) {  // a*b + c
   return {::fma(a.re, b.re, ::fma(-a.im, b.im, c.re)), ::fma(a.re, b.im, ::fma(a.im, b.re, c.im))};
 }
 
+// ---------------------------------------------------------------- raw buffer access (bounds-checked by the hardware)
+// A buffer descriptor over [base, base + bytes): loads past the end return zero and stores past the end are dropped, so a ragged edge
+// needs no branch around the memory instruction (a branch around one makes the compiler's s_waitcnt bookkeeping pessimistic: every
+// later wait becomes vmcnt(0)).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kBufferRsrcFlags = 0x00020000;         // gfx9 raw buffer: DATA_FORMAT = 32 (dword 3 of the descriptor)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* base, unsigned bytes) {
+  // `base` / `bytes` must be wavefront-uniform.  readfirstlane pins them to scalar registers: a descriptor the compiler cannot prove
+  // uniform (e.g. a size that went through a 64-bit VALU multiply) turns every access into a waterfall loop.
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  void* ub = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (int)__builtin_amdgcn_readfirstlane(bytes), kBufferRsrcFlags);
+}
+__device__ __forceinline__ c64 buffer_load_c64(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+  return __builtin_bit_cast(c64, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ void buffer_store_c64_nt(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, c64 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), rs, (int)byte_off, 0, /*nt*/ 2);
+}
+
 // ---------------------------------------------------------------- context
 struct DevBuf {
   void* p = nullptr;

@@ -250,17 +250,156 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_small_kernel(const c64* __res
 // a register-operand version of this kernel, 20 strided global loads per wave and slab: 6.4 ms.)
 constexpr int kCovPitch = 17;                                   // complex elements per (block, sample) row
 constexpr int kCovBufElems = 8 * 16 * kCovPitch;                // one slab image: 8 antenna blocks x 16 samples
-__constant__ unsigned char kCovDiagTiles[4][4] = {              // 16*I + J per (wave, slot); 255 = idle
-    {0x00, 0x01, 0x02, 255}, {0x03, 0x11, 0x12, 255}, {0x13, 0x22, 255, 255}, {0x23, 0x33, 255, 255}};
+constexpr unsigned kCovOobOffset = 0x80000000u;                 // beyond every staging descriptor (N * 256 B < 2^31, checked by the launcher)
+__constant__ unsigned char kCovDiagTiles[4][4] = {              // 16*I + J per (wave, slot); 255 = idle.  Slot 0 = the wave's diagonal tile
+    {0x00, 0x01, 0x02, 255}, {0x11, 0x03, 0x12, 255}, {0x22, 0x13, 255, 255}, {0x33, 0x23, 255, 255}};
+
+// One block pair.  DIAG (BI == BJ) is a template parameter so that the staging loop has a compile-time trip count: with a run-time
+// `j < n_stage` around the loads the wait-count pass gave up at every join and each stash waited with vmcnt(0) -- for the slab it needs AND
+// for the one issued a trip later, i.e. the second slab in flight never was.  Off-diagonal pairs also lose the operand selects of the
+// diagonal-tile form (VALU instructions are paid in full beside v_mfma_f64).
+template <bool DIAG>
+__device__ __forceinline__ void cov_block_pair(const c64* __restrict__ G, long long N, int A, int BI, int BJ, int pair, int chunk, int n_pairs,
+                                               long long slabs_per_wg, double* __restrict__ part, c64* __restrict__ lds) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  // tiles of this wave: (I, J) inside the 64 x 64 block
+  int tI[4], tJ[4];
+  bool tv[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int code = DIAG ? (int)kCovDiagTiles[wid][u] : (16 * wid + u);
+    tv[u] = !DIAG || code != 255;
+    tI[u] = tv[u] ? (code >> 4) : 0;
+    tJ[u] = tv[u] ? (code & 15) : 0;
+  }
+  constexpr int jbase = DIAG ? 0 : 4;               // LDS blocks 0..3 = antenna block BI, 4..7 = BJ (absent on diagonal pairs)
+  // staging ownership: flat = j*256 + tid -> antenna slot flat/16 (0..127), sample flat%16
+  constexpr int NS = DIAG ? 4 : 8;                  // loads per thread and slab
+  const int s_smp = tid & 15, l16 = tid >> 4;
+  // Staging step j reads antennas 64 B + 16 (j & 3) + (0..15) of block B = (j < 4 ? BI : BJ): one raw-buffer descriptor per step (uniform:
+  // scalar registers) that ends with the array's last antenna, so that padding antennas read as zero by the bounds check -- per thread
+  // the address is ONE 32-bit offset (N l16 + n) for all NS loads, the LDS address one base + immediate offsets.
+  __amdgpu_buffer_rsrc_t s_rs[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int ant0 = 64 * (j < 4 ? BI : BJ) + 16 * (j & 3);
+    int n_ant = A - ant0;
+    n_ant = n_ant < 0 ? 0 : (n_ant > 16 ? 16 : n_ant);
+    s_rs[j] = buffer_of(G + N * (long long)(ant0 < A ? ant0 : 0), (unsigned)(N * n_ant * (long long)sizeof(c64)));
+  }
+  const int s_lds0 = s_smp * kCovPitch + l16;       // + j * 16 * kCovPitch
+  // 3M form, as in cov_group_body: off-diagonal tile re = S1, im = S2, s3 = S3; diagonal tile (slot 0 of every wave of a diagonal block
+  // pair: a compile-time property, so neither selects nor branch-dependent accumulator moves) re + s3 = Re, im = M.
+  v4f64 re[4], im[4], s3[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) re[u] = im[u] = s3[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+  const long long total = (N + 15) / 16;
+  const long long s_begin = (long long)chunk * slabs_per_wg;
+  long long s_end = s_begin + slabs_per_wg;
+  if (s_end > total) s_end = total;
+  // Two slabs of global loads in flight (register sets gA / gB in rotation): one slab of MFMAs is ~1.3 us, less than a loaded HBM round
+  // trip -- with a single prefetched slab (round 2) the stash of slab s + 1 still waited for its loads (0.52 of the MFMA peak at A = 256).
+  // Samples past N and whole slabs past the chunk's end are fetched at an offset beyond every descriptor: they read as zero without a
+  // select behind the load (a select is a use of the loaded value and puts the wait for it right there) and without memory traffic.
+  c64 gA[NS], gB[NS];
+  auto fetch = [&](c64 (&g)[NS], long long slab) {
+    const long long n = slab * 16 + s_smp;
+    const unsigned voff = (n < N && slab < s_end) ? (unsigned)((N * l16 + n) * (long long)sizeof(c64)) : kCovOobOffset;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) g[j] = buffer_load_c64(s_rs[j], voff);
+  };
+  auto stash = [&](const c64 (&g)[NS], int buf) {
+    c64* d = lds + buf * kCovBufElems + s_lds0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) d[j * 16 * kCovPitch] = g[j];
+  };
+  auto mfmas = [&](int buf) {
+    const c64* cur = lds + buf * kCovBufElems;
+    if constexpr (!DIAG) {
+      // off-diagonal pair: wave w owns tile row w (tI = w, tJ = 0..3) -- the row operand is read once per sample quad and shared by
+      // the four tiles: 20 instead of 32 ds_read_b128 per slab, and the operand registers of one quad at a time
+      const c64* pa = cur + ((wid * 16 + 4 * kq) * kCovPitch + li);
+      const c64* pb = cur + ((jbase * 16 + 4 * kq) * kCovPitch + li);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const c64 xa = pa[e * kCovPitch];
+        const double dm = xa.re - xa.im;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const c64 xb = pb[(u * 16 + e) * kCovPitch];
+          re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xb.re, re[u], 0, 0, 0);
+          im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.im, xb.im, im[u], 0, 0, 0);
+          s3[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(dm, xb.re + xb.im, s3[u], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // operand reads of at most one quad ahead of their MFMAs (register budget)
+      }
+    } else {
+      {                                             // slot 0: the wave's diagonal tile -- Gr Gr', M = Gr Gi', Gi Gi'
+        const c64* pa = cur + ((tI[0] * 16 + 4 * kq) * kCovPitch + li);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const c64 xa = pa[e * kCovPitch];
+          re[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xa.re, re[0], 0, 0, 0);
+          im[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xa.im, im[0], 0, 0, 0);
+          s3[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.im, xa.im, s3[0], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int u = 1; u < 3; ++u) {                 // slots 1, 2: off-diagonal tiles (slot 2 on waves 0 and 1 only; slot 3 is never used)
+        if (u == 2 && !tv[2]) continue;             // (wave-uniform)
+        const c64* pa = cur + ((tI[u] * 16 + 4 * kq) * kCovPitch + li);
+        const c64* pb = cur + ((tJ[u] * 16 + 4 * kq) * kCovPitch + li);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const c64 xa = pa[e * kCovPitch], xb = pb[e * kCovPitch];
+          re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xb.re, re[u], 0, 0, 0);
+          im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.im, xb.im, im[u], 0, 0, 0);
+          s3[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re - xa.im, xb.re + xb.im, s3[u], 0, 0, 0);
+        }
+      }
+    }
+  };
+  // Two trips per iteration, no exit in the middle (an odd slab count runs one all-zero slab): the accumulators keep their registers
+  // over the back-edge -- with a mid-loop exit the compiler moved all twelve of them, 48 v_mov_b64 per trip, paid in full beside the MFMAs.
+  if (s_begin < s_end) {
+    fetch(gA, s_begin);
+    stash(gA, 0);
+    fetch(gA, s_begin + 1);
+    fetch(gB, s_begin + 2);
+  }
+  __syncthreads();
+  for (long long slab = s_begin; slab < s_end; slab += 2) {
+    // even trip: slab from buffer 0; gA holds slab + 1 (issued two trips ago), gB slab + 2 (in flight)
+    mfmas(0);
+    stash(gA, 1);
+    fetch(gA, slab + 3);
+    __syncthreads();
+    // odd trip: slab + 1 from buffer 1; gB holds slab + 2
+    mfmas(1);
+    stash(gB, 0);
+    fetch(gB, slab + 4);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (DIAG && !tv[u]) continue;
+    const bool td = DIAG && u == 0;
+    double* o = part + ((((long long)chunk * n_pairs + pair) * 16 + (tI[u] * 4 + tJ[u])) * 2) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[r * 64 + lane] = td ? re[u][r] + s3[u][r] : re[u][r] + im[u][r];
+      o[256 + r * 64 + lane] = td ? im[u][r] /* M: antisymmetrised by cov_block_reduce_kernel */ : (s3[u][r] - re[u][r]) + im[u][r];
+    }
+  }
+}
 
 __global__ __launch_bounds__(256, 2) void cov_mfma_block_kernel(const c64* __restrict__ G, long long N, int A, int n_blk,
                                                                 int n_pairs, long long slabs_per_wg,
                                                                 double* __restrict__ part /* [chunk][pair][16][2][256] */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);      // [2][kCovBufElems]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, kq = lane >> 4;
   // (pinning the block pairs of one sample chunk to one XCD -- workgroup b runs on XCD b % 8 -- so that a chunk's slabs enter ONE L2: 3.71 ->
   // 4.11 ms at A = 256, no change at A = 128: the diagonal pairs run 1.6x faster than the off-diagonal ones and drift out of the L2 window)
   const int pair = blockIdx.x % n_pairs, chunk = blockIdx.x / n_pairs;
@@ -270,114 +409,8 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_block_kernel(const c64* __res
     while (rem >= n_blk - BI) { rem -= n_blk - BI; ++BI; }
     BJ = BI + rem;
   }
-  const bool diag = BI == BJ;
-  // tiles of this wave: (I, J) inside the 64 x 64 block
-  int tI[4], tJ[4];
-  bool tv[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int code = diag ? (int)kCovDiagTiles[wid][u] : (16 * wid + u);
-    tv[u] = code != 255;
-    tI[u] = tv[u] ? (code >> 4) : 0;
-    tJ[u] = tv[u] ? (code & 15) : 0;
-  }
-  const int jbase = diag ? 0 : 4;                   // LDS blocks 0..3 = antenna block BI, 4..7 = BJ (absent on diagonal pairs)
-  // staging ownership: flat = j*256 + tid -> antenna slot flat/16 (0..127), sample flat%16
-  const int n_stage = diag ? 4 : 8;                 // loads per thread and slab
-  const int s_smp = tid & 15;
-  const c64* s_col[8];
-  bool s_ok[8];
-  int s_lds[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int slot = j * 16 + (tid >> 4);           // 0..127
-    const int blk = slot >> 4, l16 = slot & 15;
-    const int ant = 64 * (blk < 4 ? BI : BJ) + 16 * (blk & 3) + l16;
-    s_ok[j] = ant < A;
-    s_col[j] = G + N * (long long)(s_ok[j] ? ant : 0);
-    s_lds[j] = (blk * 16 + s_smp) * kCovPitch + l16;
-  }
-  // 3M form, as in cov_group_body: off-diagonal tile re = S1, im = S2, s3 = S3; diagonal tile (of a diagonal block pair) re + s3 = Re,
-  // im = M.  Which form a tile takes is wave-uniform but only known at run time here: the operands are selected, not branched on.
-  bool td[4];
-  v4f64 re[4], im[4], s3[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    re[u] = im[u] = s3[u] = v4f64{0.0, 0.0, 0.0, 0.0};
-    td[u] = diag && tI[u] == tJ[u];
-  }
-  const long long total = (N + 15) / 16;
-  const long long s_begin = (long long)chunk * slabs_per_wg;
-  long long s_end = s_begin + slabs_per_wg;
-  if (s_end > total) s_end = total;
-  // Two slabs of global loads in flight (register sets gA / gB in rotation): one slab of MFMAs is ~1.3 us, less than a loaded HBM round
-  // trip -- with a single prefetched slab (round 2) the stash of slab s + 1 still waited for its loads (0.52 of the MFMA peak at A = 256).
-  c64 gA[8], gB[8];
-  auto fetch = [&](c64 (&g)[8], long long slab) {
-    long long n = slab * 16 + s_smp;
-    const bool in = n < N;
-    if (!in) n = N - 1;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (j < n_stage) {                            // (uniform)
-        const c64 v = s_col[j][n];
-        g[j] = (in && s_ok[j]) ? v : mk(0.0, 0.0);
-      }
-    }
-  };
-  auto stash = [&](const c64 (&g)[8], int buf) {
-    c64* d = lds + buf * kCovBufElems;
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      if (j < n_stage) d[s_lds[j]] = g[j];
-  };
-  auto mfmas = [&](int buf) {
-    const c64* cur = lds + buf * kCovBufElems;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (!tv[u]) continue;                         // (wave-uniform)
-      const c64* pa = cur + ((tI[u] * 16 + 4 * kq) * kCovPitch + li);
-      const c64* pb = cur + (((jbase + tJ[u]) * 16 + 4 * kq) * kCovPitch + li);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const c64 xa = pa[e * kCovPitch], xb = pb[e * kCovPitch];
-        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xb.re, re[u], 0, 0, 0);
-        im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(td[u] ? xa.re : xa.im, xb.im, im[u], 0, 0, 0);
-        s3[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(td[u] ? xa.im : xa.re - xa.im, td[u] ? xb.im : xb.re + xb.im, s3[u], 0, 0, 0);
-      }
-    }
-  };
-  const long long last = s_end - 1;                 // (loads past the chunk re-read its last slab: unconditional, never consumed)
-  if (s_begin < s_end) {
-    fetch(gA, s_begin);
-    stash(gA, 0);
-    fetch(gA, s_begin + 1 < s_end ? s_begin + 1 : last);
-    fetch(gB, s_begin + 2 < s_end ? s_begin + 2 : last);
-  }
-  __syncthreads();
-  for (long long slab = s_begin; slab < s_end; slab += 2) {
-    // even trip: slab from buffer 0; gA holds slab + 1 (issued two trips ago), gB slab + 2 (in flight)
-    mfmas(0);
-    if (slab + 1 < s_end) stash(gA, 1);
-    fetch(gA, slab + 3 < s_end ? slab + 3 : last);
-    __syncthreads();
-    if (slab + 1 >= s_end) break;
-    // odd trip: slab + 1 from buffer 1; gB holds slab + 2
-    mfmas(1);
-    if (slab + 2 < s_end) stash(gB, 0);
-    fetch(gB, slab + 4 < s_end ? slab + 4 : last);
-    __syncthreads();
-  }
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (!tv[u]) continue;
-    double* o = part + ((((long long)chunk * n_pairs + pair) * 16 + (tI[u] * 4 + tJ[u])) * 2) * 256;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      o[r * 64 + lane] = td[u] ? re[u][r] + s3[u][r] : re[u][r] + im[u][r];
-      o[256 + r * 64 + lane] = td[u] ? im[u][r] /* M: antisymmetrised by cov_block_reduce_kernel */ : (s3[u][r] - re[u][r]) + im[u][r];
-    }
-  }
+  if (BI == BJ) cov_block_pair<true>(G, N, A, BI, BJ, pair, chunk, n_pairs, slabs_per_wg, part, lds);
+  else cov_block_pair<false>(G, N, A, BI, BJ, pair, chunk, n_pairs, slabs_per_wg, part, lds);
 }
 
 // fixed-order sum over the sample chunks of one tile + Hermitian fill + 1/N (block layout of cov_mfma_block_kernel)
@@ -1763,7 +1796,9 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
     long long n_chunks = 1024 / n_pairs;              // ~4 workgroups per CU over the launch, 2 resident
     if (n_chunks < 1) n_chunks = 1;
     if (n_chunks > total) n_chunks = total;
-    const long long per = (total + n_chunks - 1) / n_chunks;
+    if (N * 256 >= (1ll << 31)) return fail(ctx, ISAC_ERR_UNSUPPORTED, "covariance of more than 64 antennas: at most 2^23 - 1 samples per antenna");
+    long long per = (total + n_chunks - 1) / n_chunks;
+    per = (per + 1) & ~1ll;                           // the kernel walks slabs in pairs
     n_chunks = (total + per - 1) / per;
     ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * (size_t)n_chunks * n_pairs * 16 * 2 * 256));
     const size_t lds = sizeof(c64) * 2 * kCovBufElems;
