@@ -296,26 +296,27 @@ __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_ran
   else fft.drain(put, tid);
 }
 
-// Straight-line form of the same kernel for QT = 1..4.  The column loop above branches on `j < n_el` (uniform) and on `k < K` (per lane,
-// around the echoGrid store); SIInsertWaitcnts merges the pending-memory state conservatively at every join, and the ISA of that
-// form waits with `s_waitcnt vmcnt(0)` in front of EVERY element -- for the next group's loads just issued and for the acknowledgement
-// of the previous element's store (gfx9: one in-order counter for loads and stores).  Here no vector-memory instruction sits inside a
-// conditional: all eight elements of a thread are processed (loads at a clamped index, as before), the store is a raw buffer store
-// whose descriptor ends at the column's K-th element (lanes with k >= K are dropped by the bounds check), and the waits come out as
-// exact `vmcnt(N)` counts that leave the younger loads and every store in flight.
-//   PRO:   the three table loads (log table, W512, W4096^0..7) and the first load group are issued together, one wait (the form
-//          above: three load -> wait -> ds_write round trips in a row, the column's first loads only after the barrier);
-//   SPLIT: the generator runs per load group (draw group g under its loads, issue group g + 1, consume g) instead of all up front.
-
-template <int QT, int NZ, int PRO, bool SPLIT, int GROUP = (QT <= 1 ? 4 : 2)>
-__global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_range_kernel_sl(int K, int L_whole, int L_out, int A, int Q_rt, const c64* D,
+// Straight-line form of the same kernel for one or two LoS targets (the bench shape and most scenes).  The column loop above branches on
+// `j < n_el` (uniform) and on `k < K` (per lane, around the echoGrid store); SIInsertWaitcnts merges the pending-memory state conservatively at
+// every join, and the ISA of that form waits with `s_waitcnt vmcnt(0)` in front of EVERY element -- for the next group's loads just issued and
+// for the acknowledgement of the previous element's store (gfx9: one in-order counter for loads and stores).  Here no vector-memory instruction
+// sits inside a conditional: all eight elements of a thread are processed (loads at a clamped index, as before), the store is a raw buffer store
+// whose descriptor ends at the column's K-th element (lanes with k >= K are dropped by the bounds check), and the waits come out as exact
+// `vmcnt(N)` counts that leave the younger loads and every store in flight: 0.395 -> 0.374 ms.  With the waits exact the generator can be cut
+// in two: draw group g under its own loads, issue group g + 1, consume g (the form above draws everything up front, so that the second
+// group's loads were covered by the first group's four stores only): 0.374 -> 0.333-0.349 ms, 0.479 -> 0.405 ms with two targets; same bits.
+// (Pointers that are loaded from between stores are NOT __restrict__: an invariant load may be sunk to its first use -- below the
+// stores of the group before -- and neither sched_barrier nor a compiler fence holds it.  With three or four targets the straight-line form
+// holds 2 x GROUP x (6 + 4 Q) load registers beside the generator and spills: those counts stay on the kernel above, as measured.)
+template <int QT, int NZ, int GROUP = (QT <= 1 ? 4 : 2)>
+__global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_range_sl_kernel(int K, int L_whole, int L_out, int A, const c64* D,
                                                             const c64* __restrict__ steer_rq, double sig, uint64_t seed,
                                                             const c64* noise, const c64* __restrict__ tw,
                                                             const c64* __restrict__ logtab_g, c64* grid,
                                                             const c64* txg, const double* win_k,
                                                             const double* __restrict__ win_r, double inv_n, double sqrt_n,
                                                             int row_lo, int n_rows, c64* __restrict__ ymid) {
-  static_assert(QT >= 1 && QT <= 4, "compile-time target count");
+  static_assert(QT >= 1 && QT <= 2, "compile-time target count");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);
   using FFT = Fft4096W;
@@ -349,27 +350,11 @@ __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_ran
 #pragma unroll
       for (int q = 0; q < QT; ++q) e.d[q] = Dl[(long long)q * d_stride + kc];
     }
+    asm volatile("" ::: "memory");                                      // (compiler-only) nothing of the next phase moves above these loads
   };
-  // `asm volatile("" ::: "memory")`: a compiler-only fence.  The instruction selector is free to sink a load towards its first use
-  // (sched_barrier only binds the machine scheduler); nothing moves across a statement that may touch memory.
-#define ISAC_PIN_ORDER() asm volatile("" ::: "memory")
-  if constexpr (PRO != 0) {
-    c64 t_log = mk(0.0, 0.0);
-    if constexpr (NZ == 1) t_log = logtab_g[tid & (kLogTabSize - 1)];
-    const c64 t_w = tw[tid], t_w8 = tw[512 + (tid & 7)];
-    ISAC_PIN_ORDER();
-    if constexpr (PRO == 1) { load_group(0, 0); ISAC_PIN_ORDER(); }
-    if constexpr (NZ == 1) lt[tid & (kLogTabSize - 1)] = t_log;         // (four lanes write the same value to a slot)
-    lds[FFT::IMG + tid] = t_w;
-    lds[FFT::IMG + 512 + (tid & 7)] = t_w8;
-    __syncthreads();
-    if constexpr (PRO == 2) { load_group(0, 0); ISAC_PIN_ORDER(); }
-  } else {
-    if (NZ == 1 && tid < kLogTabSize) lt[tid] = logtab_g[tid];
-    fft.init_table(lds, tw, tid);
-    load_group(0, 0);
-    ISAC_PIN_ORDER();
-  }
+  if (NZ == 1 && tid < kLogTabSize) lt[tid] = logtab_g[tid];
+  fft.init_table(lds, tw, tid);                      // W512 (generator angle table at stride 2, FFT twiddles); barrier inside
+  load_group(0, 0);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < PER; ++j) fft.x[j] = mk(0.0, 0.0);               // unit noise first, then the range-IFFT input
@@ -386,7 +371,7 @@ __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_ran
       }
     }
   };
-  bool live = false;
+  bool live = false;                                                    // any non-zero (or NaN) matched-filter sample in this column?
   auto consume = [&](int g, int b) {
 #pragma unroll
     for (int u = 0; u < GROUP; ++u) {
@@ -397,30 +382,22 @@ __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_ran
       for (int q = 0; q < QT; ++q) v = fma(e.d[q], s[q], v);
       if constexpr (NZ == 1) v = v + fft.x[j] * sig;
       if constexpr (NZ == 2) v = v + e.nz * sig;
-      buffer_store_c64_nt(rs_dst, (unsigned)k * (unsigned)sizeof(c64), v);            // echoGrid(k, l, r); k >= K: dropped by the bounds check
+      buffer_store_c64_nt(rs_dst, (unsigned)k * (unsigned)sizeof(c64), v);   // echoGrid(k, l, r); k >= K: dropped by the bounds check
       c64 y = mul_conj(v, e.tx) * e.w;                                  // fft2D.m:37,:43 (same order as range_kernel)
       y = k < K ? y : mk(0.0, 0.0);                                     // ifft(., nIFFT, 1) zero-pads at the end
       live |= (y.re != 0.0) | (y.im != 0.0);
       fft.x[j] = y;
     }
   };
-  if constexpr (!SPLIT) {
-#pragma unroll
-    for (int c = 0; c < PER / 2; ++c) draw(c);
-    __builtin_amdgcn_sched_barrier(0);
-  }
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    if constexpr (SPLIT) {
 #pragma unroll
-      for (int c = g * GROUP / 2; c < (g + 1) * GROUP / 2; ++c) draw(c);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (g + 1 < NG) { load_group(g + 1, (g + 1) & 1); ISAC_PIN_ORDER(); }
+    for (int c = g * GROUP / 2; c < (g + 1) * GROUP / 2; ++c) draw(c);
+    __builtin_amdgcn_sched_barrier(0);
+    if (g + 1 < NG) load_group(g + 1, (g + 1) & 1);
     consume(g, g & 1);
     __builtin_amdgcn_sched_barrier(0);
   }
-#undef ISAC_PIN_ORDER
   c64* yd = ymid + (long long)n_rows * colg;
   if (!__syncthreads_or(live)) {                                        // zero-filled 'S' slot column (see echo_range_kernel)
     for (int rr = tid; rr < n_rows; rr += NT) yd[rr] = mk(0.0, 0.0);
@@ -868,20 +845,19 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
                        logtab, (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, 1.0 / ep->n_ifft, std::sqrt((double)ep->n_ifft),   \
                        row_lo, nr, (c64*)ctx->ymid.p);                                                                               \
   } while (0)
-#define ISAC_SPEC_SL(QT, NZ, PRO, SPLIT)                                                                                              \
+#define ISAC_SPEC_SL(QT, NZ)                                                                                                         \
   do {                                                                                                                               \
-    auto kern = echo_range_kernel_sl<QT, NZ, PRO, SPLIT>;                                                                            \
+    auto kern = echo_range_sl_kernel<QT, NZ>;                                                                                        \
     ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));                                                              \
-    hipLaunchKernelGGL(kern, gr, bl, lds, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, (const c64*)d_noise_unit, tw,   \
+    hipLaunchKernelGGL(kern, gr, bl, lds, ctx->stream, g.n_sc, L_whole, L_out, A, D, srq, sig, seed, (const c64*)d_noise_unit, tw,      \
                        logtab, (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, 1.0 / ep->n_ifft, std::sqrt((double)ep->n_ifft),   \
                        row_lo, nr, (c64*)ctx->ymid.p);                                                                               \
   } while (0)
-    static const int er_variant = [] { const char* e = getenv("ISAC_ER_VARIANT"); return e ? atoi(e) : 0; }();
-#define ISAC_SPEC_V(QT, NZ) do { switch (er_variant) { case 1: ISAC_SPEC_SL(QT, NZ, 0, false); break; case 2: ISAC_SPEC_SL(QT, NZ, 1, false); break; \
-      case 3: ISAC_SPEC_SL(QT, NZ, 2, false); break; case 4: ISAC_SPEC_SL(QT, NZ, 0, true); break; case 5: ISAC_SPEC_SL(QT, NZ, 2, true); break; default: ISAC_SPEC(QT, NZ); } } while (0)
-#define ISAC_SPEC_Q(QT) do { if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL) ISAC_SPEC_V(QT, 1); else ISAC_SPEC_V(QT, 2); } while (0)
-    if (Q > 4) { if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL) ISAC_SPEC(0, 1); else ISAC_SPEC(0, 2); } else
-    switch (Q) { case 1: ISAC_SPEC_Q(1); break; case 2: ISAC_SPEC_Q(2); break; case 3: ISAC_SPEC_Q(3); break; case 4: ISAC_SPEC_Q(4); break; default: break; }
+#define ISAC_SPEC_Q(QT) do { if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL) ISAC_SPEC(QT, 1); else ISAC_SPEC(QT, 2); } while (0)
+#define ISAC_SPEC_SL_Q(QT) do { if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL) ISAC_SPEC_SL(QT, 1); else ISAC_SPEC_SL(QT, 2); } while (0)
+    switch (Q) { case 1: ISAC_SPEC_SL_Q(1); break; case 2: ISAC_SPEC_SL_Q(2); break; case 3: ISAC_SPEC_Q(3); break; case 4: ISAC_SPEC_Q(4); break; default: ISAC_SPEC_Q(0); break; }
+#undef ISAC_SPEC_SL_Q
+#undef ISAC_SPEC_SL
 #undef ISAC_SPEC_Q
 #undef ISAC_SPEC
     ISAC_HIP(hipGetLastError());

@@ -45,7 +45,7 @@ PKG = "5g_based_system_level_integrated_sensing_and_communication_simulator_amd"
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix (= vector) dense peak
-DOMINANT_KERNEL = "echo_range_kernel"
+DOMINANT_KERNEL = "echo_range_"          # echo_range_sl_kernel<Q, NZ> (one / two LoS targets) or echo_range_kernel<Q, NZ>
 
 
 def profile_facts():
@@ -387,7 +387,7 @@ def roofline_entry(cell, args, ms_timed, ms_iso, n_launches, stages, cpi_bytes, 
     # (reported separately below; the end-to-end figure under concurrency is `whole_cpi`).
     ms = ms_iso
     at_shape = (args.ants == 64 and args.slots == 16 and args.targets == 1)
-    return {"bound": "hbm", "kernel": "echo_range_kernel<1,1> (fused: per-target rank-1 echo synthesis + Philox AWGN on the demodulated grid -> echoGrid; "
+    return {"bound": "hbm", "kernel": ("echo_range_sl_kernel" if args.targets <= 2 else "echo_range_kernel") + f"<{args.targets if args.targets <= 4 else 0},1> (fused: per-target rank-1 echo synthesis + Philox AWGN on the demodulated grid -> echoGrid; "
                                       "rx.*conj(tx), Kaiser, 4096-pt range IFFT, CUT rows)",
             "achieved": round(nb / 1e9 / (ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
             "traffic": facts["traffic"] if at_shape else None,

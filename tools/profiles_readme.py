@@ -47,7 +47,7 @@ if ss:
     top = max(ss, key=lambda r: float(r["total_us"]))
     out.append(f"* Largest share of GPU time: `{short(top['kernel'])}` ({float(top['pct']):.1f} %, {float(top['avg_us']):.1f} us avg).")
 fe, wr = rows("pmc_fetch_size.csv"), rows("pmc_write_size.csv")
-for name, alg in (("echo_range_kernel", 1.5029), ("cov_mfma_small_kernel", 0.7514), ("beamsum_kernel", 1.0066)):
+for name, alg in (("echo_range_", 1.5029), ("cov_mfma_small_kernel", 0.7514), ("beamsum_kernel", 1.0066)):
     a, b = kern(fe, name), kern(wr, name)
     if a and b:
         f_kb, w_kb = float(a["avg_value"]), float(b["avg_value"])
@@ -60,11 +60,11 @@ if cov:
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
         out.append(f"* `cov_mfma_small_kernel`: SQ_VALU_MFMA_BUSY_CYCLES {d['SQ_VALU_MFMA_BUSY_CYCLES']:,.0f} (per counter instance, x 32 instances) over GRBM_GUI_ACTIVE "
                    f"{d['GRBM_GUI_ACTIVE']:,.0f} cycles x 1024 SIMDs -> MfmaUtil {32 * d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] * 1024):.2f}.")
-wl = [r for r in rows("pmc_wait_lds.csv") if "echo_range_kernel" in r["kernel"]]
+wl = [r for r in rows("pmc_wait_lds.csv") if "echo_range_" in r["kernel"]]
 if wl:
     d = {r["counter"]: float(r["avg_value"]) for r in wl}
     if "SQ_WAIT_ANY" in d and "SQ_WAVE_CYCLES" in d:
-        s = f"* `echo_range_kernel` (final kernel of the round): SQ_WAIT_ANY / SQ_WAVE_CYCLES = {d['SQ_WAIT_ANY'] / d['SQ_WAVE_CYCLES']:.2f}"
+        s = f"* `echo_range_sl_kernel` (final kernel of the round): SQ_WAIT_ANY / SQ_WAVE_CYCLES = {d['SQ_WAIT_ANY'] / d['SQ_WAVE_CYCLES']:.2f}"
         if "SQ_LDS_BANK_CONFLICT" in d and "SQ_LDS_IDX_ACTIVE" in d:
             s += f"; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = {d['SQ_LDS_BANK_CONFLICT']:,.0f} / {d['SQ_LDS_IDX_ACTIVE']:,.0f} = {d['SQ_LDS_BANK_CONFLICT'] / d['SQ_LDS_IDX_ACTIVE']:.2f}"
         out.append(s + f" (`{tag}_pmc_wait_lds.csv`).")
