@@ -520,7 +520,9 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   hipStream_t s2 = single_stream ? ctx->stream : ctx->stream2;
   ISAC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
   ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+  timeline_mark(ctx, 4, s2);
   ISAC_TRY(isac_covariance_on(ctx, s2, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
+  timeline_mark(ctx, 5, s2);
   if (!upa) {                                                                                    // music.m:19
     if (sub) ISAC_TRY(isac_music_tridiag_bisect_dev(ctx, (const c64*)ctx->cov.p, A, s2));        // reflectors + eigenvalues: independent of numDets
     else ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, s2));
@@ -566,6 +568,7 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   ISAC_HIP(hipGetLastError());
   char* h = (char*)ctx->pinned;
   ISAC_HIP(hipMemcpyAsync(h, dbase, first_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  timeline_mark(ctx, 6, ctx->stream);
   // everything the host half needs later
   Fft2dPending& pd = ctx->pending;
   pd.ep = *ep; pd.cfar = *cfar;
@@ -593,6 +596,11 @@ extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
   const int n_cut_rows = cfar->row1 - cfar->row0 + 1;
   char* h = (char*)ctx->pinned;
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->tl_on) {
+    float t[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 7; ++i) (void)hipEventElapsedTime(&t[i], timeline_base(ctx->stream), ctx->tl[i]);
+    std::fprintf(stderr, "TL %p B %.1f %.1f E %.1f %.1f C %.1f %.1f T %.1f\n", (void*)ctx, 1e3 * t[0], 1e3 * t[1], 1e3 * t[2], 1e3 * t[3], 1e3 * t[4], 1e3 * t[5], 1e3 * t[6]);
+  }
   const int* hdr = (const int*)h;
   const int total = hdr[0];
   const int num_dets_dev = hdr[1];
@@ -870,6 +878,13 @@ extern "C" int isac_ctx_set_option(isac_ctx* ctx, int32_t option, int32_t value)
     default: return fail(ctx, ISAC_ERR_INVALID_ARG, "unknown option");
   }
 }
+
+hipEvent_t isac::timeline_base(hipStream_t st) {
+  static hipEvent_t base = nullptr;
+  if (!base) { (void)hipEventCreate(&base); (void)hipEventRecord(base, st); (void)hipEventSynchronize(base); }
+  return base;
+}
+
 
 extern "C" int isac_music_doa(isac_ctx* ctx, int32_t num_dets, const isac_est_params* ep, const isac_c64* Ra, int32_t A,
                               int32_t* L_out, double* azi_est, double* ele_est, int32_t cap, int32_t* n_est) {

@@ -619,6 +619,7 @@ static int prepare_echo(isac_ctx* ctx, const c64* d_tx, long long T, const isac_
   }
   // beam-sums in tiles of up to 8 targets (tx is re-read only when Q > 8)
   const unsigned gb = cdiv(T, 256);
+  timeline_mark(ctx, 0, ctx->stream);
   for (int q0 = 0; q0 < Q;) {
     int rem = Q - q0;
     const c64* st = d_steer_aq + (size_t)q0 * A;
@@ -628,6 +629,7 @@ static int prepare_echo(isac_ctx* ctx, const c64* d_tx, long long T, const isac_
     else if (rem >= 2) { hipLaunchKernelGGL(beamsum_kernel<2>, dim3(gb), dim3(256), sizeof(c64) * A * 2, ctx->stream, d_tx, T, A, st, bm); q0 += 2; }
     else { hipLaunchKernelGGL(beamsum_kernel<1>, dim3(gb), dim3(256), sizeof(c64) * A * 1, ctx->stream, d_tx, T, A, st, bm); q0 += 1; }
   }
+  timeline_mark(ctx, 1, ctx->stream);
   const double w = two_pi * rp->fc;                 // 2j*pi*fc  :30,:73
   hipLaunchKernelGGL(coef_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const c64*)ctx->beam.p, T, Q, tab, w, Ts,
                      (c64*)ctx->coef.p, (c64*)ctx->phase_rx.p);
@@ -829,6 +831,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
   ISAC_TRY(isac_get_windows(ctx, g.n_sc, ep->n_ifft, &wk, &wr));
   const double n0s = std::sqrt(rp->n0 / 2.0);
   if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));   // isac_profile_*: brackets exactly the fused kernel below
+  timeline_mark(ctx, 2, ctx->stream);
   {
     const c64* logtab = nullptr;
     ISAC_TRY(isac_get_logtab(ctx, &logtab));
@@ -863,6 +866,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
     ISAC_HIP(hipGetLastError());
   }
   if (ctx->profile) { ISAC_HIP(hipEventRecord(ctx->ev_k1, ctx->stream)); ctx->profile_recorded = true; }
+  timeline_mark(ctx, 3, ctx->stream);
   RangeCache& rc = ctx->range_cache;
   rc.rx = d_echo_grid; rc.tx = d_tx_grid; rc.K = g.n_sc; rc.L = L_out; rc.A = A; rc.n_ifft = ep->n_ifft; rc.row_lo = row_lo; rc.nr = nr;
   rc.valid = true;

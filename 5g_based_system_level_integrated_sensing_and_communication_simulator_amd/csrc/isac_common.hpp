@@ -110,6 +110,10 @@ struct isac_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // MUSIC branch (covariance/eig) overlaps the RDM branch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cfar = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+  // ISAC_TIMELINE=1 (development aid): timed events around the wide kernels of a CPI, printed by isac_fft2d_collect relative to a
+  // process-wide base event -- the device-side schedule of a multi-context pipeline WITHOUT a profiler slowing the host down
+  hipEvent_t tl[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // B0 B1 E0 E1 C0 C1 T1
+  bool tl_on = false;
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // isac_profile_*: around the dominant kernel of the last fused echo call
   bool profile = false, profile_recorded = false;
   int music_route = 0;             // ISAC_OPT_MUSIC_ROUTE: 0 = signal-subspace eigensolver for MUSIC (default), 1 = always the full eigendecomposition
@@ -148,6 +152,18 @@ inline int allow_lds(isac_ctx* ctx, const void* kernel, size_t bytes) {
     have = bytes;
   }
   return ISAC_OK;
+}
+
+hipEvent_t timeline_base(hipStream_t st);   // capi.hip
+inline void timeline_mark(isac_ctx* ctx, int i, hipStream_t st) {
+  static const bool on = std::getenv("ISAC_TIMELINE") != nullptr;
+  if (!on) return;
+  if (!ctx->tl_on) {
+    for (auto& e : ctx->tl) (void)hipEventCreate(&e);
+    ctx->tl_on = true;
+    (void)timeline_base(st);
+  }
+  (void)hipEventRecord(ctx->tl[i], st);
 }
 
 #define ISAC_HIP(call)                                                                     \

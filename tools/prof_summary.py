@@ -113,7 +113,34 @@ def gaps(path):
         print(f"  after {a:28s} before {b:28s} n={c:4d} idle {1e-6 * t:7.2f} ms  mean {1e-3 * t / c:6.1f} us")
 
 
+def timeline(path, span_ms=3.5):
+    """Start / end of every kernel launch inside a few milliseconds in the middle of the trace (relative microseconds, one line per launch,
+    queue id when the trace has one): what actually runs beside what."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    cols = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
+    q = "d.queue_id" if "queue_id" in cols else "0"
+    rows = list(cur.execute(f"select s.kernel_name, d.start, d.end, {q} from {kd} d join {ks} s on d.kernel_id=s.id order by d.start"))
+    import re
+
+    def short(n):
+        m = re.search(r"\d+([a-z][a-z0-9_]*_kernel)", n.replace("isac", ""))
+        return (m.group(1) if m else n)[:26]
+    t0, t1 = rows[0][1], max(r[2] for r in rows)
+    mid = t0 + 0.7 * (t1 - t0)
+    lo, hi = mid, mid + span_ms * 1e6
+    for n, a, b, qid in rows:
+        if b > lo and a < hi:
+            print(f"{1e-3 * (a - lo):9.1f} {1e-3 * (b - lo):9.1f}  {1e-3 * (b - a):7.1f} us  q{qid}  {short(n)}")
+
+
 if __name__ == "__main__":
+    if "--timeline" in sys.argv:
+        timeline(sys.argv[1])
+        sys.exit(0)
     if "--gaps" in sys.argv:
         gaps(sys.argv[1])
         sys.exit(0)
