@@ -1848,7 +1848,9 @@ static int launch_ql(isac_ctx* ctx, int n, hipStream_t st, int* info, const int*
   const bool live = lds_replay && !no_overlap && ctl == nullptr;
   const int n_replay = (2 * n + bt - 1) / bt;
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_formq_ql_kernel), (size_t)(160 * 1024)));
-  hipLaunchKernelGGL(eigh_formq_ql_kernel, dim3(live ? 2 + n_replay : 2), dim3(1024), live ? std::max(lds2, lds3) : lds2, st, n, gs,
+  // (as the in-stream fallback it almost always returns at its first instruction: 256 threads then -- a 1024-thread workgroup of ~110 VGPRs needs a
+  // whole CU to itself and sat 90-140 us in its queue while the next CPI's echo kernel held every CU with two workgroups, profiles/r03_device_timeline.txt)
+  hipLaunchKernelGGL(eigh_formq_ql_kernel, dim3(live ? 2 + n_replay : 2), dim3(ctl ? 256 : 1024), live ? std::max(lds2, lds3) : lds2, st, n, gs,
                      (double*)ctx->eig_w.p, info, (c64*)ctx->eig_v.p, bt, ctl);
   ISAC_HIP(hipGetLastError());
   if (!live) {
