@@ -51,7 +51,7 @@ for name, alg in (("echo_range_", 1.5029), ("cov_mfma_small_kernel", 0.7514), ("
     a, b = kern(fe, name), kern(wr, name)
     if a and b:
         f_kb, w_kb = float(a["avg_value"]), float(b["avg_value"])
-        out.append(f"* `{name}`: FETCH_SIZE 2 x {f_kb:,.0f} KB + WRITE_SIZE {w_kb:,.0f} KB = {(2 * f_kb + w_kb) * 1024 / 1e9:.3f} GB per launch "
+        out.append(f"* `{short(a['kernel'])}`: FETCH_SIZE 2 x {f_kb:,.0f} KB + WRITE_SIZE {w_kb:,.0f} KB = {(2 * f_kb + w_kb) * 1024 / 1e9:.3f} GB per launch "
                    f"(algorithmic {alg:.3f} GB); {float(a['avg_duration_us']):.1f} us in the FETCH pass.")
 mf = rows("pmc_mfma_busy.csv")
 cov = [r for r in mf if "cov_mfma_small" in r["kernel"]]
