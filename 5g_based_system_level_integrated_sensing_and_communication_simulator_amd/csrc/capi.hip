@@ -16,9 +16,20 @@ int isac_cfar_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_c
 int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st);
 // status word the device eigensolver leaves behind the eigenvalues (ctx->eig_w [A] | info[0..5]): negative = the QL
 // recurrence ran out of rotation storage (-1) or a replay block gave up waiting (-2).  Call after the stream is idle.
+int isac_eigh_replay_recover(isac_ctx* ctx, int n, hipStream_t st);   // music.hip
 static int eig_status(isac_ctx* ctx, int A) {
   int sweeps = 0;
   ISAC_HIP(hipMemcpy(&sweeps, (const char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(int), hipMemcpyDeviceToHost));
+  static const bool force = std::getenv("ISAC_EIG_FORCE_REPLAY_TIMEOUT") != nullptr;   // test hook: take the recovery path on every call ...
+  if (force && sweeps >= 0 && A > 16 && ctx->eig_scratch.p) {
+    ISAC_HIP(hipMemset(ctx->eig_v.p, 0xFF, sizeof(c64) * (size_t)A * A));               // ... with the eigenvectors destroyed first
+    sweeps = -2;
+  }
+  if (sweeps == -2) {                                // live replay blocks gave up waiting: Z and the rotations are intact, replay them offline
+    ISAC_TRY(isac_eigh_replay_recover(ctx, A, ctx->stream));
+    ISAC_HIP(hipStreamSynchronize(ctx->stream));
+    ISAC_HIP(hipMemcpy(&sweeps, (const char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(int), hipMemcpyDeviceToHost));
+  }
   if (sweeps < 0) return isac::fail(ctx, ISAC_ERR_HIP, sweeps == -1 ? "eigensolver: QL recurrence exceeded its rotation storage (no convergence)"
                                                      : sweeps == -3 ? "eigensolver: the signal-subspace vectors are not finite (NaN / Inf in the covariance)"
                                                                      : "eigensolver: a replay block timed out waiting for the recurrence");

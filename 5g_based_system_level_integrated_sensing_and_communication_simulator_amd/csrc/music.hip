@@ -240,15 +240,24 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_small_kernel(const c64* __res
 // ---- arrays wider than 64 elements (config 4: 256-element ULA): Ra is cut into 64 x 64 blocks and every workgroup owns
 // one block pair (BI <= BJ) over a chunk of samples -- a classical LDS-staged GEMM step:
 //   * the 16-sample x (64 + 64)-antenna slab is fetched once per workgroup with line-friendly loads (16 consecutive lanes
-//     read the 256 contiguous bytes of one antenna) into a double-buffered LDS image (row pitch 17 complex: the
-//     transposing writes and the MFMA operand reads are both conflict-free); the loads of slab s+1 fly under the MFMAs
-//     of slab s; one barrier per slab;
+//     read the 256 contiguous bytes of one antenna) into a double-buffered LDS image [block][sample][antenna ^ g(sample)], 16-slot rows
+//     (kCovSwizzle below: the transposing writes and the MFMA operand reads are both conflict-free); the loads of slabs s+1, s+2
+//     fly under the MFMAs of slab s; one barrier per slab;
 //   * wave w computes up to four 16 x 16 tiles per slab from LDS operands: tile row w on off-diagonal blocks, a balanced
 //     3/3/2/2 split of the 10 upper-triangular tiles on diagonal blocks.
 // Workgroups of the same sample chunk are adjacent in the grid so that block pairs sharing an antenna block stream it
 // together (Infinity Cache).  (The generic kernel above re-reads its operands once per tile triple: 8.8 ms at A = 256;
 // a register-operand version of this kernel, 20 strided global loads per wave and slab: 6.4 ms.)
-constexpr int kCovPitch = 17;                                   // complex elements per (block, sample) row
+// LDS image: slot(block, sample, antenna) = (16 block + sample) 16 + (antenna ^ g(sample)),  g(s) = (s & 3) | (s & 4 ? 12 : 0).
+//   * ds_write_b128 is served in groups of 8 contiguous lanes against 32 banks (8 slots): the lanes of a group hold samples 8h .. 8h+7 of
+//     one antenna, and g's low three bits run through 0..7 there;
+//   * ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... against 64 banks (16 slots): a group mixes
+//     antennas {0-3, 12-15} of sample quad kq with antennas {4-11} of quad kq + 1 (four samples on).  XOR with g keeps {0-3}, {4-7}, {8-11},
+//     {12-15} as sets; the 12 applied on every second quad swaps {0-3} <-> {12-15} and {4-7} <-> {8-11} -- the two halves of a group land
+//     on complementary slots.  (The 17-slot pitch of the first version served the writes but left every read group 2-way conflicted:
+//     SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.37 at A = 256.)
+constexpr int kCovPitch = 16;                                   // complex elements per (block, sample) row
+__host__ __device__ constexpr int kCovSwizzle(int smp) { return (smp & 3) | ((smp & 4) ? 12 : 0); }
 constexpr int kCovBufElems = 8 * 16 * kCovPitch;                // one slab image: 8 antenna blocks x 16 samples
 constexpr unsigned kCovOobOffset = 0x80000000u;                 // beyond every staging descriptor (N * 256 B < 2^31, checked by the launcher)
 __constant__ unsigned char kCovDiagTiles[4][4] = {              // 16*I + J per (wave, slot); 255 = idle.  Slot 0 = the wave's diagonal tile
@@ -289,7 +298,7 @@ __device__ __forceinline__ void cov_block_pair(const c64* __restrict__ G, long l
     n_ant = n_ant < 0 ? 0 : (n_ant > 16 ? 16 : n_ant);
     s_rs[j] = buffer_of(G + N * (long long)(ant0 < A ? ant0 : 0), (unsigned)(N * n_ant * (long long)sizeof(c64)));
   }
-  const int s_lds0 = s_smp * kCovPitch + l16;       // + j * 16 * kCovPitch
+  const int s_lds0 = s_smp * kCovPitch + (l16 ^ kCovSwizzle(s_smp));       // + j * 16 * kCovPitch
   // 3M form, as in cov_group_body: off-diagonal tile re = S1, im = S2, s3 = S3; diagonal tile (slot 0 of every wave of a diagonal block
   // pair: a compile-time property, so neither selects nor branch-dependent accumulator moves) re + s3 = Re, im = M.
   v4f64 re[4], im[4], s3[4];
@@ -315,20 +324,23 @@ __device__ __forceinline__ void cov_block_pair(const c64* __restrict__ G, long l
 #pragma unroll
     for (int j = 0; j < NS; ++j) d[j * 16 * kCovPitch] = g[j];
   };
+  int r_off[4];                                     // operand slot of this lane for sample 4 kq + e inside a (block, 16-sample) image
+#pragma unroll
+  for (int e = 0; e < 4; ++e) r_off[e] = (4 * kq + e) * kCovPitch + (li ^ kCovSwizzle(4 * kq + e));
   auto mfmas = [&](int buf) {
     const c64* cur = lds + buf * kCovBufElems;
     if constexpr (!DIAG) {
       // off-diagonal pair: wave w owns tile row w (tI = w, tJ = 0..3) -- the row operand is read once per sample quad and shared by
       // the four tiles: 20 instead of 32 ds_read_b128 per slab, and the operand registers of one quad at a time
-      const c64* pa = cur + ((wid * 16 + 4 * kq) * kCovPitch + li);
-      const c64* pb = cur + ((jbase * 16 + 4 * kq) * kCovPitch + li);
+      const c64* pa = cur + wid * 16 * kCovPitch;
+      const c64* pb = cur + jbase * 16 * kCovPitch;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const c64 xa = pa[e * kCovPitch];
+        const c64 xa = pa[r_off[e]];
         const double dm = xa.re - xa.im;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const c64 xb = pb[(u * 16 + e) * kCovPitch];
+          const c64 xb = pb[u * 16 * kCovPitch + r_off[e]];
           re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xb.re, re[u], 0, 0, 0);
           im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.im, xb.im, im[u], 0, 0, 0);
           s3[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(dm, xb.re + xb.im, s3[u], 0, 0, 0);
@@ -337,10 +349,10 @@ __device__ __forceinline__ void cov_block_pair(const c64* __restrict__ G, long l
       }
     } else {
       {                                             // slot 0: the wave's diagonal tile -- Gr Gr', M = Gr Gi', Gi Gi'
-        const c64* pa = cur + ((tI[0] * 16 + 4 * kq) * kCovPitch + li);
+        const c64* pa = cur + tI[0] * 16 * kCovPitch;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const c64 xa = pa[e * kCovPitch];
+          const c64 xa = pa[r_off[e]];
           re[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xa.re, re[0], 0, 0, 0);
           im[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xa.im, im[0], 0, 0, 0);
           s3[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.im, xa.im, s3[0], 0, 0, 0);
@@ -349,11 +361,11 @@ __device__ __forceinline__ void cov_block_pair(const c64* __restrict__ G, long l
 #pragma unroll
       for (int u = 1; u < 3; ++u) {                 // slots 1, 2: off-diagonal tiles (slot 2 on waves 0 and 1 only; slot 3 is never used)
         if (u == 2 && !tv[2]) continue;             // (wave-uniform)
-        const c64* pa = cur + ((tI[u] * 16 + 4 * kq) * kCovPitch + li);
-        const c64* pb = cur + ((tJ[u] * 16 + 4 * kq) * kCovPitch + li);
+        const c64* pa = cur + tI[u] * 16 * kCovPitch;
+        const c64* pb = cur + tJ[u] * 16 * kCovPitch;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const c64 xa = pa[e * kCovPitch], xb = pb[e * kCovPitch];
+          const c64 xa = pa[r_off[e]], xb = pb[r_off[e]];
           re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re, xb.re, re[u], 0, 0, 0);
           im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.im, xb.im, im[u], 0, 0, 0);
           s3[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa.re - xa.im, xb.re + xb.im, s3[u], 0, 0, 0);
@@ -1831,6 +1843,22 @@ static int launch_tridiag(isac_ctx* ctx, const c64* d_H, int n, hipStream_t st, 
 
 // zungtr || QL recurrence || replay on the tridiagonal form in ctx->eig_scratch -> ctx->eig_w / eig_v.  `ctl` (device, may be null): the
 // kernels return at once when ctl[0] == 1 (music_subspace_kernel has already delivered what MUSIC needs).
+// the recorded rotations applied to Z by a launch of its own (rows in LDS while they fit)
+static int launch_replay_offline(isac_ctx* ctx, int n, hipStream_t st, int* info, const int* ctl) {
+  void* gs = ctx->eig_scratch.p;
+  int bt = 64;
+  if ((size_t)bt * n * sizeof(double) > 150 * 1024) bt = 32;
+  const size_t rows3 = (size_t)bt * n * sizeof(double), stage3 = sizeof(c64) * 2 * (size_t)n;
+  if (rows3 <= 150 * 1024 && n <= 8 * bt) {
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_replay_kernel<true>), rows3 + stage3));
+    hipLaunchKernelGGL(eigh_replay_kernel<true>, dim3((unsigned)((2 * n + bt - 1) / bt)), dim3(bt), rows3 + stage3, st, n, gs, (c64*)ctx->eig_v.p, info, ctl);
+  } else {
+    hipLaunchKernelGGL(eigh_replay_kernel<false>, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), stage3, st, n, gs, (c64*)ctx->eig_v.p, info, ctl);
+  }
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
 static int launch_ql(isac_ctx* ctx, int n, hipStream_t st, int* info, const int* ctl) {
   void* gs = ctx->eig_scratch.p;
   // (forcing the zungtr block and the lone recurrence wavefront onto different CUs with an oversized LDS request made no
@@ -1853,16 +1881,18 @@ static int launch_ql(isac_ctx* ctx, int n, hipStream_t st, int* info, const int*
   hipLaunchKernelGGL(eigh_formq_ql_kernel, dim3(live ? 2 + n_replay : 2), dim3(ctl ? 256 : 1024), live ? std::max(lds2, lds3) : lds2, st, n, gs,
                      (double*)ctx->eig_w.p, info, (c64*)ctx->eig_v.p, bt, ctl);
   ISAC_HIP(hipGetLastError());
-  if (!live) {
-    if (lds_replay) {
-      ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_replay_kernel<true>), lds3));
-      hipLaunchKernelGGL(eigh_replay_kernel<true>, dim3((unsigned)n_replay), dim3(bt), lds3, st, n, gs, (c64*)ctx->eig_v.p, info, ctl);
-    } else {
-      hipLaunchKernelGGL(eigh_replay_kernel<false>, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), stage3, st, n, gs, (c64*)ctx->eig_v.p, info, ctl);
-    }
-    ISAC_HIP(hipGetLastError());
-  }
+  if (!live) ISAC_TRY(launch_replay_offline(ctx, n, st, info, ctl));
   return ISAC_OK;
+}
+
+// Recovery of a CPI whose LIVE replay blocks gave up waiting (info[0] == -2; co-resident workgroups of one launch are a speed assumption
+// HIP does not guarantee): the zungtr result Z and every recorded rotation are intact once the launch has finished -- the recurrence and
+// zungtr blocks never wait for the replay blocks -- so the eigenvectors are formed by the offline replay, as on the fallback route.
+int isac_eigh_replay_recover(isac_ctx* ctx, int n, hipStream_t st) {
+  if (!st) st = ctx->stream;
+  int* info = reinterpret_cast<int*>((char*)ctx->eig_w.p + sizeof(double) * (size_t)n);
+  ISAC_HIP(hipMemsetAsync(info, 0, sizeof(int), st));                 // the time-out mark; the replay below cannot time out
+  return launch_replay_offline(ctx, n, st, info, nullptr);
 }
 
 // ---- MUSIC's signal-subspace route (eigensolver III above): supported orders, and the two halves around the wait for numDets

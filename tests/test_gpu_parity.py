@@ -11,7 +11,9 @@ import pytest
 from scipy import linalg
 
 import oracle as O
-from conftest import load_pkg, make_scene
+import os
+
+from conftest import PKG_NAME, load_pkg, make_scene
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-10
@@ -332,6 +334,37 @@ def test_eigh_jacobi(pkg, ctx, a):
     assert np.abs(w - wr).max() < 1e-12 * np.abs(wr).max()
     assert np.abs(v.conj().T @ v - np.eye(a)).max() < 1e-12
     assert np.abs(h @ v - v * w).max() < 1e-11 * np.abs(wr).max()
+
+
+_RECOVER_SNIPPET = r"""
+import ctypes as C, importlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module(%r)
+ctx = pkg._lib.Context(0)
+for a in (33, 64, 100, 256):
+    rng = np.random.default_rng(a)
+    m = rng.standard_normal((a, a)) + 1j * rng.standard_normal((a, a))
+    h = np.asfortranarray(m @ m.conj().T / a + np.diag(rng.uniform(0, 3, a)))
+    w = np.zeros(a); v = np.zeros((a, a), dtype=np.complex128, order="F")
+    ctx.check(ctx.lib.isac_eigh(ctx.handle, h.ctypes.data_as(C.c_void_p), C.c_int32(a), w.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
+    wr = np.linalg.eigvalsh(h)
+    assert np.abs(w - wr).max() < 1e-12 * np.abs(wr).max(), a
+    assert np.abs(v.conj().T @ v - np.eye(a)).max() < 1e-12, a
+    assert np.abs(h @ v - v * w).max() < 1e-11 * np.abs(wr).max(), a
+print("recovered")
+"""
+
+
+def test_eigh_live_replay_timeout_is_recovered():
+    """A live replay block that gives up waiting (info[0] = -2) must not fail the call: the recorded rotations are replayed by a launch of its own.
+    ISAC_EIG_FORCE_REPLAY_TIMEOUT (read once per process, hence the subprocess) destroys the eigenvectors of every QL-pipeline call and takes
+    that path; ISAC_EIG_QL sends A <= 64 through the pipeline too."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ISAC_EIG_FORCE_REPLAY_TIMEOUT="1", ISAC_EIG_QL="1")
+    r = subprocess.run([sys.executable, "-c", _RECOVER_SNIPPET % (root, PKG_NAME)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "recovered" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.parametrize("kind,a", [("identity", 100), ("rank2", 130), ("diag_repeated", 96), ("tiny", 72), ("huge", 65),
