@@ -68,6 +68,20 @@ if wl:
         if "SQ_LDS_BANK_CONFLICT" in d and "SQ_LDS_IDX_ACTIVE" in d:
             s += f"; SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = {d['SQ_LDS_BANK_CONFLICT']:,.0f} / {d['SQ_LDS_IDX_ACTIVE']:,.0f} = {d['SQ_LDS_BANK_CONFLICT'] / d['SQ_LDS_IDX_ACTIVE']:.2f}"
         out.append(s + f" (`{tag}_pmc_wait_lds.csv`).")
+a_f, a_m, a_w = rows("pmc_a256_fetch_size.csv"), rows("pmc_a256_mfma_busy.csv"), rows("pmc_a256_wait_lds.csv")
+blk = [r for r in a_f + a_m + a_w if "cov_mfma_block" in r["kernel"]]
+if blk:
+    d = {r["counter"]: float(r["avg_value"]) for r in blk}
+    dur = {r["counter"]: float(r["avg_duration_us"]) for r in blk}
+    s = "* `cov_mfma_block_kernel` (A = 256, PMC passes of a cold 3-CPI run):"
+    if "FETCH_SIZE" in d:
+        s += f" FETCH_SIZE 2 x {d['FETCH_SIZE']:,.0f} KB = {2 * d['FETCH_SIZE'] * 1024 / 1e9:.2f} GB per launch ({dur['FETCH_SIZE']:.0f} us);"
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
+        s += (f" MfmaUtil {32 * d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] * 1024):.2f} at {d['GRBM_GUI_ACTIVE'] / dur['GRBM_GUI_ACTIVE'] / 1e3:.2f} GHz"
+              f" (GRBM_GUI_ACTIVE / duration);")
+    if "SQ_WAIT_ANY" in d and "SQ_WAVE_CYCLES" in d:
+        s += f" SQ_WAIT_ANY / SQ_WAVE_CYCLES {d['SQ_WAIT_ANY'] / d['SQ_WAVE_CYCLES']:.2f}; SQ_LDS_BANK_CONFLICT {d.get('SQ_LDS_BANK_CONFLICT', 0):,.0f} of {d.get('SQ_LDS_IDX_ACTIVE', 0):,.0f} LDS cycles"
+    out.append(s + ".")
 for name, label in (("bench_driver_invocation.json", "driver invocation (`--gpus 1 --steps 20 --warmup 5`)"), ("bench_driver_invocation_2.json", "the same again"),
                     ("bench_default_100steps.json", "100 steps"), ("bench_blocking.json", "`--inflight 1` (blocking CPIs)"),
                     ("bench_blocking_full_eig.json", "`--inflight 1`, full eigendecomposition route (`ISAC_MUSIC_FULL_EIG=1`: the round-2 eigensolver)"),
