@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libisac_hip.so")
 _lib = None
 _lock = threading.Lock()
 
-ISAC_ABI_VERSION = 3          # include/isac.h ISAC_ABI_VERSION this binding was written against (checked at load)
+ISAC_ABI_VERSION = 4          # include/isac.h ISAC_ABI_VERSION this binding was written against (checked at load)
 ISAC_MAX_EST = 4096
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX, NOISE_PHILOX_SPECTRAL, NOISE_INJECTED_SPECTRAL = 0, 1, 2, 3, 4
 
@@ -90,7 +90,7 @@ EXPORTS = [
     "isac_mono_static_sensing", "isac_mono_static_sensing_fused_dev", "isac_ofdm_symbol_count", "isac_ofdm_demodulate_dev", "isac_ofdm_modulate_dev", "isac_ofdm_modulate_windowed_dev", "isac_sentx_append_dev",
     "isac_ofdm_waveform_length", "isac_cfar2d_ca", "isac_fft2d_dev", "isac_fft2d", "isac_fft2d_submit_dev", "isac_fft2d_submit_cached_dev", "isac_fft2d_collect", "isac_fft2d_range_stage_dev", "isac_fft2d_get_detections",
     "isac_fft2d_get_power_window", "isac_fft2d_get_covariance", "isac_fft2d_get_music_spectrum",
-    "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_ctx_set_option", "isac_eigh_top", "isac_beamscan_doa", "isac_music2d_dev", "isac_eigh", "isac_cdl_apply_dev", "isac_precoded_sinr_cqi_dev", "isac_type1sp_codebook", "isac_csi_report_dev", "isac_los_check_dev", "isac_winding_number_dev", "isac_synth_qpsk_grid_dev",
+    "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_ctx_set_option", "isac_ctx_share_streams", "isac_eigh_top", "isac_beamscan_doa", "isac_music2d_dev", "isac_eigh", "isac_cdl_apply_dev", "isac_precoded_sinr_cqi_dev", "isac_type1sp_codebook", "isac_csi_report_dev", "isac_los_check_dev", "isac_winding_number_dev", "isac_synth_qpsk_grid_dev",
 ]
 
 
@@ -228,6 +228,15 @@ class Context:
     def set_tail_fusion(self, on: bool):
         """True (default) = Doppler FFT + CFAR + merge + numDets in one launch where applicable, False = separate kernels (ISAC_OPT_TAIL_FUSION)."""
         self.check(self.lib.isac_ctx_set_option(self.handle, C.c_int32(1), C.c_int32(1 if on else 0)))
+
+    def set_wide_order(self, on: bool):
+        """ISAC_OPT_WIDE_ORDER: fft2D's covariance on the main stream, every narrow kernel on the second (see include/isac.h)."""
+        self.check(self.lib.isac_ctx_set_option(self.handle, C.c_int32(2), C.c_int32(1 if on else 0)))
+
+    def share_streams(self, owner: "Context | None"):
+        """Enqueue on `owner`'s two streams from now on (None: back to this context's own): isac_ctx_share_streams."""
+        self.check(self.lib.isac_ctx_share_streams(self.handle, owner.handle if owner is not None else None))
+        self._stream_owner = owner          # keep the owner alive
 
     def eigh_top(self, h, n_top: int):
         """(w, U): all eigenvalues ascending + the eigenvectors of the n_top largest (descending order) -- isac_eigh_top."""

@@ -303,12 +303,15 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
       hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_cfar, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_h2d, hipEventDisableTiming) != hipSuccess ||
       hipEventCreate(&ctx->ev_t0) != hipSuccess || hipEventCreate(&ctx->ev_t1) != hipSuccess ||
       hipEventCreate(&ctx->ev_k0) != hipSuccess || hipEventCreate(&ctx->ev_k1) != hipSuccess) {
     delete ctx;
     return ISAC_ERR_HIP;
   }
+  ctx->own_stream = ctx->stream;
+  ctx->own_stream2 = ctx->stream2;
   *out = ctx;
   return ISAC_OK;
 }
@@ -318,6 +321,8 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream2);
+  ctx->stream = ctx->own_stream;                    // (shared streams belong to their owner)
+  ctx->stream2 = ctx->own_stream2;
   for (auto& kv : ctx->twiddles) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->kaiser3) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->sind) (void)hipFree(kv.second.p);
@@ -331,6 +336,7 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   (void)hipEventDestroy(ctx->ev_fork);
   (void)hipEventDestroy(ctx->ev_join);
   (void)hipEventDestroy(ctx->ev_cfar);
+  (void)hipEventDestroy(ctx->ev_done);
   (void)hipEventDestroy(ctx->ev_h2d);
   if (ctx->pinned_in) (void)hipHostFree(ctx->pinned_in);
   (void)hipEventDestroy(ctx->ev_t0);
@@ -529,17 +535,40 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   }
   static const bool single_stream = std::getenv("ISAC_SINGLE_STREAM") != nullptr;   // profiling aid: isolate kernel times
   hipStream_t s2 = single_stream ? ctx->stream : ctx->stream2;
-  ISAC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
-  ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
-  timeline_mark(ctx, 4, s2);
-  ISAC_TRY(isac_covariance_on(ctx, s2, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
-  timeline_mark(ctx, 5, s2);
-  if (!upa) {                                                                                    // music.m:19
-    if (sub) ISAC_TRY(isac_music_tridiag_bisect_dev(ctx, (const c64*)ctx->cov.p, A, s2));        // reflectors + eigenvalues: independent of numDets
-    else ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, s2));
-  }
+  // ISAC_OPT_WIDE_ORDER: the covariance (a wide kernel) stays on the main stream, behind the echo synthesis / range stage; everything
+  // narrow -- Doppler, CFAR, the MUSIC chain, pack, the D2H copy -- runs on the second stream in one sequence.  With contexts that share
+  // their streams (isac_ctx_share_streams) the wide kernels of consecutive CPIs then execute back to back, each with the device to itself.
+  const bool wide = ctx->wide_order != 0 && !single_stream;
+  struct StreamRestore { isac_ctx* c; hipStream_t s; ~StreamRestore() { c->stream = s; } } restore{ctx, ctx->stream};
   int nr = 0, nc = 0;
-  ISAC_TRY(isac_rdm_power_window(ctx, ep, cfar, rx, tx, K, L, A, &nr, &nc, use_cached_range));          // fft2D.m:37-46,61
+  bool rdm_done = false;
+  if (wide) {
+    if (!use_cached_range) {                                      // the range stage reads both grids: a wide kernel too
+      ISAC_TRY(isac_rdm_power_window(ctx, ep, cfar, rx, tx, K, L, A, &nr, &nc, false));
+      rdm_done = true;
+    }
+    timeline_mark(ctx, 4, ctx->stream);
+    ISAC_TRY(isac_covariance_on(ctx, ctx->stream, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
+    timeline_mark(ctx, 5, ctx->stream);
+    ISAC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+    ctx->stream = s2;                                             // (restored on every exit) the calls below enqueue on the second stream
+  } else {
+    ISAC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+    ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+    timeline_mark(ctx, 4, s2);
+    ISAC_TRY(isac_covariance_on(ctx, s2, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
+    timeline_mark(ctx, 5, s2);
+  }
+  auto eig_first_half = [&]() -> int {                                                           // music.m:19
+    if (upa) return ISAC_OK;
+    if (sub) return isac_music_tridiag_bisect_dev(ctx, (const c64*)ctx->cov.p, A, s2);           // reflectors + eigenvalues: independent of numDets
+    return isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, s2);
+  };
+  // (wide order: the many-workgroup narrow kernels -- Doppler, CFAR panels, merge -- first, while the next CPI's beam-sum holds the main stream and
+  // leaves registers free; the one-workgroup eigensolver kernels then sit under the next fused kernel, where they cost one CU each)
+  if (!wide) ISAC_TRY(eig_first_half());
+  if (!rdm_done) ISAC_TRY(isac_rdm_power_window(ctx, ep, cfar, rx, tx, K, L, A, &nr, &nc, use_cached_range));          // fft2D.m:37-46,61
   const int n_cut_rows = cfar->row1 - cfar->row0 + 1, n_cut_cols = cfar->col1 - cfar->col0 + 1;
   const long long n_cut = (long long)n_cut_rows * n_cut_cols;
   // per-antenna detection capacity: every CUT of the zone, bounded only by a 256 MB scratch budget (A x cap x 12 B) -- at the default
@@ -548,6 +577,7 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   ISAC_TRY(isac_cfar_window(ctx, ep, cfar, nr, nc, A, cap));                                 // fft2D.m:62 (+ numDets on device)
   ISAC_HIP(hipEventRecord(ctx->ev_cfar, ctx->stream));
   ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_cfar, 0));
+  if (wide) ISAC_TRY(eig_first_half());
   if (!upa) {   // numDets comes from the CFAR branch, still on the device                   music.m:12,82-91
     if (sub) ISAC_TRY(isac_music_subspace_dev(ctx, A, (const int*)ctx->misc.p, 0, s2));          // the numDets signal vectors (or the QL fallback)
     ISAC_TRY(isac_music_scan_dev(ctx, A, (const int*)ctx->misc.p, 0, d_sind, n_steps, 0.5, (double*)ctx->spec.p, s2, 0, sub ? isac_music_ctl(ctx) : nullptr));
@@ -580,6 +610,7 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   char* h = (char*)ctx->pinned;
   ISAC_HIP(hipMemcpyAsync(h, dbase, first_bytes, hipMemcpyDeviceToHost, ctx->stream));
   timeline_mark(ctx, 6, ctx->stream);
+  ISAC_HIP(hipEventRecord(ctx->ev_done, ctx->stream));
   // everything the host half needs later
   Fft2dPending& pd = ctx->pending;
   pd.ep = *ep; pd.cfar = *cfar;
@@ -606,7 +637,7 @@ extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
   const bool upa = ep->array_is_upa != 0;
   const int n_cut_rows = cfar->row1 - cfar->row0 + 1;
   char* h = (char*)ctx->pinned;
-  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  ISAC_HIP(hipEventSynchronize(ctx->ev_done));      // (not the stream: contexts that share streams have later CPIs queued behind this one)
   if (ctx->tl_on) {
     float t[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 7; ++i) (void)hipEventElapsedTime(&t[i], timeline_base(ctx->stream), ctx->tl[i]);
@@ -886,8 +917,23 @@ extern "C" int isac_ctx_set_option(isac_ctx* ctx, int32_t option, int32_t value)
   switch (option) {
     case ISAC_OPT_MUSIC_ROUTE: ctx->music_route = value; return ISAC_OK;          // 0 = signal-subspace eigensolver (default), 1 = full eig
     case ISAC_OPT_TAIL_FUSION: ctx->tail_fusion = value; return ISAC_OK;          // 1 = one Doppler + CFAR launch (default), 0 = separate kernels
+    case ISAC_OPT_WIDE_ORDER: ctx->wide_order = value; return ISAC_OK;            // 1 = covariance on the main stream, the narrow kernels on the second
     default: return fail(ctx, ISAC_ERR_INVALID_ARG, "unknown option");
   }
+}
+
+// Several contexts on ONE pair of streams: a context is then a set of buffers / scratch, and the device executes the calls of all of them
+// in submission order -- the wide kernels (beam-sum, fused echo + range, covariance with ISAC_OPT_WIDE_ORDER) one after the other on the main
+// stream, never side by side, the narrow ones of each CPI on the second stream underneath.
+extern "C" int isac_ctx_share_streams(isac_ctx* ctx, isac_ctx* owner) {
+  ISAC_ENTER(ctx);
+  if (owner && owner->device != ctx->device) return fail(ctx, ISAC_ERR_INVALID_ARG, "contexts of different devices cannot share streams");
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream2));
+  if (ctx->pending.active) return fail(ctx, ISAC_ERR_INVALID_ARG, "a submitted fft2D is pending on this context: collect it first");
+  ctx->stream = (owner && owner != ctx) ? owner->stream : ctx->own_stream;
+  ctx->stream2 = (owner && owner != ctx) ? owner->stream2 : ctx->own_stream2;
+  return ISAC_OK;
 }
 
 hipEvent_t isac::timeline_base(hipStream_t st) {

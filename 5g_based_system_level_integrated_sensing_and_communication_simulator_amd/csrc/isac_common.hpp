@@ -109,6 +109,8 @@ struct isac_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // MUSIC branch (covariance/eig) overlaps the RDM branch
+  hipStream_t own_stream = nullptr, own_stream2 = nullptr;   // the streams this context created (stream / stream2 may alias another context's: isac_ctx_share_streams)
+  hipEvent_t ev_done = nullptr;    // behind the last device operation of isac_fft2d_submit*: what isac_fft2d_collect waits for
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_cfar = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
   // ISAC_TIMELINE=1 (development aid): timed events around the wide kernels of a CPI, printed by isac_fft2d_collect relative to a
   // process-wide base event -- the device-side schedule of a multi-context pipeline WITHOUT a profiler slowing the host down
@@ -117,6 +119,7 @@ struct isac_ctx {
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // isac_profile_*: around the dominant kernel of the last fused echo call
   bool profile = false, profile_recorded = false;
   int music_route = 0;             // ISAC_OPT_MUSIC_ROUTE: 0 = signal-subspace eigensolver for MUSIC (default), 1 = always the full eigendecomposition
+  int wide_order = 0;              // ISAC_OPT_WIDE_ORDER: 1 = fft2D's covariance on the main stream, everything narrow (Doppler, CFAR, MUSIC chain, pack, D2H) on the second
   int tail_fusion = 1;             // ISAC_OPT_TAIL_FUSION: 1 = panel CFAR + per-antenna merge / numDets where applicable (default), 0 = memset + per-antenna CFAR + count
   std::string err;
   // cached device tables

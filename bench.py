@@ -127,8 +127,17 @@ class SlotPool:
     CPIs are in flight on the GPU however many cells there are (two HIP streams per context: keep 2 n within
     GPU_MAX_HW_QUEUES -- 24 streams collapse to half the rate, profiles/r02_queue_sweep.txt).  Results are collected in submission order."""
 
-    def __init__(self, pkg, device, n):
+    def __init__(self, pkg, device, n, ordered=False):
         self.ctxs = [pkg.Context(device) for _ in range(max(1, n))]
+        self.ordered = bool(ordered) and len(self.ctxs) > 1
+        if self.ordered:
+            # every context enqueues on the first one's two streams, the covariance stays on the main stream: the device runs the wide
+            # kernels of consecutive CPIs (beam-sum, fused echo + range, covariance) back to back, each alone, and the narrow MUSIC /
+            # CFAR chains underneath on the second stream (include/isac.h: isac_ctx_share_streams, ISAC_OPT_WIDE_ORDER)
+            for c in self.ctxs:
+                c.set_wide_order(True)
+            for c in self.ctxs[1:]:
+                c.share_streams(self.ctxs[0])
         self.owner = [None] * len(self.ctxs)
         self.k = 0
         self.timeline = None          # list of (collect_s, enqueue_s) per submit while recording (host-side stalls show up here)
@@ -437,6 +446,9 @@ def main():
                                                                  "un-paced time per CPI measured during the priming phase.  CPIs submitted in a burst advance in lockstep on the GPU "
                                                                  "(round-robin dispatch among their queues) and finish together, so their narrow MUSIC tails leave the GPU nearly idle "
                                                                  "once per batch; staggered arrivals keep the in-flight CPIs at different phases (profiles/r03_pacing_sweep.txt)")
+    ap.add_argument("--schedule", choices=("ordered", "free"), default="free",
+                    help="ordered: all in-flight contexts enqueue on ONE pair of streams (isac_ctx_share_streams + ISAC_OPT_WIDE_ORDER) -- the wide kernels of "
+                         "consecutive CPIs run back to back, never side by side, no pacing; free: two streams per context, the device interleaves the CPIs")
     ap.add_argument("--trace-only", action="store_true", help="profiling aid: nothing after the timed region (no isolated-kernel / blocking-CPI / stage / CPU legs), "
                                                               "so that a rocprofv3 trace holds priming + warm-up + the timed steps only")
     ap.add_argument("--n1-value", type=float, default=None, help="N > 1: the N = 1 value of the same per-GPU workload (slots/s) -> `efficiency_vs_n1` in the line")
@@ -465,7 +477,9 @@ def main():
             local_rank = local_rank % max(n_dev, 1)
             dist.init_process_group(backend)
     pkg = importlib.import_module(PKG)
-    pool = SlotPool(pkg, local_rank, args.inflight)          # the GPU's execution slots, shared by all its cells
+    pool = SlotPool(pkg, local_rank, args.inflight, ordered=args.schedule == "ordered")          # the GPU's execution slots, shared by all its cells
+    if pool.ordered:
+        args.pace_ms = 0.0                                   # submission order IS the device order: nothing to stagger
     pool.pace_s = 1e-3 * max(args.pace_ms, 0.0)
     d = importlib.import_module(PKG + "._dist")
     my_cells = d.shard_cells(args.cells, rank, world) if args.cells > 0 else [rank * args.cells_per_gpu + c for c in range(args.cells_per_gpu)]
@@ -584,7 +598,7 @@ def main():
             "pacing": {"mode": "off" if pool.pace_s == 0.0 else ("auto" if args.pace_ms < 0 else "fixed"), "pace_ms": round(1e3 * pool.pace_s, 4),
                        "unpaced_ms_per_cpi_during_priming": None if unpaced_ms is None else round(unpaced_ms, 4),
                        "note": "host-side minimum spacing of consecutive CPI submissions (staggered arrivals; 0.93 x the un-paced period measured while priming)"},
-            "pipeline": {"cpis_in_flight": args.inflight, "blocking_cpi_ms": None if blocking_ms is None else round(blocking_ms, 3),
+            "pipeline": {"cpis_in_flight": args.inflight, "schedule": args.schedule, "blocking_cpi_ms": None if blocking_ms is None else round(blocking_ms, 3),
                          "note": "the timed region starts with an empty device and ends fully drained: its K steps include one pipeline fill and "
                                  "one drain (about one blocking CPI latency in total); steady-state rate = the same command with --steps 100"},
             "priming": {"untimed_steps_before_warmup": prime_steps, "ms": round(prime_ms, 1),

@@ -32,10 +32,10 @@ extern "C" {
 #endif
 
 /* Bumped on EVERY change of a struct layout, enum value or entry-point signature below (1: round 1; 2: ISAC_MAX_EST 1024 -> 4096,
- * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top).  A host must
+ * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams).  A host must
  * compare isac_abi_version() with the ISAC_ABI_VERSION it was compiled against AND isac_abi_sizeof() with its own sizeof of every
  * struct it passes: the library writes whole structs (isac_est_result is 128 KB) into caller memory. */
-#define ISAC_ABI_VERSION 3
+#define ISAC_ABI_VERSION 4
 #define ISAC_MAX_EST 4096 /* capacity of the estimate vectors in isac_est_result: unique range bins <= nIFFT (<= 4096 for every
                              * NR numerology), unique velocity bins <= nFFT, azimuth peaks <= 180 -- never the binding limit */
 
@@ -303,9 +303,23 @@ int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_t n_top, do
  * ISAC_OPT_TAIL_FUSION  fft2D.m:59-99 after the power window:
  *   1 (default)  CA-CFAR on (antenna, 42-CUT-row panel) workgroups, then one merge workgroup per antenna (CUT order) that also forms numDets
  *                (zones whose half-window fits a 48-row panel; other shapes take setting 0 by themselves);
- *   0            memset of the row flags, one CFAR workgroup per antenna, a separate count kernel. */
-enum { ISAC_OPT_MUSIC_ROUTE = 0, ISAC_OPT_TAIL_FUSION = 1 };
+ *   0            memset of the row flags, one CFAR workgroup per antenna, a separate count kernel.
+ * ISAC_OPT_WIDE_ORDER  which stream the stages of isac_fft2d_submit*_dev are enqueued on (a scheduling choice; same results):
+ *   0 (default)  main stream: (range ->) Doppler -> CFAR -> pack;  second stream: covariance -> MUSIC chain (joined before pack) -- the
+ *                shortest latency of a single CPI;
+ *   1            main stream: (range stage when not cached,) covariance;  second stream: Doppler -> CFAR -> MUSIC chain -> pack -> D2H in one
+ *                sequence -- every wide kernel of the CPI on one stream.  Meant for contexts that share their streams (below). */
+enum { ISAC_OPT_MUSIC_ROUTE = 0, ISAC_OPT_TAIL_FUSION = 1, ISAC_OPT_WIDE_ORDER = 2 };
 int isac_ctx_set_option(isac_ctx* ctx, int32_t option, int32_t value);
+
+/* A host that keeps several CPIs in flight on one device uses one context per CPI (buffers, scratch, pending result).  By default each
+ * context enqueues on two streams of its own and the device interleaves the CPIs' kernels as it sees fit.  After
+ * isac_ctx_share_streams(ctx, owner) `ctx` enqueues on `owner`'s two streams instead: the device then executes the calls of all sharing
+ * contexts in submission order -- with ISAC_OPT_WIDE_ORDER = 1 the HBM-wide kernels (beam-sum, echo synthesis + range stage, covariance)
+ * of consecutive CPIs run back to back, each with the device to itself, and each CPI's narrow kernels run underneath on the second
+ * stream.  isac_fft2d_collect waits for its own CPI only.  owner = NULL (or ctx itself) restores the context's own streams.  `owner`
+ * must outlive the sharing; both contexts must be idle (no pending submit) and on the same device. */
+int isac_ctx_share_streams(isac_ctx* ctx, isac_ctx* owner);
 
 /* sensing.estimation.doaEstimation.music(numDets, radarEstParams, Ra) (music.m:1), ULA branch.
  * num_dets < 0 means [] (model order from determineNumTargets, music.m:109-125). */
