@@ -83,7 +83,7 @@ if blk:
         s += f" SQ_WAIT_ANY / SQ_WAVE_CYCLES {d['SQ_WAIT_ANY'] / d['SQ_WAVE_CYCLES']:.2f}; SQ_LDS_BANK_CONFLICT {d.get('SQ_LDS_BANK_CONFLICT', 0):,.0f} of {d.get('SQ_LDS_IDX_ACTIVE', 0):,.0f} LDS cycles"
     out.append(s + ".")
 for name, label in (("bench_driver_invocation.json", "driver invocation (`--gpus 1 --steps 20 --warmup 5`)"), ("bench_driver_invocation_2.json", "the same again"),
-                    ("bench_default_100steps.json", "100 steps"), ("bench_blocking.json", "`--inflight 1` (blocking CPIs)"),
+                    ("bench_default_100steps.json", "100 steps"), ("bench_default_100steps_ordered.json", "100 steps, `--schedule ordered` (all contexts on one pair of streams)"), ("bench_blocking.json", "`--inflight 1` (blocking CPIs)"),
                     ("bench_blocking_full_eig.json", "`--inflight 1`, full eigendecomposition route (`ISAC_MUSIC_FULL_EIG=1`: the round-2 eigensolver)"),
                     ("bench_default_100steps_old_cfar.json", "100 steps, per-antenna CFAR + memset + count (`ISAC_TAIL_UNFUSED=1`)"),
                     ("bench_7cells_per_gpu.json", "7 cells per GPU"), ("bench_a256.json", "`--ants 256 --inflight 3`"),
