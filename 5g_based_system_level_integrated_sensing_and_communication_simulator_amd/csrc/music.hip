@@ -63,7 +63,7 @@ __device__ __forceinline__ double wave_sum_dpp(double x) {
 // Three real MFMAs per tile and k-step instead of four (3M / Gauss form, see cov_group_body): 30 instead of 40 per four samples
 // at A = 64.  Measured at A = 64 (733 824 samples): 4M, interleaved sample map, 3 workgroups per CU 276 us / 1.37 GB fetched;
 // 3M + line map, 2 workgroups per CU 209 us / 1.05 GB; + a workgroup barrier every 8 slabs 215 us / 0.73 GB (= the input, once).
-constexpr int kCovSyncSlabs = 8;                                // power of two
+constexpr int kCovSyncSlabs = 8;                                // power of two (1, 2, 4: +3-9 %; 16 .. none: within the noise of 8 -- ISAC_COV_WGTIMES spans)
 template <int NB>
 struct CovPlan {
   static constexpr int kTiles = NB * (NB + 1) / 2;
@@ -91,10 +91,11 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int NB, int GRP>
+template <int NB, int GRP, int NBUF = 3>
 __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long long N, int A, int n_tiles, int phase, int lane,
-                                               long long s_begin, long long s_end, int part_index,
+                                               long long s0, long long s_step, long long s_cnt, long long s_lim, int part_index,
                                                double* __restrict__ part) {
+  // this wave's i-th slab (16 samples) is slab s0 + i s_step of the grid, i = 0 .. s_cnt - 1; slabs >= s_lim contribute nothing
   using P = CovPlan<NB>;
   constexpr int T0 = GRP * P::kPerGroup;
   constexpr int NT = (T0 + P::kPerGroup <= P::kTiles) ? P::kPerGroup : (P::kTiles - T0);
@@ -108,29 +109,31 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
   v4f64 re[NT], im[NT], s3[NT];
 #pragma unroll
   for (int u = 0; u < NT; ++u) re[u] = im[u] = s3[u] = v4f64{0.0, 0.0, 0.0, 0.0};
-  // column pointers of this lane's antenna in each block (clamped: loads stay unconditional)
-  const c64* colp[NB];
+  // One raw-buffer descriptor per 16-antenna block (uniform: scalar registers), ending with the array's last antenna: padding antennas read as
+  // zero by the bounds check, and per thread the address of all NB x SPL loads of a slab is ONE 32-bit offset (+ immediates) -- the 64-bit
+  // pointer arithmetic and index clamps of a pointer-per-block form were ~30 of the ~40 VALU instructions of a slab, every one of them paid in
+  // full beside the 30 v_mfma_f64 (MFMA and VALU do not co-issue).
+  __amdgpu_buffer_rsrc_t rs[NB];
   bool colok[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
-    const int a = b * 16 + li;
-    colok[b] = a < A;
-    colp[b] = G + N * (long long)(colok[b] ? a : 0);
+    int n_ant = A - 16 * b;
+    n_ant = n_ant < 0 ? 0 : (n_ant > 16 ? 16 : n_ant);
+    colok[b] = li < n_ant;
+    rs[b] = buffer_of(G + N * (long long)(n_ant > 0 ? 16 * b : 0), (unsigned)(N * n_ant * (long long)sizeof(c64)));
   }
   const long long lane_off = (16 / P::kPhases) * phase + SPL * kq;   // first sample of this lane inside a slab (see above)
+  const unsigned lane_byte = (unsigned)((N * li + lane_off) * (long long)sizeof(c64));
   // Loads are unconditional (clamped indices) and the out-of-range mask is applied when a slab is CONSUMED, not when it is loaded: a
   // select at load time makes the compiler predicate the loads (branches + `s_waitcnt vmcnt(0)` before the MFMAs), a multiply at load time
   // waits for the data right away -- either way the prefetch of the next slab would not fly under the current slab's MFMAs (ISA-checked).
+  // (samples past N of the last slab read the next antenna's first samples or, behind the last antenna, zero: masked at consumption)
   auto load_raw = [&](c64 (&dst)[NB][SPL], long long slab) {
-    const long long n0 = slab * 16 + lane_off;
+    const unsigned off = lane_byte + (unsigned)slab * (unsigned)(16 * sizeof(c64));
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int e = 0; e < SPL; ++e) {
-        long long n = n0 + e;
-        if (n >= N) n = N - 1;
-        dst[b][e] = colp[b][n];
-      }
+      for (int e = 0; e < SPL; ++e) dst[b][e] = buffer_load_c64(rs[b], off + (unsigned)(e * sizeof(c64)));
   };
   auto mask = [&](c64 (&v)[NB][SPL], long long slab) {               // padding antennas and samples past N contribute 0
     const long long n0 = slab * 16 + lane_off;
@@ -138,7 +141,7 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
     for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int e = 0; e < SPL; ++e) {
-        const double m = ((n0 + e < N) && colok[b]) ? 1.0 : 0.0;
+        const double m = ((n0 + e < N) && colok[b] && slab < s_lim) ? 1.0 : 0.0;
         v[b][e] = mk(v[b][e].re * m, v[b][e].im * m);
       }
   };
@@ -176,30 +179,28 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
     // exist only when A is not a multiple of 16 or in the very last slab: the 0/1 mask multiply runs only then (wave-uniform branch) --
     // VALU instructions do not overlap v_mfma_f64 on this hardware (tools/cobench.hip), every one of them is paid in full.
     const bool ants_full = (A == 16 * NB);
-    const long long last = s_end - 1;
-    auto step = [&](c64 (&use)[NB][SPL], c64 (&fill)[NB][SPL], long long slab) {
-      // every kCovSyncSlabs slabs the four waves re-align, so that a line is still in L1 / L2 when the other tile group asks for it
-      // (a barrier on EVERY slab costs 9-11 % of the pipelined rate: one delayed wave then stalls the workgroup each time)
-      if (((slab - s_begin) & (kCovSyncSlabs - 1)) == 0) __builtin_amdgcn_s_barrier();   // (workgroup-uniform)
-      load_raw(fill, slab + 2 < s_end ? slab + 2 : last);
+    const long long i_last = s_cnt - 1;
+    auto slab_at = [&](long long i) { return s0 + (i < i_last ? i : i_last) * s_step; };
+    c64 buf[NBUF][NB][SPL];                           // buffer r holds slab i with i mod NBUF == r; slabs i+1 .. i+NBUF-1 are in flight under slab i
+                                                      // (NBUF = 4 fits at 254 VGPRs since the buffer loads: the same 178-182 us as NBUF = 3 at A = 64)
+    auto step = [&](auto rc, long long i) {
+      constexpr int r = decltype(rc)::value, f = (r + NBUF - 1) % NBUF;
+      // every kCovSyncSlabs slabs the waves of the workgroup re-align, so that a line is still in L1 / L2 when the other tile group asks for
+      // it (a barrier on EVERY slab costs 9-11 % of the pipelined rate: one delayed wave then stalls the workgroup each time)
+      if ((i & (kCovSyncSlabs - 1)) == 0) __builtin_amdgcn_s_barrier();   // (workgroup-uniform: every wave runs s_cnt steps)
+      load_raw(buf[f], slab_at(i + NBUF - 1));
       __builtin_amdgcn_sched_barrier(0);
-      if (!ants_full || slab * 16 + 16 > N) mask(use, slab);          // (wave-uniform, rare)
-      mfmas(use);
+      const long long slab = s0 + i * s_step;
+      if (!ants_full || slab * 16 + 16 > N || slab >= s_lim) mask(buf[r], slab);          // (wave-uniform, rare)
+      mfmas(buf[r]);
       __builtin_amdgcn_sched_barrier(0);              // waits for later slabs' data belong AFTER this slab's MFMAs have been issued
     };
-    c64 b0[NB][SPL], b1[NB][SPL], b2[NB][SPL];       // (two buffers / one slab ahead: same isolated time, -0.8 % pipelined)
-    if (s_begin < s_end) {
-      load_raw(b0, s_begin);
-      load_raw(b1, s_begin + 1 < s_end ? s_begin + 1 : last);
-    }
-    long long slab = s_begin;
-    for (; slab + 3 <= s_end; slab += 3) {
-      step(b0, b2, slab);
-      step(b1, b0, slab + 1);
-      step(b2, b1, slab + 2);
-    }
-    if (slab < s_end) step(b0, b2, slab);
-    if (slab + 1 < s_end) step(b1, b0, slab + 1);
+    if (s_cnt > 0) static_for<0, NBUF - 1>([&](auto rc) { load_raw(buf[decltype(rc)::value], slab_at(decltype(rc)::value)); });
+    long long i = 0;
+    for (; i + NBUF <= s_cnt; i += NBUF) static_for<0, NBUF>([&](auto rc) { step(rc, i + decltype(rc)::value); });
+    static_for<0, NBUF - 1>([&](auto rc) {
+      if (i + decltype(rc)::value < s_cnt) step(rc, i + decltype(rc)::value);
+    });
   }
   static_for<0, NT>([&](auto uc) {
     constexpr int u = decltype(uc)::value;
@@ -218,11 +219,13 @@ __device__ __forceinline__ void cov_group_body(const c64* __restrict__ G, long l
   });
 }
 
-template <int NB>
+template <int NB, int NBUF = 3>
 __global__ __launch_bounds__(256, 2) void cov_mfma_small_kernel(const c64* __restrict__ G, long long N, int A,
                                                                 long long slabs_per_wg,
-                                                                double* __restrict__ part /* [gridX*kPhases][kTiles][2][256] */) {
+                                                                double* __restrict__ part /* [gridX*kPhases][kTiles][2][256] */,
+                                                                long long* __restrict__ dbg /* dev: (start, end, xcc) per workgroup, or null */) {
   using P = CovPlan<NB>;
+  const long long dbg_t0 = dbg ? (long long)wall_clock64() : 0;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int grp = wid / P::kPhases, phase = wid % P::kPhases;
@@ -231,9 +234,17 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_small_kernel(const c64* __res
   long long s_end = s_begin + slabs_per_wg;
   if (s_end > total) s_end = total;
   const int pidx = blockIdx.x * P::kPhases + phase;
-  if (grp == 0) cov_group_body<NB, 0>(G, N, A, P::kTiles, phase, lane, s_begin, s_end, pidx, part);
+  if (grp == 0) cov_group_body<NB, 0, NBUF>(G, N, A, P::kTiles, phase, lane, s_begin, 1, s_end - s_begin, s_end, pidx, part);
   if constexpr (P::kGroups > 1) {
-    if (grp == 1) cov_group_body<NB, 1>(G, N, A, P::kTiles, phase, lane, s_begin, s_end, pidx, part);
+    if (grp == 1) cov_group_body<NB, 1, NBUF>(G, N, A, P::kTiles, phase, lane, s_begin, 1, s_end - s_begin, s_end, pidx, part);
+  }
+  if (dbg) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned xcc = 0;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      dbg[3 * blockIdx.x] = dbg_t0; dbg[3 * blockIdx.x + 1] = (long long)wall_clock64(); dbg[3 * blockIdx.x + 2] = xcc & 15;
+    }
   }
 }
 
@@ -1771,14 +1782,38 @@ template <int NB>
 static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long long N, int A, c64* Ra) {
   using P = CovPlan<NB>;
   const long long total = (N + 15) / 16;
-  long long gx = NB == 4 ? 512 : 768;       // NB = 4: 2 workgroups per CU (register-limited occupancy: 192 VGPRs)
+  if (N * 256 >= (1ll << 32)) return fail(ctx, ISAC_ERR_UNSUPPORTED, "covariance: at most 2^24 - 1 samples per antenna");
+  long long gx = NB == 4 ? 512 : 768;       // NB = 4: 2 workgroups per CU (register-limited occupancy)
   if (gx > total) gx = total;
   const long long per = (total + gx - 1) / gx;
   gx = (total + per - 1) / per;
   const int n_part = (int)gx * P::kPhases;
   ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * ((size_t)n_part + 32) * P::kTiles * 2 * 256));
-  hipLaunchKernelGGL((cov_mfma_small_kernel<NB>), dim3((unsigned)gx), dim3(256), 0, st, G, N, A, per, (double*)ctx->cov_part.p);
+  static const bool wg_times = std::getenv("ISAC_COV_WGTIMES") != nullptr;       // dev probe: per-workgroup wall-clock spans, printed per launch
+  static long long* d_dbg = nullptr;
+  if (wg_times && !d_dbg) ISAC_HIP(hipMalloc(&d_dbg, sizeof(long long) * 3 * 4096));
+  hipLaunchKernelGGL((cov_mfma_small_kernel<NB>), dim3((unsigned)gx), dim3(256), 0, st, G, N, A, per, (double*)ctx->cov_part.p, wg_times ? d_dbg : nullptr);
   ISAC_HIP(hipGetLastError());
+  if (wg_times) {
+    std::vector<long long> h((size_t)3 * gx);
+    ISAC_HIP(hipStreamSynchronize(st));
+    ISAC_HIP(hipMemcpy(h.data(), d_dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+    long long t0 = h[0], t1 = h[1];
+    for (long long b = 0; b < gx; ++b) { t0 = std::min(t0, h[3 * b]); t1 = std::max(t1, h[3 * b + 1]); }
+    double sum[16] = {0}, mx[16] = {0}, mn[16]; int cnt[16] = {0};
+    for (int x = 0; x < 16; ++x) mn[x] = 1e30;
+    double end_sum = 0, start_max = 0;
+    for (long long b = 0; b < gx; ++b) {
+      const int x = (int)h[3 * b + 2];
+      const double d = 0.01 * (double)(h[3 * b + 1] - h[3 * b]);       // 100 MHz ticks -> us
+      sum[x] += d; mx[x] = std::max(mx[x], d); mn[x] = std::min(mn[x], d); ++cnt[x];
+      end_sum += 0.01 * (double)(h[3 * b + 1] - t0);
+      start_max = std::max(start_max, 0.01 * (double)(h[3 * b] - t0));
+    }
+    std::fprintf(stderr, "COVWG span %.1f us, last start +%.1f us, mean end +%.1f us |", 0.01 * (double)(t1 - t0), start_max, end_sum / (double)gx);
+    for (int x = 0; x < 16; ++x) if (cnt[x]) std::fprintf(stderr, " xcc%d n=%d %.0f/%.0f/%.0f", x, cnt[x], mn[x], sum[x] / cnt[x], mx[x]);
+    std::fprintf(stderr, "\n");
+  }
   const int S = 32;
   double* part2 = (double*)ctx->cov_part.p + (size_t)n_part * P::kTiles * 2 * 256;
   hipLaunchKernelGGL(cov_reduce_slice_kernel, dim3(P::kTiles, S), dim3(256), 0, st, (const double*)ctx->cov_part.p, n_part, P::kTiles, S,
