@@ -248,8 +248,12 @@ struct Fft4096W {
   static constexpr int NT = 512;
   static constexpr int PER = 8;
   static constexpr int IMG = 4096;
-  static constexpr int LDS_ELEMS = IMG + 512 + 8;    // + W512 table (second / third pass twiddles, OFDM phase ramps, the generator's angle table)
+  static constexpr int LDS_ELEMS = IMG + 512 + 8 + 64;   // + W512 table (second pass twiddles, OFDM phase ramps, the generator's angle table)
                                                      //   + W4096^0..7 (first-pass twiddles are rebuilt from the tables, see init_twiddles_lds)
+                                                     //   + W64 = W512^(8 m), contiguous: the third pass reads W64^(g h) for g = lane mod 8 -- out of the W512 table
+                                                     //     that is a stride of 8 h slots, i.e. 4 (h odd) or 8 (h even) distinct addresses on ONE 16-byte bank
+                                                     //     group per read (132 of the ~270 LDS conflict cycles of a column and wave); contiguous it is
+                                                     //     conflict-free but for h = 4 (2-way)
   static constexpr int kW256Stride = 2;              // W256^i = table[2 i]
   c64 x[PER];
   c64 wb[3];                                         // W4096^(tid * {1, 2, 4})
@@ -265,11 +269,12 @@ struct Fft4096W {
     lds[IMG + tid] = pack[tid];                      // W512^tid
     if (tid < 8) lds[IMG + 512 + tid] = pack[512 + tid];   // W4096^tid
     __syncthreads();
+    if (tid < 64) lds[IMG + 520 + tid] = lds[IMG + 8 * tid];      // W64 (first read in pass 3, several barriers from here)
   }
   // First-pass twiddles W4096^(tid {1, 2, 4}) from the LDS tables (W4096^tid = W512^(tid div 8) W4096^(tid mod 8), then two squarings;
   // a few ulp from the table values) instead of three global loads: in the fused echo kernel those loads sat behind the column's
   // echoGrid stores, and a wait for a load is a wait for every earlier store's acknowledgement as well (one in-order vmcnt on gfx9).
-  __device__ __forceinline__ void init_twiddles_lds(const c64* __restrict__ lds, int tid) {
+  __device__ __forceinline__ void init_twiddles_lds(c64* __restrict__ lds, int tid) {
     wb[0] = lds[IMG + (tid >> 3)] * lds[IMG + 512 + (tid & 7)];
     wb[1] = wb[0] * wb[0];
     wb[2] = wb[1] * wb[1];
@@ -298,6 +303,7 @@ struct Fft4096W {
   template <int DIR>
   __device__ __forceinline__ void transform(c64* __restrict__ lds, const c64* __restrict__, int tid, int only_block = -1) {
     const c64* t512 = lds + IMG;
+    const c64* t64 = lds + IMG + 520;
     // ---- pass 1
     dft8<DIR>(x);
     {
@@ -339,7 +345,7 @@ struct Fft4096W {
       c64* o = lds + ((g + k1) & 7) + 8 * e + 512 * k1;
       o[0] = x[0];
 #pragma unroll
-      for (int h = 1; h < 8; ++h) o[64 * h] = x[h] * tw_dir<DIR>(t512[8 * g * h]);      // W64^(g h)
+      for (int h = 1; h < 8; ++h) o[64 * h] = x[h] * tw_dir<DIR>(t64[g * h]);           // W64^(g h), g h <= 49
     }
     __syncthreads();
     // ---- pass 4
