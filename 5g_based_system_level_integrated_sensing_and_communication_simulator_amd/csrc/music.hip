@@ -875,6 +875,132 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
   }
 }
 
+// ---- n > 64, one pass over the trailing matrix per reflector instead of two.  zhetd2 reads A22 for p = tau A22 v and then reads AND writes it for
+// A22 -= v w' + w v'; the matrix (1 MB at n = 256) streams from L2 through one CU, and that traffic is half of the kernel.  Here the rank-2
+// update of step k - 1 is carried as a PENDING pair (v, w) and applied while the matrix-vector product of step k walks the matrix:
+//   (a) column k gets the pending update by itself (O(n)) -> d[k], the new reflector v', tau';
+//   (b) one pass over rows / columns > k:  a' = a - v_i conj(w_j) - w_i conj(v_j);  store a';  acc_i += a' v'_j   (one read + one write per element);
+//   (c) w' = tau' acc + alpha v'  becomes the pending pair of step k + 1.
+// Element for element the arithmetic is that of eigh_tridiag_kernel (same update expression, same partial-sum order of the product): d, e,
+// tau and the reflectors come out bit-identical.
+__global__ __launch_bounds__(1024) void eigh_tridiag_fused_kernel(const c64* __restrict__ Hin, int n, void* scratch, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  EighScratch S(scratch, n);
+  c64* M = S.M;                                     // [n x n] column-major working matrix (reflectors end up below the subdiagonal)
+  c64* sv = reinterpret_cast<c64*>(smem_raw);       // [n] pending reflector (zero before the first step)
+  c64* sw = sv + n;                                 // [n] pending w
+  c64* sn = sw + n;                                 // [n] the step's new reflector
+  c64* spart = sn + n;                              // [4][n] partial matrix-vector products
+  double* sred = reinterpret_cast<double*>(spart + 4 * n);   // [2 x 16] block-reduction scratch
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nt >> 6;
+  auto block_sum2 = [&](double a, double b, double& oa, double& ob) {   // sum over the workgroup of two values
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+    __syncthreads();
+    if (lane == 0) { sred[wid] = a; sred[16 + wid] = b; }
+    __syncthreads();
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < nw; ++w) { ta += sred[w]; tb += sred[16 + w]; }
+    oa = ta; ob = tb;
+  };
+  const long long t_start = clock64();
+  const double scl = eigh_safe_scale(Hin, n * n, sred);
+  for (int i = tid; i < n * n; i += nt) M[i] = Hin[i] * scl;
+  for (int i = tid; i < n; i += nt) sv[i] = sw[i] = mk(0.0, 0.0);
+  if (tid == 0) *S.scale = scl;
+  if (tid < 8) S.cnt[tid] = 0;                      // publication counters of the next two stages
+  __syncthreads();
+  constexpr int rw_shift = 8, RW = 1 << rw_shift;   // row tile of the pass
+  for (int k = 0; k < n - 1; ++k) {                 // zhetd2, lower
+    const int m = n - k - 1;                        // trailing size, rows/cols k+1 .. n-1
+    // (a) column k, rows k .. n-1: the pending update
+    {
+      const c64 wk = sw[k], vk = sv[k];
+      for (int i = k + tid; i < n; i += nt) M[i + n * k] = M[i + n * k] - mul_conj(sv[i], wk) - mul_conj(sw[i], vk);
+    }
+    __syncthreads();
+    double xn2 = 0.0, dummy = 0.0;
+    for (int i = k + 2 + tid; i < n; i += nt) { const c64 x = M[i + n * k]; xn2 += x.re * x.re + x.im * x.im; }
+    double xnorm2, unused;
+    block_sum2(xn2, dummy, xnorm2, unused);
+    const c64 alpha = M[k + 1 + n * k];
+    c64 tau = mk(0.0, 0.0), scale = mk(0.0, 0.0);
+    double beta = alpha.re;
+    if (xnorm2 != 0.0 || alpha.im != 0.0) {         // zlarfg
+      beta = -copysign(sqrt(alpha.re * alpha.re + alpha.im * alpha.im + xnorm2), alpha.re);
+      tau = mk((beta - alpha.re) / beta, -alpha.im / beta);
+      const c64 dlt = mk(alpha.re - beta, alpha.im);
+      const double dn = dlt.re * dlt.re + dlt.im * dlt.im;
+      scale = mk(dlt.re / dn, -dlt.im / dn);        // 1 / (alpha - beta)
+    }
+    for (int i = k + 1 + tid; i < n; i += nt) {
+      const c64 vi = (i == k + 1) ? mk(1.0, 0.0) : M[i + n * k] * scale;
+      sn[i] = vi;
+      if (i > k + 1) M[i + n * k] = vi;             // keep the reflector for zungtr
+    }
+    if (tid == 0) { S.d[k] = M[k + n * k].re; S.e[k] = beta; S.tau[k] = tau; }
+    __syncthreads();
+    // (b) rows / columns k+1 .. n-1: pending update applied, product with the new reflector accumulated (thread = row i, column quarter jq:
+    // rows are coalesced across lanes, the four quarters of a row are summed through LDS -- the mapping and summation order of the unfused kernel)
+    {
+      const int rows_pt = (m + RW - 1) >> rw_shift;
+      const int G = nt >> rw_shift;
+      const int jq = tid >> rw_shift, il = tid & (RW - 1);
+      const int jlen = (m + G - 1) / G;
+      const int j0 = k + 1 + jq * jlen, j1 = min(n, j0 + jlen);
+      for (int rr = 0; rr < rows_pt; ++rr) {
+        const int i = k + 1 + il + RW * rr;
+        c64 a0 = mk(0.0, 0.0), a1 = a0, a2 = a0, a3 = a0;
+        if (i < n) {
+          const c64 vi = sv[i], wi = sw[i];
+          c64* Mi = M + i;
+          int j = j0;
+          for (; j + 4 <= j1; j += 4) {
+            c64 e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) e[u] = Mi[(long long)n * (j + u)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { e[u] = e[u] - mul_conj(vi, sw[j + u]) - mul_conj(wi, sv[j + u]); Mi[(long long)n * (j + u)] = e[u]; }
+            a0 = fma(e[0], sn[j], a0); a1 = fma(e[1], sn[j + 1], a1); a2 = fma(e[2], sn[j + 2], a2); a3 = fma(e[3], sn[j + 3], a3);
+          }
+          for (; j < j1; ++j) {
+            const c64 e = Mi[(long long)n * j] - mul_conj(vi, sw[j]) - mul_conj(wi, sv[j]);
+            Mi[(long long)n * j] = e;
+            a0 = fma(e, sn[j], a0);
+          }
+          spart[jq * n + i] = (a0 + a1) + (a2 + a3);
+        }
+      }
+      __syncthreads();                                      // every read of the pending pair is done: sv / sw can take the new one
+      if (tau.re != 0.0 || tau.im != 0.0) {
+        for (int i = k + 1 + tid; i < n; i += nt) {
+          c64 acc = spart[i];
+          for (int gq = 1; gq < G; ++gq) acc = acc + spart[gq * n + i];
+          sw[i] = tau * acc;                                // p
+        }
+      }
+    }
+    __syncthreads();
+    if (tau.re != 0.0 || tau.im != 0.0) {
+      // alpha2 = -1/2 tau (p^H v);  w = p + alpha2 v
+      double pr = 0.0, pi = 0.0;
+      for (int i = k + 1 + tid; i < n; i += nt) { const c64 t = mul_conj(sn[i], sw[i]); pr += t.re; pi += t.im; }
+      double sr, si;
+      block_sum2(pr, pi, sr, si);
+      const c64 a2 = mk(-0.5, 0.0) * (tau * mk(sr, si));
+      __syncthreads();
+      for (int i = k + 1 + tid; i < n; i += nt) { const c64 vi = sn[i]; sw[i] = sw[i] + a2 * vi; sv[i] = vi; }
+    } else {
+      for (int i = k + 1 + tid; i < n; i += nt) sv[i] = sw[i] = mk(0.0, 0.0);   // H_k = I: nothing pending
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const c64 c = M[n - 1 + n * (n - 1)] - mul_conj(sv[n - 1], sw[n - 1]) - mul_conj(sw[n - 1], sv[n - 1]);   // the last pending update
+    S.d[n - 1] = c.re; S.e[n - 1] = 0.0;
+    if (info) info[1] = (int)((clock64() - t_start) >> 6);
+  }
+}
+
 // ---- n <= 64: the same zhetd2 reduction on four wavefronts with TWO barriers per step instead of ten.  Lane i owns row i; every wave
 // derives the reflector of the step redundantly (column read, norm by a wave reduction, zlarfg scalars) and keeps its own copy of v and
 // w in LDS for broadcast reads, so nothing of that needs a workgroup barrier; wave g handles the columns j = k+1+g, k+5+g, ... of the
@@ -1870,7 +1996,13 @@ static int launch_tridiag(isac_ctx* ctx, const c64* d_H, int n, hipStream_t st, 
     ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_tridiag_small_kernel), (size_t)(112 * 1024)));
     hipLaunchKernelGGL(eigh_tridiag_small_kernel, dim3(1), dim3(64 * kTriWaves), ldss, st, d_H, n, gs, info);
   } else {
-    hipLaunchKernelGGL(eigh_tridiag_kernel<false>, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
+    static const bool unfused = std::getenv("ISAC_EIG_TRIDIAG_UNFUSED") != nullptr;   // development switch: the two-pass zhetd2 kernel
+    if (unfused) hipLaunchKernelGGL(eigh_tridiag_kernel<false>, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
+    else {
+      const size_t ldsf = sizeof(c64) * 7 * (size_t)n + sizeof(double) * 32 + 64;
+      ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_tridiag_fused_kernel), ldsf));
+      hipLaunchKernelGGL(eigh_tridiag_fused_kernel, dim3(1), dim3(1024), ldsf, st, d_H, n, gs, info);
+    }
   }
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;

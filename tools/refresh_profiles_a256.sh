@@ -16,8 +16,9 @@ pmc() { local name=$1; shift
   rm -rf /tmp/p3 && ISAC_SINGLE_STREAM=1 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/p3 -- $B --ants 256 --steps 2 --warmup 1 --inflight 1 --prime-ms 0 --no-cpu-baseline > /dev/null 2>&1
   $PS $(db /tmp/p3) --pmc --csv $OUT/${TAG}_pmc_a256_$name.csv > /dev/null
 }
+if [ "${A256_PMC:-1}" = "1" ]; then
 pmc fetch_size FETCH_SIZE
 pmc mfma_busy SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES
 pmc wait_lds SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+fi
 head -4 $OUT/${TAG}_kernel_stats_single_stream_a256.txt
-cd $ROOT; (timeout 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_parity.py -m gpu -q -x -n 4 --timeout=800 -p no:cacheprovider | tail -3) 2>&1
