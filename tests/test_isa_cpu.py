@@ -130,6 +130,15 @@ def test_covariance_small_kernel_budget(music_co):
     assert sum(1 for x in w if x == 0) <= 6 and len(w) >= 60, (len(w), sum(1 for x in w if x == 0))
 
 
+def test_one_pass_householder_kernel_budget(music_co):
+    """1024-thread workgroup: 128 VGPRs is all a wave gets; the fused pass keeps four matrix loads in flight per thread (eight spilled)."""
+    name, meta, asm = music_co.find("eigh_tridiag_fused_kernel")
+    assert meta["private_segment_fixed_size"] == 0 and meta["vgpr_count"] <= 128, meta
+    loads = sum(1 for ln in asm if ln.startswith("global_load_dwordx4"))
+    stores = sum(1 for ln in asm if ln.startswith("global_store_dwordx4"))
+    assert loads >= 4 and stores >= 4
+
+
 def test_scratch_users_are_the_known_ones(echo_co, music_co):
     known = ("echo_range_kernelILi4E", "eigh_replay_kernel")       # spill a few registers by design (DESIGN.md 3c / 3b)
     for co in (echo_co, music_co):

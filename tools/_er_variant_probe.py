@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Development probe: one variant of the fused echo-synthesis + range kernel (ISAC_ER_VARIANT, read by the library once per process) at
-the bench shape -- kernel time from the library's own HIP events, and a digest of everything the CPI produced (echo grid + estimate),
-so that variants can be compared for bit-identity across processes."""
+"""Development probe: the fused echo-synthesis + range kernel at the bench shape -- kernel time from the library's own HIP events, and a digest
+of everything the CPI produced (echo grid + estimate), so that two builds (or two settings of a development switch) can be compared for
+bit-identity across processes.  ER_TARGETS = number of LoS targets (1: digest 99744bff7fea44d1, 2: 4272ba4af33d73b2 since round 3)."""
 import ctypes as C, hashlib, importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -20,4 +20,4 @@ for k in sorted(vars(est)) if est is not None and hasattr(est, "__dict__") else 
     v = getattr(est, k)
     if isinstance(v, np.ndarray):
         h.update(np.ascontiguousarray(v).tobytes())
-print(f"variant {os.environ.get('ISAC_ER_VARIANT', '0')} targets {n_targets}: fused kernel {ms.mean():.4f} ms (min {ms.min():.4f}, max {ms.max():.4f}) digest {h.hexdigest()[:16]}")
+print(f"targets {n_targets}: fused kernel {ms.mean():.4f} ms (min {ms.min():.4f}, max {ms.max():.4f}) digest {h.hexdigest()[:16]}")
