@@ -55,6 +55,48 @@ def householder_tridiag(h):
     return d, e, v_all, tau
 
 
+def householder_tridiag_one_pass(h):
+    """The same reduction the way eigh_tridiag_fused_kernel (csrc/music.hip, n > 64) walks the matrix: the rank-2 update of reflector k - 1 is
+    carried as a pending pair (v, w) and applied element by element while the matrix-vector product of reflector k is accumulated -- column
+    k first (it defines the reflector), then one pass over the trailing rows / columns.  Returns what householder_tridiag returns."""
+    a = np.array(h, dtype=np.complex128)
+    n = a.shape[0]
+    d = np.zeros(n)
+    e = np.zeros(max(n - 1, 0))
+    tau = np.zeros(max(n - 1, 0), dtype=np.complex128)
+    v_all = np.zeros((n, n), dtype=np.complex128)
+    pv = np.zeros(n, dtype=np.complex128)                             # pending reflector / w (zero: nothing pending)
+    pw = np.zeros(n, dtype=np.complex128)
+    for k in range(n - 1):
+        a[k:, k] = a[k:, k] - pv[k:] * np.conj(pw[k]) - pw[k:] * np.conj(pv[k])          # (a) column k
+        alpha = a[k + 1, k]
+        x = a[k + 2:, k]
+        xnorm2 = float(np.sum(x.real ** 2 + x.imag ** 2))
+        v = np.zeros(n, dtype=np.complex128)
+        v[k + 1] = 1.0
+        if xnorm2 != 0.0 or alpha.imag != 0.0:                         # zlarfg
+            beta = -np.copysign(np.sqrt(alpha.real ** 2 + alpha.imag ** 2 + xnorm2), alpha.real)
+            t = complex((beta - alpha.real) / beta, -alpha.imag / beta)
+            v[k + 2:] = x / (alpha - beta)
+        else:
+            beta, t = alpha.real, 0.0
+        d[k] = a[k, k].real
+        e[k] = beta
+        tau[k] = t
+        v_all[:, k] = v
+        r = slice(k + 1, n)                                            # (b) one pass: update, store, accumulate
+        a[r, r] = a[r, r] - np.outer(pv[r], pw[r].conj()) - np.outer(pw[r], pv[r].conj())
+        acc = a[r, r] @ v[r]
+        pv[:] = 0.0
+        pw[:] = 0.0
+        if t != 0:                                                     # (c) the new pending pair
+            p = t * acc
+            pw[r] = p - 0.5 * t * np.vdot(p, v[r]) * v[r]
+            pv[r] = v[r]
+    d[n - 1] = (a[n - 1, n - 1] - pv[n - 1] * np.conj(pw[n - 1]) - pw[n - 1] * np.conj(pv[n - 1])).real
+    return d, e, v_all, tau
+
+
 def sturm_count(d, e2, x, pivmin):
     """Number of eigenvalues of tridiag(d, e) below x (negative pivots of T - x I, dstebz-style pivmin clamp)."""
     cnt = 0

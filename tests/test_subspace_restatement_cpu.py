@@ -5,6 +5,7 @@ tests/test_gpu_music_subspace.py."""
 from __future__ import annotations
 
 import numpy as np
+import pytest
 from scipy import linalg
 
 import oracle as O
@@ -62,3 +63,21 @@ def test_restatement_building_blocks():
     z = SM.signal_vectors_tridiag(d, e, w, 3)
     assert np.abs(z.T @ z - np.eye(3)).max() < 1e-13
     assert np.abs(t @ z - z * w[::-1][:3]).max() < 1e-11 * np.abs(h).max()
+
+
+@pytest.mark.parametrize("n", [3, 8, 33, 65, 130])
+def test_one_pass_householder_equals_zhetd2(n):
+    """The deferred-update walk of eigh_tridiag_fused_kernel (restated in oracle.subspace_music.householder_tridiag_one_pass) is zhetd2:
+    same d, e, tau and reflectors (the device kernels agree bit for bit -- tools/_tridiag_ab.py; the NumPy forms order their sums differently)."""
+    from oracle.subspace_music import householder_tridiag, householder_tridiag_one_pass
+    rng = np.random.default_rng(n)
+    m = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    h = m @ m.conj().T / n + np.diag(rng.uniform(0, 3, n))
+    if n == 8:                                        # a column that needs no reflector (tau = 0) in the middle of the walk
+        h[4:, 2] = 0.0; h[2, 4:] = 0.0
+        h[3, 2] = h[2, 3] = 0.7
+    d0, e0, v0, t0 = householder_tridiag(h)
+    d1, e1, v1, t1 = householder_tridiag_one_pass(h)
+    s = np.abs(h).max()
+    assert np.abs(d0 - d1).max() < 1e-13 * s and np.abs(e0 - e1).max() < 1e-13 * s
+    assert np.abs(t0 - t1).max() < 1e-13 and np.abs(v0 - v1).max() < 1e-12
