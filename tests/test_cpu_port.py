@@ -57,3 +57,33 @@ def test_cpu_port_edge_cases():
     nzv = (noisy - clean) / (np.sqrt(sc.rp.N0 / 2.0) * np.sqrt(sc.wave.Nfft))
     assert abs(nzv.real.std() - 1) < 0.03 and abs(nzv.imag.std() - 1) < 0.03 and abs(nzv.mean()) < 0.02
     assert P.threads() >= 1
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_cpu_port_matches_oracle_random_scenes(seed):
+    """Seeded random scenes (array size, bandwidth, CPI length, target count / geometry / speed, S-slot pattern): the two restatements
+    agree on every field, or fail the same way where the scene yields no detection (fft2D.m errors inside findpeaks there)."""
+    rng = np.random.default_rng(4200 + seed)
+    n_t = int(rng.integers(1, 4))
+    r = rng.uniform(60.0, 400.0, n_t)
+    az = np.deg2rad(rng.uniform(-70.0, 70.0, n_t))
+    kw = dict(n_ants=int(rng.integers(1, 10)), n_slots=int(rng.integers(2, 9)), nrb=int(rng.choice([24, 51, 106])),
+              targets=tuple((float(r[i] * np.cos(az[i])), float(r[i] * np.sin(az[i])), 1.5) for i in range(n_t)),
+              velocity=tuple(float(v) for v in rng.integers(-12, 13, n_t)), seed=seed, zero_s_slots=bool(rng.integers(0, 2)))
+    kw["num_slots_param"] = kw["n_slots"] + int(rng.integers(0, 3))
+    sc = make_scene(**kw)
+    want_echo = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, sc.noise, nfft=sc.wave.Nfft)
+    got_echo = P.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los, sc.noise, nfft=sc.wave.Nfft)
+    assert rel(got_echo, want_echo) < 1e-10
+    cf = O.cfar2d_config(sc.rp)
+    try:
+        want, odbg = O.fft2d(sc.rp, cf, want_echo, sc.tx_grid, return_debug=True, rdm_fn=O.rdm_explicit)
+    except ValueError:
+        with pytest.raises(ValueError):
+            P.fft2d(sc.rp, cf, want_echo, sc.tx_grid)
+        return
+    got, gdbg = P.fft2d(sc.rp, cf, want_echo, sc.tx_grid, return_debug=True)
+    for a in range(sc.A):
+        assert np.array_equal(gdbg.detections[a], odbg.detections[a]), f"antenna {a}"
+    assert np.array_equal(got.rngEst, want.rngEst) and np.array_equal(got.velEst, want.velEst) and np.array_equal(got.aziEst, want.aziEst)
+    assert rel(gdbg.Ra, odbg.Ra) < 1e-10
