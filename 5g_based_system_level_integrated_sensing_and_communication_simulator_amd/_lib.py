@@ -226,7 +226,8 @@ class Context:
         self.check(self.lib.isac_ctx_set_option(self.handle, C.c_int32(0), C.c_int32(int(route))))
 
     def set_tail_fusion(self, on: bool):
-        """True (default) = Doppler FFT + CFAR + merge + numDets in one launch where applicable, False = separate kernels (ISAC_OPT_TAIL_FUSION)."""
+        """True (default) = panel CFAR (antenna x 42-CUT-row workgroups) + per-antenna merge that also forms numDets, where the zone allows;
+        False = memset of the row flags + one CFAR workgroup per antenna + a separate count kernel (ISAC_OPT_TAIL_FUSION, include/isac.h)."""
         self.check(self.lib.isac_ctx_set_option(self.handle, C.c_int32(1), C.c_int32(1 if on else 0)))
 
     def set_wide_order(self, on: bool):

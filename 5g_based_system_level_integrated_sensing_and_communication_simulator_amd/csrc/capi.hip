@@ -317,12 +317,15 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
 }
 
 extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
-  ISAC_ENTER(ctx);
-  (void)hipSetDevice(ctx->device);
+  ISAC_ENTER_NOJOIN(ctx);
+  // Shared streams (isac_ctx_share_streams) belong to their owner, which may already be gone: never touch them here.  This context's own work
+  // is complete when its last submit's completion event has fired (it is recorded behind everything the submit enqueued) and its own streams are idle.
+  const bool borrowed = ctx->stream != ctx->own_stream || ctx->stream2 != ctx->own_stream2;
+  ctx->stream = ctx->own_stream;
+  ctx->stream2 = ctx->own_stream2;
+  if (borrowed) (void)hipEventSynchronize(ctx->ev_done);
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream2);
-  ctx->stream = ctx->own_stream;                    // (shared streams belong to their owner)
-  ctx->stream2 = ctx->own_stream2;
   for (auto& kv : ctx->twiddles) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->kaiser3) (void)hipFree(kv.second.p);
   for (auto& kv : ctx->sind) (void)hipFree(kv.second.p);
@@ -343,6 +346,8 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   (void)hipEventDestroy(ctx->ev_t1);
   (void)hipEventDestroy(ctx->ev_k0);
   (void)hipEventDestroy(ctx->ev_k1);
+  for (hipEvent_t e : ctx->tl)
+    if (e) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(ctx->stream);
   (void)hipStreamDestroy(ctx->stream2);
   delete ctx;
@@ -611,6 +616,7 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   ISAC_HIP(hipMemcpyAsync(h, dbase, first_bytes, hipMemcpyDeviceToHost, ctx->stream));
   timeline_mark(ctx, 6, ctx->stream);
   ISAC_HIP(hipEventRecord(ctx->ev_done, ctx->stream));
+  ctx->tail_unjoined = wide;                          // (wide order: recorded on the second stream; the main stream joins at this context's next call)
   // everything the host half needs later
   Fft2dPending& pd = ctx->pending;
   pd.ep = *ep; pd.cfar = *cfar;
@@ -622,7 +628,7 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
 }
 
 extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
-  ISAC_ENTER(ctx);
+  ISAC_ENTER_NOJOIN(ctx);                             // (waits for ev_done on the host below: no stream-side join, which would stall a shared main stream)
   if (!out) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
   Fft2dPending& pd = ctx->pending;
   if (!pd.active) return fail(ctx, ISAC_ERR_INVALID_ARG, "isac_fft2d_collect without a pending isac_fft2d_submit_dev");
@@ -638,6 +644,7 @@ extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
   const int n_cut_rows = cfar->row1 - cfar->row0 + 1;
   char* h = (char*)ctx->pinned;
   ISAC_HIP(hipEventSynchronize(ctx->ev_done));      // (not the stream: contexts that share streams have later CPIs queued behind this one)
+  ctx->tail_unjoined = false;                       // the narrow chain of this CPI has finished: nothing left for the main stream to wait for
   if (ctx->tl_on) {
     float t[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 7; ++i) (void)hipEventElapsedTime(&t[i], timeline_base(ctx->stream), ctx->tl[i]);

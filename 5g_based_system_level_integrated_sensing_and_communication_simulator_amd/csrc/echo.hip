@@ -199,25 +199,17 @@ template <int QT, int NZ>
 __global__ __launch_bounds__(256) void echo_spectral_kernel(int K, int L_whole, int L_out, int A, int Q_rt, const c64* __restrict__ D,
                                                             const c64* __restrict__ steer_rq, double sig, uint64_t seed,
                                                             const c64* __restrict__ noise /* [K x L_out x A] unit, NZ == 2 */,
-                                                            const c64* __restrict__ w256_g, const c64* __restrict__ logtab_g,
                                                             c64* __restrict__ grid) {
-  __shared__ __attribute__((aligned(16))) c64 s_w256[256];
-  __shared__ __attribute__((aligned(16))) c64 s_lt[kLogTabSize];
   const int tid = threadIdx.x;
   int l, r;
-  if (!spectral_tile_map(blockIdx.x, L_whole, A, l, r)) return;       // padding workgroup of the tile grid (before any barrier)
-  if constexpr (NZ == 1) {
-    s_w256[tid] = w256_g[tid];
-    if (tid < kLogTabSize) s_lt[tid] = logtab_g[tid];
-    __syncthreads();
-  }
+  if (!spectral_tile_map(blockIdx.x, L_whole, A, l, r)) return;       // padding workgroup of the tile grid
   const int Q = QT ? QT : Q_rt;
   const long long colg = (long long)l + (long long)L_out * r;
   c64* dst = grid + (long long)K * colg;
   struct None_ {};
   c64 acc[16];
-  spectral_echo_column<QT, NZ, 4, 256, 1>(tid, K, Q, D + (long long)K * l, (long long)K * L_whole, steer_rq + (long long)r * Q, sig, seed, colg,
-                                  NZ == 2 ? noise + (long long)K * colg : nullptr, s_w256, s_lt, acc, [](int) { return None_{}; },
+  spectral_echo_column<QT, NZ, 4, 256>(tid, K, Q, D + (long long)K * l, (long long)K * L_whole, steer_rq + (long long)r * Q, sig, seed, colg,
+                                  NZ == 2 ? noise + (long long)K * colg : nullptr, acc, [](int) { return None_{}; },
                                   [&](int, int k, c64 v, None_) {
                                     if (k < K) {
                                       __builtin_nontemporal_store(v.re, &dst[k].re);
@@ -241,7 +233,7 @@ template <int QT, int NZ, int GROUP = (QT <= 1 ? 4 : 2)>   // loads in flight pe
 __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_range_kernel(int K, int L_whole, int L_out, int A, int Q_rt, const c64* __restrict__ D,
                                                             const c64* __restrict__ steer_rq, double sig, uint64_t seed,
                                                             const c64* __restrict__ noise, const c64* __restrict__ tw,
-                                                            const c64* __restrict__ logtab_g, c64* __restrict__ grid,
+                                                            c64* __restrict__ grid,
                                                             const c64* __restrict__ txg, const double* __restrict__ win_k,
                                                             const double* __restrict__ win_r, double inv_n, double sqrt_n,
                                                             int row_lo, int n_rows, c64* __restrict__ ymid) {
@@ -254,18 +246,16 @@ __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_ran
   int l, r;
   if (!spectral_tile_map(blockIdx.x, L_whole, A, l, r)) return;       // padding workgroup of the tile grid (before any barrier)
   const long long colg = (long long)l + (long long)L_out * r;
-  c64* lt = lds + FFT::LDS_ELEMS;
-  if (NZ == 1 && tid < kLogTabSize) lt[tid] = logtab_g[tid];
-  fft.init_table(lds, tw, tid);                      // W512 (generator angle table at stride 2, FFT twiddles); barrier inside
+  fft.init_table(lds, tw, tid);                      // W512 (FFT twiddles); barrier inside
   c64* dst = grid + (long long)K * colg;
   const c64* ptx = txg + (long long)K * colg;
 #pragma unroll
   for (int j = 0; j < FFT::PER; ++j) fft.x[j] = mk(0.0, 0.0);       // ifft(., nIFFT, 1) zero-pads at the end
   struct TxWin { c64 tx; double w; };
   bool live = false;                                       // any non-zero (or NaN) matched-filter sample in this column?
-  spectral_echo_column<QT, NZ, GROUP, FFT::NT, FFT::kW256Stride>(
+  spectral_echo_column<QT, NZ, GROUP, FFT::NT>(
       tid, K, Q, D + (long long)K * l, (long long)K * L_whole, steer_rq + (long long)r * Q, sig, seed, colg,
-      NZ == 2 ? noise + (long long)K * colg : nullptr, lds + FFT::IMG, lt, fft.x,
+      NZ == 2 ? noise + (long long)K * colg : nullptr, fft.x,
       [&](int kc) { return TxWin{ptx[kc], win_k[kc]}; },   // txGrid sample + range window, loads unconditional
       [&](int, int k, c64 v, TxWin t) {
         if (k < K) {
@@ -312,7 +302,7 @@ template <int QT, int NZ, int GROUP = (QT <= 1 ? 4 : 2)>
 __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_range_sl_kernel(int K, int L_whole, int L_out, int A, const c64* D,
                                                             const c64* __restrict__ steer_rq, double sig, uint64_t seed,
                                                             const c64* noise, const c64* __restrict__ tw,
-                                                            const c64* __restrict__ logtab_g, c64* grid,
+                                                            c64* grid,
                                                             const c64* txg, const double* win_k,
                                                             const double* __restrict__ win_r, double inv_n, double sqrt_n,
                                                             int row_lo, int n_rows, c64* __restrict__ ymid) {
@@ -320,14 +310,12 @@ __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_ran
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);
   using FFT = Fft4096W;
-  constexpr int NT = FFT::NT, PER = FFT::PER, NG = PER / GROUP, WS = FFT::kW256Stride;
+  constexpr int NT = FFT::NT, PER = FFT::PER, NG = PER / GROUP;
   const int tid = threadIdx.x;
   FFT fft;
   int l, r;
   if (!spectral_tile_map(blockIdx.x, L_whole, A, l, r)) return;       // padding workgroup of the tile grid (before any barrier)
   const long long colg = (long long)l + (long long)L_out * r;
-  c64* lt = lds + FFT::LDS_ELEMS;
-  const c64* w256 = lds + FFT::IMG;
   const c64* Dl = D + (long long)K * l;
   const long long d_stride = (long long)K * L_whole;
   const c64* ptx = txg + (long long)K * colg;
@@ -352,8 +340,7 @@ __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_ran
     }
     asm volatile("" ::: "memory");                                      // (compiler-only) nothing of the next phase moves above these loads
   };
-  if (NZ == 1 && tid < kLogTabSize) lt[tid] = logtab_g[tid];
-  fft.init_table(lds, tw, tid);                      // W512 (generator angle table at stride 2, FFT twiddles); barrier inside
+  fft.init_table(lds, tw, tid);                      // W512 (FFT twiddles); barrier inside
   load_group(0, 0);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -366,8 +353,8 @@ __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_ran
         const uint64_t ctr = (uint64_t)(tid + NT * c) + (uint64_t)kSpectralSlotsPerColumn * (uint64_t)colg;
         uint32_t o[4];
         philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), kSpectralStream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
-        fft.x[j0] = box_muller32_tab<WS>(o[0], o[1], w256, lt);
-        if (wave_k0 + NT * j1 < K) fft.x[j1] = box_muller32_tab<WS>(o[2], o[3], w256, lt);
+        fft.x[j0] = box_muller32_hw(o[0], o[1]);
+        if (wave_k0 + NT * j1 < K) fft.x[j1] = box_muller32_hw(o[2], o[3]);
       }
     }
   };
@@ -695,18 +682,15 @@ static bool spectral_mode(int noise_mode) { return noise_mode == ISAC_NOISE_PHIL
 template <int QT>
 static int launch_echo_spectral(isac_ctx* ctx, const OfdmGeom& g, int A, int L_whole, int L_out, int Q, int noise_mode,
                                 const c64* noise, double sig, uint64_t seed, c64* grid) {
-  const c64 *w256 = nullptr, *logtab = nullptr;
-  ISAC_TRY(isac_get_twiddles(ctx, 256, &w256));
-  ISAC_TRY(isac_get_logtab(ctx, &logtab));
   const dim3 gr((unsigned)spectral_grid_size(L_whole, A)), bl(256);
   const c64* D = (const c64*)ctx->dgrid.p;
   const c64* srq = (const c64*)ctx->steer.p + (size_t)A * Q;
   if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL)
-    hipLaunchKernelGGL((echo_spectral_kernel<QT, 1>), gr, bl, 0, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, noise, w256, logtab, grid);
+    hipLaunchKernelGGL((echo_spectral_kernel<QT, 1>), gr, bl, 0, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, noise, grid);
   else if (noise_mode == ISAC_NOISE_INJECTED_SPECTRAL)
-    hipLaunchKernelGGL((echo_spectral_kernel<QT, 2>), gr, bl, 0, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, noise, w256, logtab, grid);
+    hipLaunchKernelGGL((echo_spectral_kernel<QT, 2>), gr, bl, 0, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, noise, grid);
   else
-    hipLaunchKernelGGL((echo_spectral_kernel<QT, 0>), gr, bl, 0, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, noise, w256, logtab, grid);
+    hipLaunchKernelGGL((echo_spectral_kernel<QT, 0>), gr, bl, 0, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, noise, grid);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }
@@ -833,10 +817,8 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
   if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));   // isac_profile_*: brackets exactly the fused kernel below
   timeline_mark(ctx, 2, ctx->stream);
   {
-    const c64* logtab = nullptr;
-    ISAC_TRY(isac_get_logtab(ctx, &logtab));
     const double sig = n0s * std::sqrt((double)g.nfft);
-    const size_t lds = sizeof(c64) * (Fft4096W::LDS_ELEMS + kLogTabSize);
+    const size_t lds = sizeof(c64) * Fft4096W::LDS_ELEMS;
     const dim3 gr((unsigned)spectral_grid_size(L_whole, A)), bl(Fft4096W::NT);
     const c64* D = (const c64*)ctx->dgrid.p;
     const c64* srq = (const c64*)ctx->steer.p + (size_t)A * Q;
@@ -845,7 +827,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
     auto kern = echo_range_kernel<QT, NZ>;                                                                                           \
     ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));                                                              \
     hipLaunchKernelGGL(kern, gr, bl, lds, ctx->stream, g.n_sc, L_whole, L_out, A, Q, D, srq, sig, seed, (const c64*)d_noise_unit, tw,   \
-                       logtab, (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, 1.0 / ep->n_ifft, std::sqrt((double)ep->n_ifft),   \
+                       (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, 1.0 / ep->n_ifft, std::sqrt((double)ep->n_ifft),   \
                        row_lo, nr, (c64*)ctx->ymid.p);                                                                               \
   } while (0)
 #define ISAC_SPEC_SL(QT, NZ)                                                                                                         \
@@ -853,7 +835,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
     auto kern = echo_range_sl_kernel<QT, NZ>;                                                                                        \
     ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));                                                              \
     hipLaunchKernelGGL(kern, gr, bl, lds, ctx->stream, g.n_sc, L_whole, L_out, A, D, srq, sig, seed, (const c64*)d_noise_unit, tw,      \
-                       logtab, (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, 1.0 / ep->n_ifft, std::sqrt((double)ep->n_ifft),   \
+                       (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, 1.0 / ep->n_ifft, std::sqrt((double)ep->n_ifft),   \
                        row_lo, nr, (c64*)ctx->ymid.p);                                                                               \
   } while (0)
 #define ISAC_SPEC_Q(QT) do { if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL) ISAC_SPEC(QT, 1); else ISAC_SPEC(QT, 2); } while (0)

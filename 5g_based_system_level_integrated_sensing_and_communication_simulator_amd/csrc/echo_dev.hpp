@@ -123,9 +123,17 @@ __device__ __forceinline__ c64 philox_normal_pair_tab(uint64_t e, uint64_t seed,
 // (basicRadarChannel.m:67-69) therefore arrives on the kept subcarriers as i.i.d. CN(0, 2 Nfft s^2).  The performance
 // noise modes draw it there directly: K instead of Nfft (+CP) normals per symbol and antenna, and no generator inside the
 // FFT's sample producers.
-// Generator: ONE Philox4x32-10 call per PAIR of grid elements -- (o0, o1) -> element "half 0", (o2, o3) -> "half 1";
-// each Box-Muller transform takes a 32-bit radius uniform u1 = (o + 1) 2^-32 in (0, 1] and a 32-bit angle 2 pi o' 2^-32
-// (the resolution cuRAND's single-precision normals use; |z| <= sqrt(-2 ln 2^-32) = 6.66 sigma), evaluated in fp64.
+// Generator: ONE Philox4x32-10 call per PAIR of grid elements -- (o0, o1) -> element "half 0", (o2, o3) -> "half 1".
+// Each Box-Muller transform is evaluated in SINGLE precision on the hardware transcendental unit (round 4; rounds 2-3 evaluated the
+// same two 32-bit uniforms in fp64 through LDS tables: ~55 fp64 instructions + two random LDS look-ups per element, the largest VALU
+// item of the fused kernel) and widened to fp64 once:
+//   u     = fl32(o) * 2^-32 + 2^-33            in (0, 1]   (v_cvt_f32_u32 rounds to nearest even; small o -- the tail -- are exact)
+//   rad   = v_sqrt_f32( -2 ln2 * v_log_f32(u) )            |z| <= sqrt(2 * 33 ln 2) = 6.76 sigma
+//   turns = fl32(o') * 2^-32                   in [0, 1]   (v_sin_f32 / v_cos_f32 take their argument in revolutions)
+//   z     = (double)(rad * cos) + j (double)(rad * sin)
+// 11 VALU instructions (4 of them transcendental) + 2 conversions, no LDS.  The field is therefore defined to float32 accuracy: the
+// oracle restates it in float32 (oracle/philox.py) and the tests compare with a float32 bound (the hardware log2 / sin / cos are ~1 ulp
+// approximations, not correctly rounded); the INJECTED noise modes are untouched and stay bit-for-bit.
 // Pairing (defined on the subcarrier index k only, so every kernel shape draws the same field): elements k and k + 512 share a call,
 //   slot(k) = (k mod 512) + 512 * ((k div 512) div 2),  half(k) = (k div 512) mod 2,
 //   counter = slot + 2048 * column,  column = l + L * a  (the grid's own column index),  key = seed, stream word = 2.
@@ -133,40 +141,11 @@ __device__ __forceinline__ c64 philox_normal_pair_tab(uint64_t e, uint64_t seed,
 constexpr uint32_t kSpectralStream = 2u;
 constexpr int kSpectralSlotsPerColumn = 2048;
 
-template <int WSTRIDE = 1>
-__device__ __forceinline__ c64 box_muller32_tab(uint32_t ur, uint32_t ua, const c64* __restrict__ w256 /* LDS: exp(-2 pi j i / 256) at [WSTRIDE i] */,
-                                                const c64* __restrict__ logtab /* LDS: (1/c_i, ln c_i) */) {
-  // ---- radius
-  const double u1 = ((double)ur + 1.0) * 0x1.0p-32;                 // exact
-  int ex;
-  const double m = frexp(u1, &ex);                                   // m in [0.5, 1)
-  const int idx = (int)((__double2hiint(m) >> 13) & (kLogTabSize - 1));
-  const c64 lt = logtab[idx];
-  const double r = ::fma(m, lt.re, -1.0);
-  double q = 1.0 / 7.0;
-  q = ::fma(q, r, -1.0 / 6.0); q = ::fma(q, r, 1.0 / 5.0); q = ::fma(q, r, -1.0 / 4.0); q = ::fma(q, r, 1.0 / 3.0); q = ::fma(q, r, -0.5);
-  const double l1p = ::fma(r * r, q, r);
-  const double ln_u = ::fma((double)ex, 0.69314718055994530942, lt.im + l1p);
-  const double y = -2.0 * ln_u;
-  double rad = 0.0;
-  if (y > 0.0) {
-    const double rs = __builtin_amdgcn_rsq(y);
-    double sq = y * rs;
-    const double h = 0.5 * rs;
-    sq = ::fma(::fma(-sq, sq, y), h, sq);
-    sq = ::fma(::fma(-sq, sq, y), h, sq);
-    rad = sq;
-  }
-  // ---- angle: theta = 2 pi ua 2^-32 = 2 pi i / 256 + phi
-  const int i = (int)(ua >> 24);
-  const double phi = (double)(ua & 0x00FFFFFFu) * (6.28318530717958647692 * 0x1.0p-32);
-  const double p2 = phi * phi;
-  const double sphi = phi * ::fma(p2, ::fma(p2, ::fma(p2, -1.0 / 5040.0, 1.0 / 120.0), -1.0 / 6.0), 1.0);
-  const double cphi = ::fma(p2, ::fma(p2, ::fma(p2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
-  const c64 w = w256[WSTRIDE * i];                                   // (cos a, -sin a)
-  const double c = ::fma(w.re, cphi, w.im * sphi);
-  const double sn = ::fma(w.re, sphi, -w.im * cphi);
-  return c64{rad * c, rad * sn};
+__device__ __forceinline__ c64 box_muller32_hw(uint32_t ur, uint32_t ua) {
+  const float u = __builtin_fmaf((float)ur, 0x1.0p-32f, 0x1.0p-33f);
+  const float rad = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u) * -1.3862943611198906f);   // -2 ln 2 * log2 u >= 0
+  const float turns = (float)ua * 0x1.0p-32f;
+  return c64{(double)(rad * __builtin_amdgcn_cosf(turns)), (double)(rad * __builtin_amdgcn_sinf(turns))};
 }
 
 // Workgroup -> (symbol l, antenna r) for the spectral synthesis kernels.  Every column (l, r) reads the per-target grids
@@ -198,11 +177,11 @@ __device__ __forceinline__ bool spectral_tile_map(int wg, int L_whole, int A, in
 // Memory-level parallelism is laid out by hand: the loads of a GROUP of elements -- the caller's `pre(kc)` (e.g. the txGrid sample and
 // window) and the D values -- are issued one group ahead of their use, the first group before the generator's VALU work.  GROUP bounds
 // the registers held by loads in flight (2 x GROUP x (4 Q + sizeof(pre)/4) VGPRs).
-template <int QT, int NZ, int GROUP, int NT, int WSTRIDE, class PRE, class E>
+template <int QT, int NZ, int GROUP, int NT, class PRE, class E>
 __device__ __forceinline__ void spectral_echo_column(int tid, int K, int Q_rt, const c64* __restrict__ Dl /* D + K*l */,
                                                      long long d_stride /* K * L_whole */, const c64* __restrict__ sr /* [Q] */,
                                                      double sig, uint64_t seed, long long column, const c64* __restrict__ nz,
-                                                     const c64* __restrict__ w256, const c64* __restrict__ logtab, c64 (&acc)[4096 / NT],
+                                                     c64 (&acc)[4096 / NT],
                                                      PRE&& pre, E&& emit) {
   constexpr int QM = QT ? QT : 1;
   constexpr int PER = 4096 / NT;
@@ -243,8 +222,8 @@ __device__ __forceinline__ void spectral_echo_column(int tid, int K, int Q_rt, c
         const uint64_t ctr = (uint64_t)(tid + NT * c) + (uint64_t)kSpectralSlotsPerColumn * (uint64_t)column;   // slot = tid + NT c
         uint32_t o[4];
         philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), kSpectralStream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), o);
-        acc[j0] = box_muller32_tab<WSTRIDE>(o[0], o[1], w256, logtab);
-        if (wave_k0 + NT * j1 < K) acc[j1] = box_muller32_tab<WSTRIDE>(o[2], o[3], w256, logtab);
+        acc[j0] = box_muller32_hw(o[0], o[1]);
+        if (wave_k0 + NT * j1 < K) acc[j1] = box_muller32_hw(o[2], o[3]);
       }
     }
   }

@@ -119,6 +119,7 @@ struct isac_ctx {
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // isac_profile_*: around the dominant kernel of the last fused echo call
   bool profile = false, profile_recorded = false;
   int music_route = 0;             // ISAC_OPT_MUSIC_ROUTE: 0 = signal-subspace eigensolver for MUSIC (default), 1 = always the full eigendecomposition
+  bool tail_unjoined = false;      // wide order: ev_done of the last submit has not been waited for by the main stream (ISAC_ENTER joins lazily)
   int wide_order = 0;              // ISAC_OPT_WIDE_ORDER: 1 = fft2D's covariance on the main stream, everything narrow (Doppler, CFAR, MUSIC chain, pack, D2H) on the second
   int tail_fusion = 1;             // ISAC_OPT_TAIL_FUSION: 1 = panel CFAR + per-antenna merge / numDets where applicable (default), 0 = memset + per-antenna CFAR + count
   std::string err;
@@ -179,11 +180,23 @@ inline void timeline_mark(isac_ctx* ctx, int i, hipStream_t st) {
 // Top of every extern "C" entry point that takes a context: NULL check + make the context's device current on the
 // calling thread (scratch allocations, table uploads and hipFuncSetAttribute all act on the CURRENT device, so a
 // process that holds contexts on several GPUs, or uses a context from a thread other than its creator, must switch).
-#define ISAC_ENTER(ctx)                                                                            \
+#define ISAC_ENTER_NOJOIN(ctx)                                                                     \
   do {                                                                                             \
     if (!(ctx)) return ISAC_ERR_INVALID_ARG;                                                       \
     if (hipSetDevice((ctx)->device) != hipSuccess)                                                 \
       return isac::fail((ctx), ISAC_ERR_HIP, "hipSetDevice failed for the context's device");     \
+  } while (0)
+#define ISAC_ENTER(ctx)                                                                            \
+  do {                                                                                             \
+    ISAC_ENTER_NOJOIN(ctx);                                                                        \
+    if ((ctx)->tail_unjoined) {                                                                    \
+      /* ISAC_OPT_WIDE_ORDER: the previous CPI's narrow chain (Doppler .. D2H) sits on the second  \
+         stream and the main stream was never joined behind it; the next call on THIS context       \
+         may overwrite ymid / cov / beam / the result buffers that chain still reads */             \
+      (ctx)->tail_unjoined = false;                                                                \
+      if (hipStreamWaitEvent((ctx)->stream, (ctx)->ev_done, 0) != hipSuccess)                       \
+        return isac::fail((ctx), ISAC_ERR_HIP, "hipStreamWaitEvent failed");                       \
+    }                                                                                              \
   } while (0)
 
 #define ISAC_TRY(call)              \

@@ -247,7 +247,8 @@ int isac_fft2d(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config*
                int32_t K, int32_t L, int32_t A, isac_est_result* out);
 /* The same call split in two so that a host loop can keep several CPIs / cells in flight on
  * different contexts: submit enqueues every kernel and the result copy without waiting;
- * collect waits for that context's stream and runs the host half (fft2D.m:63-99, music.m:94-104).
+ * collect waits for the completion event of that submit (not for the stream: contexts that share streams have
+ * later CPIs queued behind it) and runs the host half (fft2D.m:63-99, music.m:94-104).
  * isac_fft2d_dev == submit + collect.  d_rx_grid / d_tx_grid must stay valid until collect. */
 int isac_fft2d_submit_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
                           const isac_c64* d_rx_grid, const isac_c64* d_tx_grid,
@@ -308,7 +309,10 @@ int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_t n_top, do
  *   0 (default)  main stream: (range ->) Doppler -> CFAR -> pack;  second stream: covariance -> MUSIC chain (joined before pack) -- the
  *                shortest latency of a single CPI;
  *   1            main stream: (range stage when not cached,) covariance;  second stream: Doppler -> CFAR -> MUSIC chain -> pack -> D2H in one
- *                sequence -- every wide kernel of the CPI on one stream.  Meant for contexts that share their streams (below). */
+ *                sequence -- every wide kernel of the CPI on one stream.  Meant for contexts that share their streams (below).
+ *                The main stream is NOT joined behind that sequence at submit time; any later call on the SAME context other than
+ *                isac_fft2d_collect first makes the main stream wait for the pending submit's completion event, so a host that
+ *                re-uses a context without collecting loses the overlap but never races its own buffers. */
 enum { ISAC_OPT_MUSIC_ROUTE = 0, ISAC_OPT_TAIL_FUSION = 1, ISAC_OPT_WIDE_ORDER = 2 };
 int isac_ctx_set_option(isac_ctx* ctx, int32_t option, int32_t value);
 

@@ -41,7 +41,8 @@ isac_ctx* ctx() {
     if (isac_abi_version() != ISAC_ABI_VERSION || isac_abi_sizeof(ISAC_SIZEOF_EST_RESULT) != (int)sizeof(isac_est_result) ||
         isac_abi_sizeof(ISAC_SIZEOF_EST_PARAMS) != (int)sizeof(isac_est_params) || isac_abi_sizeof(ISAC_SIZEOF_CFAR_CONFIG) != (int)sizeof(isac_cfar_config) ||
         isac_abi_sizeof(ISAC_SIZEOF_RADAR_CHANNEL_PARAMS) != (int)sizeof(isac_radar_channel_params) ||
-        isac_abi_sizeof(ISAC_SIZEOF_CSI_REPORT) != (int)sizeof(isac_csi_report))
+        isac_abi_sizeof(ISAC_SIZEOF_CSI_REPORT) != (int)sizeof(isac_csi_report) || isac_abi_sizeof(ISAC_SIZEOF_CARRIER) != (int)sizeof(isac_carrier) ||
+        isac_abi_sizeof(ISAC_SIZEOF_MUSIC2D_PARAMS) != (int)sizeof(isac_music2d_params))
       mexErrMsgIdAndTxt("isac:INVALID_ARG", "libisac_hip.so ABI %d does not match the gateway's isac.h (ABI %d): rebuild both", isac_abi_version(), ISAC_ABI_VERSION);
     const char* dev = std::getenv("ISAC_DEVICE");                    // parallel workers: one process per GPU (cellID mod nGPU)
     if (isac_ctx_create(dev ? std::atoi(dev) : 0, &g_ctx) != ISAC_OK) mexErrMsgIdAndTxt("isac:HIP", "no MI355X visible");

@@ -145,7 +145,7 @@ def test_full_size_spectral_fused_path(pkg, name):
     wcol = O.philox_spectral_noise(sc.K, sc.L, sc.A, 99, columns=[l + sc.L * a for l, a in pick])
     for j, (l, a) in enumerate(pick):
         nz = (h3[:, l, a] - clean[:, l, a]) / sig
-        assert np.abs(nz - wcol[:, j]).max() < 1e-6, (l, a)
+        assert np.abs(nz - wcol[:, j]).max() < O.philox.SPECTRAL_NOISE_ATOL, (l, a)     # float32 hardware Box-Muller vs float32 restatement
     nz_all = (h3[:, :, 5] - clean[:, :, 5]) / sig
     assert abs(nz_all.real.std() - 1) < 0.01 and abs(nz_all.imag.std() - 1) < 0.01 and abs(nz_all.mean()) < 0.01
 

@@ -202,7 +202,9 @@ def test_spectral_fused_path_on_random_scene(pkg, seed):
     wp = O.philox_spectral_noise(sc.K, sc.L, sc.A, 0x77 + seed)
     ref_p = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los,
                                   spectral_to_time_noise(wp, sc.T, 4096, 30, sc.rp.fc, sc.rp.fs), nfft=4096)
-    assert rel(e_p.numpy(), ref_p) < RTOL
+    # float32 hardware Box-Muller on the device vs its float32 restatement: a float32 bound on the unit samples (oracle/philox.py)
+    sig_w = np.sqrt(sc.rp.N0 / 2.0) * 64.0
+    assert np.abs(e_p.numpy() - ref_p).max() < sig_w * O.philox.SPECTRAL_NOISE_ATOL + RTOL * np.abs(ref_p).max()
     # detections / estimates of the injected-field run against the oracle
     ocf = O.cfar2d_config(sc.rp)
     e_f = pkg.sensing.monoStaticSensing(d_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=4096, spectral_noise=d_w, fuse_fft2d=(rp, cf, d_txg))

@@ -78,15 +78,19 @@ def test_philox_spectral_matches_restated_generator(pkg, ctx, nrb, n_ants, n_slo
     w = O.philox_spectral_noise(sc.K, sc.L, sc.A, seed)
     got = pkg.sensing.monoStaticSensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, seed=seed, noise_domain="spectral", nfft=sc.wave.Nfft)
     inj = pkg.sensing.monoStaticSensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, spectral_noise=w, nfft=sc.wave.Nfft)
-    assert rel(got, inj) < RTOL
+    # the generator's Box-Muller runs on the float32 hardware transcendentals (csrc/echo_dev.hpp): device field and restated field agree to a
+    # float32 bound on the unit samples (O.philox.SPECTRAL_NOISE_ATOL), not bit for bit -- the injected modes above / below are the exact ones
+    sig = np.sqrt(sc.rp.N0 / 2.0) * np.sqrt(sc.wave.Nfft)
+    atol = sig * O.philox.SPECTRAL_NOISE_ATOL
+    assert np.abs(got - inj).max() < atol
     want = O.mono_static_sensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, sc.rp, sc.los,
                                  spectral_to_time_noise(w, sc.T, sc.wave.Nfft, 30, sc.rp.fc, sc.rp.fs), nfft=sc.wave.Nfft)
-    assert rel(got, want) < RTOL
+    assert np.abs(got - want).max() < atol + RTOL * np.abs(want).max()
     # the noise the device added, recovered: unit variance, matches the restatement element by element
     clean = pkg.sensing.monoStaticSensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, nfft=sc.wave.Nfft)
-    sig = np.sqrt(sc.rp.N0 / 2.0) * np.sqrt(sc.wave.Nfft)
     nz = (got - clean) / sig
-    assert np.abs(nz - w).max() < 1e-6 and abs(nz.real.std() - 1) < 0.02 and abs(nz.imag.std() - 1) < 0.02
+    assert np.abs(nz - w).max() < O.philox.SPECTRAL_NOISE_ATOL and abs(nz.real.std() - 1) < 0.02 and abs(nz.imag.std() - 1) < 0.02
+    assert np.abs(nz).max() <= O.philox.SPECTRAL_NOISE_MAX + 1e-5
     # another seed gives another field; basicRadarChannel (time-domain output) rejects the spectral modes
     got2 = pkg.sensing.monoStaticSensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, rp, sc.los, seed=seed + 1, noise_domain="spectral", nfft=sc.wave.Nfft)
     assert not np.array_equal(got2, got)
