@@ -418,6 +418,184 @@ __device__ __forceinline__ void cov_block_pair(const c64* __restrict__ G, long l
   }
 }
 
+// ---- 33..64 antennas (NB = 3, 4: two tile groups), LDS-staged and software-pipelined INSIDE the wave (round 4).
+// Two measurements of this round decide the shape (profiles/r04_cobench.txt, r04_gbench.txt, r04_cov_probe_variants.txt):
+//  * cov_mfma_small_kernel feeds the MFMAs from registers: lane (i, kq) loads its own operand, i.e. 16 consecutive lanes read 16 different
+//    antenna columns, 16 bytes each.  The texture path serves such a gather at about one lane per cycle (64 cycles per wave instruction where a
+//    coalesced 1 KB load takes 16), and with two tile groups both waves of a sample phase load (nearly) every block: the loads alone take
+//    152-173 us of that kernel's 190.  Here a slab (16 samples x 64 antennas = 16 KB) is fetched ONCE per workgroup with coalesced loads
+//    (16 lanes read 256 contiguous bytes of one antenna, 4 loads per thread), transposed through the block kernel's swizzled LDS image, and
+//    every wave reads its operands with ds_read_b128 (conflict-free, 6-8 per slab).
+//  * A wave that wants to issue a v_mfma_f64 into the busy pipe holds the SIMD's issue port: beside a wave that streams MFMAs, ANOTHER wave's
+//    ds_read / ds_write / global loads cost their full stand-alone time (cobench: together = sum for every instruction kind, not only VALU).  A
+//    kernel whose waves alternate "burst of memory instructions" / "run of 30 MFMAs" therefore leaves the pipe idle while both waves of a SIMD do
+//    their bursts one after the other -- the first staged version of this kernel (burst form) ran 193 us; without its barriers 180, without its
+//    staging instructions 170, as a bare MFMA stream 159.  The fix is to hide every non-MFMA instruction in the 64-cycle shadow of the wave's OWN
+//    MFMAs: each slab step issues its 30 MFMAs on operands already in registers and, one instruction per MFMA gap, reads the NEXT slab's operands
+//    from LDS, writes the slab after that into LDS and re-issues the global loads (sched_barrier pins the positions).
+// Three LDS images in rotation (operands of slab s + 1 are read while slab s + 2 is written: one barrier per slab covers both hazards), two
+// staging register sets (two slabs of global loads in flight), two operand register sets.  Same tile groups / sample phases / 3M accumulators /
+// partial layout as cov_group_body, so the reducers are shared; a phase owns the k-steps e = 2 p, 2 p + 1 of the image (samples {e, 4 + e, 8 + e, 12 + e}).
+constexpr int kCovLdsBufs = 3;
+template <int NB, int GRP>
+__device__ __forceinline__ void cov_lds_body(const c64* __restrict__ G, long long N, int A, int phase, long long s_begin, long long s_end,
+                                             int part_index, double* __restrict__ part, c64* __restrict__ lds) {
+  using P = CovPlan<NB>;
+  static_assert(P::kGroups == 2 && P::kPhases == 2, "two tile groups x two sample phases");
+  constexpr int T0 = GRP * P::kPerGroup;
+  constexpr int NT = (T0 + P::kPerGroup <= P::kTiles) ? P::kPerGroup : (P::kTiles - T0);
+  constexpr int kBuf = NB * 16 * kCovPitch;         // one slab image
+  constexpr int kBlk = 16 * kCovPitch;              // one 16-antenna block of it
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int li = lane & 15, kq = lane >> 4;
+  v4f64 re[NT], im[NT], s3[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) re[u] = im[u] = s3[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+  // staging: thread -> (sample tid & 15, antenna 16 j + (tid >> 4)), j = 0 .. NB - 1; one descriptor per 16-antenna block that ends with the
+  // array's last antenna (padding antennas read as zero by the bounds check)
+  const int s_smp = tid & 15, l16 = tid >> 4;
+  __amdgpu_buffer_rsrc_t s_rs[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    int n_ant = A - 16 * j;
+    n_ant = n_ant < 0 ? 0 : (n_ant > 16 ? 16 : n_ant);
+    s_rs[j] = buffer_of(G + N * (long long)(n_ant > 0 ? 16 * j : 0), (unsigned)(N * n_ant * (long long)sizeof(c64)));
+  }
+  const int s_lds0 = s_smp * kCovPitch + (l16 ^ kCovSwizzle(s_smp));
+  auto voff_of = [&](long long slab) {               // samples past N / slabs past the chunk: an offset beyond every descriptor reads zero
+    const long long n = slab * 16 + s_smp;
+    return (n < N && slab < s_end) ? (unsigned)((N * l16 + n) * (long long)sizeof(c64)) : kCovOobOffset;
+  };
+  int r_off[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int smp = 4 * kq + 2 * phase + e;
+    r_off[e] = smp * kCovPitch + (li ^ kCovSwizzle(smp));
+  }
+  c64 g[2][NB];                                      // staging sets: at the top of the step for slab s, g[s & 1] holds slab s + 2, the other s + 3
+  c64 ops[2][NB][2];                                 // operand sets: ops[s & 1] holds slab s
+  // One slab step.  PAR = parity of the step (compile time: register sets), rd / wr = LDS images of slab + 1 (complete) and slab + 2 (free).
+  auto step = [&](auto par_c, long long slab, int rd, int wr) {
+    constexpr int PAR = decltype(par_c)::value;
+    const c64 (&cur)[NB][2] = ops[PAR];
+    c64 (&nxt)[NB][2] = ops[PAR ^ 1];
+    c64 (&gs)[NB] = g[PAR];
+    const c64* img = lds + rd * kBuf;
+    c64* dst = lds + wr * kBuf + s_lds0;
+    const unsigned voff = voff_of(slab + 4);
+    double dm[2][NB], sp[2][NB];                     // Gr - Gi (row operand), Gr + Gi (column operand) of the 3M form
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { dm[e][b] = cur[b][e].re - cur[b][e].im; sp[e][b] = cur[b][e].re + cur[b][e].im; }
+    __builtin_amdgcn_sched_barrier(0);
+    // filler k goes into the gap behind the k-th MFMA of the step (6 NT MFMAs: 30 at NB = 4): gaps 0 .. 2 NB - 1 the operand reads of the
+    // next slab, then the NB staging writes, then the NB staging loads into the registers just written out
+    auto filler = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k < 2 * NB) {
+        constexpr int e = k / NB, b = k % NB;
+        nxt[b][e] = img[b * kBlk + r_off[e]];        // (blocks no tile of this group touches: dead reads, dropped by the compiler)
+        __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (k < 3 * NB) {
+        constexpr int j = k - 2 * NB;
+        dst[j * kBlk] = gs[j];
+        __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (k < 4 * NB) {
+        constexpr int j = k - 3 * NB;
+        gs[j] = buffer_load_c64(s_rs[j], voff);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    static_for<0, 2>([&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      static_for<0, NT>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);
+        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].re, re[u], 0, 0, 0);
+        filler(std::integral_constant<int, e * 3 * NT + u>{});
+      });
+      static_for<0, NT>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);
+        if constexpr (I == J) im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].im, im[u], 0, 0, 0);
+        else                  im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].im, im[u], 0, 0, 0);
+        filler(std::integral_constant<int, e * 3 * NT + NT + u>{});
+      });
+      static_for<0, NT>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);
+        if constexpr (I == J) re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].im, re[u], 0, 0, 0);
+        else                  s3[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(dm[e][I], sp[e][J], s3[u], 0, 0, 0);
+        filler(std::integral_constant<int, e * 3 * NT + 2 * NT + u>{});
+      });
+    });
+    static_assert(6 * NT >= 4 * NB, "every filler has its gap");
+    __syncthreads();
+  };
+  auto fetch = [&](c64 (&gg)[NB], long long slab) {
+    const unsigned voff = voff_of(slab);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) gg[j] = buffer_load_c64(s_rs[j], voff);
+  };
+  auto stash = [&](const c64 (&gg)[NB], int buf) {
+    c64* d = lds + buf * kBuf + s_lds0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) d[j * kBlk] = gg[j];
+  };
+  // prologue: slab 0 -> image 0 -> ops[0]; slab 1 -> image 1; slabs 2, 3 in flight
+  fetch(g[0], s_begin);
+  fetch(g[1], s_begin + 1);
+  stash(g[0], 0);
+  stash(g[1], 1);
+  fetch(g[0], s_begin + 2);
+  fetch(g[1], s_begin + 3);
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) ops[0][b][e] = lds[b * kBlk + r_off[e]];
+  int rd = 1, wr = 2;                                // (uniform) image of slab + 1, image for slab + 2
+  auto rot = [&]() { rd = wr; wr = wr == kCovLdsBufs - 1 ? 0 : wr + 1; };
+  for (long long slab = s_begin; slab < s_end; slab += 2) {       // (an odd slab count runs one all-zero slab: no exit in the middle)
+    step(std::integral_constant<int, 0>{}, slab, rd, wr);
+    rot();
+    step(std::integral_constant<int, 1>{}, slab + 1, rd, wr);
+    rot();
+  }
+  static_for<0, NT>([&](auto uc) {
+    constexpr int u = decltype(uc)::value;
+    constexpr bool diag = cov_tile_i(NB, T0 + u) == cov_tile_j(NB, T0 + u);
+    double* o = part + (((long long)part_index * P::kTiles + (T0 + u)) * 2) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if constexpr (!diag) {
+        o[0 * 256 + r * 64 + lane] = re[u][r] + im[u][r];
+        o[1 * 256 + r * 64 + lane] = (s3[u][r] - re[u][r]) + im[u][r];
+      } else {
+        o[0 * 256 + r * 64 + lane] = re[u][r];
+        o[1 * 256 + r * 64 + lane] = im[u][r];             // diagonal tile: M, antisymmetrised by cov_reduce_kernel
+      }
+    }
+  });
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void cov_mfma_lds_kernel(const c64* __restrict__ G, long long N, int A, long long slabs_per_wg,
+                                                              double* __restrict__ part /* [gridX*2][kTiles][2][256] */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* lds = reinterpret_cast<c64*>(smem_raw);      // [kCovLdsBufs][NB * 16 * kCovPitch]
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wid >> 1, phase = wid & 1;
+  const long long total = (N + 15) / 16;
+  const long long s_begin = (long long)blockIdx.x * slabs_per_wg;
+  long long s_end = s_begin + slabs_per_wg;
+  if (s_end > total) s_end = total;
+  const int pidx = blockIdx.x * 2 + phase;
+  if (grp == 0) cov_lds_body<NB, 0>(G, N, A, phase, s_begin, s_end, pidx, part, lds);
+  else cov_lds_body<NB, 1>(G, N, A, phase, s_begin, s_end, pidx, part, lds);
+}
+
 __global__ __launch_bounds__(256, 2) void cov_mfma_block_kernel(const c64* __restrict__ G, long long N, int A, int n_blk,
                                                                 int n_pairs, long long slabs_per_wg,
                                                                 double* __restrict__ part /* [chunk][pair][16][2][256] */) {
@@ -1911,10 +2089,22 @@ static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long lo
   if (N * 256 >= (1ll << 32)) return fail(ctx, ISAC_ERR_UNSUPPORTED, "covariance: at most 2^24 - 1 samples per antenna");
   long long gx = NB == 4 ? 512 : 768;       // NB = 4: 2 workgroups per CU (register-limited occupancy)
   if (gx > total) gx = total;
-  const long long per = (total + gx - 1) / gx;
+  long long per = (total + gx - 1) / gx;
+  static const bool reg_operands = std::getenv("ISAC_COV_REG_OPERANDS") != nullptr;   // development switch: the register-operand kernel for every A <= 64
+  const bool staged = (NB >= 3) && !reg_operands && N * 256 < (1ll << 31);           // two tile groups: fetch each slab once per workgroup, through LDS
+  if (staged) { gx = 512 < total ? 512 : total; per = (total + gx - 1) / gx; per = (per + 1) & ~1ll; }   // (the staged kernel walks slabs in pairs)
   gx = (total + per - 1) / per;
   const int n_part = (int)gx * P::kPhases;
   ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * ((size_t)n_part + 32) * P::kTiles * 2 * 256));
+  if constexpr (NB >= 3) {
+    if (staged) {
+      const size_t lds = sizeof(c64) * kCovLdsBufs * NB * 16 * kCovPitch;
+      ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cov_mfma_lds_kernel<NB>), lds));
+      hipLaunchKernelGGL((cov_mfma_lds_kernel<NB>), dim3((unsigned)gx), dim3(256), lds, st, G, N, A, per, (double*)ctx->cov_part.p);
+      ISAC_HIP(hipGetLastError());
+    }
+  }
+  if (!staged) {
   static const bool wg_times = std::getenv("ISAC_COV_WGTIMES") != nullptr;       // dev probe: per-workgroup wall-clock spans, printed per launch
   static long long* d_dbg = nullptr;
   if (wg_times && !d_dbg) ISAC_HIP(hipMalloc(&d_dbg, sizeof(long long) * 3 * 4096));
@@ -1939,6 +2129,7 @@ static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long lo
     std::fprintf(stderr, "COVWG span %.1f us, last start +%.1f us, mean end +%.1f us |", 0.01 * (double)(t1 - t0), start_max, end_sum / (double)gx);
     for (int x = 0; x < 16; ++x) if (cnt[x]) std::fprintf(stderr, " xcc%d n=%d %.0f/%.0f/%.0f", x, cnt[x], mn[x], sum[x] / cnt[x], mx[x]);
     std::fprintf(stderr, "\n");
+  }
   }
   const int S = 32;
   double* part2 = (double*)ctx->cov_part.p + (size_t)n_part * P::kTiles * 2 * 256;

@@ -130,6 +130,24 @@ def test_covariance_small_kernel_budget(music_co):
     assert sum(1 for x in w if x == 0) <= 6 and len(w) >= 60, (len(w), sum(1 for x in w if x == 0))
 
 
+def test_covariance_staged_kernel_is_pipelined_inside_the_wave(music_co):
+    """A = 33..64: on gfx950 every instruction of either wave of a SIMD waits while a v_mfma_f64 is pending (tools/cobench.hip), so the staged
+    covariance kernel hides its LDS reads / staging writes / staging loads one by one behind its own MFMAs.  A scheduler change that regroups
+    them into a burst in front of the MFMA run costs ~10 us per launch and no numerical test would notice."""
+    name, meta, asm = music_co.find("cov_mfma_lds_kernelILi4E")
+    assert meta["private_segment_fixed_size"] == 0 and meta["agpr_count"] == 0 and meta["vgpr_count"] <= 248, meta   # two workgroups per CU
+    mf = [i for i, ln in enumerate(asm) if ln.startswith("v_mfma_f64_16x16x4")]
+    assert len(mf) == 120                                          # 2 tile groups x 2 unrolled slab steps x 30
+    gaps = sorted(mf[i + 1] - mf[i] - 1 for i in range(len(mf) - 1))
+    assert gaps[-1] > 100 and gaps[-2] <= 20, gaps[-8:]            # (the one long gap: group 0's epilogue + group 1's prologue)
+    assert sum(1 for g in gaps if g > 6) <= 6, gaps[-12:]          # barrier + loop bookkeeping once per slab step, nothing else bunches up
+    mem = [i for i, ln in enumerate(asm) if ln.startswith(("ds_read_b128", "ds_write_b128", "buffer_load_dwordx4"))]
+    in_loop = [i for i in mem if any(a < i < b for a, b in zip(mf, mf[1:]) if b - a <= 21)]
+    assert len(in_loop) >= 2 * (16 + 14)                           # group 0: 8 reads + 4 writes + 4 loads per step; group 1: 6 + 4 + 4
+    for i in in_loop:                                              # each of them directly between two MFMAs (with at most its wait / address op)
+        assert any(asm[j].startswith("v_mfma") for j in range(i - 3, i)) and any(asm[j].startswith("v_mfma") for j in range(i + 1, i + 4)), asm[i - 3:i + 4]
+
+
 def test_one_pass_householder_kernel_budget(music_co):
     """1024-thread workgroup: 128 VGPRs is all a wave gets; the fused pass keeps four matrix loads in flight per thread (eight spilled)."""
     name, meta, asm = music_co.find("eigh_tridiag_fused_kernel")

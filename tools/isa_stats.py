@@ -34,3 +34,5 @@ if os.environ.get("ISA_OPS"):
     ops = collections.Counter(ln.split()[0] for ln in asm)
     for k, v in sorted(ops.items(), key=lambda kv: -kv[1])[:int(os.environ["ISA_OPS"])]:
         print(f"    {k:32s} {v}")
+if os.environ.get("ISA_DUMP"):
+    open(os.environ["ISA_DUMP"], "w").write("\n".join(asm) + "\n")
