@@ -25,7 +25,10 @@
 namespace isac {
 
 // ---------------------------------------------------------------- beam-sum: 1 read of tx
-template <int QT>
+// HBM-bound: T x A x 16 B read once (1.007 GB at the bench shape), nothing else.  Each workgroup walks blocks of 256 consecutive samples
+// (grid-stride: 1024 long-lived workgroups, four per CU) with its antenna loop unrolled UNROLL deep: 170.6 us = 5.90 TB/s, against 178 us of the
+// 8-deep one-block-per-workgroup form of rounds 1-3 (profiles/r04_beamsum_sweep.txt; a plain streaming read tops out at 6.0-6.2 TB/s, tools/gbench.hip).
+template <int QT, int UNROLL>
 __global__ __launch_bounds__(256) void beamsum_kernel(const c64* __restrict__ tx, long long T, int A,
                                                       const c64* __restrict__ steer /* [A x QT] compacted LoS */,
                                                       c64* __restrict__ beam /* [QT x T] */) {
@@ -33,29 +36,33 @@ __global__ __launch_bounds__(256) void beamsum_kernel(const c64* __restrict__ tx
   c64* s_steer = reinterpret_cast<c64*>(smem_raw);
   for (int i = threadIdx.x; i < A * QT; i += blockDim.x) s_steer[i] = steer[i];
   __syncthreads();
-  long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= T) return;
-  c64 acc[QT];
+  for (long long t0 = (long long)blockIdx.x * 256; t0 < T; t0 += (long long)gridDim.x * 256) {
+    const long long t = t0 + threadIdx.x;
+    const long long tc = t < T ? t : T - 1;                            // unconditional loads (clamped), one conditional store
+    c64 acc[QT];
 #pragma unroll
-  for (int q = 0; q < QT; ++q) acc[q] = mk(0.0, 0.0);
-  const c64* p = tx + t;
-  int a = 0;
-  for (; a + 8 <= A; a += 8) {
-    c64 v[8];
+    for (int q = 0; q < QT; ++q) acc[q] = mk(0.0, 0.0);
+    const c64* p = tx + tc;
+    int a = 0;
+    for (; a + UNROLL <= A; a += UNROLL) {
+      c64 v[UNROLL];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(long long)(a + u) * T];
+      for (int u = 0; u < UNROLL; ++u) v[u] = p[(long long)(a + u) * T];
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-      for (int q = 0; q < QT; ++q) acc[q] = fma(v[u], s_steer[q * A + a + u], acc[q]);
+        for (int q = 0; q < QT; ++q) acc[q] = fma(v[u], s_steer[q * A + a + u], acc[q]);
+    }
+    for (; a < A; ++a) {
+      c64 v = p[(long long)a * T];
+#pragma unroll
+      for (int q = 0; q < QT; ++q) acc[q] = fma(v, s_steer[q * A + a], acc[q]);
+    }
+    if (t < T) {
+#pragma unroll
+      for (int q = 0; q < QT; ++q) beam[(long long)q * T + t] = acc[q];
+    }
   }
-  for (; a < A; ++a) {
-    c64 v = p[(long long)a * T];
-#pragma unroll
-    for (int q = 0; q < QT; ++q) acc[q] = fma(v, s_steer[q * A + a], acc[q]);
-  }
-#pragma unroll
-  for (int q = 0; q < QT; ++q) beam[(long long)q * T + t] = acc[q];
 }
 
 // ---------------------------------------------------------------- per-target coefficient vectors
@@ -605,17 +612,26 @@ static int prepare_echo(isac_ctx* ctx, const c64* d_tx, long long T, const isac_
     ISAC_HIP(hipEventRecord(ctx->ev_h2d, ctx->stream));
   }
   // beam-sums in tiles of up to 8 targets (tx is re-read only when Q > 8)
-  const unsigned gb = cdiv(T, 256);
+  static const int bs_wgs = std::getenv("ISAC_BEAMSUM_WGS") ? std::atoi(std::getenv("ISAC_BEAMSUM_WGS")) : 1024;   // development switch: workgroups of the launch
+  static const int bs_unroll = std::getenv("ISAC_BEAMSUM_UNROLL") ? std::atoi(std::getenv("ISAC_BEAMSUM_UNROLL")) : 32;   // (sweep: profiles/r04_beamsum_sweep.txt)
+  const unsigned gb = (unsigned)std::min<long long>(cdiv(T, 256), bs_wgs > 0 ? bs_wgs : (1 << 30));
   timeline_mark(ctx, 0, ctx->stream);
+#define ISAC_BEAMSUM(QT)                                                                                                                    \
+  do {                                                                                                                                      \
+    if (bs_unroll >= 32) hipLaunchKernelGGL((beamsum_kernel<QT, (QT <= 2 ? 32 : 8)>), dim3(gb), dim3(256), sizeof(c64) * A * QT, ctx->stream, d_tx, T, A, st, bm);      \
+    else if (bs_unroll >= 16) hipLaunchKernelGGL((beamsum_kernel<QT, (QT <= 4 ? 16 : 8)>), dim3(gb), dim3(256), sizeof(c64) * A * QT, ctx->stream, d_tx, T, A, st, bm); \
+    else hipLaunchKernelGGL((beamsum_kernel<QT, 8>), dim3(gb), dim3(256), sizeof(c64) * A * QT, ctx->stream, d_tx, T, A, st, bm);           \
+  } while (0)
   for (int q0 = 0; q0 < Q;) {
     int rem = Q - q0;
     const c64* st = d_steer_aq + (size_t)q0 * A;
     c64* bm = (c64*)ctx->beam.p + (size_t)q0 * T;
-    if (rem >= 8) { hipLaunchKernelGGL(beamsum_kernel<8>, dim3(gb), dim3(256), sizeof(c64) * A * 8, ctx->stream, d_tx, T, A, st, bm); q0 += 8; }
-    else if (rem >= 4) { hipLaunchKernelGGL(beamsum_kernel<4>, dim3(gb), dim3(256), sizeof(c64) * A * 4, ctx->stream, d_tx, T, A, st, bm); q0 += 4; }
-    else if (rem >= 2) { hipLaunchKernelGGL(beamsum_kernel<2>, dim3(gb), dim3(256), sizeof(c64) * A * 2, ctx->stream, d_tx, T, A, st, bm); q0 += 2; }
-    else { hipLaunchKernelGGL(beamsum_kernel<1>, dim3(gb), dim3(256), sizeof(c64) * A * 1, ctx->stream, d_tx, T, A, st, bm); q0 += 1; }
+    if (rem >= 8) { ISAC_BEAMSUM(8); q0 += 8; }
+    else if (rem >= 4) { ISAC_BEAMSUM(4); q0 += 4; }
+    else if (rem >= 2) { ISAC_BEAMSUM(2); q0 += 2; }
+    else { ISAC_BEAMSUM(1); q0 += 1; }
   }
+#undef ISAC_BEAMSUM
   timeline_mark(ctx, 1, ctx->stream);
   const double w = two_pi * rp->fc;                 // 2j*pi*fc  :30,:73
   hipLaunchKernelGGL(coef_kernel, dim3(gb), dim3(256), 0, ctx->stream, (const c64*)ctx->beam.p, T, Q, tab, w, Ts,

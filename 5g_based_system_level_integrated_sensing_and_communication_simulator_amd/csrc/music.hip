@@ -418,6 +418,183 @@ __device__ __forceinline__ void cov_block_pair(const c64* __restrict__ G, long l
   }
 }
 
+// ---- the same block pairs, software-pipelined inside the wave (round 4; the shipped kernel for A > 64, cov_block_pair above stays as the
+// fallback for sample counts beyond this kernel's 32-bit staging offsets).  cov_block_pair issues, per 16-sample slab and wave,
+// [5 ds_read, wait, 12 MFMAs] x 4, then 8 ds_write + 8 loads + barrier: on gfx950 a wave that wants to issue a v_mfma_f64 into the busy pipe
+// holds the SIMD's issue port, so nothing of the OTHER workgroup's wave hides those bursts (tools/cobench.hip: together = sum for LDS and
+// global-memory instructions too) -- 0.53 of the MFMA peak at A = 256.  Here the pipeline step is ONE k-step (4 samples: 12 MFMAs on an
+// off-diagonal pair) on operands read during the step before, and its gaps carry, one instruction each, the operand reads of the next k-step,
+// a quarter of the staging writes of the unit after next and the re-issue of those staging loads.  Unit = 8 samples (two k-steps); four
+// 16 KB images in rotation (the same 64 KB): unit u is read during u - 1 / u, unit u + 2 written during u, one barrier per unit.
+// Image of a unit: [antenna block 0..7][sample 0..7][antenna ^ g(sample)] (16-slot rows, kCovSwizzle): staging writes (8 lanes = the 8
+// samples of one antenna) and operand reads (sample 4 e + kq) are conflict-free as in the 16-sample image.
+constexpr int kCovUnit = 8;
+constexpr int kCovUBlk = kCovUnit * kCovPitch;                  // complex elements per (antenna block, unit)
+constexpr int kCovUImg = 8 * kCovUBlk;                          // one image (16 KB)
+constexpr int kCovUImgs = 4;
+template <bool DIAG, int NSLOT>                                 // NSLOT: tiles of this wave -- 4 on an off-diagonal pair, 3 / 2 on a diagonal one (waves 0, 1 / 2, 3)
+__device__ __forceinline__ void cov_block_pair_pl(const c64* __restrict__ G, long long N, int A, int BI, int BJ, int pair, int chunk, int n_pairs,
+                                                  long long units_per_wg, double* __restrict__ part, c64* __restrict__ lds) {
+  static_assert(DIAG ? (NSLOT == 2 || NSLOT == 3) : NSLOT == 4, "");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  int tI[NSLOT], tJ[NSLOT];
+#pragma unroll
+  for (int u = 0; u < NSLOT; ++u) {
+    const int code = DIAG ? (int)kCovDiagTiles[wid][u] : (16 * wid + u);
+    tI[u] = code >> 4;
+    tJ[u] = code & 15;
+  }
+  // operands of one k-step.  Off-diagonal pair: op 0 = the wave's row tile (LDS block wid), op 1 + u = column tile u (LDS block 4 + u).
+  // Diagonal pair: op 0 = the diagonal tile (slot 0), ops 2 u - 1, 2 u = row / column tile of slot u >= 1.
+  constexpr int NOP = DIAG ? 2 * NSLOT - 1 : 1 + NSLOT;
+  int a_off[NOP][2];                                // element offset of operand i, k-step e inside an image
+#pragma unroll
+  for (int i = 0; i < NOP; ++i) {
+    int blk;
+    if constexpr (DIAG) blk = i == 0 ? tI[0] : ((i & 1) ? tI[(i + 1) >> 1] : tJ[i >> 1]);
+    else blk = i == 0 ? wid : 3 + i;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int smp = 4 * e + kq;
+      a_off[i][e] = blk * kCovUBlk + smp * kCovPitch + (li ^ kCovSwizzle(smp));
+    }
+  }
+  // staging: load j of a unit covers antennas 32 j .. 32 j + 31 of the pair's 128 (64) x the unit's 8 samples -- thread -> (sample tid & 7,
+  // antenna tid >> 3); 8 consecutive lanes read one 128-byte line.  One descriptor per load (uniform), ending with the array's last antenna.
+  constexpr int NS = DIAG ? 2 : 4;
+  const int s_smp = tid & 7, l32 = tid >> 3;
+  __amdgpu_buffer_rsrc_t s_rs[NS];
+#pragma unroll
+  for (int j = 0; j < NS; ++j) {
+    const int ant0 = 64 * (j < 2 ? BI : BJ) + 32 * (j & 1);
+    int n_ant = A - ant0;
+    n_ant = n_ant < 0 ? 0 : (n_ant > 32 ? 32 : n_ant);
+    s_rs[j] = buffer_of(G + N * (long long)(ant0 < A ? ant0 : 0), (unsigned)(N * n_ant * (long long)sizeof(c64)));
+  }
+  const int s_lds0 = ((l32 >> 4) * kCovUnit + s_smp) * kCovPitch + ((l32 & 15) ^ kCovSwizzle(s_smp));   // + 2 j kCovUBlk: LDS block 2 j + (l32 >> 4)
+  const long long total = (N + kCovUnit - 1) / kCovUnit;
+  const long long u_begin = (long long)chunk * units_per_wg;
+  long long u_end = u_begin + units_per_wg;
+  if (u_end > total) u_end = total;
+  auto voff_of = [&](long long unit) {               // samples past N / units past the chunk: an offset beyond every descriptor reads zero
+    const long long n = unit * kCovUnit + s_smp;
+    return (n < N && unit < u_end) ? (unsigned)((N * l32 + n) * (long long)sizeof(c64)) : kCovOobOffset;
+  };
+  v4f64 re[NSLOT], im[NSLOT], s3[NSLOT];             // 3M form as in cov_block_pair: off-diagonal tile S1, S2, S3; diagonal tile (slot 0) Gr Gr', M, Gi Gi'
+#pragma unroll
+  for (int u = 0; u < NSLOT; ++u) re[u] = im[u] = s3[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+  c64 g[2][NS];                                      // staging sets: during unit u, g[u & 1] holds unit u + 2 (then u + 4), the other u + 3
+  c64 ops[2][NOP];                                   // operand sets by k-step parity
+  // One k-step.  UQ = unit index mod 4 (its image), E = k-step of the unit: compile time, the loop below is unrolled over four units.
+  auto kstep = [&](auto uq_c, auto e_c, long long unit) {
+    constexpr int UQ = decltype(uq_c)::value, E = decltype(e_c)::value, SET = UQ & 1;
+    constexpr int IMG_RD = E == 0 ? UQ : ((UQ + 1) & 3), E_RD = E ^ 1, IMG_WR = (UQ + 2) & 3;
+    const c64 (&cur)[NOP] = ops[E];
+    c64 (&nxt)[NOP] = ops[E ^ 1];
+    const unsigned voff = voff_of(unit + 4);
+    double dm[NSLOT], sp[NSLOT];                     // Gr - Gi of the row operand, Gr + Gi of the column operand (slot 0 of a diagonal pair: unused)
+#pragma unroll
+    for (int u = DIAG ? 1 : 0; u < NSLOT; ++u) {
+      const c64 xa = DIAG ? cur[2 * u - 1] : cur[0], xb = DIAG ? cur[2 * u] : cur[1 + u];
+      dm[u] = xa.re - xa.im;
+      sp[u] = xb.re + xb.im;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // filler k sits in the gap behind the k-th MFMA of the k-step: the NOP operand reads of the next k-step, NS / 2 staging writes, NS / 2 staging loads
+    auto filler = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k < NOP) {
+        nxt[k] = lds[IMG_RD * kCovUImg + a_off[k][E_RD]];
+        __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (k < NOP + NS / 2) {
+        constexpr int j = E * (NS / 2) + (k - NOP);
+        lds[IMG_WR * kCovUImg + s_lds0 + 2 * j * kCovUBlk] = g[SET][j];
+        __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (k < NOP + NS) {
+        constexpr int j = E * (NS / 2) + (k - NOP - NS / 2);
+        g[SET][j] = buffer_load_c64(s_rs[j], voff);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    static_assert(3 * NSLOT >= NOP + NS, "every filler has its gap");
+    static_for<0, NSLOT>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      if constexpr (DIAG && u == 0) re[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[0].re, cur[0].re, re[0], 0, 0, 0);
+      else if constexpr (DIAG) re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[2 * u - 1].re, cur[2 * u].re, re[u], 0, 0, 0);
+      else re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[0].re, cur[1 + u].re, re[u], 0, 0, 0);
+      filler(std::integral_constant<int, u>{});
+    });
+    static_for<0, NSLOT>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      if constexpr (DIAG && u == 0) im[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[0].re, cur[0].im, im[0], 0, 0, 0);
+      else if constexpr (DIAG) im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[2 * u - 1].im, cur[2 * u].im, im[u], 0, 0, 0);
+      else im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[0].im, cur[1 + u].im, im[u], 0, 0, 0);
+      filler(std::integral_constant<int, NSLOT + u>{});
+    });
+    static_for<0, NSLOT>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      if constexpr (DIAG && u == 0) s3[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[0].im, cur[0].im, s3[0], 0, 0, 0);
+      else s3[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(dm[u], sp[u], s3[u], 0, 0, 0);
+      filler(std::integral_constant<int, 2 * NSLOT + u>{});
+    });
+    if constexpr (E == 1) __syncthreads();
+  };
+  auto fetch = [&](c64 (&gg)[NS], long long unit) {
+    const unsigned voff = voff_of(unit);
+#pragma unroll
+    for (int j = 0; j < NS; ++j) gg[j] = buffer_load_c64(s_rs[j], voff);
+  };
+  auto stash = [&](const c64 (&gg)[NS], int img) {
+#pragma unroll
+    for (int j = 0; j < NS; ++j) lds[img * kCovUImg + s_lds0 + 2 * j * kCovUBlk] = gg[j];
+  };
+  // prologue: units 0, 1 -> images 0, 1; units 2, 3 in flight; operands of (unit 0, k-step 0)
+  fetch(g[0], u_begin);
+  fetch(g[1], u_begin + 1);
+  stash(g[0], 0);
+  stash(g[1], 1);
+  fetch(g[0], u_begin + 2);
+  fetch(g[1], u_begin + 3);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NOP; ++i) ops[0][i] = lds[a_off[i][0]];
+  for (long long unit = u_begin; unit < u_end; unit += 4) {     // (a unit count that is no multiple of four runs all-zero units: no exit in the middle)
+    static_for<0, 4>([&](auto uq_c) {
+      kstep(uq_c, std::integral_constant<int, 0>{}, unit + decltype(uq_c)::value);
+      kstep(uq_c, std::integral_constant<int, 1>{}, unit + decltype(uq_c)::value);
+    });
+  }
+#pragma unroll
+  for (int u = 0; u < NSLOT; ++u) {
+    const bool td = DIAG && u == 0;
+    double* o = part + ((((long long)chunk * n_pairs + pair) * 16 + (tI[u] * 4 + tJ[u])) * 2) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o[r * 64 + lane] = td ? re[u][r] + s3[u][r] : re[u][r] + im[u][r];
+      o[256 + r * 64 + lane] = td ? im[u][r] /* M: antisymmetrised by cov_block_reduce_kernel */ : (s3[u][r] - re[u][r]) + im[u][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void cov_mfma_block_pl_kernel(const c64* __restrict__ G, long long N, int A, int n_blk, int n_pairs,
+                                                                   long long units_per_wg, double* __restrict__ part /* [chunk][pair][16][2][256] */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* lds = reinterpret_cast<c64*>(smem_raw);      // [kCovUImgs][kCovUImg]
+  const int pair = blockIdx.x % n_pairs, chunk = blockIdx.x / n_pairs;
+  int BI = 0, BJ = 0;
+  {
+    int rem = pair;                                 // pair-th (BI <= BJ) in row-major order
+    while (rem >= n_blk - BI) { rem -= n_blk - BI; ++BI; }
+    BJ = BI + rem;
+  }
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (BI != BJ) cov_block_pair_pl<false, 4>(G, N, A, BI, BJ, pair, chunk, n_pairs, units_per_wg, part, lds);
+  else if (wid < 2) cov_block_pair_pl<true, 3>(G, N, A, BI, BJ, pair, chunk, n_pairs, units_per_wg, part, lds);
+  else cov_block_pair_pl<true, 2>(G, N, A, BI, BJ, pair, chunk, n_pairs, units_per_wg, part, lds);
+}
+
 // ---- 33..64 antennas (NB = 3, 4: two tile groups), LDS-staged and software-pipelined INSIDE the wave (round 4).
 // Two measurements of this round decide the shape (profiles/r04_cobench.txt, r04_gbench.txt, r04_cov_probe_variants.txt):
 //  * cov_mfma_small_kernel feeds the MFMAs from registers: lane (i, kq) loads its own operand, i.e. 16 consecutive lanes read 16 different
@@ -2165,10 +2342,18 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
     per = (per + 1) & ~1ll;                           // the kernel walks slabs in pairs
     n_chunks = (total + per - 1) / per;
     ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * (size_t)n_chunks * n_pairs * 16 * 2 * 256));
-    const size_t lds = sizeof(c64) * 2 * kCovBufElems;
-    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cov_mfma_block_kernel), (size_t)(lds)));
-    hipLaunchKernelGGL(cov_mfma_block_kernel, dim3((unsigned)(n_chunks * n_pairs)), dim3(256), lds, st, (const c64*)d_grid, (long long)N, A,
-                       n_blk, n_pairs, per, (double*)ctx->cov_part.p);
+    static const bool burst_form = std::getenv("ISAC_COV_BLOCK_BURST") != nullptr;    // development switch: cov_mfma_block_kernel for every N
+    if (!burst_form && N * 512 < (1ll << 31)) {       // (32 antennas per staging descriptor: 32-bit offsets up to N x 31 x 16 B)
+      const size_t lds = sizeof(c64) * kCovUImgs * kCovUImg;
+      ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cov_mfma_block_pl_kernel), (size_t)(lds)));
+      hipLaunchKernelGGL(cov_mfma_block_pl_kernel, dim3((unsigned)(n_chunks * n_pairs)), dim3(256), lds, st, (const c64*)d_grid, (long long)N, A,
+                         n_blk, n_pairs, 2 * per, (double*)ctx->cov_part.p);
+    } else {
+      const size_t lds = sizeof(c64) * 2 * kCovBufElems;
+      ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cov_mfma_block_kernel), (size_t)(lds)));
+      hipLaunchKernelGGL(cov_mfma_block_kernel, dim3((unsigned)(n_chunks * n_pairs)), dim3(256), lds, st, (const c64*)d_grid, (long long)N, A,
+                         n_blk, n_pairs, per, (double*)ctx->cov_part.p);
+    }
     ISAC_HIP(hipGetLastError());
     hipLaunchKernelGGL(cov_block_reduce_kernel, dim3(16, n_pairs), dim3(256, 4), 0, st, (const double*)ctx->cov_part.p, (int)n_chunks,
                        n_blk, n_pairs, A, 1.0 / (double)N, (c64*)d_Ra);
