@@ -42,6 +42,7 @@ _TABLES = {
         dict(cASD=5.0, cASA=8.0, cZSD=3.0, cZSA=3.0, XPR=11.0), True),
 }
 FILTER_TAPS, FILTER_DELAY = 16, 7
+_TAPS_CACHE: dict = {}
 _STATIC_CACHE: dict = {}                      # time-independent channel quantities shared by equally configured channels
 
 
@@ -168,14 +169,116 @@ class CDLChannel:
         return h
 
     def filter_taps(self):
+        key = (self.DelayProfile, self.DelaySpread, self.SampleRate)
+        if key in _TAPS_CACHE:
+            return _TAPS_CACHE[key]
         d = self.path_delays() * self.SampleRate
         shift = np.floor(d).astype(np.int32)
         x = np.arange(FILTER_TAPS, dtype=np.float64)[None, :] - FILTER_DELAY - (d - shift)[:, None]
         g = np.sinc(x) * np.where(np.abs(x) < FILTER_TAPS / 2, 0.5 + 0.5 * np.cos(np.pi * x / (FILTER_TAPS / 2)), 0.0)
-        return np.ascontiguousarray(g), shift
+        _TAPS_CACHE[key] = (np.ascontiguousarray(g), shift)
+        return _TAPS_CACHE[key]
 
     def __call__(self, waveform, *, ctx=None):
         return applyCDL(self, waveform, ctx=ctx)
+
+    # ---- device-resident form (round 4): the time-independent per-ray terms live on the device, the sample-and-hold path gains of any number
+    # of gain blocks are formed there (isac_cdl_path_gains_dev), and applyCDLBatch applies many (channel, waveform) pairs in one call
+    def _device_static(self, ctx):
+        """(d_base [n][m][s][u], d_rate [n][m], d_los [s][u] | None, los_rate) on `ctx`'s device; cached per context and channel configuration."""
+        st = self._static()
+        cache = st.__dict__.setdefault("_dev", {})
+        key = id(ctx)
+        if key not in cache:
+            d_base = ctx.to_device(np.ascontiguousarray(st.base).reshape(-1))
+            d_rate = ctx.to_device(np.ascontiguousarray(st.rate, dtype=np.float64).reshape(-1))
+            d_los = ctx.to_device(np.ascontiguousarray(st.los).reshape(-1)) if st.los is not None else None
+            cache[key] = (ctx, d_base, d_rate, d_los, float(getattr(st, "los_rate", 0.0)))
+        return cache[key][1:]
+
+    def block_plan(self, T: int):
+        """Gain blocks that the next T samples touch: (snapshot times, first output sample of each block) -- plain Python scalars (this runs once
+        per (UE, slot) job in front of every batched apply)."""
+        rate = 2.0 * self.SampleDensity * self.MaximumDopplerShift
+        b0 = math.floor(self.time * rate + 1e-9)
+        b1 = math.floor((self.time + (T - 1) / self.SampleRate) * rate + 1e-9)
+        # first output sample of each block: smallest t with floor((time + t/fs) rate + 1e-9) >= b
+        starts = [0] + [max(0, math.ceil(((b - 1e-9) / rate - self.time) * self.SampleRate - 1e-6)) for b in range(b0 + 1, b1 + 1)]
+        return [b / rate for b in range(b0, b1 + 1)], starts
+
+    def path_gains_device(self, t_snaps, ctx, out=None):
+        """H [b][n][s][u] (u fastest) on the device for the channel times `t_snaps` -- the device evaluation of path_gains()."""
+        d_base, d_rate, d_los, los_rate = self._device_static(ctx)
+        st = self._static()
+        n_paths, n_rays, nt, nr = st.base.shape
+        t = np.ascontiguousarray(np.asarray(t_snaps, dtype=np.float64).reshape(-1))
+        d_h = out if out is not None else ctx.empty((t.size * n_paths * nt * nr,))
+        ctx.check(ctx.lib.isac_cdl_path_gains_dev(ctx.handle, C.c_void_p(d_base.ptr), C.c_void_p(d_rate.ptr), C.c_int32(n_paths), C.c_int32(n_rays), C.c_int32(nt),
+                                                  C.c_int32(nr), C.c_void_p(d_los.ptr if d_los is not None else 0), C.c_double(los_rate),
+                                                  t.ctypes.data_as(C.c_void_p), C.c_int32(t.size), C.c_void_p(d_h.ptr)))
+        return d_h
+
+
+def applyCDLBatch(channels, waveforms, *, ctx=None, outs=None, gains=None):
+    """rxWaveform_i = channel_i(waveform_i) for many (UE, slot) pairs in ONE library call (isac_cdl_apply_batch_dev): uePhy.m:729-731 inside the
+    per-UE loop of a cell, or the slots of a frame.  All channels must share antenna counts, sample rate, delay profile length and filter taps
+    (the reference builds every UE's channel from the same cdl.m:57-64 template); `waveforms` are DeviceArrays [T x Nt] -- the same array may appear
+    several times (the UEs of one cell receive one downlink waveform).  Path gains are formed on the device.  Advances every channel's time.
+    `outs` / `gains`: caller-owned output arrays and a path-gain scratch DeviceArray (>= total gain blocks x n_paths x Nt x Nr elements) that a
+    frame loop reuses from slot to slot -- without them every call allocates and (when the previous outputs are dropped) frees, and a free
+    synchronises the stream.  Returns the list of output DeviceArrays [T x Nr]."""
+    channels, waveforms = list(channels), list(waveforms)
+    if not channels or len(channels) != len(waveforms):
+        raise ValueError("applyCDLBatch: one waveform per channel")
+    ctx = ctx or waveforms[0].ctx
+    c0 = channels[0]
+    T, nt = waveforms[0].shape
+    nr = int(np.prod(c0.ReceiveAntennaArraySize))
+    g, shift = c0.filter_taps()
+    n_paths = g.shape[0]
+    for ch, w in zip(channels, waveforms):
+        if not isinstance(w, L.DeviceArray) or tuple(w.shape) != (T, nt):
+            raise ValueError("applyCDLBatch: waveforms must be DeviceArrays of one shape [T x Nt]")
+        if int(np.prod(ch.TransmitAntennaArraySize)) != nt or int(np.prod(ch.ReceiveAntennaArraySize)) != nr:
+            raise ValueError("applyCDLBatch: channels must share the antenna counts")
+        g2, s2 = ch.filter_taps()
+        if g2 is not g and (g2.shape != g.shape or not np.array_equal(s2, shift) or not np.array_equal(g2, g)):
+            raise ValueError("applyCDLBatch: channels must share path delays / filter taps (one delay profile and delay spread per batch)")
+    scale = 1.0 / math.sqrt(nr) if c0.NormalizeChannelOutputs else 1.0
+    jobs = (L.CdlJob * len(channels))()
+    keep = []
+    outs = list(outs) if outs is not None else [ctx.empty((T, nr)) for _ in channels]
+    per_block = n_paths * nt * nr
+    plans = [ch.block_plan(T) for ch in channels]
+    # path gains: ONE device evaluation per distinct channel configuration (the reference gives every UE of a delay profile the same seed,
+    # cdl.m:57-64: their channels differ in channel time only) over the concatenated snapshot times of its jobs
+    groups: dict = {}
+    for i, ch in enumerate(channels):
+        groups.setdefault(id(ch._static()), []).append(i)
+    n_blk_total = sum(len(p[0]) for p in plans)
+    if gains is not None and int(np.prod(gains.shape)) < n_blk_total * per_block:
+        raise ValueError("applyCDLBatch: `gains` scratch too small for this batch's gain blocks")
+    d_h_all = gains if gains is not None else ctx.empty((n_blk_total * per_block,))
+    off = 0
+    for idx in groups.values():
+        t_cat = np.array([t for i in idx for t in plans[i][0]], dtype=np.float64)
+        d_grp = L.DeviceArray(ctx, d_h_all.ptr + 16 * off * per_block, (t_cat.size * per_block,), np.complex128, owner=False)   # view into d_h_all
+        channels[idx[0]].path_gains_device(t_cat, ctx, out=d_grp)
+        for i in idx:
+            st = np.array(plans[i][1], dtype=np.int64)
+            keep.append(st)
+            jobs[i].d_x, jobs[i].d_y, jobs[i].d_H = waveforms[i].ptr, outs[i].ptr, d_h_all.ptr + 16 * off * per_block
+            jobs[i].block_start = st.ctypes.data_as(C.c_void_p).value
+            jobs[i].n_blocks = st.size
+            off += st.size
+    ctx.check(ctx.lib.isac_cdl_apply_batch_dev(ctx.handle, jobs, C.c_int32(len(channels)), C.c_int64(T), C.c_int32(nt), C.c_int32(nr), C.c_int32(n_paths),
+                                               g.ctypes.data_as(C.c_void_p), C.c_int32(FILTER_TAPS), shift.ctypes.data_as(C.c_void_p), C.c_double(scale)))
+    for ch in channels:
+        ch.time += T / ch.SampleRate
+    if gains is None:
+        for o in outs:
+            o._cdl_keep = d_h_all                   # the gains stay alive until the outputs are dropped (the launches are asynchronous)
+    return outs
 
 
 def applyCDL(channel: CDLChannel, waveform, *, ctx=None):
@@ -187,20 +290,15 @@ def applyCDL(channel: CDLChannel, waveform, *, ctx=None):
     if nt != int(np.prod(channel.TransmitAntennaArraySize)):
         raise ValueError("waveform columns differ from the transmit array size")
     nr = int(np.prod(channel.ReceiveAntennaArraySize))
-    rate = 2.0 * channel.SampleDensity * channel.MaximumDopplerShift
-    tt = channel.time + np.array([0, T - 1]) / channel.SampleRate
-    b0, b1 = (np.floor(tt * rate + 1e-9)).astype(np.int64)
-    blocks = np.arange(b0, b1 + 1)
-    # first output sample of each block: smallest t with floor((time + t/fs) rate + 1e-9) >= b
-    starts = np.maximum(0, np.ceil(((blocks - 1e-9) / rate - channel.time) * channel.SampleRate - 1e-6)).astype(np.int64)
-    starts[0] = 0
-    h = np.ascontiguousarray(np.stack([channel.path_gains(b / rate) for b in blocks]))        # [b, n, s, u]
+    t_snap, st_list = channel.block_plan(T)
+    starts = np.array(st_list, dtype=np.int64)
+    h = np.ascontiguousarray(np.stack([channel.path_gains(t) for t in t_snap]))               # [b, n, s, u]
     g, shift = channel.filter_taps()
     scale = 1.0 / math.sqrt(nr) if channel.NormalizeChannelOutputs else 1.0
     d_x = waveform if dev else ctx.to_device(L.as_c128_f(waveform))
     d_y = ctx.empty((T, nr))
     ctx.check(ctx.lib.isac_cdl_apply_dev(ctx.handle, C.c_void_p(d_x.ptr), C.c_int64(T), C.c_int32(nt), C.c_int32(nr), C.c_int32(h.shape[1]),
-                                         h.ctypes.data_as(C.c_void_p), C.c_int32(len(blocks)), starts.ctypes.data_as(C.c_void_p),
+                                         h.ctypes.data_as(C.c_void_p), C.c_int32(len(t_snap)), starts.ctypes.data_as(C.c_void_p),
                                          g.ctypes.data_as(C.c_void_p), C.c_int32(FILTER_TAPS), shift.ctypes.data_as(C.c_void_p),
                                          C.c_double(scale), C.c_void_p(d_y.ptr)))
     channel.time += T / channel.SampleRate

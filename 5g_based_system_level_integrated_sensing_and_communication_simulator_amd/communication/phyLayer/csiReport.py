@@ -70,6 +70,44 @@ def cqiSelect(carrier, csirs, reportConfig, nLayers, H, nVar, SINRTable, *, ctx=
     return cqi, pmi, info, pinfo
 
 
+def cqiSelectBatch(carrier, csirs, reportConfig, nLayers, H_list, nVar_list, SINRTable, *, ctx=None, codebook=None):
+    """cqiSelect for many UEs that share the CSI-RS / report configuration (uePhy.m:901-908 runs it once per UE; isac_csi_report_batch_dev runs the
+    cell's UEs in one call: one upload, one launch per stage, one synchronisation).  H_list: DeviceArrays [nRE x nRx x P] gathered at the CSI-RS REs;
+    nVar_list: one noise variance per UE.  Returns a list of (CQI, PMISet, CQIInfo) per UE.  `codebook`: W from type1SinglePanelCodebook (built if None)."""
+    H_list = list(H_list)
+    if not H_list:
+        return []
+    ctx = ctx or H_list[0].ctx
+    k = np.ascontiguousarray(np.asarray(csirs.k, dtype=np.int32).reshape(-1) - 1)
+    l = np.ascontiguousarray(np.asarray(csirs.l, dtype=np.int32).reshape(-1) - 1)
+    n_re, nr, p = H_list[0].shape
+    if n_re != k.size or any(tuple(h.shape) != (n_re, nr, p) for h in H_list):
+        raise ValueError("cqiSelectBatch: every H must be [nRE x nRx x P] at the same CSI-RS resource elements")
+    w = codebook if codebook is not None else type1SinglePanelCodebook(reportConfig, nLayers, p)
+    dims = (C.c_int32 * 4)(*w.shape[2:])
+    table = np.ascontiguousarray(np.asarray(SINRTable, dtype=np.float64))
+    n_ue = len(H_list)
+    ptrs = (C.c_void_p * n_ue)(*[h.ptr for h in H_list])
+    nvar = np.ascontiguousarray(np.asarray(nVar_list, dtype=np.float64).reshape(-1))
+    if nvar.size != n_ue:
+        raise ValueError("cqiSelectBatch: one noise variance per UE")
+    reps = (L.CsiReport * n_ue)()
+    n_size = int(getattr(reportConfig, "NSizeBWP", None) or carrier.NSizeGrid)
+    n_start = int(getattr(reportConfig, "NStartBWP", 0) or 0)
+    ctx.check(ctx.lib.isac_csi_report_batch_dev(ctx.handle, C.c_int32(n_ue), ptrs, C.c_int64(n_re), C.c_int32(nr), C.c_int32(p), k.ctypes.data_as(C.c_void_p),
+                                                l.ctypes.data_as(C.c_void_p), C.c_int32(n_size), C.c_int32(n_start), C.c_int32(int(reportConfig.SubbandSize)),
+                                                C.c_int32(1 if str(reportConfig.PMIMode).lower() == "subband" else 0),
+                                                C.c_int32(1 if str(reportConfig.CQIMode).lower() == "subband" else 0), w.ctypes.data_as(C.c_void_p),
+                                                C.c_int32(int(nLayers)), dims, nvar.ctypes.data_as(C.c_void_p), table.ctypes.data_as(C.c_void_p),
+                                                C.c_int32(table.size), reps, None))
+    out = []
+    for rep in reps:
+        pmi = SimpleNamespace(i1=np.array(rep.i1[:3]), i2=np.array(rep.i2[: rep.n_subbands_pmi]))
+        info = SimpleNamespace(SINRPerSubbandPerCW=np.array(rep.sinr_per_subband_cw[: rep.n_cqi]), SubbandCQI=np.array(rep.subband_cqi[: rep.n_cqi]))
+        out.append((np.array(rep.cqi[: rep.n_cqi]), pmi, info))
+    return out
+
+
 def dlPMISelect(carrier, csirs, reportConfig, nLayers, H, nVar=1e-10, *, ctx=None):
     """[PMISet, info] = dlPMISelect(carrier, csirs, reportConfig, nLayers, H, nVar) (dlPMISelect.m:1)."""
     rc = SimpleNamespace(**vars(reportConfig))

@@ -332,7 +332,7 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->beam, &ctx->coef, &ctx->phase_rx, &ctx->steer, &ctx->dgrid,
                     &ctx->ymid, &ctx->pwin, &ctx->flags, &ctx->det_cut, &ctx->det_pow, &ctx->det_cnt, &ctx->cov_part,
                     &ctx->cov, &ctx->eig_w, &ctx->eig_v, &ctx->eig_scratch, &ctx->spec, &ctx->misc, &ctx->stage_a, &ctx->stage_b, &ctx->seg,
-                    &ctx->stage_c, &ctx->sind_tab};
+                    &ctx->stage_c, &ctx->sind_tab, &ctx->cdl_h};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -5,202 +5,416 @@
 // +parameters/+channelModels/+communication/cdl.m:57-64,78-85.  TR 38.901 7.7.1:
 //     y[t,u] = norm * sum_n sum_s h_{n,s,u}(t) (x_s * g_n)[t]
 // Path gains are sample-and-hold (SampleDensity), so inside one gain block the antenna contraction
-// commutes with the per-path delay filter.  The heavy part becomes ONE complex GEMM on fp64 MFMA
+// commutes with the per-path delay filter.  Downlink (Nt >= Nr: 64 -> 2): ONE complex GEMM on fp64 MFMA
 //     Z[t, n*Nr+u] = sum_s X[t,s] H_n[s,u]            (M = T, N = n_paths*Nr, K = Nt)
-// followed by a light per-(t,u) FIR over the reduced signals:  y[t,u] = sum_n sum_k g_n[k] Z[t-shift_n-k, n,u].
+// followed by the per-(t,u) FIR over the reduced signals:  y[t,u] = sum_n sum_k g_n[k] Z[t-shift_n-k, n,u].
+// Uplink (Nr > Nt: 2 -> 64): the delay filters run on the Nt transmit signals first, the contraction follows with K = n_paths*Nt.
+//
+// Round 4: everything is device resident and batched -- a call takes any number of (UE, slot) jobs that share the numerology, builds one
+// segment table (one entry per job and gain block), uploads it through pinned staging without synchronising, and issues ONE GEMM launch and ONE
+// filter launch for the whole batch.  The GEMM is in 3M form (three real MFMAs per complex tile step), reads its path gains straight from the
+// caller's [block][path][s][u] array into an LDS image in MFMA operand order (with hr + hi precomputed), streams X with coalesced 256-byte
+// runs per 16 lanes, and computes two 16-row tiles per wave against each B operand read.  The filter stages each column window in LDS once.
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
 #include "isac_common.hpp"
 
 namespace isac {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
-constexpr int kCdlColTiles = 4;   // 16-column tiles per wave
 
-// X [T x Nt] column-major, Hm [Nt x Nc] column-major (Nc multiple of 16, zero padded), Z [T x Nc] column-major
-// rows [r0, r1) only (one gain block's output samples in the filter-first order); Z = scale * X Hm
-__global__ __launch_bounds__(256, 2) void cdl_contract_kernel(const c64* __restrict__ X, long long T, int Nt,
-                                                              const c64* __restrict__ Hm, int Nc, c64* __restrict__ Z,
-                                                              long long r0, long long r1, double scale) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int li = lane & 15, kq = lane >> 4;
-  const long long t0 = r0 + ((long long)blockIdx.x * 4 + wid) * 16;
-  if (t0 >= r1) return;
-  const int c_base = blockIdx.y * kCdlColTiles * 16;
-  v4f64 rr[kCdlColTiles], ii[kCdlColTiles], im[kCdlColTiles];
-#pragma unroll
-  for (int u = 0; u < kCdlColTiles; ++u) rr[u] = ii[u] = im[u] = v4f64{0.0, 0.0, 0.0, 0.0};
-  long long t = t0 + li;
-  const bool tok = t < r1;
-  if (!tok) t = r1 - 1;
-  for (int s0 = 0; s0 < Nt; s0 += 4) {
-    const int s = s0 + kq;
-    const bool sok = s < Nt;
-    const c64 xv = X[t + T * (long long)(sok ? s : 0)];           // unconditional load, select afterwards
-    const double xr = (tok && sok) ? xv.re : 0.0, xi = (tok && sok) ? xv.im : 0.0;
-#pragma unroll
-    for (int u = 0; u < kCdlColTiles; ++u) {
-      const int c = c_base + u * 16 + li;
-      const bool cok = (c < Nc) && sok;
-      const c64 hv = Hm[(sok ? s : 0) + (long long)Nt * (c < Nc ? c : 0)];
-      const double hr = cok ? hv.re : 0.0, hi = cok ? hv.im : 0.0;
-      rr[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, hr, rr[u], 0, 0, 0);
-      ii[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, hi, ii[u], 0, 0, 0);
-      im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, hi, im[u], 0, 0, 0);
-      im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, hr, im[u], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int u = 0; u < kCdlColTiles; ++u) {
-    const int c = c_base + u * 16 + (lane & 15);
-    if (c >= Nc) continue;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long row = t0 + (lane >> 4) + 4 * r;             // f64 MFMA C/D layout
-      if (row < r1) Z[row + T * (long long)c] = mk((rr[u][r] - ii[u][r]) * scale, im[u][r] * scale);
-    }
+template <int U, int NT, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (U < NT) {
+    f(std::integral_constant<int, U>{});
+    static_for<U + 1, NT>(f);
   }
 }
 
-// y[t,u] = scale * sum_n sum_k g[n][k] Z_b(t)[t - shift[n] - k, n*Nr + u]
-__global__ __launch_bounds__(256) void cdl_filter_kernel(const c64* __restrict__ Z /* [n_blocks][T x Nc] */, long long T, int Nc,
-                                                         int Nr, int n_paths, int n_taps, const double* __restrict__ taps,
-                                                         const int* __restrict__ shift, const long long* __restrict__ block_start,
-                                                         int n_blocks, double scale, c64* __restrict__ Y /* [T x Nr] */) {
+// one (job, gain block) of the batch
+struct CdlSeg {
+  const c64* A;        // GEMM: [lda x K] column-major left operand (DL: the job's x; UL: its prefiltered signals)
+  const c64* H;        // path gains of this block, [n_paths][Nt][Nr] (u fastest)
+  c64* C;              // GEMM output, [ldc x *] column-major (DL: Z of this block; UL: the job's y)
+  long long r0, r1;    // GEMM rows [r0, r1)
+  long long o0, o1;    // filter (DL): output rows [o0, o1) of this block
+  c64* Y;              // filter (DL) output: the job's y;  (UL prefilter: unused)
+};
+
+__host__ __device__ constexpr int cdl_rt(int nct) { return nct >= 3 ? 2 : 3; }   // 16-row MFMA tiles per wave (accumulators: RT x NCT x 3 x 8 VGPRs <= 144)
+__host__ __device__ constexpr int cdl_rows_per_wg(int nct) { return 4 * 16 * cdl_rt(nct); }
+constexpr int kCdlMaxTilesPerWg = 4;                // consecutive row tiles a workgroup walks per LDS image (launcher: fewer while the grid is small)
+constexpr int kCdlKChunk = 64;                      // contraction depth per LDS image
+constexpr int kCdlMaxColTiles = 3;                  // 16-column tiles per workgroup (accumulators: 2 x 3 x 3 x 8 VGPRs)
+
+// C[r0:r1, cols] = scale * A[r0:r1, 0:K] * B,  B[k, col] = H[n][s][u] with  DL: k = s, col = n Nr + u;  UL: k = n Nt + s, col = u.
+// LDS image of one K chunk: [k-step 16][column tile NCT][form 3: hr, hi, hr + hi][lane 64] doubles, lane = 16 (k & 3) + (col & 15) -- exactly the
+// B-operand order of v_mfma_f64_16x16x4_f64, so every operand is one conflict-free ds_read_b64.
+// B images in LDS order, one per (segment, column group, K chunk): [k-step 16][column tile NCT][form 3: hr, hi, hr + hi][lane 64] doubles.
+// (Built once per call by this small kernel; the contraction kernel's workgroups -- hundreds per segment -- copy them with coalesced 16-byte loads
+// instead of each gathering 3 072 path gains through index arithmetic: that gather cost about half a row tile's MFMA time.)
+template <bool UL>
+__global__ __launch_bounds__(256) void cdl_pack_kernel(const CdlSeg* __restrict__ segs, int nct, int Nt, int Nr, int K, int Nc, double* __restrict__ bimg) {
+  const CdlSeg sg = segs[blockIdx.z];
+  const int n_chunks = (K + kCdlKChunk - 1) / kCdlKChunk, per = 16 * nct * 3 * 64;
+  const int ct0 = blockIdx.y * nct, kc0 = blockIdx.x * kCdlKChunk;
+  double* img = bimg + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * (size_t)n_chunks + blockIdx.x) * (size_t)per;
+  for (int i = threadIdx.x; i < 16 * nct * 64; i += blockDim.x) {
+    const int ks = i / (nct * 64), ct = (i >> 6) % nct, ln = i & 63;
+    const int k = kc0 + 4 * ks + (ln >> 4), col = 16 * (ct0 + ct) + (ln & 15);
+    const bool ok = k < K && col < Nc;
+    const int kk = ok ? k : 0, cc = ok ? col : 0;
+    const int n = UL ? kk / Nt : cc / Nr, s = UL ? kk % Nt : kk, u = UL ? cc : cc % Nr;
+    const c64 h = sg.H[((long long)n * Nt + s) * Nr + u];             // unconditional load, select afterwards
+    double* d = img + ((ks * nct + ct) * 3) * 64 + ln;
+    d[0] = ok ? h.re : 0.0;
+    d[64] = ok ? h.im : 0.0;
+    d[128] = ok ? h.re + h.im : 0.0;
+  }
+}
+
+template <int NCT, bool UL>
+__global__ __launch_bounds__(256, 2) void cdl_gemm_kernel(const CdlSeg* __restrict__ segs, const c64* __restrict__ bimg, long long lda, long long ldc, int K,
+                                                          int Nc, double scale, int tiles_per_wg, int n_segs) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* s_g = reinterpret_cast<double*>(smem_raw);               // [n_paths x n_taps]
-  int* s_shift = reinterpret_cast<int*>(s_g + n_paths * n_taps);
-  for (int i = threadIdx.x; i < n_paths * n_taps; i += blockDim.x) s_g[i] = taps[i];
-  for (int i = threadIdx.x; i < n_paths; i += blockDim.x) s_shift[i] = shift[i];
-  __syncthreads();
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int u = blockIdx.y;
-  if (t >= T) return;
-  int b = 0;
-  for (int i = 1; i < n_blocks; ++i) b = (t >= block_start[i]) ? i : b;   // gain block of the OUTPUT sample
-  const c64* Zb = Z + (long long)b * T * Nc;
-  c64 acc = mk(0.0, 0.0);
-  for (int n = 0; n < n_paths; ++n) {
-    const c64* zc = Zb + T * (long long)(n * Nr + u);
-    const long long base = t - s_shift[n];
-    for (int k = 0; k < n_taps; ++k) {
-      const long long idx = base - k;
-      const c64 z = zc[idx >= 0 ? idx : 0];
-      const double g = idx >= 0 ? s_g[n * n_taps + k] : 0.0;
-      acc.re = ::fma(g, z.re, acc.re);
-      acc.im = ::fma(g, z.im, acc.im);
+  double* lds = reinterpret_cast<double*>(smem_raw);
+  // (segment = slowest grid dimension.  Making the jobs that share a waveform adjacent in dispatch order -- plain, or grouped per XCD -- so that they
+  // read x through one L2 together measured 7-13 % SLOWER: x (63 MB) is served by the Infinity Cache either way, profiles/r04_negative_results.txt)
+  const int seg_i = blockIdx.z, tile_x = blockIdx.x;
+  const CdlSeg sg = segs[seg_i];
+  // A workgroup walks `tiles_per_wg` consecutive tiles of 4 waves x RT x 16 rows: when the contraction fits one LDS image (K <= 64: the downlink's 64 transmit
+  // elements, the uplink's n_paths x 2) the image is loaded ONCE for all of them.
+  constexpr int RT = cdl_rt(NCT), kRows = cdl_rows_per_wg(NCT);
+  const long long wg_row0 = sg.r0 + (long long)tile_x * (kRows * tiles_per_wg);
+  if (wg_row0 >= sg.r1) return;                                       // (uniform: before any barrier)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int ct0 = blockIdx.y * NCT;
+  const long long last = sg.r1 - 1;
+  const __amdgpu_buffer_rsrc_t rs_a = buffer_of(sg.A, (unsigned)(lda * K * (long long)sizeof(c64)));           // (the launcher keeps lda K 16 B below 4 GB)
+  // the B images of this (segment, column group) were packed by cdl_pack_kernel in exactly the LDS order: the fill is a straight 16-byte copy
+  constexpr int kImgVec = 16 * NCT * 3 * 64 / 2;                      // 16-byte vectors per image
+  const int n_chunks = (K + kCdlKChunk - 1) / kCdlKChunk;
+  const c64* img_g = bimg + ((size_t)seg_i * gridDim.y + blockIdx.y) * (size_t)n_chunks * kImgVec;
+  auto fill = [&](int kc0) {
+    const c64* src = img_g + (size_t)(kc0 / kCdlKChunk) * kImgVec;
+    c64* dst = reinterpret_cast<c64*>(lds);
+#pragma unroll 6
+    for (int i = tid; i < kImgVec; i += 256) dst[i] = src[i];
+  };
+  const bool one_image = K <= kCdlKChunk;
+  if (one_image) { fill(0); __syncthreads(); }
+  for (int tile = 0; tile < tiles_per_wg; ++tile) {
+    const long long wg_row = wg_row0 + (long long)tile * kRows;
+    if (wg_row >= sg.r1) break;                                       // (uniform)
+    const long long t0 = wg_row + (long long)wid * (16 * RT);
+    unsigned ro[RT];                                                  // byte offset of this lane's row in each row tile (loads clamped, stores masked)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) { const long long r = t0 + 16 * rt + li; ro[rt] = (unsigned)((r < last ? r : last) * (long long)sizeof(c64)); }
+    v4f64 p1[RT][NCT], p2[RT][NCT], p3[RT][NCT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) p1[rt][ct] = p2[rt][ct] = p3[rt][ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+    for (int kc0 = 0; kc0 < K; kc0 += kCdlKChunk) {
+      if (!one_image) { __syncthreads(); fill(kc0); __syncthreads(); }
+      // 16 k-steps, straight-line (k >= K meets an all-zero B row): the A operands and the B operands of k-step ks + 1 are requested before the
+      // 6 NCT MFMAs of k-step ks are issued -- neither a global load nor an LDS read is waited for in front of the MFMAs that consume it
+      const unsigned col_step = (unsigned)(4 * lda * (long long)sizeof(c64));          // one k-step = four columns of A
+      const int k_last = K - 1 - kc0 - kq;                                              // (k-steps whose column k >= K re-read column K - 1: B is zero there)
+      const unsigned col0 = (unsigned)((long long)(kc0 + kq) * lda * (long long)sizeof(c64)), col_last = (unsigned)((long long)(K - 1) * lda * (long long)sizeof(c64));
+      c64 xa[2][RT];
+      double hb[2][NCT][3];
+      auto load_a = [&](int ks, c64 (&x)[RT]) {
+        const unsigned co = 4 * ks <= k_last ? col0 + (unsigned)ks * col_step : col_last;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) x[rt] = buffer_load_c64(rs_a, ro[rt] + co);
+      };
+      auto load_b = [&](int ks, double (&h)[NCT][3]) {
+        const double* bp = lds + (ks * NCT * 3) * 64 + lane;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+          for (int f = 0; f < 3; ++f) h[ct][f] = bp[(ct * 3 + f) * 64];
+      };
+      load_a(0, xa[0]);
+      load_b(0, hb[0]);
+      static_for<0, 16>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value, cur = ks & 1;
+        if constexpr (ks + 1 < 16) {
+          load_a(ks + 1, xa[cur ^ 1]);
+          load_b(ks + 1, hb[cur ^ 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double xs[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) xs[rt] = xa[cur][rt].re + xa[cur][rt].im;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) p1[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[cur][rt].re, hb[cur][ct][0], p1[rt][ct], 0, 0, 0);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) p2[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[cur][rt].im, hb[cur][ct][1], p2[rt][ct], 0, 0, 0);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) p3[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[rt], hb[cur][ct][2], p3[rt][ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
     }
+    // (xr + j xi)(hr + j hi):  Re = P1 - P2,  Im = P3 - P1 - P2  with  P1 = xr hr, P2 = xi hi, P3 = (xr + xi)(hr + hi)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int col = 16 * (ct0 + ct) + li;
+        if (col >= Nc) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long row = t0 + 16 * rt + kq + 4 * r;            // f64 MFMA C/D layout
+          if (row < sg.r1)
+            sg.C[row + ldc * (long long)col] = mk((p1[rt][ct][r] - p2[rt][ct][r]) * scale, ((p3[rt][ct][r] - p1[rt][ct][r]) - p2[rt][ct][r]) * scale);
+        }
+      }
   }
-  Y[t + T * (long long)u] = acc * scale;
 }
 
-// Filter-first order for Nr > Nt (uplink: 2 UE antennas -> 64 gNB antennas, cdl.m:78-85): the delay filters run on the Nt transmit
-// signals (n_paths * Nt filtered signals instead of n_paths * Nr reduced ones), the antenna contraction follows as a GEMM with
-// K = n_paths * Nt.  XF[t, n*Nt + s] = sum_k g[n][k] x_s[t - shift[n] - k]
-__global__ __launch_bounds__(256) void cdl_prefilter_kernel(const c64* __restrict__ X /* [T x Nt] */, long long T, int Nt, int n_paths, int n_taps,
-                                                            const double* __restrict__ taps, const int* __restrict__ shift,
-                                                            c64* __restrict__ XF /* [T x n_paths*Nt] */) {
-  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c = blockIdx.y, n = c / Nt, s_ = c % Nt;
-  if (t >= T) return;
-  const c64* xc = X + T * (long long)s_;
-  const long long base = t - shift[n];
+// Delay filters.  DL (UL = false): y[t, u] = scale * sum_n sum_k g[n][k] Z_b[t - shift[n] - k, n Nr + u]  for the output rows [o0, o1) of a
+// (job, block) segment; UL (prefilter): XF[t, n Nt + s] = sum_k g[n][k] x[t - shift[n] - k, s]  for rows [0, o1).  Samples before the start of
+// the waveform are zero.  One workgroup = 256 consecutive output samples of one output column; every term's window (256 + n_taps - 1 samples of
+// one input column) goes through LDS once, double buffered (one barrier per term).
+template <bool UL>
+__global__ __launch_bounds__(256) void cdl_fir_kernel(const CdlSeg* __restrict__ segs, long long ld_in, long long ld_out, int Nt, int Nr, int n_paths,
+                                                      int n_taps, const double* __restrict__ taps, const int* __restrict__ shift, double scale) {
+  __shared__ __attribute__((aligned(16))) c64 s_win[2][256 + 64];
+  const CdlSeg sg = segs[blockIdx.z];
+  const long long t0 = sg.o0 + (long long)blockIdx.x * 256;
+  if (t0 >= sg.o1) return;                                            // (uniform)
+  const int tid = threadIdx.x;
+  const long long t = t0 + tid;
+  const int oc = blockIdx.y;                                          // DL: receive antenna u;  UL: filtered signal n Nt + s
+  const c64* in = UL ? sg.A : sg.C;
+  const int n_terms = UL ? 1 : n_paths;
   c64 acc = mk(0.0, 0.0);
-  for (int k = 0; k < n_taps; ++k) {
-    const long long idx = base - k;
-    const c64 z = xc[idx >= 0 ? idx : 0];
-    const double g = idx >= 0 ? taps[n * n_taps + k] : 0.0;
-    acc.re = ::fma(g, z.re, acc.re);
-    acc.im = ::fma(g, z.im, acc.im);
+  // window of term j: rows base_j .. base_j + 254 + n_taps of its input column, base_j = t0 - shift - (n_taps - 1); thread tid fetches row base_j + tid and
+  // (tid < n_taps - 1) row base_j + 256 + tid.  The fetch of term j + 1 is issued before term j is consumed: global latency hides under the taps loop.
+  auto term_n = [&](int j) { return UL ? oc / Nt : j; };
+  auto fetch = [&](int j, c64& v0, c64& v1) {
+    const int n = term_n(j);
+    const c64* col = in + ld_in * (long long)(UL ? oc % Nt : n * Nr + oc);
+    const long long base = t0 - shift[n] - (n_taps - 1);
+    const long long i0 = base + tid, i1 = base + 256 + tid;
+    const long long c0 = i0 < 0 ? 0 : (i0 < ld_in ? i0 : ld_in - 1), c1 = i1 < 0 ? 0 : (i1 < ld_in ? i1 : ld_in - 1);
+    const c64 a0 = col[c0], a1 = col[tid < n_taps - 1 ? c1 : c0];     // unconditional loads (clamped), select afterwards
+    v0 = i0 >= 0 ? a0 : mk(0.0, 0.0);
+    v1 = i1 >= 0 ? a1 : mk(0.0, 0.0);
+  };
+  c64 v0, v1;
+  fetch(0, v0, v1);
+  for (int j = 0; j < n_terms; ++j) {
+    c64* w = s_win[j & 1];
+    w[tid] = v0;
+    if (tid < n_taps - 1) w[256 + tid] = v1;
+    if (j + 1 < n_terms) fetch(j + 1, v0, v1);
+    __syncthreads();                                                  // (one barrier per term: the other buffer was last read before the previous barrier)
+    const double* g = taps + term_n(j) * n_taps;
+    const c64* p = w + tid + (n_taps - 1);                            // row t - shift - k  <->  window index tid + n_taps - 1 - k
+    for (int k = 0; k < n_taps; ++k) {
+      const c64 z = p[-k];
+      acc.re = ::fma(g[k], z.re, acc.re);
+      acc.im = ::fma(g[k], z.im, acc.im);
+    }
   }
-  XF[t + T * (long long)c] = acc;
+  if (t < sg.o1) (UL ? sg.C : sg.Y)[t + ld_out * (long long)oc] = acc * scale;
+}
+
+// H[snap][n][s][u] = sum_m base[n][m][s][u] exp(j rate[n][m] t_snap) (+ los[s][u] exp(j los_rate t_snap) on path 0): the sample-and-hold path gains
+// of TR 38.901 eq. 7.5-22 / 7.5-29 from the time-independent per-ray terms (the Python mirror's CDLChannel._static()).
+__global__ __launch_bounds__(256) void cdl_path_gains_kernel(const c64* __restrict__ base, const double* __restrict__ rate, int n_paths, int n_rays, int nsu,
+                                                             const c64* __restrict__ los, double los_rate, const double* __restrict__ t_snap,
+                                                             c64* __restrict__ H) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_paths * nsu) return;
+  const int n = e / nsu, r = e % nsu;
+  const double t = t_snap[blockIdx.y];
+  c64 acc = mk(0.0, 0.0);
+  for (int m = 0; m < n_rays; ++m) {
+    double sn, cs;
+    sincos(rate[n * n_rays + m] * t, &sn, &cs);
+    acc = fma(base[((long long)n * n_rays + m) * nsu + r], mk(cs, sn), acc);
+  }
+  if (los && n == 0) {
+    double sn, cs;
+    sincos(los_rate * t, &sn, &cs);
+    acc = fma(los[r], mk(cs, sn), acc);
+  }
+  H[(long long)blockIdx.y * n_paths * nsu + e] = acc;
 }
 
 }  // namespace isac
 
 using namespace isac;
 
+namespace {
+
+template <bool UL>
+int launch_gemm(isac_ctx* ctx, const CdlSeg* d_segs, int n_segs, long long max_rows, long long lda, long long ldc, int Nt, int Nr, int K, int Nc, double scale) {
+  const int tiles = (Nc + 15) / 16, groups = (tiles + kCdlMaxColTiles - 1) / kCdlMaxColTiles, nct = (tiles + groups - 1) / groups;
+  const int n_chunks = (K + kCdlKChunk - 1) / kCdlKChunk;
+  const size_t img_bytes = sizeof(double) * 16 * (size_t)nct * 3 * 64;
+  ISAC_TRY(ensure(ctx, ctx->stage_a, img_bytes * (size_t)n_segs * groups * n_chunks));
+  hipLaunchKernelGGL(cdl_pack_kernel<UL>, dim3((unsigned)n_chunks, (unsigned)groups, (unsigned)n_segs), dim3(256), 0, ctx->stream, d_segs, nct, Nt, Nr, K, Nc,
+                     (double*)ctx->stage_a.p);
+  ISAC_HIP(hipGetLastError());
+  // row tiles per workgroup: one while the launch has fewer than ~16 workgroups per CU-slot pair (a coarser grid quantises into rounds: 605 four-tile
+  // workgroups on 512 slots ran 0.133 ms where 2 420 one-tile ones ran 0.096), more only for very large batches
+  const int rows_wg = cdl_rows_per_wg(nct);
+  const long long n_tiles = cdiv(max_rows, rows_wg) * (long long)groups * n_segs;
+  const int tpw = (int)std::min<long long>(kCdlMaxTilesPerWg, std::max<long long>(1, n_tiles / 8192));
+  const dim3 grid((unsigned)cdiv(max_rows, rows_wg * tpw), (unsigned)groups, (unsigned)n_segs), block(256);
+#define ISAC_CDL_GEMM(NCT)                                                                                                   \
+  do {                                                                                                                       \
+    auto kern = cdl_gemm_kernel<NCT, UL>;                                                                                     \
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), img_bytes));                                                \
+    hipLaunchKernelGGL(kern, grid, block, img_bytes, ctx->stream, d_segs, (const c64*)ctx->stage_a.p, lda, ldc, K, Nc, scale, tpw, n_segs); \
+  } while (0)
+  switch (nct) { case 1: ISAC_CDL_GEMM(1); break; case 2: ISAC_CDL_GEMM(2); break; default: ISAC_CDL_GEMM(3); break; }
+#undef ISAC_CDL_GEMM
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long T, int Nt, int Nr, int n_paths, const double* taps, int n_taps,
+                   const int32_t* shift, double out_scale) {
+  if (!jobs || !taps || !shift) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (n_jobs <= 0 || T <= 0 || Nt <= 0 || Nr <= 0 || n_paths <= 0 || n_taps <= 0 || n_taps > 64 || n_paths > 64)
+    return fail(ctx, ISAC_ERR_INVALID_ARG, "bad dimensions (1 <= n_taps <= 64, 1 <= n_paths <= 64)");
+  int max_shift = 0;
+  for (int n = 0; n < n_paths; ++n) {
+    if (shift[n] < 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "negative path delay");
+    max_shift = std::max(max_shift, (int)shift[n]);
+  }
+  const bool ul = Nr > Nt;
+  const int Kc = n_paths * Nt, Nc_dl = n_paths * Nr, Ncp = (Nc_dl + 15) / 16 * 16;
+  if ((long long)T * (ul ? Kc : Nt) >= (1ll << 28)) return fail(ctx, ISAC_ERR_UNSUPPORTED, "CDL apply: T x contraction length must stay below 2^28 elements (32-bit buffer offsets)");
+  // ---- segment table: one entry per (job, gain block); the gain block of an OUTPUT sample decides its H
+  std::vector<CdlSeg> segs;
+  long long max_rows = 0;
+  size_t n_seg_total = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    if (!jobs[j].d_x || !jobs[j].d_y || !jobs[j].d_H || !jobs[j].block_start || jobs[j].n_blocks <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "incomplete CDL job");
+    n_seg_total += (size_t)jobs[j].n_blocks;
+    ctx->range_cache.touch(jobs[j].d_y, sizeof(c64) * (size_t)T * Nr);   // an output that overlaps a cached grid drops the cached range rows
+  }
+  if (n_seg_total > 65535) return fail(ctx, ISAC_ERR_CAPACITY, "more than 65535 (job, gain block) segments in one batch");
+  // workspace: DL: Z [T x Ncp] per segment;  UL: prefiltered signals [T x Kc] per job
+  const size_t ws_elems = ul ? (size_t)n_jobs * (size_t)T * Kc : n_seg_total * (size_t)T * Ncp;
+  ISAC_TRY(ensure(ctx, ctx->stage_b, sizeof(c64) * ws_elems));
+  c64* ws = (c64*)ctx->stage_b.p;
+  segs.reserve(n_seg_total + (size_t)n_jobs);
+  size_t si = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const isac_cdl_job& jb = jobs[j];
+    for (int b = 0; b < jb.n_blocks; ++b) {
+      const long long o0 = b == 0 ? 0 : jb.block_start[b], o1 = b + 1 < jb.n_blocks ? jb.block_start[b + 1] : T;
+      if (o0 < 0 || o1 > T) return fail(ctx, ISAC_ERR_INVALID_ARG, "block_start outside the waveform");
+      CdlSeg s{};
+      s.H = (const c64*)jb.d_H + (size_t)b * n_paths * Nt * Nr;
+      s.o0 = o0; s.o1 = o1 > o0 ? o1 : o0;
+      s.Y = (c64*)jb.d_y;
+      if (ul) {                                                       // rows of y that use this block: contraction of the job's prefiltered signals
+        s.A = ws + (size_t)j * (size_t)T * Kc;
+        s.C = (c64*)jb.d_y;
+        s.r0 = s.o0; s.r1 = s.o1;
+      } else {                                                        // Z of this block: the rows its outputs reach back to
+        s.A = (const c64*)jb.d_x;
+        s.C = ws + si * (size_t)T * Ncp;
+        s.r0 = std::max<long long>(0, s.o0 - max_shift - (n_taps - 1)); s.r1 = s.o1;
+      }
+      max_rows = std::max(max_rows, s.r1 - s.r0);
+      segs.push_back(s);
+      ++si;
+    }
+  }
+  const size_t n_gemm = segs.size();
+  if (ul)
+    for (int j = 0; j < n_jobs; ++j) {                                // prefilter segments: one per job, all rows
+      CdlSeg s{};
+      s.A = (const c64*)jobs[j].d_x;
+      s.C = ws + (size_t)j * (size_t)T * Kc;
+      s.o0 = 0; s.o1 = T;
+      segs.push_back(s);
+    }
+  // ---- one upload: segments | taps | shifts
+  const size_t seg_bytes = (sizeof(CdlSeg) * segs.size() + 63) & ~(size_t)63, tap_bytes = (sizeof(double) * (size_t)n_paths * n_taps + 63) & ~(size_t)63;
+  const size_t meta = seg_bytes + tap_bytes + sizeof(int) * (size_t)n_paths;
+  std::vector<char> host(meta);
+  std::memcpy(host.data(), segs.data(), sizeof(CdlSeg) * segs.size());
+  std::memcpy(host.data() + seg_bytes, taps, sizeof(double) * (size_t)n_paths * n_taps);
+  std::memcpy(host.data() + seg_bytes + tap_bytes, shift, sizeof(int) * (size_t)n_paths);
+  ISAC_TRY(ensure(ctx, ctx->stage_c, meta + 64));
+  char* dm = (char*)ctx->stage_c.p;
+  ISAC_TRY(stage_upload(ctx, dm, host.data(), meta));
+  const CdlSeg* d_segs = (const CdlSeg*)dm;
+  const double* d_taps = (const double*)(dm + seg_bytes);
+  const int* d_shift = (const int*)(dm + seg_bytes + tap_bytes);
+  if (ul) {
+    hipLaunchKernelGGL(cdl_fir_kernel<true>, dim3((unsigned)cdiv(T, 256), (unsigned)Kc, (unsigned)n_jobs), dim3(256), 0, ctx->stream, d_segs + n_gemm, (long long)T,
+                       (long long)T, Nt, Nr, n_paths, n_taps, d_taps, d_shift, 1.0);
+    ISAC_HIP(hipGetLastError());
+    if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));   // isac_profile_*: brackets exactly the contraction launch
+    ISAC_TRY((launch_gemm<true>(ctx, d_segs, (int)n_gemm, max_rows, T, T, Nt, Nr, Kc, Nr, out_scale)));
+    if (ctx->profile) { ISAC_HIP(hipEventRecord(ctx->ev_k1, ctx->stream)); ctx->profile_recorded = true; }
+    return ISAC_OK;
+  }
+  if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));
+  ISAC_TRY((launch_gemm<false>(ctx, d_segs, (int)n_gemm, max_rows, T, T, Nt, Nr, Nt, Nc_dl, 1.0)));
+  if (ctx->profile) { ISAC_HIP(hipEventRecord(ctx->ev_k1, ctx->stream)); ctx->profile_recorded = true; }
+  long long max_out = 0;
+  for (size_t i = 0; i < n_gemm; ++i) max_out = std::max(max_out, segs[i].o1 - segs[i].o0);
+  if (max_out > 0) {
+    hipLaunchKernelGGL(cdl_fir_kernel<false>, dim3((unsigned)cdiv(max_out, 256), (unsigned)Nr, (unsigned)n_gemm), dim3(256), 0, ctx->stream, d_segs, (long long)T,
+                       (long long)T, Nt, Nr, n_paths, n_taps, d_taps, d_shift, out_scale);
+    ISAC_HIP(hipGetLastError());
+  }
+  return ISAC_OK;
+}
+
+}  // namespace
+
+extern "C" int isac_cdl_apply_batch_dev(isac_ctx* ctx, const isac_cdl_job* jobs, int32_t n_jobs, int64_t T, int32_t Nt, int32_t Nr, int32_t n_paths,
+                                        const double* taps, int32_t n_taps, const int32_t* shift, double out_scale) {
+  ISAC_ENTER(ctx);
+  return cdl_apply_jobs(ctx, jobs, n_jobs, T, Nt, Nr, n_paths, taps, n_taps, shift, out_scale);
+}
+
 extern "C" int isac_cdl_apply_dev(isac_ctx* ctx, const isac_c64* d_x, int64_t T, int32_t Nt, int32_t Nr, int32_t n_paths,
                                   const isac_c64* H, int32_t n_blocks, const int64_t* block_start, const double* taps,
                                   int32_t n_taps, const int32_t* shift, double out_scale, isac_c64* d_y) {
   ISAC_ENTER(ctx);
   if (!d_x || !d_y || !H || !block_start || !taps || !shift) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
-  if (T <= 0 || Nt <= 0 || Nr <= 0 || n_paths <= 0 || n_blocks <= 0 || n_taps <= 0 || n_taps > 64 || n_paths > 64)
-    return fail(ctx, ISAC_ERR_INVALID_ARG, "bad dimensions");
-  ctx->range_cache.touch(d_y, sizeof(c64) * (size_t)T * Nr);   // an output that overlaps a cached grid drops the cached range rows
-  if (Nr > Nt) {
-    // ---- filter first, contract second (see cdl_prefilter_kernel): Hm_b [Kc x Nrp], row c = n*Nt + s
-    const int Kc = n_paths * Nt, Nrp = (Nr + 15) / 16 * 16;
-    std::vector<c64> hm2((size_t)n_blocks * Kc * Nrp, mk(0.0, 0.0));
-    for (int b = 0; b < n_blocks; ++b)
-      for (int n = 0; n < n_paths; ++n)
-        for (int s = 0; s < Nt; ++s)
-          for (int u = 0; u < Nr; ++u) {
-            const isac_c64 v = H[(((size_t)b * n_paths + n) * Nt + s) * Nr + u];
-            hm2[(size_t)b * Kc * Nrp + (size_t)(n * Nt + s) + (size_t)Kc * u] = mk(v.re, v.im);
-          }
-    const size_t hm_bytes2 = sizeof(c64) * hm2.size(), tap_bytes2 = sizeof(double) * (size_t)n_paths * n_taps;
-    ISAC_TRY(ensure(ctx, ctx->stage_c, hm_bytes2 + tap_bytes2 + sizeof(int) * (size_t)n_paths + 64));
-    ISAC_TRY(ensure(ctx, ctx->stage_b, sizeof(c64) * (size_t)T * Kc));
-    char* dm2 = (char*)ctx->stage_c.p;
-    c64* d_hm2 = (c64*)dm2;
-    double* d_taps2 = (double*)(dm2 + hm_bytes2);
-    int* d_shift2 = (int*)(dm2 + hm_bytes2 + tap_bytes2);
-    ISAC_HIP(hipMemcpyAsync(d_hm2, hm2.data(), hm_bytes2, hipMemcpyHostToDevice, ctx->stream));
-    ISAC_HIP(hipMemcpyAsync(d_taps2, taps, tap_bytes2, hipMemcpyHostToDevice, ctx->stream));
-    ISAC_HIP(hipMemcpyAsync(d_shift2, shift, sizeof(int) * (size_t)n_paths, hipMemcpyHostToDevice, ctx->stream));
-    ISAC_HIP(hipStreamSynchronize(ctx->stream));   // host staging vectors go out of scope
-    c64* d_xf = (c64*)ctx->stage_b.p;
-    hipLaunchKernelGGL(cdl_prefilter_kernel, dim3(cdiv(T, 256), (unsigned)Kc), dim3(256), 0, ctx->stream, (const c64*)d_x, (long long)T, Nt, n_paths,
-                       n_taps, (const double*)d_taps2, (const int*)d_shift2, d_xf);
-    ISAC_HIP(hipGetLastError());
-    const unsigned gy2 = (unsigned)((Nrp / 16 + kCdlColTiles - 1) / kCdlColTiles);
-    for (int b = 0; b < n_blocks; ++b) {            // the gain block of an OUTPUT sample decides its H
-      const long long r0 = b == 0 ? 0 : block_start[b], r1 = b + 1 < n_blocks ? block_start[b + 1] : T;
-      if (r1 <= r0) continue;
-      hipLaunchKernelGGL(cdl_contract_kernel, dim3(cdiv(r1 - r0, 64), gy2), dim3(256), 0, ctx->stream, (const c64*)d_xf, (long long)T, Kc,
-                         (const c64*)(d_hm2 + (size_t)b * Kc * Nrp), Nr, (c64*)d_y, r0, r1, out_scale);
-      ISAC_HIP(hipGetLastError());
-    }
-    return ISAC_OK;
-  }
-  const int Nc = n_paths * Nr;
-  const int Ncp = (Nc + 15) / 16 * 16;
-  // Hm [Nt x Ncp] per block, column c = n*Nr + u  <-  H [b][n][s][u]
-  std::vector<c64> hm((size_t)n_blocks * Nt * Ncp, mk(0.0, 0.0));
-  for (int b = 0; b < n_blocks; ++b)
-    for (int n = 0; n < n_paths; ++n)
-      for (int s = 0; s < Nt; ++s)
-        for (int u = 0; u < Nr; ++u) {
-          const isac_c64 v = H[(((size_t)b * n_paths + n) * Nt + s) * Nr + u];
-          hm[(size_t)b * Nt * Ncp + (size_t)s + (size_t)Nt * (n * Nr + u)] = mk(v.re, v.im);
-        }
-  const size_t hm_bytes = sizeof(c64) * hm.size();
-  const size_t tap_bytes = sizeof(double) * (size_t)n_paths * n_taps;
-  const size_t meta = hm_bytes + tap_bytes + sizeof(int) * (size_t)n_paths + sizeof(long long) * (size_t)n_blocks + 64;
-  ISAC_TRY(ensure(ctx, ctx->stage_c, meta));
-  ISAC_TRY(ensure(ctx, ctx->stage_b, sizeof(c64) * (size_t)n_blocks * (size_t)T * Ncp));
-  char* dm = (char*)ctx->stage_c.p;
-  c64* d_hm = (c64*)dm;
-  double* d_taps = (double*)(dm + hm_bytes);
-  long long* d_bs = (long long*)(dm + hm_bytes + tap_bytes);
-  int* d_shift = (int*)(dm + hm_bytes + tap_bytes + sizeof(long long) * (size_t)n_blocks);
-  std::vector<long long> bs(block_start, block_start + n_blocks);
-  ISAC_HIP(hipMemcpyAsync(d_hm, hm.data(), hm_bytes, hipMemcpyHostToDevice, ctx->stream));
-  ISAC_HIP(hipMemcpyAsync(d_taps, taps, tap_bytes, hipMemcpyHostToDevice, ctx->stream));
-  ISAC_HIP(hipMemcpyAsync(d_bs, bs.data(), sizeof(long long) * (size_t)n_blocks, hipMemcpyHostToDevice, ctx->stream));
-  ISAC_HIP(hipMemcpyAsync(d_shift, shift, sizeof(int) * (size_t)n_paths, hipMemcpyHostToDevice, ctx->stream));
-  ISAC_HIP(hipStreamSynchronize(ctx->stream));   // host staging vectors go out of scope
-  c64* d_z = (c64*)ctx->stage_b.p;
-  const unsigned gx = cdiv(T, 64);
-  const unsigned gy = (unsigned)((Ncp / 16 + kCdlColTiles - 1) / kCdlColTiles);
-  for (int b = 0; b < n_blocks; ++b) {
-    hipLaunchKernelGGL(cdl_contract_kernel, dim3(gx, gy), dim3(256), 0, ctx->stream, (const c64*)d_x, (long long)T, Nt,
-                       (const c64*)(d_hm + (size_t)b * Nt * Ncp), Ncp, d_z + (size_t)b * (size_t)T * Ncp, 0LL, (long long)T, 1.0);
-    ISAC_HIP(hipGetLastError());
-  }
-  const size_t lds = tap_bytes + sizeof(int) * (size_t)n_paths + 16;
-  hipLaunchKernelGGL(cdl_filter_kernel, dim3(cdiv(T, 256), Nr), dim3(256), lds, ctx->stream, (const c64*)d_z, (long long)T, Ncp, Nr,
-                     n_paths, n_taps, (const double*)d_taps, (const int*)d_shift, (const long long*)d_bs, n_blocks, out_scale,
-                     (c64*)d_y);
+  if (T <= 0 || Nt <= 0 || Nr <= 0 || n_paths <= 0 || n_blocks <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad dimensions");
+  // host path gains: one staged upload into context scratch, then the batch path with a single job
+  const size_t h_bytes = sizeof(c64) * (size_t)n_blocks * n_paths * Nt * Nr;
+  ISAC_TRY(ensure(ctx, ctx->cdl_h, h_bytes));
+  ISAC_TRY(stage_upload(ctx, ctx->cdl_h.p, H, h_bytes));
+  isac_cdl_job job{};
+  job.d_x = d_x; job.d_y = d_y; job.d_H = (const isac_c64*)ctx->cdl_h.p; job.block_start = block_start; job.n_blocks = n_blocks;
+  return cdl_apply_jobs(ctx, &job, 1, T, Nt, Nr, n_paths, taps, n_taps, shift, out_scale);
+}
+
+extern "C" int isac_cdl_path_gains_dev(isac_ctx* ctx, const isac_c64* d_base, const double* d_rate, int32_t n_paths, int32_t n_rays, int32_t Nt, int32_t Nr,
+                                       const isac_c64* d_los, double los_rate, const double* t_snap, int32_t n_snap, isac_c64* d_H) {
+  ISAC_ENTER(ctx);
+  if (!d_base || !d_rate || !t_snap || !d_H) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (n_paths <= 0 || n_rays <= 0 || Nt <= 0 || Nr <= 0 || n_snap <= 0 || n_snap > 65535) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad dimensions");
+  ISAC_TRY(ensure(ctx, ctx->sind_tab, sizeof(double) * (size_t)n_snap));     // (scratch of this entry point only; stream order protects reuse)
+  ISAC_TRY(stage_upload(ctx, ctx->sind_tab.p, t_snap, sizeof(double) * (size_t)n_snap));
+  const int nsu = Nt * Nr;
+  hipLaunchKernelGGL(cdl_path_gains_kernel, dim3((unsigned)cdiv((long long)n_paths * nsu, 256), (unsigned)n_snap), dim3(256), 0, ctx->stream, (const c64*)d_base,
+                     d_rate, n_paths, n_rays, nsu, (const c64*)d_los, los_rate, (const double*)ctx->sind_tab.p, (c64*)d_H);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }

@@ -76,10 +76,11 @@ __global__ __launch_bounds__(128) void precoded_sinr_kernel(const c64* __restric
 // ---------------------------------------------------------------- Type-I codebook PMI search (dlPMISelect.m:385-427,1825-1834)
 // One thread per (CSI-RS RE, codebook entry): per-layer LMMSE SINR  real(1 / (nVar (W^H H^H H W + nVar I)^-1)_ll - 1).
 // An all-zero (restricted) entry leaves NaN, as the reference's pre-filled SINRPerRE does.
+// blockIdx.z = UE of a batch: its channel estimate H_list[ue], its noise variance nvar_list[ue], its slice of `sinr`.
 template <int NL>
-__global__ __launch_bounds__(128) void pmi_sinr_kernel(const c64* __restrict__ H /* [nRE x Nr x P] (RE fastest) */, long long n_re, int Nr, int P,
-                                                       const c64* __restrict__ W /* [P x NL x nE] */, double nvar,
-                                                       double* __restrict__ sinr /* [nRE x NL x nE] (RE fastest) */) {
+__global__ __launch_bounds__(128) void pmi_sinr_kernel(const c64* const* __restrict__ H_list /* per UE: [nRE x Nr x P] (RE fastest) */, long long n_re, int Nr, int P,
+                                                       const c64* __restrict__ W /* [P x NL x nE] */, const double* __restrict__ nvar_list,
+                                                       double* __restrict__ sinr_all /* per UE: [nRE x NL x nE] (RE fastest) */, long long ue_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* s_w = reinterpret_cast<c64*>(smem_raw);
   __shared__ int s_any;
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(128) void pmi_sinr_kernel(const c64* __restrict__ H
   __syncthreads();
   const long long re = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (re >= n_re) return;
-  double* out = sinr + re + n_re * (long long)NL * e;
+  const c64* H = H_list[blockIdx.z];
+  const double nvar = nvar_list[blockIdx.z];
+  double* out = sinr_all + ue_stride * blockIdx.z + re + n_re * (long long)NL * e;
   if (!s_any) {
 #pragma unroll
     for (int l = 0; l < NL; ++l) out[n_re * l] = __builtin_nan("");
@@ -150,9 +153,13 @@ __global__ __launch_bounds__(128) void pmi_sinr_kernel(const c64* __restrict__ H
 //   thread t <  nE                       total[e]  = sum over REs and layers, NaN omitted              dlPMISelect.m:446
 //   thread t >= nE: (sb, layer, entry)   sb_sinr   = mean over symbols of (mean over the subband's REs of that symbol), NaN omitted
 //                                                    -- mean(mean(., 'omitnan'), 'omitnan')             dlPMISelect.m:481, cqiSelect.m:797
-__global__ __launch_bounds__(128) void pmi_reduce_kernel(const double* __restrict__ sinr, long long n_re, int NL, int nE, const int* __restrict__ re_sb,
-                                                         const int* __restrict__ re_sym, int n_sb, double* __restrict__ total /* [nE] or null */,
-                                                         double* __restrict__ sb_sinr /* [n_sb x NL x nE] */) {
+__global__ __launch_bounds__(128) void pmi_reduce_kernel(const double* __restrict__ sinr_all, long long ue_stride, long long n_re, int NL, int nE,
+                                                         const int* __restrict__ re_sb, const int* __restrict__ re_sym, int n_sb,
+                                                         double* __restrict__ total_all /* per UE (stride res_stride): [nE], or null */,
+                                                         double* __restrict__ sb_all /* per UE (stride res_stride): [n_sb x NL x nE] */, long long res_stride) {
+  const double* sinr = sinr_all + ue_stride * blockIdx.y;            // blockIdx.y = UE of the batch
+  double* total = total_all ? total_all + res_stride * blockIdx.y : nullptr;
+  double* sb_sinr = sb_all + res_stride * blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (total && t < nE) {
     double acc = 0.0;
@@ -361,93 +368,49 @@ extern "C" int isac_type1sp_codebook(int32_t n_ports, int32_t n1, int32_t n2, in
 }
 
 template <int NL>
-static int launch_pmi_sinr(isac_ctx* ctx, const c64* H, long long n_re, int Nr, int P, const c64* W, int nE, double nvar, double* out) {
-  hipLaunchKernelGGL(pmi_sinr_kernel<NL>, dim3(cdiv(n_re, 128), (unsigned)nE), dim3(128), sizeof(c64) * (size_t)P * NL, ctx->stream, H, n_re, Nr, P, W,
-                     nvar, out);
+static int launch_pmi_sinr(isac_ctx* ctx, const c64* const* d_H_list, long long n_re, int Nr, int P, const c64* W, int nE, const double* d_nvar, double* out,
+                           long long ue_stride, int n_ue) {
+  hipLaunchKernelGGL(pmi_sinr_kernel<NL>, dim3(cdiv(n_re, 128), (unsigned)nE, (unsigned)n_ue), dim3(128), sizeof(c64) * (size_t)P * NL, ctx->stream, d_H_list, n_re,
+                     Nr, P, W, d_nvar, out, ue_stride);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }
 
-extern "C" int isac_csi_report_dev(isac_ctx* ctx, const isac_c64* d_H, int64_t n_re, int32_t Nr, int32_t P, const int32_t* re_k,
-                                   const int32_t* re_l, int32_t n_size_bwp, int32_t n_start_bwp, int32_t subband_size, int32_t pmi_subband,
-                                   int32_t cqi_subband, const isac_c64* W, int32_t n_layers, const int32_t dims[4], double nvar,
-                                   const double* sinr_table_db, int32_t n_table, isac_csi_report* out, double* total_sinr_out,
-                                   double* d_sinr_per_re_out) {
-  ISAC_ENTER(ctx);
-  if (!out) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+namespace {
+
+struct CsiShape {                                                         // what every UE of a batch shares
+  Subbands pmi_sb, cqi_sb;
+  int NL, nE, dims[4];
+  bool cqi_subband;
+  const double* sinr_table_db;
+  int n_table;
+};
+
+void csi_all_nan(const CsiShape& sh, isac_csi_report* out) {              // cqiSelect.m:633-647
+  const int n = sh.cqi_sb.n == 1 ? 0 : sh.cqi_sb.n;
+  out->n_cqi = n + 1;
+  for (int i = 0; i <= n; ++i) out->cqi[i] = out->subband_cqi[i] = out->sinr_per_subband_cw[i] = NAN;
+}
+
+void csi_init_report(const CsiShape& sh, isac_csi_report* out) {
   std::memset(out, 0, sizeof(*out));
-  if (!W || !dims || n_re < 0 || Nr <= 0 || Nr > kMaxRx || P <= 0 || n_layers < 1 || n_layers > 4 || !(nvar > 0) || n_size_bwp <= 0 || subband_size <= 0 ||
-      (n_re > 0 && (!d_H || !re_k || !re_l)))
-    return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments (1 <= layers <= 4, nVar > 0)");
-  const Subbands pmi_sb = subband_info(pmi_subband != 0, n_start_bwp, n_size_bwp, subband_size);
-  const Subbands cqi_sb = subband_info(cqi_subband != 0, n_start_bwp, n_size_bwp, subband_size);
-  if (pmi_sb.n > ISAC_MAX_SUBBANDS || cqi_sb.n > ISAC_MAX_SUBBANDS) return fail(ctx, ISAC_ERR_CAPACITY, "more subbands than ISAC_MAX_SUBBANDS");
-  out->n_subbands_pmi = pmi_sb.n;
-  out->n_subbands_cqi = cqi_sb.n;
-  const int nE = dims[0] * dims[1] * dims[2] * dims[3];
-  const int NL = n_layers;
+  out->n_subbands_pmi = sh.pmi_sb.n;
+  out->n_subbands_cqi = sh.cqi_sb.n;
   for (double& v : out->i1) v = NAN;
-  for (int s = 0; s < pmi_sb.n; ++s) out->i2[s] = NAN;
-  const int n_out = (cqi_subband && cqi_sb.n > 1) || pmi_sb.n > 1 ? (cqi_subband ? cqi_sb.n + 1 : 1) : 1;
-  auto all_nan_report = [&]() {                                           // cqiSelect.m:633-647
-    const int n = cqi_sb.n == 1 ? 0 : cqi_sb.n;
-    out->n_cqi = n + 1;
-    for (int i = 0; i <= n; ++i) out->cqi[i] = out->subband_cqi[i] = out->sinr_per_subband_cw[i] = NAN;
-    return ISAC_OK;
-  };
-  (void)n_out;
-  if (n_re == 0 || nE == 0) return all_nan_report();                      // no CSI-RS in the BWP: dlPMISelect.m:364-376
-  // ---- subband membership of every RE (host, integer)
-  auto membership = [&](const Subbands& sb, std::vector<int>& dst) {
-    std::vector<int> rb2sb((size_t)n_size_bwp);
-    int rb = 0;
-    for (int s = 0; s < sb.n; ++s) for (int i = 0; i < sb.size[(size_t)s] && rb < n_size_bwp; ++i) rb2sb[(size_t)rb++] = s;
-    dst.resize((size_t)n_re);
-    for (long long i = 0; i < n_re; ++i) {
-      const int r = re_k[i] / 12;
-      dst[(size_t)i] = (re_k[i] >= 0 && r < n_size_bwp) ? rb2sb[(size_t)r] : -1;
-    }
-  };
-  std::vector<int> sb_pmi, sb_cqi, sym((size_t)n_re);
-  membership(pmi_sb, sb_pmi);
-  membership(cqi_sb, sb_cqi);
-  for (long long i = 0; i < n_re; ++i) sym[(size_t)i] = re_l[i];
-  // ---- device buffers: W | sinr | int tables | total | sb_sinr (pmi) | sb_sinr (cqi)
-  const size_t w_bytes = sizeof(c64) * (size_t)P * NL * nE, sinr_elems = (size_t)n_re * NL * nE;
-  ISAC_TRY(ensure(ctx, ctx->stage_c, w_bytes + 64));
-  double* d_sinr = d_sinr_per_re_out;
-  if (!d_sinr) { ISAC_TRY(ensure(ctx, ctx->stage_a, sizeof(double) * sinr_elems)); d_sinr = (double*)ctx->stage_a.p; }
-  const size_t n_sbp = (size_t)pmi_sb.n * NL * nE, n_sbc = (size_t)cqi_sb.n * NL * nE;
-  const size_t ints = sizeof(int) * (size_t)n_re * 3;
-  const size_t off_tot = (ints + 63) & ~(size_t)63, off_p = off_tot + sizeof(double) * (size_t)nE, off_c = off_p + sizeof(double) * n_sbp;
-  ISAC_TRY(ensure(ctx, ctx->stage_b, off_c + sizeof(double) * n_sbc + 64));
-  char* base = (char*)ctx->stage_b.p;
-  int* d_sbp = (int*)base; int* d_sbc = d_sbp + n_re; int* d_sym = d_sbc + n_re;
-  ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, W, w_bytes, hipMemcpyHostToDevice, ctx->stream));
-  ISAC_HIP(hipMemcpyAsync(d_sbp, sb_pmi.data(), sizeof(int) * (size_t)n_re, hipMemcpyHostToDevice, ctx->stream));
-  ISAC_HIP(hipMemcpyAsync(d_sbc, sb_cqi.data(), sizeof(int) * (size_t)n_re, hipMemcpyHostToDevice, ctx->stream));
-  ISAC_HIP(hipMemcpyAsync(d_sym, sym.data(), sizeof(int) * (size_t)n_re, hipMemcpyHostToDevice, ctx->stream));
-  const c64* dW = (const c64*)ctx->stage_c.p;
-  switch (NL) {
-    case 1: ISAC_TRY(launch_pmi_sinr<1>(ctx, (const c64*)d_H, n_re, Nr, P, dW, nE, nvar, d_sinr)); break;
-    case 2: ISAC_TRY(launch_pmi_sinr<2>(ctx, (const c64*)d_H, n_re, Nr, P, dW, nE, nvar, d_sinr)); break;
-    case 3: ISAC_TRY(launch_pmi_sinr<3>(ctx, (const c64*)d_H, n_re, Nr, P, dW, nE, nvar, d_sinr)); break;
-    default: ISAC_TRY(launch_pmi_sinr<4>(ctx, (const c64*)d_H, n_re, Nr, P, dW, nE, nvar, d_sinr)); break;
-  }
-  double* d_tot = (double*)(base + off_tot);
-  double* d_p = (double*)(base + off_p);
-  double* d_c = (double*)(base + off_c);
-  hipLaunchKernelGGL(pmi_reduce_kernel, dim3(cdiv((long long)nE + (long long)n_sbp, 128)), dim3(128), 0, ctx->stream, (const double*)d_sinr, (long long)n_re,
-                     NL, nE, (const int*)d_sbp, (const int*)d_sym, pmi_sb.n, d_tot, d_p);
-  hipLaunchKernelGGL(pmi_reduce_kernel, dim3(cdiv((long long)nE + (long long)n_sbc, 128)), dim3(128), 0, ctx->stream, (const double*)d_sinr, (long long)n_re,
-                     NL, nE, (const int*)d_sbc, (const int*)d_sym, cqi_sb.n, (double*)nullptr, d_c);
-  ISAC_HIP(hipGetLastError());
-  std::vector<double> tot((size_t)nE), sp(n_sbp), sc(n_sbc);
-  ISAC_HIP(hipMemcpyAsync(tot.data(), d_tot, sizeof(double) * tot.size(), hipMemcpyDeviceToHost, ctx->stream));
-  ISAC_HIP(hipMemcpyAsync(sp.data(), d_p, sizeof(double) * sp.size(), hipMemcpyDeviceToHost, ctx->stream));
-  ISAC_HIP(hipMemcpyAsync(sc.data(), d_c, sizeof(double) * sc.size(), hipMemcpyDeviceToHost, ctx->stream));
-  ISAC_HIP(hipStreamSynchronize(ctx->stream));
-  if (total_sinr_out) std::memcpy(total_sinr_out, tot.data(), sizeof(double) * tot.size());
+  for (int s = 0; s < sh.pmi_sb.n; ++s) out->i2[s] = NAN;
+}
+
+// host half of one UE's report from its device results: tot [nE], sp [n_sb_pmi x NL x nE], sc [n_sb_cqi x NL x nE]
+int csi_finish(const CsiShape& sh, const double* tot_p, const double* sp_p, const double* sc_p, isac_csi_report* out) {
+  const Subbands& pmi_sb = sh.pmi_sb;
+  const Subbands& cqi_sb = sh.cqi_sb;
+  const int NL = sh.NL, nE = sh.nE;
+  const int* dims = sh.dims;
+  const bool cqi_subband = sh.cqi_subband;
+  const double* sinr_table_db = sh.sinr_table_db;
+  const int n_table = sh.n_table;
+  const std::vector<double> tot(tot_p, tot_p + nE), sp(sp_p, sp_p + (size_t)pmi_sb.n * NL * nE), sc(sc_p, sc_p + (size_t)cqi_sb.n * NL * nE);
+  auto all_nan_report = [&]() { csi_all_nan(sh, out); return ISAC_OK; };
   // "all(isnan(SINRPerRE))": every entry restricted (dlPMISelect.m:436-444) -- a subband mean is NaN for every entry then
   bool any_valid = false;
   for (double v : sp) any_valid |= !std::isnan(v);
@@ -524,4 +487,114 @@ extern "C" int isac_csi_report_dev(isac_ctx* ctx, const isac_c64* d_H, int64_t n
     out->sinr_per_subband_cw[0] = sinr_cw[0];
   }
   return ISAC_OK;
+}
+
+}  // namespace
+
+// d_H_list: HOST array of n_ue device pointers; nvar: HOST [n_ue]; out: [n_ue]; total_sinr_out: [n_ue x nE] or NULL.
+static int csi_report_batch(isac_ctx* ctx, int n_ue, const isac_c64* const* d_H_list, int64_t n_re, int32_t Nr, int32_t P, const int32_t* re_k,
+                            const int32_t* re_l, int32_t n_size_bwp, int32_t n_start_bwp, int32_t subband_size, int32_t pmi_subband, int32_t cqi_subband,
+                            const isac_c64* W, int32_t n_layers, const int32_t dims[4], const double* nvar, const double* sinr_table_db, int32_t n_table,
+                            isac_csi_report* out, double* total_sinr_out, double* d_sinr_per_re_out) {
+  if (!out || n_ue <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  for (int u = 0; u < n_ue; ++u) std::memset(&out[u], 0, sizeof(out[u]));
+  if (!W || !dims || !nvar || n_re < 0 || Nr <= 0 || Nr > kMaxRx || P <= 0 || n_layers < 1 || n_layers > 4 || n_size_bwp <= 0 || subband_size <= 0 ||
+      (n_re > 0 && (!d_H_list || !re_k || !re_l)))
+    return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments (1 <= layers <= 4, nVar > 0)");
+  for (int u = 0; u < n_ue; ++u)
+    if (!(nvar[u] > 0) || (n_re > 0 && !d_H_list[u])) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments (1 <= layers <= 4, nVar > 0)");
+  CsiShape sh;
+  sh.pmi_sb = subband_info(pmi_subband != 0, n_start_bwp, n_size_bwp, subband_size);
+  sh.cqi_sb = subband_info(cqi_subband != 0, n_start_bwp, n_size_bwp, subband_size);
+  if (sh.pmi_sb.n > ISAC_MAX_SUBBANDS || sh.cqi_sb.n > ISAC_MAX_SUBBANDS) return fail(ctx, ISAC_ERR_CAPACITY, "more subbands than ISAC_MAX_SUBBANDS");
+  sh.NL = n_layers; sh.nE = dims[0] * dims[1] * dims[2] * dims[3];
+  for (int i = 0; i < 4; ++i) sh.dims[i] = dims[i];
+  sh.cqi_subband = cqi_subband != 0; sh.sinr_table_db = sinr_table_db; sh.n_table = n_table;
+  const int NL = sh.NL, nE = sh.nE;
+  for (int u = 0; u < n_ue; ++u) csi_init_report(sh, &out[u]);
+  if (n_re == 0 || nE == 0) {                                            // no CSI-RS in the BWP: dlPMISelect.m:364-376
+    for (int u = 0; u < n_ue; ++u) csi_all_nan(sh, &out[u]);
+    return ISAC_OK;
+  }
+  // ---- subband membership of every RE (host, integer; shared by the batch)
+  std::vector<int> ints((size_t)n_re * 3);
+  auto membership = [&](const Subbands& sb, int* dst) {
+    std::vector<int> rb2sb((size_t)n_size_bwp);
+    int rb = 0;
+    for (int s = 0; s < sb.n; ++s) for (int i = 0; i < sb.size[(size_t)s] && rb < n_size_bwp; ++i) rb2sb[(size_t)rb++] = s;
+    for (long long i = 0; i < n_re; ++i) {
+      const int r = re_k[i] / 12;
+      dst[i] = (re_k[i] >= 0 && r < n_size_bwp) ? rb2sb[(size_t)r] : -1;
+    }
+  };
+  membership(sh.pmi_sb, ints.data());
+  membership(sh.cqi_sb, ints.data() + n_re);
+  for (long long i = 0; i < n_re; ++i) ints[(size_t)(2 * n_re + i)] = re_l[i];
+  // ---- ONE staged upload: W | int tables | H pointers | noise variances
+  const size_t w_bytes = (sizeof(c64) * (size_t)P * NL * nE + 63) & ~(size_t)63, int_bytes = (sizeof(int) * ints.size() + 63) & ~(size_t)63;
+  const size_t ptr_bytes = (sizeof(void*) * (size_t)n_ue + 63) & ~(size_t)63, nv_bytes = (sizeof(double) * (size_t)n_ue + 63) & ~(size_t)63;
+  const size_t meta = w_bytes + int_bytes + ptr_bytes + nv_bytes;
+  std::vector<char> host(meta, 0);
+  std::memcpy(host.data(), W, sizeof(c64) * (size_t)P * NL * nE);
+  std::memcpy(host.data() + w_bytes, ints.data(), sizeof(int) * ints.size());
+  std::memcpy(host.data() + w_bytes + int_bytes, d_H_list, sizeof(void*) * (size_t)n_ue);
+  std::memcpy(host.data() + w_bytes + int_bytes + ptr_bytes, nvar, sizeof(double) * (size_t)n_ue);
+  ISAC_TRY(ensure(ctx, ctx->stage_c, meta + 64));
+  char* dm = (char*)ctx->stage_c.p;
+  ISAC_TRY(stage_upload(ctx, dm, host.data(), meta));
+  const c64* dW = (const c64*)dm;
+  const int* d_sbp = (const int*)(dm + w_bytes);
+  const int* d_sbc = d_sbp + n_re;
+  const int* d_sym = d_sbc + n_re;
+  const c64* const* d_hl = (const c64* const*)(dm + w_bytes + int_bytes);
+  const double* d_nv = (const double*)(dm + w_bytes + int_bytes + ptr_bytes);
+  // ---- device results: per UE [total nE | sb_sinr pmi | sb_sinr cqi]; per-RE SINRs per UE
+  const size_t sinr_elems = (size_t)n_re * NL * nE;
+  const size_t n_sbp = (size_t)sh.pmi_sb.n * NL * nE, n_sbc = (size_t)sh.cqi_sb.n * NL * nE, res_stride = (size_t)nE + n_sbp + n_sbc;
+  double* d_sinr = d_sinr_per_re_out;                                    // (single-UE calls may ask for the per-RE values)
+  if (!d_sinr || n_ue > 1) { ISAC_TRY(ensure(ctx, ctx->stage_a, sizeof(double) * sinr_elems * (size_t)n_ue)); d_sinr = (double*)ctx->stage_a.p; }
+  ISAC_TRY(ensure(ctx, ctx->stage_b, sizeof(double) * res_stride * (size_t)n_ue + 64));
+  double* d_res = (double*)ctx->stage_b.p;
+  switch (NL) {
+    case 1: ISAC_TRY(launch_pmi_sinr<1>(ctx, d_hl, n_re, Nr, P, dW, nE, d_nv, d_sinr, (long long)sinr_elems, n_ue)); break;
+    case 2: ISAC_TRY(launch_pmi_sinr<2>(ctx, d_hl, n_re, Nr, P, dW, nE, d_nv, d_sinr, (long long)sinr_elems, n_ue)); break;
+    case 3: ISAC_TRY(launch_pmi_sinr<3>(ctx, d_hl, n_re, Nr, P, dW, nE, d_nv, d_sinr, (long long)sinr_elems, n_ue)); break;
+    default: ISAC_TRY(launch_pmi_sinr<4>(ctx, d_hl, n_re, Nr, P, dW, nE, d_nv, d_sinr, (long long)sinr_elems, n_ue)); break;
+  }
+  hipLaunchKernelGGL(pmi_reduce_kernel, dim3(cdiv((long long)nE + (long long)n_sbp, 128), (unsigned)n_ue), dim3(128), 0, ctx->stream, (const double*)d_sinr,
+                     (long long)sinr_elems, (long long)n_re, NL, nE, d_sbp, d_sym, sh.pmi_sb.n, d_res, d_res + nE, (long long)res_stride);
+  hipLaunchKernelGGL(pmi_reduce_kernel, dim3(cdiv((long long)nE + (long long)n_sbc, 128), (unsigned)n_ue), dim3(128), 0, ctx->stream, (const double*)d_sinr,
+                     (long long)sinr_elems, (long long)n_re, NL, nE, d_sbc, d_sym, sh.cqi_sb.n, (double*)nullptr, d_res + nE + n_sbp, (long long)res_stride);
+  ISAC_HIP(hipGetLastError());
+  // ---- ONE copy back, ONE synchronisation for the whole batch
+  const size_t res_bytes = sizeof(double) * res_stride * (size_t)n_ue;
+  ISAC_TRY(ensure_pinned(ctx, res_bytes));
+  ISAC_HIP(hipMemcpyAsync(ctx->pinned, d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  const double* res = (const double*)ctx->pinned;
+  for (int u = 0; u < n_ue; ++u) {
+    const double* r = res + res_stride * (size_t)u;
+    if (total_sinr_out) std::memcpy(total_sinr_out + (size_t)u * nE, r, sizeof(double) * (size_t)nE);
+    ISAC_TRY(csi_finish(sh, r, r + nE, r + nE + n_sbp, &out[u]));
+  }
+  return ISAC_OK;
+}
+
+extern "C" int isac_csi_report_dev(isac_ctx* ctx, const isac_c64* d_H, int64_t n_re, int32_t Nr, int32_t P, const int32_t* re_k,
+                                   const int32_t* re_l, int32_t n_size_bwp, int32_t n_start_bwp, int32_t subband_size, int32_t pmi_subband,
+                                   int32_t cqi_subband, const isac_c64* W, int32_t n_layers, const int32_t dims[4], double nvar,
+                                   const double* sinr_table_db, int32_t n_table, isac_csi_report* out, double* total_sinr_out,
+                                   double* d_sinr_per_re_out) {
+  ISAC_ENTER(ctx);
+  return csi_report_batch(ctx, 1, &d_H, n_re, Nr, P, re_k, re_l, n_size_bwp, n_start_bwp, subband_size, pmi_subband, cqi_subband, W, n_layers, dims, &nvar,
+                          sinr_table_db, n_table, out, total_sinr_out, d_sinr_per_re_out);
+}
+
+extern "C" int isac_csi_report_batch_dev(isac_ctx* ctx, int32_t n_ue, const isac_c64* const* d_H_list, int64_t n_re, int32_t Nr, int32_t P,
+                                         const int32_t* re_k, const int32_t* re_l, int32_t n_size_bwp, int32_t n_start_bwp, int32_t subband_size,
+                                         int32_t pmi_subband, int32_t cqi_subband, const isac_c64* W, int32_t n_layers, const int32_t dims[4],
+                                         const double* nvar, const double* sinr_table_db, int32_t n_table, isac_csi_report* out, double* total_sinr_out) {
+  ISAC_ENTER(ctx);
+  return csi_report_batch(ctx, n_ue, d_H_list, n_re, Nr, P, re_k, re_l, n_size_bwp, n_start_bwp, subband_size, pmi_subband, cqi_subband, W, n_layers, dims, nvar,
+                          sinr_table_db, n_table, out, total_sinr_out, nullptr);
 }

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <string>
 #include <utility>
@@ -130,7 +131,7 @@ struct isac_ctx {
   std::map<std::pair<long long, long long>, isac::DevBuf> sind;     // (scale, granularity) -> sind(scan angles)
   // scratch
   isac::DevBuf beam, coef, phase_rx, steer, dgrid, ymid, pwin, flags, det_cut, det_pow, det_cnt, cov_part, cov,
-      eig_w, eig_v, eig_scratch, spec, misc, stage_a, stage_b, stage_c, sind_tab, seg;
+      eig_w, eig_v, eig_scratch, spec, misc, stage_a, stage_b, stage_c, sind_tab, seg, cdl_h;
   void* pinned = nullptr; size_t pinned_cap = 0;
   isac::Fft2dLast last;
   isac::Fft2dPending pending;
@@ -226,6 +227,23 @@ inline int ensure_pinned(isac_ctx* ctx, size_t bytes) {
   ctx->pinned_cap = 0;
   ISAC_HIP(hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
   ctx->pinned_cap = bytes;
+  return ISAC_OK;
+}
+
+// Small host block -> device scratch through the context's pinned staging buffer: asynchronous, no stream synchronisation; the event guards reuse.
+inline int stage_upload(isac_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+  if (ctx->pinned_in_cap < bytes) {
+    if (ctx->pinned_in) { ISAC_HIP(hipEventSynchronize(ctx->ev_h2d)); ISAC_HIP(hipHostFree(ctx->pinned_in)); }
+    ctx->pinned_in = nullptr; ctx->pinned_in_cap = 0;
+    const size_t want = bytes < 65536 ? 65536 : bytes;
+    ISAC_HIP(hipHostMalloc(&ctx->pinned_in, want, hipHostMallocDefault));
+    ctx->pinned_in_cap = want;
+  } else {
+    ISAC_HIP(hipEventSynchronize(ctx->ev_h2d));                        // the previous upload has left the staging buffer
+  }
+  std::memcpy(ctx->pinned_in, src, bytes);
+  ISAC_HIP(hipMemcpyAsync(d_dst, ctx->pinned_in, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_HIP(hipEventRecord(ctx->ev_h2d, ctx->stream));
   return ISAC_OK;
 }
 

@@ -303,6 +303,174 @@ class Cell:
         return 2 * self.K * self.Lsym * self.A * 16
 
 
+def csirs_positions(nrb):
+    """First-port CSI-RS resource elements of the reference's row-5 / density-1 / symbol-0 configuration (setupCSIRS.m:8-11): two adjacent
+    subcarriers per RB on the slot's first symbol -- 1-based (k, l) subscripts as dlPMISelect.m:354-362 uses them."""
+    k = np.concatenate([[12 * r + 1, 12 * r + 2] for r in range(nrb)])
+    return k, np.ones_like(k)
+
+
+def freq_response(ch, k_sub, n_sc, scs_hz, ports):
+    """Perfect CSI-RS channel estimate at the subcarriers k_sub (1-based): H[i, u, p] = sum_n h[n, p, u] exp(-2 pi j f_i tau_n)."""
+    h = ch.path_gains(ch.time)[:, :ports, :]                # [n, p, u]
+    tau = ch.path_delays()
+    f = ((np.asarray(k_sub) - 1) - n_sc / 2) * scs_hz
+    e = np.exp(-2j * np.pi * f[:, None] * tau[None, :])     # [i, n]
+    return np.asfortranarray(np.einsum("kn,npu->kup", e, h))
+
+
+class CommCell:
+    """BASELINE configs[4] ("full ISAC: MIMO PDSCH beamforming + SINR->CQI + mono-static sensing, 21 cells x 10 UE"): the communication seams of
+    ONE cell over ONE 20-slot frame, as the reference steps them --
+      * every slot that carries downlink symbols (12 'D' + 4 'S' of DDDSU x 4): the slot waveform (+ MaxChannelDelay zero rows) through EVERY UE's
+        nrCDLChannel (uePhy.m:724-731: applyChannelModel on each gNB packet; CDL-D for LoS UEs, CDL-A otherwise, updateCDLModels.m:9-14);
+      * every CSI-RS occasion (setupCSIRS.m:11: period 5 slots -> 4 per frame): every UE's Type-I PMI search + subband CQI (uePhy.m:901-908).
+    Inputs are synthetic and resident in HBM before the timed region: the 16 slot waveforms (QPSK grids through the OFDM modulator), one channel
+    estimate per UE at the CSI-RS REs (the channel's own frequency response -- the estimator is out of scope).  Channel time advances from slot to
+    slot and from frame to frame (path gains formed on the device per gain block)."""
+    DL_SLOTS, CSI_OCCASIONS, SLOT_T = 16, 4, 61440
+
+    def __init__(self, pkg, ctx_cdl, ctx_csi, cell_id, n_ants, n_ues):
+        CM, self.PL, L = pkg.communication.channelModels, pkg.communication.phyLayer, pkg._lib
+        self.CM, self.ctx, self.ctx_csi, self.n_ues, self.A = CM, ctx_cdl, ctx_csi, n_ues, n_ants
+        rng = np.random.default_rng(0xC5000 + cell_id)
+        self.los = rng.random(n_ues) < 0.5
+        nt_shape = (n_ants // 16, 8, 2, 1, 1) if n_ants >= 16 else (1, n_ants // 2, 2, 1, 1)
+        self.chans = [CM.CDLChannel(DelayProfile="CDL-D" if lo else "CDL-A", TransmitAntennaArraySize=nt_shape, Seed=73) for lo in self.los]   # cdl.m:57-64
+        self.T = self.SLOT_T + max(ch.info().MaxChannelDelay for ch in self.chans)            # uePhy.m:729: zero rows appended
+        K = 3276
+        car = L.Carrier(K, 4096, 30, 0)
+        self.waves = []
+        grid = ctx_cdl.empty((K, 14, n_ants))
+        for s_ in range(self.DL_SLOTS):
+            w = ctx_cdl.empty((self.T, n_ants))
+            ctx_cdl.check(ctx_cdl.lib.isac_synth_qpsk_grid_dev(ctx_cdl.handle, C.c_void_p(grid.ptr), K, 14, n_ants, C.c_uint64(0xD100 + 64 * cell_id + s_), 0))
+            ctx_cdl.check(ctx_cdl.lib.isac_ofdm_modulate_dev(ctx_cdl.handle, C.c_void_p(grid.ptr), 14, n_ants, C.byref(car), C.c_double(1.0), C.c_void_p(w.ptr), C.c_int64(self.T)))
+            self.waves.append(w)
+        self.groups = [[u for u in range(n_ues) if self.los[u]], [u for u in range(n_ues) if not self.los[u]]]
+        self.groups = [g for g in self.groups if g]
+        self.rx = [[ctx_cdl.empty((self.T, 2)) for _ in g] for g in self.groups]
+        self.gains = []
+        for g in self.groups:
+            st = self.chans[g[0]]._static()
+            self.gains.append(ctx_cdl.empty((len(g) * 4 * st.base.shape[0] * st.base.shape[2] * st.base.shape[3],)))    # up to 4 gain blocks per job
+        # CSI inputs (setupCSIRS.m:5-23): 4-port row-5 CSI-RS on 273 PRBs, Type-I single panel (2, 1), subband PMI / CQI, 16-PRB subbands
+        self.csi_k, self.csi_l = csirs_positions(273)
+        self.report = SimpleNamespace(NSizeBWP=273, NStartBWP=0, PanelDimensions=(2, 1), CodebookMode=1, PMIMode="Subband", CQIMode="Subband", SubbandSize=16)
+        self.carrier = SimpleNamespace(NSizeGrid=273, NStartGrid=0, SymbolsPerSlot=14)
+        self.codebook = self.PL.type1SinglePanelCodebook(self.report, 1, 4)
+        r = rng.uniform(30.0, 350.0, n_ues)
+        pl_db = 32.4 + 20.0 * np.log10(3.5) + 30.0 * np.log10(np.maximum(r, 10.0))
+        self.nvar = 10.0 ** (-(46.0 - pl_db - (-174.0 + 10.0 * np.log10(100e6) + 7.0)) / 10.0)
+        self.h_est = [ctx_csi.to_device(freq_response(ch, self.csi_k, K, 30e3, 4)) for ch in self.chans]
+        self.last_cqi = None
+        ctx_cdl.sync(); ctx_csi.sync()
+
+    def enqueue_frame(self):
+        """All downlink slots of the frame through every UE's channel (asynchronous: two launches per slot and delay profile)."""
+        for s_ in range(self.DL_SLOTS):
+            for g, rx, gn in zip(self.groups, self.rx, self.gains):
+                self.CM.applyCDLBatch([self.chans[u] for u in g], [self.waves[s_]] * len(g), ctx=self.ctx, outs=rx, gains=gn)
+
+    def csi_reports(self):
+        """The frame's CSI-RS occasions: every UE's report, one batched call (one synchronisation of the CSI context) per occasion."""
+        for _ in range(self.CSI_OCCASIONS):
+            rep = self.PL.cqiSelectBatch(self.carrier, SimpleNamespace(k=self.csi_k, l=self.csi_l), self.report, 1, self.h_est, self.nvar, DOWNLINK_SINR90PC,
+                                         ctx=self.ctx_csi, codebook=self.codebook)
+        self.last_cqi = [None if np.isnan(c[0][0]) else int(c[0][0]) for c in rep]
+
+    def gemm_launch(self):
+        """(jobs, issued 3M flops, bytes) of one contraction launch of the larger delay-profile group: what `roofline` prices."""
+        gi = int(np.argmax([len(g) for g in self.groups]))
+        n_paths = self.chans[self.groups[gi][0]].path_delays().size
+        cols = -(-(2 * n_paths) // 16) * 16
+        return gi, len(self.groups[gi]), 6.0 * self.T * cols * self.A * len(self.groups[gi]), n_paths
+
+
+DOWNLINK_SINR90PC = np.array([-3.46, 1.54, 6.54, 11.05, 13.54, 16.04, 17.54, 20.04, 22.04, 24.43, 26.93, 27.43, 29.43, 32.43, 35.43])   # setupSINRtoCQIMappingTable.m:7-11
+
+
+def run_config5(args, pkg, rank, world, local_rank, dist, torch):
+    """`--workload config5`: cells sharded cell c -> rank c mod world; per frame and cell one sensing CPI (16 slots, pipelined over the SlotPool),
+    the frame's CDL applies and CSI reports.  A step = one 20-slot frame of every cell of the rank.  value = cells x 20 slots x frames / time."""
+    d = importlib.import_module(PKG + "._dist")
+    n_cells = args.cells if args.cells > 0 else 21
+    mine = d.shard_cells(n_cells, rank, world)
+    pool = SlotPool(pkg, local_rank, args.inflight)
+    ctx_cdl, ctx_csi = pkg.Context(local_rank), pkg.Context(local_rank)
+    n_buf = -(-args.inflight // max(len(mine), 1))
+    sense = [Cell(pkg, local_rank, c, args.ants, args.slots, args.targets, pool=pool, n_buf=min(n_buf, 2)) for c in mine]
+    comm = [CommCell(pkg, ctx_cdl, ctx_csi, c, args.ants, args.ues) for c in mine]
+
+    def barrier():
+        pool.sync(); ctx_cdl.sync(); ctx_csi.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def frame():
+        for sc, cc in zip(sense, comm):
+            pool.submit(sc)
+            cc.enqueue_frame()
+        for cc in comm:
+            cc.csi_reports()
+
+    for _ in range(args.warmup):
+        frame()
+    pool.drain()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    pool.drain()
+    barrier()
+    dt = time.perf_counter() - t0
+    print(f"bench.py: rank {rank}/{world}: device {local_rank}, {len(mine)} cell(s) {mine}, timed region {1e3 * dt:.3f} ms for {args.steps} frame(s), config5", file=sys.stderr, flush=True)
+    recs = np.array([d.make_record(cid, sc.last, dt) for cid, sc in zip(mine, sense)]).reshape(-1, d.RECORD_LEN)
+    on_gpu = dist is not None and dist.get_backend() == "nccl"
+    allr = d.gather_records(recs, dist, torch.device("cuda", local_rank) if on_gpu else None)
+    dt_max = float(np.nanmax(allr[:, 6])) if allr.size else dt
+    if rank != 0:
+        return
+    # ---- the contraction kernel with the device to itself: 10 launches of the larger group's batch, HIP events around exactly that launch
+    cc = comm[0]
+    gi, n_jobs, flops, n_paths = cc.gemm_launch()
+    ctx_cdl.check(ctx_cdl.lib.isac_profile_enable(ctx_cdl.handle, 1))
+    ms_k, ms_call = [], []
+    for i in range(11):
+        ctx_cdl.sync(); ctx_cdl.timer_start()
+        cc.CM.applyCDLBatch([cc.chans[u] for u in cc.groups[gi]], [cc.waves[i % cc.DL_SLOTS]] * n_jobs, ctx=ctx_cdl, outs=cc.rx[gi], gains=cc.gains[gi])
+        v = C.c_double(0.0)
+        ctx_cdl.check(ctx_cdl.lib.isac_profile_last_kernel_ms(ctx_cdl.handle, C.byref(v)))
+        ms_call.append(ctx_cdl.timer_stop_ms()); ms_k.append(v.value)
+    ms_k, ms_call = float(np.mean(ms_k[1:])), float(np.mean(ms_call[1:]))
+    t1 = time.perf_counter()
+    for _ in range(3):
+        cc.csi_reports()
+    ms_csi = 1e3 * (time.perf_counter() - t1) / (3 * cc.CSI_OCCASIONS * cc.n_ues)
+    n_applies = sum(c_.n_ues for c_ in comm) * CommCell.DL_SLOTS
+    res = {"metric": "sensing slots/sec (CDL echo->2D-FFT->2D-CFAR)", "value": round(n_cells * 20 * args.steps / dt_max, 2), "unit": "slots/sec (whole cells: sensing CPI + CDL applies + CSI reports)",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[4]: {n_cells} cells x {args.ues} UE, {args.ants}-antenna gNB; per 20-slot frame and cell: one sensing CPI ({args.slots} slots, "
+                                  f"echo -> 2D-FFT -> 2D-CFAR -> MUSIC), {CommCell.DL_SLOTS} DL slot waveforms [{cc.T} x {args.ants}] through every UE's CDL-D / CDL-A channel "
+                                  f"({CommCell.DL_SLOTS * args.ues} applies), {CommCell.CSI_OCCASIONS} CSI reports per UE (Type-I PMI search + subband CQI, 546 CSI-RS REs x 32 entries)",
+                      "parallelism": f"cells sharded over {world} GPU(s)"},
+           "per_frame_and_rank": {"cells": len(mine), "cdl_applies": n_applies, "csi_reports": len(mine) * args.ues * CommCell.CSI_OCCASIONS, "sensing_cpis": len(mine)},
+           "roofline": {"bound": "mfma", "kernel": "cdl_gemm_kernel<3,false> (DL contraction of a batch: X [T x Nt] against the path gains of n UEs, 3M form on v_mfma_f64_16x16x4_f64)",
+                        "achieved": round(flops / 1e12 / (ms_k / 1e3), 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / 1e12 / (ms_k / 1e3) / FP64_MFMA_PEAK_TFLOPS, 4),
+                        "traffic": None, "avg_launch_ms": round(ms_k, 4), "launches_averaged": 10, "jobs_per_launch": n_jobs, "paths": n_paths,
+                        "issued_flops_per_launch": flops, "flops_note": "3 real MFMAs x 2 flops per complex multiply-add, padded to 16-column tiles: 6 T cols Nt per job",
+                        "whole_batch_call_ms": round(ms_call, 4), "whole_batch_note": "path gains + contraction + delay filter of the same batch, HIP events around the call",
+                        "timing": "HIP events recorded by the library around every contraction launch (isac_profile_*), device otherwise idle"},
+           "comm_seams": {"cdl_apply_ms_per_job": round(ms_call / n_jobs, 4), "csi_report_ms_per_ue": round(ms_csi, 4),
+                          "csi_note": "host wall per UE of the batched report (one synchronisation per cell and occasion), device otherwise idle"},
+           "cells": [{"cell": int(r[0]), "nRng": None if np.isnan(r[1]) else int(r[1]), "rngEst0": None if np.isnan(r[2]) else round(float(r[2]), 6),
+                      "aziEst0": None if np.isnan(r[4]) else float(r[4])} for r in allr[:64]],
+           "rank0_cqi": [c_.last_cqi for c_ in comm[:4]]}
+    print(json.dumps(res))
+
+
 def stage_table(cell, reps=5):
     """Isolated per-stage durations (HIP events on the context stream, one CPI resident, nothing else running) with each
     stage's own roofline -- so that the JSON line shows every large kernel, not only the one quoted in `roofline`."""
@@ -451,6 +619,10 @@ def main():
                          "consecutive CPIs run back to back, never side by side, no pacing; free: two streams per context, the device interleaves the CPIs")
     ap.add_argument("--trace-only", action="store_true", help="profiling aid: nothing after the timed region (no isolated-kernel / blocking-CPI / stage / CPU legs), "
                                                               "so that a rocprofv3 trace holds priming + warm-up + the timed steps only")
+    ap.add_argument("--workload", choices=("config2", "config5"), default="config2",
+                    help="config2 (default): the sensing CPI BASELINE's metric is quoted on; config5: BASELINE configs[4] -- per frame and cell one sensing CPI + every "
+                         "DL slot through every UE's CDL channel + every UE's CSI reports (--cells, default 21; --ues)")
+    ap.add_argument("--ues", type=int, default=10, help="config5: UEs per cell")
     ap.add_argument("--n1-value", type=float, default=None, help="N > 1: the N = 1 value of the same per-GPU workload (slots/s) -> `efficiency_vs_n1` in the line")
     ap.add_argument("--n1-leg", action="store_true", help="N > 1: before the timed region rank 0 times the same per-GPU workload ALONE (the other ranks idle at a "
                                                           "barrier) and the line carries `n1_in_run` + `efficiency_vs_n1`: the whole scaling point in one command")
@@ -471,12 +643,27 @@ def main():
         n_dev = torch.cuda.device_count()
         backend = os.environ.get("ISAC_DIST_BACKEND", "nccl")          # "gloo": test hook (several ranks on one GPU)
         if backend == "nccl":
+            # one rank per GPU, never two ranks on one device: a launcher that starts more local ranks than there are GPUs is an error here,
+            # not something to paper over by wrapping device indices (the scaling point would be measured on shared devices)
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            if n_dev < local_world or local_rank >= n_dev:
+                sys.exit(f"bench.py: rank {rank}: {local_world} local rank(s) but {n_dev} visible GPU(s) (LOCAL_RANK={local_rank}); "
+                         "the RCCL run needs one GPU per rank (ISAC_DIST_BACKEND=gloo is the several-ranks-per-GPU test hook)")
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             local_rank = local_rank % max(n_dev, 1)
             dist.init_process_group(backend)
     pkg = importlib.import_module(PKG)
+    if args.workload == "config5":
+        if "--steps" not in sys.argv:
+            args.steps = 3
+        if "--warmup" not in sys.argv:
+            args.warmup = 1
+        run_config5(args, pkg, rank, world, local_rank, dist, torch)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     pool = SlotPool(pkg, local_rank, args.inflight, ordered=args.schedule == "ordered")          # the GPU's execution slots, shared by all its cells
     if pool.ordered:
         args.pace_ms = 0.0                                   # submission order IS the device order: nothing to stagger
@@ -554,6 +741,10 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # one line per rank on stderr: which device it ran on, how many cells it held, its own timed region (the first multi-GPU run must be diagnosable)
+    print(f"bench.py: rank {rank}/{world}: device {local_rank} ({torch.cuda.get_device_name(local_rank) if torch.cuda.is_available() else 'no GPU'}), "
+          f"{len(cells)} cell(s) {my_cells}, timed region {1e3 * dt:.3f} ms for {args.steps} step(s), backend {dist.get_backend() if dist is not None else 'none'}",
+          file=sys.stderr, flush=True)
     tl, pool.timeline = np.array(pool.timeline).reshape(-1, 2), None
     for cell in cells:
         cell.profile_sink = None

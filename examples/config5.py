@@ -49,20 +49,7 @@ PROBE = None
 DOWNLINK_SINR90PC = np.array([-3.46, 1.54, 6.54, 11.05, 13.54, 16.04, 17.54, 20.04, 22.04, 24.43, 26.93, 27.43, 29.43, 32.43, 35.43])   # setupSINRtoCQIMappingTable.m:7-11
 
 
-def csirs_positions(nrb):
-    """First-port CSI-RS resource elements of the reference's row-5 / density-1 / symbol-0 configuration (setupCSIRS.m:8-11): two adjacent
-    subcarriers per RB on the slot's first symbol -- 1-based (k, l) subscripts as dlPMISelect.m:354-362 uses them."""
-    k = np.concatenate([[12 * r + 1, 12 * r + 2] for r in range(nrb)])
-    return k, np.ones_like(k)
-
-
-def freq_response(ch, k_sub, n_sc, scs_hz, ports):
-    """Perfect CSI-RS channel estimate at the subcarriers k_sub (1-based): H[i, u, p] = sum_n h[n, p, u] exp(-2 pi j f_i tau_n)."""
-    h = ch.path_gains(ch.time)[:, :ports, :]                # [n, p, u]
-    tau = ch.path_delays()
-    f = ((np.asarray(k_sub) - 1) - n_sc / 2) * scs_hz
-    e = np.exp(-2j * np.pi * f[:, None] * tau[None, :])     # [i, n]
-    return np.asfortranarray(np.einsum("kn,npu->kup", e, h))
+csirs_positions, freq_response = bench.csirs_positions, bench.freq_response       # (shared with bench.py --workload config5)
 
 
 def main():

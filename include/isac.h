@@ -32,10 +32,10 @@ extern "C" {
 #endif
 
 /* Bumped on EVERY change of a struct layout, enum value or entry-point signature below (1: round 1; 2: ISAC_MAX_EST 1024 -> 4096,
- * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams).  A host must
+ * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev).  A host must
  * compare isac_abi_version() with the ISAC_ABI_VERSION it was compiled against AND isac_abi_sizeof() with its own sizeof of every
  * struct it passes: the library writes whole structs (isac_est_result is 128 KB) into caller memory. */
-#define ISAC_ABI_VERSION 4
+#define ISAC_ABI_VERSION 5
 #define ISAC_MAX_EST 4096 /* capacity of the estimate vectors in isac_est_result: unique range bins <= nIFFT (<= 4096 for every
                              * NR numerology), unique velocity bins <= nFFT, azimuth peaks <= 180 -- never the binding limit */
 
@@ -83,8 +83,9 @@ int isac_timer_start(isac_ctx* ctx);
 int isac_timer_stop_ms(isac_ctx* ctx, double* elapsed_ms); /* synchronises */
 
 /* Per-kernel timing hook (bench.py's roofline entry): when enabled, the context brackets the dominant kernel of every
- * isac_mono_static_sensing_fused_dev call -- the fused echo-synthesis + range-stage kernel -- with a pair of HIP events
- * on the stream it is launched on; isac_profile_last_kernel_ms waits for the most recent pair and returns its duration. */
+ * isac_mono_static_sensing_fused_dev call -- the fused echo-synthesis + range-stage kernel -- and the contraction launch of every
+ * isac_cdl_apply[_batch]_dev call with a pair of HIP events on the stream it is launched on; isac_profile_last_kernel_ms waits for the
+ * most recent pair and returns its duration. */
 int isac_profile_enable(isac_ctx* ctx, int on);
 int isac_profile_last_kernel_ms(isac_ctx* ctx, double* ms);
 
@@ -363,11 +364,34 @@ int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w, isac_c64* 
  *   y[t,u] = out_scale * sum_n sum_k taps[n][k] * sum_s H_b(t)[n][s][u] * x[t - shift[n] - k, s]
  * x [T x Nt], y [T x Nr] column-major device arrays; H [n_blocks][n_paths][Nt][Nr] (host, u fastest),
  * block_start[b] = first OUTPUT sample that uses gain block b (block_start[0] = 0); taps [n_paths x n_taps].
- * The antenna contraction runs as one complex GEMM on fp64 MFMA, the delay filter on the reduced signals.
- * Path gains, delays and filter taps are host-side scalar prep (Python mirror: communication.channelModels). */
+ * The antenna contraction runs as one complex GEMM on fp64 MFMA (3M form), the delay filter on the reduced signals (Nt >= Nr) or on the
+ * transmit signals in front of the contraction (Nr > Nt).  This entry takes the path gains from the host (one pinned, asynchronous upload, no
+ * synchronisation) and is the single-job form of isac_cdl_apply_batch_dev below. */
 int isac_cdl_apply_dev(isac_ctx* ctx, const isac_c64* d_x, int64_t T, int32_t Nt, int32_t Nr, int32_t n_paths,
                        const isac_c64* H, int32_t n_blocks, const int64_t* block_start,
                        const double* taps, int32_t n_taps, const int32_t* shift, double out_scale, isac_c64* d_y);
+
+/* The same apply, batched and with the path gains already on the device: n_jobs (UE, slot) applies that share the numerology (T, Nt, Nr,
+ * paths, taps) run as ONE contraction launch + ONE filter launch; nothing is staged per job on the host and nothing synchronises
+ * (the per-(job, gain block) segment table goes through pinned staging).  Jobs whose d_x is the same waveform (the UEs of one cell in one
+ * slot: uePhy.m:729-731 inside the per-UE loop of cellSimulation.m) read it through L2 together.
+ * d_H: [n_blocks][n_paths][Nt][Nr] (u fastest) on the device -- e.g. from isac_cdl_path_gains_dev; block_start: HOST, as above. */
+typedef struct {
+  const isac_c64* d_x;                 /* [T x Nt] */
+  isac_c64* d_y;                       /* [T x Nr] */
+  const isac_c64* d_H;                 /* device path gains of this job's gain blocks */
+  const int64_t* block_start;          /* host: first output sample of each gain block (block_start[0] = 0) */
+  int32_t n_blocks, reserved;
+} isac_cdl_job;
+int isac_cdl_apply_batch_dev(isac_ctx* ctx, const isac_cdl_job* jobs, int32_t n_jobs, int64_t T, int32_t Nt, int32_t Nr, int32_t n_paths,
+                             const double* taps, int32_t n_taps, const int32_t* shift, double out_scale);
+
+/* Sample-and-hold path gains on the device (TR 38.901 eq. 7.5-22 / 7.5-29; what nrCDLChannel evaluates internally at every gain block):
+ *   H[i][n][s][u] = sum_m base[n][m][s][u] exp(j rate[n][m] t_snap[i])  (+ los[s][u] exp(j los_rate t_snap[i]) on path 0 when d_los != NULL)
+ * d_base [n_paths][n_rays][Nt][Nr] and d_rate [n_paths][n_rays] are the time-independent per-ray terms (device; the Python mirror's
+ * CDLChannel uploads them once per channel configuration); t_snap: HOST [n_snap] channel times; d_H [n_snap][n_paths][Nt][Nr]. */
+int isac_cdl_path_gains_dev(isac_ctx* ctx, const isac_c64* d_base, const double* d_rate, int32_t n_paths, int32_t n_rays, int32_t Nt, int32_t Nr,
+                            const isac_c64* d_los, double los_rate, const double* t_snap, int32_t n_snap, isac_c64* d_H);
 
 /* ------------------------------------------------------------------ SINR -> CQI (config 5)
  * precodedSINR(H, sigma, W) (+communication/+phyLayer/precodedSINR.m:11-17) for every resource element of a
@@ -408,6 +432,13 @@ int isac_csi_report_dev(isac_ctx* ctx, const isac_c64* d_H, int64_t n_re, int32_
                         int32_t cqi_subband, const isac_c64* W, int32_t n_layers, const int32_t dims[4], double nvar,
                         const double* sinr_table_db, int32_t n_table, isac_csi_report* out, double* total_sinr_out,
                         double* d_sinr_per_re_out);
+/* The same report for n_ue UEs that share the CSI-RS / report configuration (the UEs of one cell, uePhy.m:901-908 once per UE): ONE parameter
+ * upload, ONE launch per stage over all UEs, ONE copy back and ONE synchronisation for the batch.  d_H_list: HOST array of n_ue device pointers
+ * (each [n_re x Nr x P]); nvar: HOST [n_ue]; out: [n_ue]; total_sinr_out: [n_ue x nE] or NULL. */
+int isac_csi_report_batch_dev(isac_ctx* ctx, int32_t n_ue, const isac_c64* const* d_H_list, int64_t n_re, int32_t Nr, int32_t P, const int32_t* re_k,
+                              const int32_t* re_l, int32_t n_size_bwp, int32_t n_start_bwp, int32_t subband_size, int32_t pmi_subband,
+                              int32_t cqi_subband, const isac_c64* W, int32_t n_layers, const int32_t dims[4], const double* nvar,
+                              const double* sinr_table_db, int32_t n_table, isac_csi_report* out, double* total_sinr_out);
 
 /* ------------------------------------------------------------------ line-of-sight blockage
  * Batched openStreetMapCity.checkLoS (+networkTopology/+blockages/openStreetMapCity.m:67-93): for every link

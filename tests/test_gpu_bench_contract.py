@@ -46,3 +46,23 @@ def test_bench_line_carries_the_contract_fields():
     # host-side bookkeeping of the pipelined run
     assert d["pacing"]["mode"] in ("auto", "fixed", "off") and d["hw_queues"]["GPU_MAX_HW_QUEUES"] == "16" and d["host_timeline"]["enqueue_ms"]["p50"] > 0
     assert d["per_rank_ms"] and abs(d["per_rank_ms"][0] - d["ms_per_step"] * d["steps"]) <= 1e-2 * d["per_rank_ms"][0]
+
+
+def test_config5_workload_line():
+    """`bench.py --workload config5` (BASELINE configs[4]): per frame and cell one sensing CPI + every DL slot through every UE's CDL channel + every
+    UE's CSI reports; one JSON line with slots/s, the MFMA roofline entry of the CDL contraction kernel and the per-job / per-UE seam times."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "bench.py", "--workload", "config5", "--cells", "2", "--ues", "4", "--steps", "1", "--warmup", "0", "--inflight", "2"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["dtype"] == "f64" and d["data"] == "synthetic" and "configs[4]" in d["config"]["workload"]
+    assert d["per_frame_and_rank"] == {"cells": 2, "cdl_applies": 2 * 4 * 16, "csi_reports": 2 * 4 * 4, "sensing_cpis": 2}
+    assert abs(d["value"] - 2 * 20 / (d["ms_per_step"] / 1e3)) <= 1e-3 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6 and 0.0 < rf["frac"] < 1.0
+    assert abs(rf["achieved"] - rf["issued_flops_per_launch"] / 1e12 / (rf["avg_launch_ms"] / 1e3)) <= 1e-2 * rf["achieved"]
+    assert d["comm_seams"]["cdl_apply_ms_per_job"] > 0 and d["comm_seams"]["csi_report_ms_per_ue"] > 0
+    assert len(d["cells"]) == 2 and all(c is None or 0 <= c <= 15 for ue in d["rank0_cqi"] for c in ue)

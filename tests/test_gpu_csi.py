@@ -74,6 +74,33 @@ def test_csi_report_matches_oracle(pkg, nrb, ports, panel, layers, mode, sbsize,
     assert not np.all(np.isnan(got_cqi)) and got_cqi[0] >= 1
 
 
+def test_csi_report_batch_equals_single_reports(pkg):
+    """isac_csi_report_batch_dev: six UEs of one cell (different channels and noise variances, one of them with an all-NaN-prone tiny channel) in one
+    call -- every field of every UE's report equals the single-UE call's (same kernels, same host half, one synchronisation instead of six)."""
+    from conftest import load_pkg as _lp
+    rng = np.random.default_rng(20)
+    nrb, ports, layers = 273, 4, 1
+    carrier = SimpleNamespace(NSizeGrid=nrb, NStartGrid=0, SymbolsPerSlot=14)
+    rep = SimpleNamespace(NSizeBWP=nrb, NStartBWP=0, PanelDimensions=(2, 1), CodebookMode=1, PMIMode="Subband", CQIMode="Subband", SubbandSize=16)
+    k = np.concatenate([[12 * r + 1, 12 * r + 2] for r in range(nrb)])
+    l = np.ones_like(k)
+    csirs = SimpleNamespace(k=k, l=l)
+    ctx = pkg.default_context()
+    hs, nvars = [], []
+    for u in range(6):
+        h = channel(rng, nrb, 2, ports) * (3.0 if u != 4 else 1e-3)
+        hs.append(ctx.to_device(np.asfortranarray(h[k - 1, l - 1, :, :])))
+        nvars.append(0.02 * (1 + u))
+    batch = pkg.communication.phyLayer.cqiSelectBatch(carrier, csirs, rep, layers, hs, nvars, OQ.DOWNLINK_SINR90PC, ctx=ctx)
+    assert len(batch) == 6
+    for u in range(6):
+        cqi1, pmi1, ci1, _ = pkg.communication.phyLayer.cqiSelect(carrier, csirs, rep, layers, hs[u], nvars[u], OQ.DOWNLINK_SINR90PC, ctx=ctx)
+        cqi, pmi, ci = batch[u]
+        assert same(cqi, cqi1) and same(pmi.i1, pmi1.i1) and same(pmi.i2, pmi1.i2) and same(ci.SubbandCQI, ci1.SubbandCQI)
+        assert same(ci.SINRPerSubbandPerCW, ci1.SINRPerSubbandPerCW)
+    assert len({tuple(np.nan_to_num(b[0], nan=-1.0)) for b in batch}) > 1          # the UEs do report different things
+
+
 def test_csi_report_without_csirs_is_all_nan(pkg):
     rep = SimpleNamespace(NSizeBWP=52, NStartBWP=0, PanelDimensions=(2, 1), CodebookMode=1, PMIMode="Subband", CQIMode="Subband", SubbandSize=8)
     carrier = SimpleNamespace(NSizeGrid=52, NStartGrid=0, SymbolsPerSlot=14)

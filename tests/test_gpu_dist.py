@@ -53,6 +53,55 @@ def test_gpus_flag_spawns_ranks_itself():
     assert res["n_gpus"] == 2 and [c["cell"] for c in res["cells"]] == [0, 1]
 
 
+def _torchrun_bench(world, args, env=None):
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", str(world), *args]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0]), r.stderr
+
+
+def test_world8_gloo_seven_cells():
+    """BASELINE configs[2] on a full node: 7 cells on EIGHT ranks -- rank 7 holds no cell (empty record block in the gather, no buffers, no
+    timed work) and the line must still come out with one per-rank time for every rank that held a cell.  Eight gloo ranks on this box's GPU."""
+    common = ["--cells", "7", "--steps", "1", "--warmup", "0", "--prime-ms", "0", "--no-cpu-baseline", "--inflight", "2", "--slots", "4", "--ants", "16"]
+    one = _run([sys.executable, "bench.py", "--gpus", "1", *common])
+    res, err = _torchrun_bench(8, common, {"ISAC_DIST_BACKEND": "gloo"})
+    assert res["n_gpus"] == 8 and res["scaling"] == "strong" and res["cells"] == one["cells"]
+    assert len(res["per_rank_ms"]) == 8 and res["per_rank_ms"][7] is None and all(v is not None and v > 0 for v in res["per_rank_ms"][:7])
+    assert res["value"] > 0 and res["ms_per_step"] >= max(res["per_rank_ms"][:7]) - 2e-3         # max over ranks defines the value (3- / 4-decimal rounding)
+    # every rank reports itself on stderr: device, cells, timed region
+    for r in range(8):
+        line = [ln for ln in err.splitlines() if f"rank {r}/8:" in ln]
+        assert len(line) == 1, err[-2000:]
+        assert (f"{0 if r == 7 else 1} cell(s)" in line[0]) and "backend gloo" in line[0]
+
+
+def test_world4_gloo_seven_cells_per_gpu():
+    """Weak-scaling shape with several cells per rank: --cells-per-gpu 7 at world 4 = 28 cells, cell ids rank * 7 + c."""
+    res, err = _torchrun_bench(4, ["--cells-per-gpu", "7", "--steps", "1", "--warmup", "0", "--prime-ms", "0", "--no-cpu-baseline", "--inflight", "2",
+                                   "--slots", "4", "--ants", "16"], {"ISAC_DIST_BACKEND": "gloo"})
+    assert res["n_gpus"] == 4 and res["scaling"] == "weak" and [c["cell"] for c in res["cells"]] == list(range(28))
+    assert len(res["per_rank_ms"]) == 4 and all(v is not None and v > 0 for v in res["per_rank_ms"])
+    assert sum(c["nRng"] is not None for c in res["cells"]) >= 20
+    assert sum(1 for ln in err.splitlines() if "7 cell(s)" in ln and "/4:" in ln) == 4
+
+
+def test_nccl_refuses_more_ranks_than_gpus():
+    """The RCCL path is one rank per GPU: two local ranks on a one-GPU box must fail loudly instead of wrapping both onto device 0."""
+    if _device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ISAC_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "0", "--prime-ms", "0", "--no-cpu-baseline", "--slots", "4",
+                        "--ants", "16", "--inflight", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "visible GPU" in r.stderr
+
+
 # ------------------------------------------------------------------ configs[2] AT ITS STATED SIZE, against the oracle
 def _device_count():
     import ctypes as C

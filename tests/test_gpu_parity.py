@@ -490,6 +490,42 @@ def test_cdl_apply_matches_oracle(pkg, ctx, profile, tx_size, rx_size, t_len, t0
     assert rel(got2, OC.apply_cdl(cfg, x, t0 + t_len / fs)) < RTOL
 
 
+@pytest.mark.parametrize("profile,tx_size,rx_size", [("CDL-D", GNB64, UE_ARRAY), ("CDL-A", (1, 8, 2, 1, 1), UE_ARRAY), ("CDL-A", UE_ARRAY, (1, 8, 2, 1, 1))])
+def test_cdl_batch_apply_matches_oracle(pkg, ctx, profile, tx_size, rx_size):
+    """isac_cdl_apply_batch_dev + isac_cdl_path_gains_dev: five (UE, slot) jobs in one call -- three UEs on ONE waveform at different channel times
+    (one of them across a path-gain refresh), two more on a second waveform -- every output against the oracle's apply for that channel time;
+    the device path gains against the host evaluation; channel time advances as with the single-job call."""
+    import oracle.cdl as OC
+    CM = pkg.communication.channelModels
+    fs, t_len = 15.36e6, 4097
+    cfg = OC.cdl_config(profile, 3.5e9, tx_size, rx_size, fs)
+    nt, nr = int(np.prod(tx_size)), int(np.prod(rx_size))
+    rng = np.random.default_rng(7 * nt + nr)
+    xs = [np.asfortranarray(rng.standard_normal((t_len, nt)) + 1j * rng.standard_normal((t_len, nt))) for _ in range(2)]
+    d_xs = [ctx.to_device(x) for x in xs]
+    t0s = [0.0, 1.0 / 640 - 1000 / fs, 0.25, 0.0, 0.5]
+    which = [0, 0, 0, 1, 1]
+    chans = []
+    for t0 in t0s:
+        ch = CM.CDLChannel(profile, 300e-9, 3.5e9, tx_size, rx_size, fs)
+        ch.time = t0
+        chans.append(ch)
+    # device path gains == host path gains
+    snaps = np.array([0.0, 0.1, 1.0 / 640, 0.3333])
+    h_dev = chans[0].path_gains_device(snaps, ctx).numpy().reshape(snaps.size, *chans[0]._static().base.shape[:1], nt, nr)
+    h_host = np.stack([chans[0].path_gains(t) for t in snaps])
+    assert rel(h_dev, h_host) < 1e-12
+    outs = CM.applyCDLBatch(chans, [d_xs[w] for w in which], ctx=ctx)
+    for t0, w, ch, o in zip(t0s, which, chans, outs):
+        want = OC.apply_cdl(cfg, xs[w], t0)
+        assert o.shape == (t_len, nr) and rel(o.numpy(), want) < RTOL, (t0, w)
+        assert ch.time == pytest.approx(t0 + t_len / fs)
+    # a second batch continues from the advanced channel times
+    outs2 = CM.applyCDLBatch(chans[:2], [d_xs[0], d_xs[1]], ctx=ctx)
+    assert rel(outs2[0].numpy(), OC.apply_cdl(cfg, xs[0], t0s[0] + t_len / fs)) < RTOL
+    assert rel(outs2[1].numpy(), OC.apply_cdl(cfg, xs[1], t0s[1] + t_len / fs)) < RTOL
+
+
 # ------------------------------------------------------------------ SINR -> CQI
 @pytest.mark.parametrize("nr,p,nl", [(2, 4, 1), (2, 4, 2), (4, 8, 4), (8, 32, 8)])
 def test_precoded_sinr_and_cqi(pkg, ctx, nr, p, nl):
