@@ -614,13 +614,14 @@ static int prepare_echo(isac_ctx* ctx, const c64* d_tx, long long T, const isac_
   // beam-sums in tiles of up to 8 targets (tx is re-read only when Q > 8)
   static const int bs_wgs = std::getenv("ISAC_BEAMSUM_WGS") ? std::atoi(std::getenv("ISAC_BEAMSUM_WGS")) : 1024;   // development switch: workgroups of the launch
   static const int bs_unroll = std::getenv("ISAC_BEAMSUM_UNROLL") ? std::atoi(std::getenv("ISAC_BEAMSUM_UNROLL")) : 32;   // (sweep: profiles/r04_beamsum_sweep.txt)
-  const unsigned gb = (unsigned)std::min<long long>(cdiv(T, 256), bs_wgs > 0 ? bs_wgs : (1 << 30));
+  const unsigned gb = cdiv(T, 256);                                   // one thread per sample (coef_kernel below)
+  const unsigned gbs = (unsigned)std::min<long long>(gb, bs_wgs > 0 ? bs_wgs : (1 << 30));   // beam-sum: long-lived workgroups
   timeline_mark(ctx, 0, ctx->stream);
 #define ISAC_BEAMSUM(QT)                                                                                                                    \
   do {                                                                                                                                      \
-    if (bs_unroll >= 32) hipLaunchKernelGGL((beamsum_kernel<QT, (QT <= 2 ? 32 : 8)>), dim3(gb), dim3(256), sizeof(c64) * A * QT, ctx->stream, d_tx, T, A, st, bm);      \
-    else if (bs_unroll >= 16) hipLaunchKernelGGL((beamsum_kernel<QT, (QT <= 4 ? 16 : 8)>), dim3(gb), dim3(256), sizeof(c64) * A * QT, ctx->stream, d_tx, T, A, st, bm); \
-    else hipLaunchKernelGGL((beamsum_kernel<QT, 8>), dim3(gb), dim3(256), sizeof(c64) * A * QT, ctx->stream, d_tx, T, A, st, bm);           \
+    if (bs_unroll >= 32) hipLaunchKernelGGL((beamsum_kernel<QT, (QT <= 2 ? 32 : 8)>), dim3(gbs), dim3(256), sizeof(c64) * A * QT, ctx->stream, d_tx, T, A, st, bm);      \
+    else if (bs_unroll >= 16) hipLaunchKernelGGL((beamsum_kernel<QT, (QT <= 4 ? 16 : 8)>), dim3(gbs), dim3(256), sizeof(c64) * A * QT, ctx->stream, d_tx, T, A, st, bm); \
+    else hipLaunchKernelGGL((beamsum_kernel<QT, 8>), dim3(gbs), dim3(256), sizeof(c64) * A * QT, ctx->stream, d_tx, T, A, st, bm);           \
   } while (0)
   for (int q0 = 0; q0 < Q;) {
     int rem = Q - q0;

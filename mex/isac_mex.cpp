@@ -85,6 +85,7 @@ void dims3(const mxArray* a, mwSize d[3]) {
   const mwSize* s = mxGetDimensions(a);
   const mwSize n = mxGetNumberOfDimensions(a);
   d[0] = s[0]; d[1] = n > 1 ? s[1] : 1; d[2] = n > 2 ? s[2] : 1;
+  for (mwSize i = 3; i < n; ++i) d[2] *= s[i];                     // (trailing dimensions fold into the third: batched [.. x n] arguments)
 }
 // device view of a complex array argument: a handle as it is, a MATLAB array uploaded into a temporary
 struct DevIn {
@@ -353,6 +354,60 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (s2 == ISAC_OK) s2 = isac_memcpy_d2h(ctx(), mxGetComplexDoubles(plhs[0]), d_y, sizeof(isac_c64) * T * Nr);
     isac_dev_free(ctx(), d_y);
     check(s2);
+  } else if (fn == "applyCDLBatch") {
+    // Y [T x Nr x n] = (waveform [T x Nt] shared by the n jobs or [T x Nt x n], pathGains [Ncs x Np x Nt x Nr x n], sampleTimes [Ncs x n],
+    //                   pathFilters [Nh x Np], sampleRate, normalizeOutputs): the UEs of one cell on one slot waveform (uePhy.m:729-731 inside the
+    // per-UE loop) in ONE library call -- one contraction launch + one filter launch for all of them (isac_cdl_apply_batch_dev).
+    const mxArray *wv = prhs[1], *pg = prhs[2], *stm = prhs[3], *pf = prhs[4];
+    const double fs = mxGetScalar(prhs[5]);
+    const bool norm = nrhs > 6 ? mxGetScalar(prhs[6]) != 0 : true;
+    mwSize wd[3];
+    dims3(wv, wd);
+    const mwSize T = wd[0], Nt = wd[1];
+    const mwSize* gd = mxGetDimensions(pg);
+    const mwSize ng = mxGetNumberOfDimensions(pg);
+    const int Ncs = (int)gd[0], Np = (int)gd[1], Nr = ng > 3 ? (int)gd[3] : 1, nj = ng > 4 ? (int)gd[4] : 1;
+    if ((ng > 2 ? gd[2] : 1) != Nt || (wd[2] != 1 && (int)wd[2] != nj) || (int)mxGetM(stm) != Ncs || (int)mxGetN(stm) != nj)
+      mexErrMsgIdAndTxt("isac:INVALID_ARG", "applyCDLBatch: waveform / pathGains / sampleTimes dimensions differ");
+    const int Nh = (int)mxGetM(pf);
+    const size_t per_job = (size_t)Ncs * Np * Nt * Nr;
+    std::vector<isac_c64> H(per_job * (size_t)nj);
+    const mxComplexDouble* g = mxGetComplexDoubles(pg);
+    for (int j = 0; j < nj; ++j)
+      for (int b = 0; b < Ncs; ++b) for (int n = 0; n < Np; ++n) for (mwSize s_ = 0; s_ < Nt; ++s_) for (int u = 0; u < Nr; ++u) {
+        const mxComplexDouble v = g[(size_t)b + (size_t)Ncs * ((size_t)n + (size_t)Np * (s_ + Nt * ((size_t)u + (size_t)Nr * j)))];
+        H[per_job * j + (((size_t)b * Np + n) * Nt + s_) * Nr + u] = isac_c64{v.real, v.imag};
+      }
+    std::vector<int64_t> start((size_t)Ncs * nj);
+    const double* st = mxGetDoubles(stm);
+    for (int j = 0; j < nj; ++j)
+      for (int b = 0; b < Ncs; ++b) start[(size_t)j * Ncs + b] = b == 0 ? 0 : (int64_t)std::llround((st[(size_t)j * Ncs + b] - st[(size_t)j * Ncs]) * fs);
+    std::vector<double> taps((size_t)Np * Nh);
+    const double* f = mxGetDoubles(pf);
+    for (int n = 0; n < Np; ++n) for (int k = 0; k < Nh; ++k) taps[(size_t)n * Nh + k] = f[(size_t)k + (size_t)Nh * n];
+    std::vector<int32_t> shift((size_t)Np, 0);
+    DevIn d_x(wv);
+    void *d_y = nullptr, *d_h = nullptr;
+    check(isac_dev_alloc(ctx(), sizeof(isac_c64) * T * Nr * nj, &d_y));
+    int s2 = isac_dev_alloc(ctx(), sizeof(isac_c64) * H.size(), &d_h);
+    if (s2 == ISAC_OK) s2 = isac_memcpy_h2d(ctx(), d_h, H.data(), sizeof(isac_c64) * H.size());
+    std::vector<isac_cdl_job> jobs((size_t)nj);
+    for (int j = 0; j < nj; ++j) {
+      jobs[(size_t)j].d_x = d_x.p + (wd[2] == 1 ? 0 : (size_t)j * T * Nt);
+      jobs[(size_t)j].d_y = (isac_c64*)d_y + (size_t)j * T * Nr;
+      jobs[(size_t)j].d_H = (const isac_c64*)d_h + per_job * j;
+      jobs[(size_t)j].block_start = start.data() + (size_t)j * Ncs;
+      jobs[(size_t)j].n_blocks = Ncs;
+      jobs[(size_t)j].reserved = 0;
+    }
+    if (s2 == ISAC_OK)
+      s2 = isac_cdl_apply_batch_dev(ctx(), jobs.data(), nj, (int64_t)T, (int)Nt, Nr, Np, taps.data(), Nh, shift.data(), norm ? 1.0 / std::sqrt((double)Nr) : 1.0);
+    const mwSize yd[3] = {T, (mwSize)Nr, (mwSize)nj};
+    plhs[0] = mxCreateNumericArray(3, yd, mxDOUBLE_CLASS, mxCOMPLEX);
+    if (s2 == ISAC_OK) s2 = isac_memcpy_d2h(ctx(), mxGetComplexDoubles(plhs[0]), d_y, sizeof(isac_c64) * T * Nr * nj);
+    isac_dev_free(ctx(), d_y);
+    if (d_h) isac_dev_free(ctx(), d_h);
+    check(s2);
   } else if (fn == "precodedSINR") {
     // sinr = precodedSINR(H [Nr x P], sigma, W [P x nLayers])                                    precodedSINR.m:11-17
     const mxArray *h = prhs[1], *w = prhs[3];
@@ -392,6 +447,45 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     plhs[2] = vec(rep.i2, rep.n_subbands_pmi, false);
     plhs[3] = vec(rep.subband_cqi, rep.n_cqi, true);
     plhs[4] = vec(rep.sinr_per_subband_cw, rep.n_cqi, true);
+  } else if (fn == "csiReportBatch") {
+    // [CQI (nCQI x n), i1 (3 x n), i2 (nSbPMI x n), subbandCQI (nCQI x n), sinrPerSubband (nCQI x n)] = (Hre [nRE x nRx x P x n], k, l, reportConfig, nLayers,
+    //   nVar [n], SINRTable): the UEs of one cell at one CSI-RS occasion in ONE library call (isac_csi_report_batch_dev: one synchronisation)
+    const mxArray *h = prhs[1], *kk = prhs[2], *ll = prhs[3], *rc = prhs[4];
+    const int nl = (int)mxGetScalar(prhs[5]);
+    const mxArray *nv = prhs[6], *tab = prhs[7];
+    const mwSize* hd = mxGetDimensions(h);
+    const mwSize nhd = mxGetNumberOfDimensions(h);
+    const int64_t n_re = (int64_t)hd[0];
+    const int nrx = nhd > 1 ? (int)hd[1] : 1, P = nhd > 2 ? (int)hd[2] : 1, nu = nhd > 3 ? (int)hd[3] : 1;
+    if ((int)mxGetNumberOfElements(nv) != nu) mexErrMsgIdAndTxt("isac:INVALID_ARG", "csiReportBatch: one noise variance per UE");
+    std::vector<int32_t> k((size_t)n_re), l((size_t)n_re);
+    for (int64_t i = 0; i < n_re; ++i) { k[(size_t)i] = (int32_t)mxGetDoubles(kk)[i] - 1; l[(size_t)i] = (int32_t)mxGetDoubles(ll)[i] - 1; }
+    const double* pd = mxGetDoubles(sub(rc, "PanelDimensions"));
+    int32_t dims[4];
+    check(isac_type1sp_codebook(P, P > 2 ? (int)pd[0] : 1, P > 2 ? (int)pd[1] : 1, (int)fld(rc, "CodebookMode"), nl, nullptr, 0, dims));
+    std::vector<isac_c64> W((size_t)P * nl * dims[0] * dims[1] * dims[2] * dims[3]);
+    check(isac_type1sp_codebook(P, P > 2 ? (int)pd[0] : 1, P > 2 ? (int)pd[1] : 1, (int)fld(rc, "CodebookMode"), nl, W.data(), (int64_t)W.size(), dims));
+    auto is_sub = [&](const char* f) { char* s_ = mxArrayToString(sub(rc, f)); const bool r = s_ && (s_[0] == 'S' || s_[0] == 's'); mxFree(s_); return r; };
+    DevIn d_h(h);
+    std::vector<const isac_c64*> hl((size_t)nu);
+    for (int u = 0; u < nu; ++u) hl[(size_t)u] = d_h.p + (size_t)u * (size_t)n_re * nrx * P;
+    std::vector<isac_csi_report> rep((size_t)nu);
+    check(isac_csi_report_batch_dev(ctx(), nu, hl.data(), n_re, nrx, P, k.data(), l.data(), (int)fld(rc, "NSizeBWP"), (int)fld(rc, "NStartBWP"), (int)fld(rc, "SubbandSize"),
+                                    is_sub("PMIMode"), is_sub("CQIMode"), W.data(), nl, dims, mxGetDoubles(nv), mxGetDoubles(tab), (int)mxGetNumberOfElements(tab),
+                                    rep.data(), nullptr));
+    const int ncqi = rep[0].n_cqi, nsb = rep[0].n_subbands_pmi;
+    plhs[0] = mxCreateDoubleMatrix((mwSize)ncqi, (mwSize)nu, mxREAL);
+    plhs[1] = mxCreateDoubleMatrix(3, (mwSize)nu, mxREAL);
+    plhs[2] = mxCreateDoubleMatrix((mwSize)nsb, (mwSize)nu, mxREAL);
+    plhs[3] = mxCreateDoubleMatrix((mwSize)ncqi, (mwSize)nu, mxREAL);
+    plhs[4] = mxCreateDoubleMatrix((mwSize)ncqi, (mwSize)nu, mxREAL);
+    for (int u = 0; u < nu; ++u) {
+      std::memcpy(mxGetDoubles(plhs[0]) + (size_t)u * ncqi, rep[(size_t)u].cqi, sizeof(double) * (size_t)ncqi);
+      std::memcpy(mxGetDoubles(plhs[1]) + (size_t)u * 3, rep[(size_t)u].i1, sizeof(double) * 3);
+      std::memcpy(mxGetDoubles(plhs[2]) + (size_t)u * nsb, rep[(size_t)u].i2, sizeof(double) * (size_t)nsb);
+      std::memcpy(mxGetDoubles(plhs[3]) + (size_t)u * ncqi, rep[(size_t)u].subband_cqi, sizeof(double) * (size_t)ncqi);
+      std::memcpy(mxGetDoubles(plhs[4]) + (size_t)u * ncqi, rep[(size_t)u].sinr_per_subband_cw, sizeof(double) * (size_t)ncqi);
+    }
   } else if (fn == "senTxAppend") {
     // tLen = isac_mex('senTxAppend', gridHandle, waveHandle, txGrid [K x 14 x A], currSlot, isDLslot, carrierInfo, signalAmp, windowing,
     //                   slotsAlready, samplesAlready)                                          gNBPhy.m:591-612

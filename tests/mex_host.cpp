@@ -262,6 +262,27 @@ int comm(const char* in, const char* out) {
     mxArray* y = call("applyCDL", {cplx_array(wave.data(), T, Nt, 1), m_pg, real_mat(st, Ncs, 1), real_mat(pf, Nh, Np), scalar(fs), scalar(norm)})[0];
     if ((int)mxGetM(y) != T || (int)mxGetN(y) != Nr) { std::fprintf(stderr, "applyCDL output shape\n"); return 4; }
     write_cplx(o, y);
+    // applyCDLBatch: three jobs on the SAME waveform whose path gains are (1 + j) x the single job's -> outputs (1 + j) x y (the apply is linear in H)
+    const int nj = 3;
+    const mwSize gd5[5] = {(mwSize)Ncs, (mwSize)Np, (mwSize)Nt, (mwSize)Nr, (mwSize)nj};
+    mxArray* m_pg5 = mxCreateNumericArray(5, gd5, mxDOUBLE_CLASS, mxCOMPLEX);
+    std::vector<double> st3((size_t)Ncs * nj);
+    for (int j = 0; j < nj; ++j) {
+      for (size_t i = 0; i < pg.size(); ++i) mxGetComplexDoubles(m_pg5)[pg.size() * j + i] = mxComplexDouble{pg[i].re * (1 + j), pg[i].im * (1 + j)};
+      for (int b = 0; b < Ncs; ++b) st3[(size_t)j * Ncs + b] = st[(size_t)b];
+    }
+    mxArray* yb = call("applyCDLBatch", {cplx_array(wave.data(), T, Nt, 1), m_pg5, real_mat(st3, Ncs, nj), real_mat(pf, Nh, Np), scalar(fs), scalar(norm)})[0];
+    if (mxGetNumberOfElements(yb) != (size_t)T * Nr * nj) { std::fprintf(stderr, "applyCDLBatch output shape\n"); return 4; }
+    double worst = 0.0, ymax = 0.0;
+    for (size_t i = 0; i < (size_t)T * Nr; ++i) {
+      const mxComplexDouble a = mxGetComplexDoubles(y)[i];
+      ymax = std::max(ymax, std::hypot(a.real, a.imag));
+      for (int j = 0; j < nj; ++j) {
+        const mxComplexDouble b = mxGetComplexDoubles(yb)[(size_t)j * T * Nr + i];
+        worst = std::max(worst, std::hypot(b.real - (1 + j) * a.real, b.imag - (1 + j) * a.imag));
+      }
+    }
+    if (!(worst <= 1e-12 * ymax * nj)) { std::fprintf(stderr, "applyCDLBatch differs from the single-job apply: %g vs max %g\n", worst, ymax); return 4; }
   }
   {   // ---- precodedSINR(H, sigma, W)                                                                precodedSINR.m:11-17
     int32_t d[3]; double sigma;
@@ -287,6 +308,25 @@ int comm(const char* in, const char* out) {
     std::vector<mxArray*> r = call("csiReport", {cplx_array(H.data(), n_re, nrx, P), real_mat(k, n_re, 1), real_mat(l, n_re, 1), rc, scalar(nl), scalar(nvar),
                                                  real_mat(tab, nt, 1)}, 5);
     for (int i = 0; i < 5; ++i) write_vec(o, r[(size_t)i]);
+    // csiReportBatch: the same estimate for three UEs at three noise variances == three csiReport calls, field for field
+    const int nu = 3;
+    const double nv3[3] = {nvar, 4.0 * nvar, 0.25 * nvar};
+    const mwSize hd4[4] = {(mwSize)n_re, (mwSize)nrx, (mwSize)P, (mwSize)nu};
+    mxArray* h4 = mxCreateNumericArray(4, hd4, mxDOUBLE_CLASS, mxCOMPLEX);
+    for (int u = 0; u < nu; ++u) std::memcpy(mxGetComplexDoubles(h4) + H.size() * u, H.data(), sizeof(isac_c64) * H.size());
+    std::vector<mxArray*> rb = call("csiReportBatch", {h4, real_mat(k, n_re, 1), real_mat(l, n_re, 1), rc, scalar(nl), real_row(nv3, 3), real_mat(tab, nt, 1)}, 5);
+    for (int u = 0; u < nu; ++u) {
+      std::vector<mxArray*> r1 = call("csiReport", {cplx_array(H.data(), n_re, nrx, P), real_mat(k, n_re, 1), real_mat(l, n_re, 1), rc, scalar(nl), scalar(nv3[u]),
+                                                    real_mat(tab, nt, 1)}, 5);
+      for (int i = 0; i < 5; ++i) {
+        const size_t n1 = mxGetNumberOfElements(r1[(size_t)i]);
+        if (mxGetNumberOfElements(rb[(size_t)i]) != n1 * nu) { std::fprintf(stderr, "csiReportBatch output %d shape\n", i); return 4; }
+        for (size_t e = 0; e < n1; ++e) {
+          const double a = mxGetDoubles(r1[(size_t)i])[e], b = mxGetDoubles(rb[(size_t)i])[n1 * u + e];
+          if (!((a != a && b != b) || a == b)) { std::fprintf(stderr, "csiReportBatch differs from csiReport: output %d ue %d element %zu: %g vs %g\n", i, u, e, b, a); return 4; }
+        }
+      }
+    }
   }
   {   // ---- senTx accumulation: allocDevice x2, senTxAppend per PDSCH slot, gather                      gNBPhy.m:591-612
     int32_t d[6]; double amp;

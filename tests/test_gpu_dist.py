@@ -89,7 +89,8 @@ def test_world4_gloo_seven_cells_per_gpu():
     assert res["n_gpus"] == 4 and res["scaling"] == "weak" and [c["cell"] for c in res["cells"]] == list(range(28))
     assert len(res["per_rank_ms"]) == 4 and all(v is not None and v > 0 for v in res["per_rank_ms"])
     assert sum(c["nRng"] is not None for c in res["cells"]) >= 20
-    assert sum(1 for ln in err.splitlines() if "7 cell(s)" in ln and "/4:" in ln) == 4
+    import re
+    assert sorted(set(re.findall(r"rank (\d)/4: device \d+ \([^)]*\), 7 cell\(s\)", err))) == ["0", "1", "2", "3"], err[-1500:]
 
 
 def test_nccl_refuses_more_ranks_than_gpus():
