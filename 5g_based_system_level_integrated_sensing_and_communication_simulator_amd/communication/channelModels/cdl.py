@@ -223,7 +223,8 @@ def applyCDLBatch(channels, waveforms, *, ctx=None, outs=None, gains=None):
     """rxWaveform_i = channel_i(waveform_i) for many (UE, slot) pairs in ONE library call (isac_cdl_apply_batch_dev): uePhy.m:729-731 inside the
     per-UE loop of a cell, or the slots of a frame.  All channels must share antenna counts, sample rate, delay profile length and filter taps
     (the reference builds every UE's channel from the same cdl.m:57-64 template); `waveforms` are DeviceArrays [T x Nt] -- the same array may appear
-    several times (the UEs of one cell receive one downlink waveform).  Path gains are formed on the device.  Advances every channel's time.
+    several times (the UEs of one cell receive one downlink waveform), and so may a channel (consecutive slots of one UE: its time advances from
+    job to job in list order).  Path gains are formed on the device.  Advances every channel's time by T samples per appearance.
     `outs` / `gains`: caller-owned output arrays and a path-gain scratch DeviceArray (>= total gain blocks x n_paths x Nt x Nr elements) that a
     frame loop reuses from slot to slot -- without them every call allocates and (when the previous outputs are dropped) frees, and a free
     synchronises the stream.  Returns the list of output DeviceArrays [T x Nr]."""
@@ -249,7 +250,12 @@ def applyCDLBatch(channels, waveforms, *, ctx=None, outs=None, gains=None):
     keep = []
     outs = list(outs) if outs is not None else [ctx.empty((T, nr)) for _ in channels]
     per_block = n_paths * nt * nr
-    plans = [ch.block_plan(T) for ch in channels]
+    # (channel time advances job by job: a channel that appears several times in the list -- consecutive slots of one UE in one call -- sees
+    # consecutive stretches of channel time, exactly as consecutive single calls would give it)
+    plans = []
+    for ch in channels:
+        plans.append(ch.block_plan(T))
+        ch.time += T / ch.SampleRate
     # path gains: ONE device evaluation per distinct channel configuration (the reference gives every UE of a delay profile the same seed,
     # cdl.m:57-64: their channels differ in channel time only) over the concatenated snapshot times of its jobs
     groups: dict = {}
@@ -273,8 +279,6 @@ def applyCDLBatch(channels, waveforms, *, ctx=None, outs=None, gains=None):
             off += st.size
     ctx.check(ctx.lib.isac_cdl_apply_batch_dev(ctx.handle, jobs, C.c_int32(len(channels)), C.c_int64(T), C.c_int32(nt), C.c_int32(nr), C.c_int32(n_paths),
                                                g.ctypes.data_as(C.c_void_p), C.c_int32(FILTER_TAPS), shift.ctypes.data_as(C.c_void_p), C.c_double(scale)))
-    for ch in channels:
-        ch.time += T / ch.SampleRate
     if gains is None:
         for o in outs:
             o._cdl_keep = d_h_all                   # the gains stay alive until the outputs are dropped (the launches are asynchronous)

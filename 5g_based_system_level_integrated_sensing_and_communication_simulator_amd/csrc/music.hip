@@ -1363,6 +1363,10 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_fused_kernel(const c64* __r
 // updated column).  The matrix lives in LDS, the reflectors go straight to the scratch zungtr reads.  222 -> ~120 us at n = 64
 // (host-call time of the whole eigensolver 0.905 -> 0.807 ms).
 constexpr int kTriWaves = 4;       // wavefronts of eigh_tridiag_small_kernel (eight: the same 124 us at n = 64 -- every step is a chain of LDS round trips, DPP sums and two barriers, ~5 000 cycles whatever the column count per wave)
+// (Round 4 tried the matrix in REGISTERS: wave w owns the columns j = w (mod 4), the 63 steps unrolled, per-column operands by v_readlane, LDS only for
+// the new reflector and the partial products -- 35 000 instructions, 128.9 us against this kernel's 129.3: the step is bound by what ONE wave can issue
+// (~8 cycles per instruction: ~550 instructions per step either way) and by the serial zlarfg chain (sqrt + three fp64 divides + three DPP sums),
+// not by the LDS traffic it removed.  profiles/r04_negative_results.txt.)
 __global__ __launch_bounds__(64 * kTriWaves) void eigh_tridiag_small_kernel(const c64* __restrict__ Hin, int n, void* scratch, int* __restrict__ info) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int NW = kTriWaves;

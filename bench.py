@@ -349,11 +349,11 @@ class CommCell:
             self.waves.append(w)
         self.groups = [[u for u in range(n_ues) if self.los[u]], [u for u in range(n_ues) if not self.los[u]]]
         self.groups = [g for g in self.groups if g]
-        self.rx = [[ctx_cdl.empty((self.T, 2)) for _ in g] for g in self.groups]
+        self.rx = [[ctx_cdl.empty((self.T, 2)) for _ in range(len(g) * self.SLOTS_PER_CALL)] for g in self.groups]
         self.gains = []
         for g in self.groups:
             st = self.chans[g[0]]._static()
-            self.gains.append(ctx_cdl.empty((len(g) * 4 * st.base.shape[0] * st.base.shape[2] * st.base.shape[3],)))    # up to 4 gain blocks per job
+            self.gains.append(ctx_cdl.empty((len(g) * self.SLOTS_PER_CALL * 4 * st.base.shape[0] * st.base.shape[2] * st.base.shape[3],)))    # up to 4 gain blocks per job
         # CSI inputs (setupCSIRS.m:5-23): 4-port row-5 CSI-RS on 273 PRBs, Type-I single panel (2, 1), subband PMI / CQI, 16-PRB subbands
         self.csi_k, self.csi_l = csirs_positions(273)
         self.report = SimpleNamespace(NSizeBWP=273, NStartBWP=0, PanelDimensions=(2, 1), CodebookMode=1, PMIMode="Subband", CQIMode="Subband", SubbandSize=16)
@@ -366,11 +366,16 @@ class CommCell:
         self.last_cqi = None
         ctx_cdl.sync(); ctx_csi.sync()
 
+    SLOTS_PER_CALL = 4
+
     def enqueue_frame(self):
-        """All downlink slots of the frame through every UE's channel (asynchronous: two launches per slot and delay profile)."""
-        for s_ in range(self.DL_SLOTS):
+        """All downlink slots of the frame through every UE's channel: one library call per delay profile and SLOTS_PER_CALL consecutive slots (every UE of
+        the group appears once per slot, its channel time advancing from slot to slot) -- asynchronous, one contraction + one filter launch per call."""
+        for s0 in range(0, self.DL_SLOTS, self.SLOTS_PER_CALL):
             for g, rx, gn in zip(self.groups, self.rx, self.gains):
-                self.CM.applyCDLBatch([self.chans[u] for u in g], [self.waves[s_]] * len(g), ctx=self.ctx, outs=rx, gains=gn)
+                slots = range(s0, min(s0 + self.SLOTS_PER_CALL, self.DL_SLOTS))
+                self.CM.applyCDLBatch([self.chans[u] for s_ in slots for u in g], [self.waves[s_] for s_ in slots for u in g], ctx=self.ctx,
+                                      outs=[rx[(s_ - s0) * len(g) + i] for s_ in slots for i in range(len(g))], gains=gn)
 
     def csi_reports(self):
         """The frame's CSI-RS occasions: every UE's report, one batched call (one synchronisation of the CSI context) per occasion."""
@@ -439,7 +444,7 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
     ms_k, ms_call = [], []
     for i in range(11):
         ctx_cdl.sync(); ctx_cdl.timer_start()
-        cc.CM.applyCDLBatch([cc.chans[u] for u in cc.groups[gi]], [cc.waves[i % cc.DL_SLOTS]] * n_jobs, ctx=ctx_cdl, outs=cc.rx[gi], gains=cc.gains[gi])
+        cc.CM.applyCDLBatch([cc.chans[u] for u in cc.groups[gi]], [cc.waves[i % cc.DL_SLOTS]] * n_jobs, ctx=ctx_cdl, outs=cc.rx[gi][:n_jobs], gains=cc.gains[gi])
         v = C.c_double(0.0)
         ctx_cdl.check(ctx_cdl.lib.isac_profile_last_kernel_ms(ctx_cdl.handle, C.byref(v)))
         ms_call.append(ctx_cdl.timer_stop_ms()); ms_k.append(v.value)

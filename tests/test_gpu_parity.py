@@ -524,6 +524,11 @@ def test_cdl_batch_apply_matches_oracle(pkg, ctx, profile, tx_size, rx_size):
     outs2 = CM.applyCDLBatch(chans[:2], [d_xs[0], d_xs[1]], ctx=ctx)
     assert rel(outs2[0].numpy(), OC.apply_cdl(cfg, xs[0], t0s[0] + t_len / fs)) < RTOL
     assert rel(outs2[1].numpy(), OC.apply_cdl(cfg, xs[1], t0s[1] + t_len / fs)) < RTOL
+    # one channel twice in a batch = two consecutive slots of that UE: its time advances from job to job
+    t_now = chans[2].time
+    outs3 = CM.applyCDLBatch([chans[2], chans[2]], [d_xs[0], d_xs[1]], ctx=ctx)
+    assert rel(outs3[0].numpy(), OC.apply_cdl(cfg, xs[0], t_now)) < RTOL and rel(outs3[1].numpy(), OC.apply_cdl(cfg, xs[1], t_now + t_len / fs)) < RTOL
+    assert chans[2].time == pytest.approx(t_now + 2 * t_len / fs)
 
 
 # ------------------------------------------------------------------ SINR -> CQI
