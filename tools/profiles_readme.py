@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def rows(name):
@@ -47,18 +47,18 @@ if ss:
     top = max(ss, key=lambda r: float(r["total_us"]))
     out.append(f"* Largest share of GPU time: `{short(top['kernel'])}` ({float(top['pct']):.1f} %, {float(top['avg_us']):.1f} us avg).")
 fe, wr = rows("pmc_fetch_size.csv"), rows("pmc_write_size.csv")
-for name, alg in (("echo_range_", 1.5029), ("cov_mfma_small_kernel", 0.7514), ("beamsum_kernel", 1.0066)):
+for name, alg in (("echo_range_", 1.5029), ("cov_mfma_lds_kernel", 0.7514), ("cov_mfma_small_kernel", 0.7514), ("beamsum_kernel", 1.0066)):
     a, b = kern(fe, name), kern(wr, name)
     if a and b:
         f_kb, w_kb = float(a["avg_value"]), float(b["avg_value"])
         out.append(f"* `{short(a['kernel'])}`: FETCH_SIZE 2 x {f_kb:,.0f} KB + WRITE_SIZE {w_kb:,.0f} KB = {(2 * f_kb + w_kb) * 1024 / 1e9:.3f} GB per launch "
                    f"(algorithmic {alg:.3f} GB); {float(a['avg_duration_us']):.1f} us in the FETCH pass.")
 mf = rows("pmc_mfma_busy.csv")
-cov = [r for r in mf if "cov_mfma_small" in r["kernel"]]
+cov = [r for r in mf if "cov_mfma_lds" in r["kernel"] or "cov_mfma_small" in r["kernel"]]
 if cov:
     d = {r["counter"]: float(r["avg_value"]) for r in cov}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
-        out.append(f"* `cov_mfma_small_kernel`: SQ_VALU_MFMA_BUSY_CYCLES {d['SQ_VALU_MFMA_BUSY_CYCLES']:,.0f} (per counter instance, x 32 instances) over GRBM_GUI_ACTIVE "
+        out.append(f"* `{short(cov[0]['kernel'])}`: SQ_VALU_MFMA_BUSY_CYCLES {d['SQ_VALU_MFMA_BUSY_CYCLES']:,.0f} (per counter instance, x 32 instances) over GRBM_GUI_ACTIVE "
                    f"{d['GRBM_GUI_ACTIVE']:,.0f} cycles x 1024 SIMDs -> MfmaUtil {32 * d['SQ_VALU_MFMA_BUSY_CYCLES'] / (d['GRBM_GUI_ACTIVE'] * 1024):.2f}.")
 wl = [r for r in rows("pmc_wait_lds.csv") if "echo_range_" in r["kernel"]]
 if wl:
@@ -73,7 +73,7 @@ blk = [r for r in a_f + a_m + a_w if "cov_mfma_block" in r["kernel"]]
 if blk:
     d = {r["counter"]: float(r["avg_value"]) for r in blk}
     dur = {r["counter"]: float(r["avg_duration_us"]) for r in blk}
-    s = "* `cov_mfma_block_kernel` (A = 256, PMC passes of a cold 3-CPI run):"
+    s = f"* `{short(blk[0]['kernel'])}` (A = 256, PMC passes of a cold 3-CPI run):"
     if "FETCH_SIZE" in d:
         s += f" FETCH_SIZE 2 x {d['FETCH_SIZE']:,.0f} KB = {2 * d['FETCH_SIZE'] * 1024 / 1e9:.2f} GB per launch ({dur['FETCH_SIZE']:.0f} us);"
     if "SQ_VALU_MFMA_BUSY_CYCLES" in d and "GRBM_GUI_ACTIVE" in d:
@@ -94,6 +94,22 @@ for name, label in (("bench_driver_invocation.json", "driver invocation (`--gpus
         out.append(f"* bench, {label}: **{d['value']:,.0f} slots/s**, {d['ms_per_step']:.3f} ms per step" +
                    (f", blocking CPI {d['pipeline']['blocking_cpi_ms']} ms" if d.get("pipeline", {}).get("blocking_cpi_ms") else "") +
                    (f", `roofline.frac` {rf.get('frac')} ({rf.get('avg_launch_ms')} ms per launch), whole-CPI frac {rf.get('whole_cpi', {}).get('frac')}" if rf.get("frac") else "") + ".")
+c5 = jline("bench_config5_21x10.json")
+if c5:
+    rf = c5["roofline"]
+    out.append(f"* bench, `--workload config5` (21 cells x 10 UE on ONE GPU; per 20-slot frame: {c5['per_frame_and_rank']['sensing_cpis']} sensing CPIs + {c5['per_frame_and_rank']['cdl_applies']} CDL applies + "
+               f"{c5['per_frame_and_rank']['csi_reports']} CSI reports): **{c5['value']:,.0f} slots/s**, {c5['ms_per_step']:.1f} ms per frame; `cdl_gemm_kernel` {rf['avg_launch_ms']} ms per {rf['jobs_per_launch']}-job launch = "
+               f"{rf['achieved']} TFLOP/s issued = `roofline.frac` {rf['frac']} of the fp64 MFMA peak; CDL apply {c5['comm_seams']['cdl_apply_ms_per_job']} ms per job, CSI report {c5['comm_seams']['csi_report_ms_per_ue']} ms per UE.")
+c5k = rows("kernel_stats_config5.csv")
+if c5k:
+    out.append(f"* config 5 under rocprofv3 (`{tag}_kernel_stats_config5.csv`, warm-up + one frame): " + "; ".join(f"`{short(r['kernel'])}` {float(r['avg_us']):.1f} us x {r['calls']} ({float(r['pct']):.1f} %)" for r in c5k[:8]) + ".")
+d0 = jline("bench_driver_invocation.json")
+if d0 and d0.get("cpu_baseline"):
+    cb = d0["cpu_baseline"]
+    impl = cb.get("implementations", {})
+    out.append(f"* `cpu_baseline` of the driver's line: {cb['value']} slots/s ({cb.get('language')}, {cb['cores']} threads)" +
+               (f"; both implementations: C++/OpenMP port {impl['cpp_openmp_port']['value']} slots/s, NumPy / SciPy oracle {impl['numpy_scipy_oracle']['value']} slots/s ({impl['numpy_scipy_oracle']['cpi_s']} s per CPI)" if impl else "") +
+               f"; GPU / CPU = {d0.get('gpu_vs_cpu_baseline')}.")
 for name in ("pipeline_overlap.txt", "pipeline_gaps.txt"):
     f = os.path.join(P, f"{tag}_{name}")
     if os.path.exists(f):

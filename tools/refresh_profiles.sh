@@ -1,10 +1,10 @@
 #!/bin/bash
 # Regenerates the round's files under profiles/ on a GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh r03'
+#   gpurun --timeout 2400 -- 'bash tools/refresh_profiles.sh r04'
 # Outputs go to gpurun_out/profiles_<tag>/ ; copy them into profiles/ afterwards and run `python tools/profiles_readme.py <tag>`
 # (profiles/README.md's headline numbers are generated from the CSV / JSON files, never typed).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -24,7 +24,12 @@ $B --no-cpu-baseline --ants 256 --inflight 1 --steps 5 --warmup 1 2>/dev/null | 
 $B --no-cpu-baseline --ants 256 --inflight 3 --steps 12 --warmup 3 2>/dev/null | tail -1 > $OUT/${TAG}_bench_a256.json
 $B --no-cpu-baseline --ants 16 2>/dev/null | tail -1 > $OUT/${TAG}_bench_a16.json
 ISAC_MUSIC_FULL_EIG=1 $B --no-cpu-baseline --inflight 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_blocking_full_eig.json
-ISAC_TAIL_UNFUSED=1 $B --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/${TAG}_bench_default_100steps_old_cfar.json
+$B --no-cpu-baseline --schedule ordered 2>/dev/null | tail -1 > $OUT/${TAG}_bench_default_100steps_ordered.json
+# warm-up sensitivity: the driver's invocation without the untimed priming phase
+{ echo "# python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline [--prime-ms 0]: value (slots/s), ms per CPI, untimed priming steps"; for pm in 300 0 300 0; do
+  $B --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --prime-ms $pm 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('--prime-ms $pm:', d['value'], d['ms_per_step'], d['priming']['untimed_steps_before_warmup'])"; done; } > $OUT/${TAG}_warmup_sensitivity.txt
+# BASELINE configs[4]: 21 cells x 10 UE on this one GPU
+$B --workload config5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_config5_21x10.json
 
 # ---- rocprofv3: kernel trace of the blocking call sequence on one stream, then of a long pipelined run with nothing but the timed loop
 rm -rf /tmp/p1 && ISAC_SINGLE_STREAM=1 rocprofv3 --kernel-trace --stats -d /tmp/p1 -- $B --steps 20 --warmup 5 --inflight 1 --no-cpu-baseline > /dev/null 2>&1
@@ -47,9 +52,20 @@ pmc mfma_busy SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES
 pmc valu_busy SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVE_CYCLES
 pmc wait_lds SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
 
+pmc_a256() { local name=$1; shift
+  rm -rf /tmp/p3 && ISAC_SINGLE_STREAM=1 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/p3 -- $B --ants 256 --steps 2 --warmup 1 --inflight 1 --prime-ms 0 --no-cpu-baseline > /dev/null 2>&1
+  $PS $(db /tmp/p3) --pmc --csv $OUT/${TAG}_pmc_a256_$name.csv > /dev/null
+}
+pmc_a256 fetch_size FETCH_SIZE
+pmc_a256 mfma_busy SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES
+pmc_a256 wait_lds SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+
 # ---- HIP-event probes
 python $ROOT/tools/stage_times.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_stage_times_hip_events.txt
-python $ROOT/tools/_comm_time.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_comm_seam_times.txt
+python $ROOT/tools/comm_probe.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_comm_seam_times.txt
 $ROOT/tests/_build/abi_host time 64 3 2>/dev/null | tail -1 > $OUT/${TAG}_abi_host_timing.json
-(time python $ROOT/examples/config5.py --cells 21 --ues 10 > $OUT/${TAG}_config5_21x10.json) 2> $OUT/${TAG}_config5_wall.txt
+# config 5 under rocprofv3: per-kernel stats of one frame of 21 cells (CDL / CSI kernels beside the sensing kernels)
+rm -rf /tmp/p9 && rocprofv3 --kernel-trace --stats -d /tmp/p9 -- $B --workload config5 --steps 1 --warmup 1 > /dev/null 2>&1
+$PS $(db /tmp/p9) --csv $OUT/${TAG}_kernel_stats_config5.csv > $OUT/${TAG}_kernel_stats_config5.txt
+python $ROOT/tools/cov_probe.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_cov_probe.txt; python $ROOT/tools/cov_probe.py --ants 256 --reps 10 2>/dev/null | grep -v amdgpu.ids >> $OUT/${TAG}_cov_probe.txt
 ls -la $OUT
