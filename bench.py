@@ -330,9 +330,10 @@ class CommCell:
     slot and from frame to frame (path gains formed on the device per gain block)."""
     DL_SLOTS, CSI_OCCASIONS, SLOT_T = 16, 4, 61440
 
-    def __init__(self, pkg, ctx_cdl, ctx_csi, cell_id, n_ants, n_ues):
+    def __init__(self, pkg, ctxs_cdl, ctx_csi, cell_id, n_ants, n_ues):
         CM, self.PL, L = pkg.communication.channelModels, pkg.communication.phyLayer, pkg._lib
-        self.CM, self.ctx, self.ctx_csi, self.n_ues, self.A = CM, ctx_cdl, ctx_csi, n_ues, n_ants
+        ctx_cdl = ctxs_cdl[0]
+        self.CM, self.ctx, self.ctxs, self.ctx_csi, self.n_ues, self.A = CM, ctx_cdl, list(ctxs_cdl), ctx_csi, n_ues, n_ants
         rng = np.random.default_rng(0xC5000 + cell_id)
         self.los = rng.random(n_ues) < 0.5
         nt_shape = (n_ants // 16, 8, 2, 1, 1) if n_ants >= 16 else (1, n_ants // 2, 2, 1, 1)
@@ -364,7 +365,9 @@ class CommCell:
         self.nvar = 10.0 ** (-(46.0 - pl_db - (-174.0 + 10.0 * np.log10(100e6) + 7.0)) / 10.0)
         self.h_est = [ctx_csi.to_device(freq_response(ch, self.csi_k, K, 30e3, 4)) for ch in self.chans]
         self.last_cqi = None
-        ctx_cdl.sync(); ctx_csi.sync()
+        for c_ in self.ctxs:
+            c_.sync()
+        ctx_csi.sync()
 
     SLOTS_PER_CALL = 4
 
@@ -372,9 +375,10 @@ class CommCell:
         """All downlink slots of the frame through every UE's channel: one library call per delay profile and SLOTS_PER_CALL consecutive slots (every UE of
         the group appears once per slot, its channel time advancing from slot to slot) -- asynchronous, one contraction + one filter launch per call."""
         for s0 in range(0, self.DL_SLOTS, self.SLOTS_PER_CALL):
-            for g, rx, gn in zip(self.groups, self.rx, self.gains):
+            for gi, (g, rx, gn) in enumerate(zip(self.groups, self.rx, self.gains)):
                 slots = range(s0, min(s0 + self.SLOTS_PER_CALL, self.DL_SLOTS))
-                self.CM.applyCDLBatch([self.chans[u] for s_ in slots for u in g], [self.waves[s_] for s_ in slots for u in g], ctx=self.ctx,
+                # (one context per delay-profile group: the filter launch of one group runs beside the contraction launch of the other)
+                self.CM.applyCDLBatch([self.chans[u] for s_ in slots for u in g], [self.waves[s_] for s_ in slots for u in g], ctx=self.ctxs[gi % len(self.ctxs)],
                                       outs=[rx[(s_ - s0) * len(g) + i] for s_ in slots for i in range(len(g))], gains=gn)
 
     def csi_reports(self):
@@ -402,13 +406,17 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
     n_cells = args.cells if args.cells > 0 else 21
     mine = d.shard_cells(n_cells, rank, world)
     pool = SlotPool(pkg, local_rank, args.inflight)
-    ctx_cdl, ctx_csi = pkg.Context(local_rank), pkg.Context(local_rank)
+    n_cdl_ctx = int(os.environ.get("ISAC_C5_CDL_CONTEXTS", "2"))
+    ctxs_cdl, ctx_csi = [pkg.Context(local_rank) for _ in range(max(1, n_cdl_ctx))], pkg.Context(local_rank)
+    ctx_cdl = ctxs_cdl[0]
     n_buf = -(-args.inflight // max(len(mine), 1))
     sense = [Cell(pkg, local_rank, c, args.ants, args.slots, args.targets, pool=pool, n_buf=min(n_buf, 2)) for c in mine]
-    comm = [CommCell(pkg, ctx_cdl, ctx_csi, c, args.ants, args.ues) for c in mine]
+    comm = [CommCell(pkg, ctxs_cdl, ctx_csi, c, args.ants, args.ues) for c in mine]
 
     def barrier():
-        pool.sync(); ctx_cdl.sync(); ctx_csi.sync()
+        pool.sync(); ctx_csi.sync()
+        for c_ in ctxs_cdl:
+            c_.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
