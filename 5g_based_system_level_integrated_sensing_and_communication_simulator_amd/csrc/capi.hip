@@ -812,8 +812,11 @@ extern "C" int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w,
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_TRY(eig_status(ctx, A));
   if (std::getenv("ISAC_DEBUG")) {
-    int inf[6] = {-1, 0, 0, 0, 0, 0};
+    int inf[16] = {-1, 0, 0, 0, 0, 0};
     ISAC_HIP(hipMemcpy(inf, (char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(inf), hipMemcpyDeviceToHost));
+    if (A > 64 && A <= 256)
+      std::fprintf(stderr, "[isac] eigh A=%d distributed tridiagonalisation, phases(x64 clk): column + p published=%d exchange wait=%d vector work=%d rank-2 update=%d\n", A,
+                   inf[12], inf[13], inf[14], inf[15]);
     if (inf[5] < 0)
       std::fprintf(stderr, "[isac] eigh A=%d Jacobi sweeps=%d phases(x64 clk): rotation parameters=%d two-sided updates=%d\n", A, inf[0], inf[1], inf[2]);
     else

@@ -120,6 +120,7 @@ struct isac_ctx {
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // isac_profile_*: around the dominant kernel of the last fused echo call
   bool profile = false, profile_recorded = false;
   int music_route = 0;             // ISAC_OPT_MUSIC_ROUTE: 0 = signal-subspace eigensolver for MUSIC (default), 1 = always the full eigendecomposition
+  long long eig_epoch = 0;         // launches of eigh_tridiag_dist_kernel on this context (its exchange stamps carry the epoch: no reset between launches)
   bool tail_unjoined = false;      // wide order: ev_done of the last submit has not been waited for by the main stream (ISAC_ENTER joins lazily)
   int wide_order = 0;              // ISAC_OPT_WIDE_ORDER: 1 = fft2D's covariance on the main stream, everything narrow (Doppler, CFAR, MUSIC chain, pack, D2H) on the second
   int tail_fusion = 1;             // ISAC_OPT_TAIL_FUSION: 1 = panel CFAR + per-antenna merge / numDets where applicable (default), 0 = memset + per-antenna CFAR + count

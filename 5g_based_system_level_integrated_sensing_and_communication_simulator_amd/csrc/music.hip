@@ -15,6 +15,7 @@
 #include <type_traits>
 
 #include <algorithm>
+#include <atomic>
 #include "isac_common.hpp"
 
 namespace isac {
@@ -1077,14 +1078,19 @@ struct EighScratch {   // carve of ctx->eig_scratch for order n
   c64 *M, *Z, *tau, *rot;
   double *d, *e, *scale;
   double* wsc;         // [n] eigenvalues of the (safe-scaled) tridiagonal, ascending -- eigh_bisect_kernel
+  char* xch;           // exchange area of eigh_tridiag_dist_kernel (kTdXchBytes, 128-byte aligned)
   int *desc, *cnt;     // desc: (mm, l, first rotation, -) per sweep; cnt: {sweeps published, n_rot, overflow, zungtr done, QL done}
   long long rot_cap;
   int desc_cap;
   __host__ __device__ static size_t bytes(int n) {
-    return sizeof(c64) * ((size_t)2 * n * n + n + (size_t)16 * n * n) + sizeof(double) * (3 * n + 4) + sizeof(int) * (4 * (size_t)(30 * n + 2) + 8) + 256;
+    return sizeof(c64) * ((size_t)2 * n * n + n + (size_t)16 * n * n) + sizeof(double) * (3 * n + 4) + sizeof(int) * (4 * (size_t)(30 * n + 2) + 8) + 256 +
+           kXchBytes;
   }
+  static constexpr size_t kXchBytes = 2048 + 2 * 256 * 64;               // per-wavefront (maximum, XCC id) | 2 parities x 256 rows x (p_i, next column's entry) as tagged granules: at the
+                                                                           // START of the scratch, wherever n puts the rest (the host zeroes a fresh allocation)
   __host__ __device__ EighScratch(void* base, int n) {
-    c64* p = reinterpret_cast<c64*>(base);
+    xch = reinterpret_cast<char*>(base);
+    c64* p = reinterpret_cast<c64*>(xch + kXchBytes);
     M = p; p += (size_t)n * n;
     Z = p; p += (size_t)n * n;
     tau = p; p += n;
@@ -1353,6 +1359,254 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_fused_kernel(const c64* __r
     const c64 c = M[n - 1 + n * (n - 1)] - mul_conj(sv[n - 1], sw[n - 1]) - mul_conj(sw[n - 1], sv[n - 1]);   // the last pending update
     S.d[n - 1] = c.re; S.e[n - 1] = 0.0;
     if (info) info[1] = (int)((clock64() - t_start) >> 6);
+  }
+}
+
+// ---- 64 < n <= 256: the reduction DISTRIBUTED over ceil(n / 4) single-wavefront workgroups that hold the whole working matrix in registers.
+// The one-workgroup kernels above stream the trailing matrix (1 MB at n = 256) from L2 through ONE compute unit once per reflector: 3.1-3.2 ms at
+// n = 256, all of it that traffic.  Here wavefront q owns the 4 columns 4 q .. 4 q + 3 -- ALL their rows, both triangles: lane (c, rg) keeps the rows
+// i = rg, rg + 16, ... of column 4 q + c in 16 complex registers -- so that, the matrix being Hermitian, p_j = tau sum_i conj(a_ij) v_i needs nothing but
+// the owner's registers and the reflector, and the rank-2 update a_ij -= v_i conj(w_j) + w_i conj(v_j) nothing but v and w.  What crosses wavefronts per
+// reflector is ONE exchange: every wavefront publishes its 4 entries of p and -- the owner -- the next column as it stands; from those, every
+// wavefront forms w, the updated next column, its norm, zlarfg and the next reflector REDUNDANTLY (lane l: rows l, l + 64, l + 128, l + 192; identical
+// instructions on identical data: identical bits), so the chain per reflector is  registers -> publish -> poll -> O(n) vector work -> registers  with no
+// workgroup barrier and no pass over a matrix in memory.
+//   Exchange protocol (placement-independent; MI355X guide, inter-workgroup visibility, form R2): the data carry their own tags.  Every double
+// travels as one 16-byte write-through (sc1) store of two 8-byte granules {low word, tag}, {high word, tag}, tag = launch epoch << 12 | step -- no flag,
+// no fence, no reset between launches; the consumer re-reads the 64 bytes of each of its rows (p_i and the next column's entry) with sc1 loads until
+// all tags match.  Two parities of the area alternate: a wavefront can overwrite parity k & 1 at step k + 2 only after it has consumed every other
+// wavefront's step k + 1, which they publish after reading step k.  A wavefront returns after the step that consumed its last column; a poll that
+// sees no progress for ~2 s gives up with info[0] = -3.
+//   History (n = 256, profiles/r04_tridiag_dist.txt): 16 workgroups of 256 threads, agent-scope atomics + one step stamp per workgroup behind
+// s_waitcnt 1.0 ms (with __threadfence() instead 2.8 ms); tagged granules 0.9 ms -- 58 % of it the O(n) vector work, a chain of ~550 dependent
+// instructions through two workgroup-wide sums per reflector; this form: the sums stay inside the wavefront (DPP), four independent rows per lane.
+constexpr int kTdMaxN = 256;
+constexpr unsigned kTdRowBytes = 64, kTdParBytes = kTdMaxN * kTdRowBytes, kTdMxBytes = 2048;      // per row: p_i (32 B) | column entry (32 B)
+static_assert(EighScratch::kXchBytes == kTdMxBytes + 2 * kTdParBytes, "exchange area");
+__device__ __forceinline__ void td_put(__amdgpu_buffer_rsrc_t rs, unsigned off, double v, unsigned tag, bool near = false) {
+  const u32x4_t q = {(unsigned)__double2loint(v), tag, (unsigned)__double2hiint(v), tag};
+  if (near) __builtin_amdgcn_raw_buffer_store_b128(q, rs, (int)off, 0, 0);             // stays in this XCD's L2: readers on the same XCD only
+  else __builtin_amdgcn_raw_buffer_store_b128(q, rs, (int)off, 0, /*sc1*/ 16);          // write-through: visible at any placement
+}
+__device__ __forceinline__ bool td_get(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned tag, double& v) {
+  const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, /*sc1*/ 16);
+  v = __hiloint2double((int)q.z, (int)q.x);
+  return q.y == tag && q.w == tag;
+}
+__device__ __forceinline__ double row16_sum_dpp(double x) {      // every lane: the sum over its row of 16 lanes
+  x += dpp_move<0xB1, 0xf>(x);
+  x += dpp_move<0x4E, 0xf>(x);
+  x += dpp_move<0x124, 0xf>(x);
+  x += dpp_move<0x128, 0xf>(x);
+  return x;
+}
+__global__ __launch_bounds__(256) void eigh_tridiag_dist_kernel(const c64* __restrict__ Hin, int n, void* scratch, int* __restrict__ info, unsigned base,
+                                                                      int stride, int slot, int far_only) {
+  if ((int)(blockIdx.x % (unsigned)stride) != slot) return;
+  __shared__ __attribute__((aligned(16))) c64 sv[2][kTdMaxN];      // the reflector of the step, by parity   (sv, sw: every wavefront writes the same bits)
+  __shared__ __attribute__((aligned(16))) c64 sw[kTdMaxN];         // w of the step
+  __shared__ __attribute__((aligned(16))) c64 scol4[4][kTdMaxN];   // per wavefront: the owner's next column, row by row
+  __shared__ __attribute__((aligned(16))) c64 sp[2][kTdMaxN];      // the exchange as polled (wavefront w: rows 64 w ..), by parity: p ...
+  __shared__ __attribute__((aligned(16))) c64 sc[2][kTdMaxN];      // ... and the next column
+  __shared__ int s_abort;
+  const int wid = threadIdx.x >> 6;
+  const int g = (int)(blockIdx.x / (unsigned)stride), G = (n + 15) >> 4, q = 4 * g + wid, Q = (n + 3) >> 2;
+  const int lane = threadIdx.x & 63;
+  c64* scol = scol4[wid];
+  if (threadIdx.x == 0) s_abort = 0;
+  const int c = lane >> 4, rg = lane & 15, j = 4 * q + c;
+  EighScratch S(scratch, n);
+  const __amdgpu_buffer_rsrc_t xr = buffer_of(S.xch, (unsigned)EighScratch::kXchBytes);
+  const bool writer = g == G - 1 && wid == 0;                        // (alive to the last step) stores d, e, tau and the reflectors
+  const long long t_start = clock64();
+  auto give_up = [&](const long long t0, int& spins) -> bool {       // (wave-uniform) ~2 s without progress
+    if ((++spins & 255) != 0 || (long long)wall_clock64() - t0 < 200000000ll) return false;
+    if (lane == 0) s_abort = 1;
+    return true;
+  };
+  // ---- load: my columns' rows; the safe scale needs the maximum over the whole matrix: first exchange
+  c64 a[16];
+  double mx = 0.0;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int i = 16 * u + rg;
+    a[u] = (i < n && j < n) ? Hin[i + (long long)n * j] : mk(0.0, 0.0);
+    mx = fmax(mx, fmax(fabs(a[u].re), fabs(a[u].im)));
+  }
+  double scl = 1.0;
+  bool near = false;                                                 // every wavefront of the launch runs on ONE XCD (seen in the first exchange): the exchange may stay in its L2
+  c64 col[4];                                                        // column 0 (lane l: rows l + 64 r): every wavefront derives the first reflector itself
+#pragma unroll
+  for (int r = 0; r < 4; ++r) col[r] = lane + 64 * r < n ? Hin[lane + 64 * r] : mk(0.0, 0.0);
+  {
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    unsigned xcc = 0;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 15;
+    if (lane == 0) { td_put(xr, 32u * (unsigned)q, mx, base + 1); td_put(xr, 32u * (unsigned)q + 16, (double)xcc, base + 1); }
+    double t = 0.0;
+    const long long t0 = (long long)wall_clock64();
+    int spins = 0;
+    for (;;) {
+      asm volatile("" ::: "memory");
+      double m = 0.0, x = (double)xcc;
+      const bool ok = lane >= Q || (td_get(xr, 32u * (unsigned)lane, base + 1, m) && td_get(xr, 32u * (unsigned)lane + 16, base + 1, x));
+      if (__all(ok)) { t = lane < Q ? m : 0.0; near = !far_only && __all(x == (double)xcc); break; }
+      if (give_up(t0, spins)) break;
+    }
+    for (int o = 32; o > 0; o >>= 1) t = fmax(t, __shfl_xor(t, o));
+    __syncthreads();
+    if (s_abort) { if (threadIdx.x == 0 && info) info[0] = -3; return; }
+    if (t > 0.0 && t < 1.7976931348623157e308) {                     // (eigh_safe_scale's rule)
+      const int ex = ilogb(t);
+      if (ex < -400 || ex > 400) scl = ldexp(1.0, -ex);
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a[u] = a[u] * scl;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) col[r] = col[r] * scl;
+    if (writer) {
+      if (lane == 0) *S.scale = scl;
+      if (lane < 8) S.cnt[lane] = 0;                                 // publication counters of the next two stages
+    }
+  }
+  // the reflector of step k2 from its column: into vn (registers) and sv[k2 & 1] (LDS), tau returned; d, e, tau and the reflector stored by the writer
+  c64 vcur[4];
+  auto derive = [&](int k2, const c64 (&ci)[4], const c64 alpha /* row k2 + 1 */, const double dd /* row k2, real part */) -> c64 {
+    double xn2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const int i = lane + 64 * r; if (i > k2 + 1 && i < n) xn2 += ci[r].re * ci[r].re + ci[r].im * ci[r].im; }
+    xn2 = wave_sum_dpp(xn2);
+    c64 tau = mk(0.0, 0.0), scale = mk(0.0, 0.0);
+    double beta = alpha.re;
+    if (xn2 != 0.0 || alpha.im != 0.0) {                             // zlarfg (two reciprocals instead of four divisions)
+      beta = -copysign(sqrt(alpha.re * alpha.re + alpha.im * alpha.im + xn2), alpha.re);
+      const double ib = 1.0 / beta;
+      tau = mk((beta - alpha.re) * ib, -alpha.im * ib);
+      const c64 dlt = mk(alpha.re - beta, alpha.im);
+      const double idn = 1.0 / (dlt.re * dlt.re + dlt.im * dlt.im);
+      scale = mk(dlt.re * idn, -dlt.im * idn);                       // 1 / (alpha - beta)
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = lane + 64 * r;
+      const bool below = i > k2 + 1 && i < n;
+      const c64 vi = i == k2 + 1 ? mk(1.0, 0.0) : (below ? ci[r] * scale : mk(0.0, 0.0));
+      vcur[r] = vi;
+      sv[k2 & 1][i] = vi;
+      if (writer && below) S.M[i + (long long)n * k2] = vi;          // the reflector, where zungtr / the back-transform expect it
+    }
+    if (writer && lane == 0) { S.d[k2] = dd; S.e[k2] = beta; S.tau[k2] = tau; }
+    return tau;
+  };
+  c64 tau = derive(0, col, Hin[1] * scl, Hin[0].re * scl);
+  long long c_pub = 0, c_poll = 0, c_vec = 0, c_upd = 0;          // phase instrumentation (ISAC_DEBUG): cycles of the last wavefront
+  for (int k = 0; k < n - 1; ++k) {
+    const long long c0 = clock64();
+    const int par = k & 1;
+    const c64* v = sv[par];
+    const unsigned tag = base + 2 + (unsigned)k;
+    const unsigned area = kTdMxBytes + (unsigned)par * kTdParBytes;
+    // ---- the owner of column k + 1 publishes it as it stands (the update of step k - 1 is in), spread over the wavefront through LDS
+    if (q == ((k + 1) >> 2)) {                                       // (wave-uniform)
+      if (c == ((k + 1) & 3)) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) scol[16 * u + rg] = a[u];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = lane + 64 * r;
+        if (i > k && i < n) {
+          const c64 x = scol[i];
+          td_put(xr, area + kTdRowBytes * (unsigned)i + 32, x.re, tag, near);
+          td_put(xr, area + kTdRowBytes * (unsigned)i + 48, x.im, tag, near);
+        }
+      }
+    }
+    // ---- p_j = tau sum_i conj(a_ij) v_i over my columns
+    {
+      c64 acc0 = mk(0.0, 0.0), acc1 = acc0;
+#pragma unroll
+      for (int u = 0; u < 16; u += 2) {
+        acc0 = fma(conj(a[u]), v[16 * u + rg], acc0);
+        acc1 = fma(conj(a[u + 1]), v[16 * (u + 1) + rg], acc1);
+      }
+      const c64 pj = tau * mk(row16_sum_dpp(acc0.re + acc1.re), row16_sum_dpp(acc0.im + acc1.im));
+      if (rg < 2 && j > k && j < n) td_put(xr, area + kTdRowBytes * (unsigned)j + 16 * (unsigned)rg, rg == 0 ? pj.re : pj.im, tag, near);
+    }
+    if (g != G - 1 && 16 * g + 15 == k + 1) return;                  // that was my workgroup's last column
+    // ---- the exchange: wavefront w polls the rows 64 w .. 64 w + 63 for the workgroup
+    const long long c1 = clock64();
+    c_pub += c1 - c0;
+    {
+      const int i = 64 * wid + lane;
+      const bool alive = i > k && i < n;
+      c64 pr = mk(0.0, 0.0), cr = pr;
+      if (__any(alive)) {                                            // (wave-uniform)
+        const long long t0 = (long long)wall_clock64();
+        int spins = 0;
+        const unsigned off = area + kTdRowBytes * (unsigned)i;
+        for (;;) {
+          asm volatile("" ::: "memory");
+          bool ok = true;
+          if (alive) {
+            const bool o0 = td_get(xr, off, tag, pr.re), o1 = td_get(xr, off + 16, tag, pr.im);
+            const bool o2 = td_get(xr, off + 32, tag, cr.re), o3 = td_get(xr, off + 48, tag, cr.im);
+            ok = o0 && o1 && o2 && o3;
+          }
+          if (__all(ok)) break;
+          if (give_up(t0, spins)) break;
+        }
+      }
+      sp[par][i] = pr;
+      sc[par][i] = cr;
+    }
+    __syncthreads();
+    if (s_abort) { if (threadIdx.x == 0 && info) info[0] = -3; return; }
+    c64 pi[4], ci[4];
+    bool live[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { pi[r] = sp[par][lane + 64 * r]; ci[r] = sc[par][lane + 64 * r]; live[r] = lane + 64 * r > k && lane + 64 * r < n; }
+    const long long c2 = clock64();
+    c_poll += c2 - c1;
+    double sr = 0.0, si = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const c64 t = mul_conj(vcur[r], pi[r]); sr += t.re; si += t.im; }   // conj(p_i) v_i  (dead rows: p_i = 0)
+    sr = wave_sum_dpp(sr); si = wave_sum_dpp(si);
+    const c64 a2 = mk(-0.5, 0.0) * (tau * mk(sr, si));               // -1/2 tau (p^H v)
+    const c64 wk1 = sp[par][k + 1] + a2;                             // (v_{k+1} = 1)
+    c64 cn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const c64 wi = live[r] ? pi[r] + a2 * vcur[r] : mk(0.0, 0.0);
+      sw[lane + 64 * r] = wi;
+      cn[r] = ci[r] - mul_conj(vcur[r], wk1) - wi;                   // column k+1 after the update (row k+1: its diagonal)
+    }
+    const double d_next = sc[par][k + 1].re - 2.0 * wk1.re;          // row k+1 of the updated column (v = 1, w = wk1): the next diagonal entry
+    if (k + 1 == n - 1) {
+      if (writer && lane == 0) { S.d[n - 1] = d_next; S.e[n - 1] = 0.0; }
+      break;
+    }
+    const c64 v2 = v[k + 2];                                         // row k+2 of it, formed by every lane (broadcast reads): the next alpha
+    const c64 alpha_next = sc[par][k + 2] - mul_conj(v2, wk1) - (sp[par][k + 2] + a2 * v2);
+    const c64 tau_next = derive(k + 1, cn, alpha_next, d_next);      // (overwrites vcur; the update below reads v_k from LDS)
+    const long long c3 = clock64();
+    c_vec += c3 - c2;
+    // ---- rank-2 update of my columns
+    if (j > k && j < n) {
+      const c64 wj = sw[j], vj = v[j];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int i = 16 * u + rg;
+        a[u] = a[u] - mul_conj(v[i], wj) - mul_conj(sw[i], vj);
+      }
+    }
+    tau = tau_next;
+    c_upd += clock64() - c3;
+  }
+  if (writer && lane == 0 && info) {
+    info[1] = (int)((clock64() - t_start) >> 6);
+    info[12] = (int)(c_pub >> 6); info[13] = (int)(c_poll >> 6); info[14] = (int)(c_vec >> 6); info[15] = (int)(c_upd >> 6);
   }
 }
 
@@ -2366,9 +2620,19 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
   }
 }
 
+// launches of eigh_tridiag_dist_kernel in this process: consecutive ones (of any context) go to consecutive XCDs, so that concurrent reductions of a
+// multi-context pipeline do not compete for the workgroup slots of one XCD (each needs its <= 16 workgroups resident together)
+static std::atomic<unsigned> td_launches{0};
+
 // Householder tridiagonalisation of H (order n >= 3) into ctx->eig_scratch, on stream st
 static int launch_tridiag(isac_ctx* ctx, const c64* d_H, int n, hipStream_t st, int* info) {
-  ISAC_TRY(ensure(ctx, ctx->eig_scratch, EighScratch::bytes(n)));
+  {
+    const void* before = ctx->eig_scratch.p;
+    const size_t cap_before = ctx->eig_scratch.cap;
+    ISAC_TRY(ensure(ctx, ctx->eig_scratch, EighScratch::bytes(n)));
+    if (ctx->eig_scratch.p != before || ctx->eig_scratch.cap != cap_before)                // fresh memory: the step stamps of eigh_tridiag_dist_kernel must not look like stamps of a later epoch
+      ISAC_HIP(hipMemsetAsync(ctx->eig_scratch.p, 0, ctx->eig_scratch.cap, st));
+  }
   void* gs = ctx->eig_scratch.p;
   const size_t lds1 = sizeof(c64) * 6 * (size_t)n + sizeof(double) * 32 + 64;
   if (n <= 64) {       // four waves, two barriers per step, matrix in LDS (the general kernel with its matrix in LDS: 222 us at n = 64; this one ~120)
@@ -2377,7 +2641,20 @@ static int launch_tridiag(isac_ctx* ctx, const c64* d_H, int n, hipStream_t st, 
     hipLaunchKernelGGL(eigh_tridiag_small_kernel, dim3(1), dim3(64 * kTriWaves), ldss, st, d_H, n, gs, info);
   } else {
     static const bool unfused = std::getenv("ISAC_EIG_TRIDIAG_UNFUSED") != nullptr;   // development switch: the two-pass zhetd2 kernel
-    if (unfused) hipLaunchKernelGGL(eigh_tridiag_kernel<false>, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
+    static const char* td_env = std::getenv("ISAC_EIG_TRIDIAG_DIST");   // development switch: "0" the one-workgroup kernels for every n; "far" write-through exchange at stride 8; "s1" stride 1
+    const bool td_off = td_env && td_env[0] == '0';
+    const int td_stride = td_env && td_env[0] == 's' ? std::max(1, std::atoi(td_env + 1)) : 8, td_far = td_env && td_env[0] == 'f';
+    const bool dist = n <= kTdMaxN && !unfused && !td_off;
+    if (dist) {
+      if (((++ctx->eig_epoch) & 0xFFFFF) == 0) {                                      // the 20-bit epoch of the tags wraps: start over from a clean area
+        ++ctx->eig_epoch;
+        ISAC_HIP(hipMemsetAsync(ctx->eig_scratch.p, 0, EighScratch::kXchBytes, st));
+      }
+      // every 8th workgroup of the grid works (the others return at once): the dispatcher deals workgroups round-robin to the 8 XCDs, so the working ones share
+      // an L2 and the exchange can stay in it -- verified by the kernel (XCC ids in its first exchange), never assumed
+      hipLaunchKernelGGL(eigh_tridiag_dist_kernel, dim3((unsigned)(((n + 15) / 16) * td_stride)), dim3(256), 0, st, d_H, n, gs, info,
+                         (unsigned)((ctx->eig_epoch & 0xFFFFF) << 12), td_stride, (int)(td_launches.fetch_add(1) % (unsigned)td_stride), td_far);
+    } else if (unfused) hipLaunchKernelGGL(eigh_tridiag_kernel<false>, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
     else {
       const size_t ldsf = sizeof(c64) * 7 * (size_t)n + sizeof(double) * 32 + 64;
       ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_tridiag_fused_kernel), ldsf));
