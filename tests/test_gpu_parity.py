@@ -367,6 +367,43 @@ def test_eigh_live_replay_timeout_is_recovered():
     assert r.returncode == 0 and "recovered" in r.stdout, r.stdout + r.stderr
 
 
+_TRIDIAG_SNIPPET = """
+import ctypes as C, hashlib, importlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module(%r)
+ctx = pkg._lib.Context(0)
+for a in (65, 97, 128, 200, 255, 256):
+    rng = np.random.default_rng(a)
+    m = rng.standard_normal((a, a)) + 1j * rng.standard_normal((a, a))
+    h = np.asfortranarray(m @ m.conj().T / a + np.diag(rng.uniform(0, 3, a)))
+    w = np.zeros(a); v = np.zeros((a, a), dtype=np.complex128, order="F")
+    for rep in range(3):                                   # (repeated launches: the exchange tags carry the launch epoch, nothing is reset in between)
+        ctx.check(ctx.lib.isac_eigh(ctx.handle, h.ctypes.data_as(C.c_void_p), C.c_int32(a), w.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
+        wr = np.linalg.eigvalsh(h)
+        assert np.abs(w - wr).max() < 1e-12 * np.abs(wr).max() and np.abs(h @ v - v * w).max() < 1e-11 * np.abs(wr).max(), (a, rep)
+    print("digest", a, hashlib.sha256(w.tobytes() + v.tobytes()).hexdigest())
+"""
+
+
+def test_distributed_tridiagonalisation_modes_agree():
+    """eigh_tridiag_dist_kernel (64 < n <= 256) under its development switches (read once per process, hence the subprocesses): the default (every working
+    workgroup on one XCD, exchange resident in its L2), write-through exchange on one XCD ("far"), workgroups dealt over all XCDs ("s1": the kernel sees
+    different XCC ids and uses the write-through stores by itself) -- the SAME bits, as placement must never change a result; the one-workgroup kernels
+    ("0") agree to rounding (checked against numpy.linalg in every mode)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mode in ("", "far", "s1", "0"):
+        env = dict(os.environ, ISAC_EIG_TRIDIAG_DIST=mode)
+        r = subprocess.run([sys.executable, "-c", _TRIDIAG_SNIPPET % (root, PKG_NAME)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[mode] = [ln for ln in r.stdout.splitlines() if ln.startswith("digest")]
+        assert len(out[mode]) == 6
+    assert out[""] == out["far"] == out["s1"]
+    assert out["0"] != out[""]                              # (the switch did switch)
+
+
 @pytest.mark.parametrize("kind,a", [("identity", 100), ("rank2", 130), ("diag_repeated", 96), ("tiny", 72), ("huge", 65),
                                     ("clustered", 200), ("tridiag_zero_blocks", 128),
                                     ("identity", 12), ("rank2", 40), ("tiny", 33), ("huge", 64), ("clustered", 48), ("zero", 20), ("zero", 80)])

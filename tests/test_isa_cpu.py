@@ -157,6 +157,20 @@ def test_one_pass_householder_kernel_budget(music_co):
     assert loads >= 4 and stores >= 4
 
 
+def test_distributed_householder_kernel_exchange_code(music_co):
+    """eigh_tridiag_dist_kernel: the matrix stays in registers (no scratch, one wave per SIMD), the exchange is tagged 16-byte granules -- write-through (sc1)
+    and L2-resident stores both present, every polling load sc1 (never served by the CU's L1) -- with no release / acquire fence anywhere (no L2 write-back or
+    L1 invalidate per reflector) and ONE workgroup barrier per reflector besides the two of the prologue."""
+    name, meta, asm = music_co.find("eigh_tridiag_dist_kernel")
+    assert meta["private_segment_fixed_size"] == 0 and meta["vgpr_count"] <= 256, meta
+    assert not any(ln.startswith(("buffer_wbl2", "buffer_inv")) for ln in asm)
+    st = [ln for ln in asm if ln.startswith("buffer_store_dwordx4")]
+    ld = [ln for ln in asm if ln.startswith("buffer_load_dwordx4")]
+    assert sum(" sc1" in ln for ln in st) >= 4 and sum(" sc1" not in ln for ln in st) >= 4, st
+    assert len(ld) >= 6 and all(" sc1" in ln for ln in ld), ld
+    assert sum(1 for ln in asm if ln.startswith("s_barrier")) <= 4
+
+
 def test_scratch_users_are_the_known_ones(echo_co, music_co):
     known = ("echo_range_kernelILi4E", "eigh_replay_kernel")       # spill a few registers by design (DESIGN.md 3c / 3b)
     for co in (echo_co, music_co):
