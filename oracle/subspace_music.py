@@ -97,6 +97,68 @@ def householder_tridiag_one_pass(h):
     return d, e, v_all, tau
 
 
+def householder_tridiag_distributed(h, cols_per_owner=4):
+    """The same reduction the way eigh_tridiag_dist_kernel (csrc/music.hip, 64 < n <= 256) distributes it: the matrix is held COLUMN-wise by owners of
+    `cols_per_owner` columns each (full columns, both triangles); per reflector every owner forms its entries of p from its own columns only
+    (p_j = tau sum_i conj(a_ij) v_i -- the matrix is Hermitian, no row access), ONE exchange makes p and the next column (as the owner holds it, the
+    current update not yet applied) known to everybody, and everybody derives w, the updated next column and the next reflector redundantly before
+    updating its own columns.  zlarfg uses two reciprocals (1 / beta, 1 / |alpha - beta|^2) instead of four divisions.  Returns what
+    householder_tridiag returns."""
+    a = np.array(h, dtype=np.complex128)
+    n = a.shape[0]
+    d = np.zeros(n)
+    e = np.zeros(max(n - 1, 0))
+    tau = np.zeros(max(n - 1, 0), dtype=np.complex128)
+    v_all = np.zeros((n, n), dtype=np.complex128)
+    owners = [range(c0, min(n, c0 + cols_per_owner)) for c0 in range(0, n, cols_per_owner)]
+
+    def derive(k, col):                                                # the reflector of step k from column k (rows >= k valid)
+        alpha = col[k + 1]
+        x = col[k + 2:]
+        xnorm2 = float(np.sum(x.real ** 2 + x.imag ** 2))
+        v = np.zeros(n, dtype=np.complex128)
+        v[k + 1] = 1.0
+        beta, t = alpha.real, 0.0
+        if xnorm2 != 0.0 or alpha.imag != 0.0:
+            beta = -np.copysign(np.sqrt(alpha.real ** 2 + alpha.imag ** 2 + xnorm2), alpha.real)
+            ib = 1.0 / beta
+            t = complex((beta - alpha.real) * ib, -alpha.imag * ib)
+            dl = alpha - beta
+            idn = 1.0 / (dl.real ** 2 + dl.imag ** 2)
+            v[k + 2:] = x * complex(dl.real * idn, -dl.imag * idn)
+        d[k] = col[k].real
+        e[k] = beta
+        tau[k] = t
+        v_all[:, k] = v
+        return v, t
+
+    if n < 2:
+        d[:] = a.diagonal().real
+        return d, e, v_all, tau
+    v, t = derive(0, a[:, 0].copy())
+    for k in range(n - 1):
+        p = np.zeros(n, dtype=np.complex128)                           # the exchange: p (each owner its columns) + column k + 1 as its owner holds it
+        for own in owners:
+            for j in own:
+                if j > k:
+                    p[j] = t * np.vdot(a[:, j], v)                     # sum_i conj(a_ij) v_i  (v is zero above row k + 1)
+        col = a[:, k + 1].copy()
+        a2 = -0.5 * t * np.vdot(p, v)                                  # everybody: w, the next column brought up to date
+        w = np.where(np.arange(n) > k, p + a2 * v, 0.0)
+        wk1 = p[k + 1] + a2
+        cn = col - v * np.conj(wk1) - w
+        if k + 1 == n - 1:
+            d[n - 1] = (col[k + 1] - 2.0 * wk1.real).real
+            break
+        v_next, t_next = derive(k + 1, cn)
+        for own in owners:                                             # rank-2 update of the owners' columns
+            for j in own:
+                if j > k:
+                    a[:, j] = a[:, j] - v * np.conj(w[j]) - w * np.conj(v[j])
+        v, t = v_next, t_next
+    return d, e, v_all, tau
+
+
 def sturm_count(d, e2, x, pivmin):
     """Number of eigenvalues of tridiag(d, e) below x (negative pivots of T - x I, dstebz-style pivmin clamp)."""
     cnt = 0

@@ -81,3 +81,23 @@ def test_one_pass_householder_equals_zhetd2(n):
     s = np.abs(h).max()
     assert np.abs(d0 - d1).max() < 1e-13 * s and np.abs(e0 - e1).max() < 1e-13 * s
     assert np.abs(t0 - t1).max() < 1e-13 and np.abs(v0 - v1).max() < 1e-12
+
+
+@pytest.mark.parametrize("n", [3, 8, 33, 65, 130, 256])
+def test_distributed_householder_equals_zhetd2(n):
+    """The column-owner walk of eigh_tridiag_dist_kernel (restated in oracle.subspace_music.householder_tridiag_distributed: p from the owners' columns
+    only, one exchange per reflector, the next column updated and the next reflector derived by everybody, two reciprocals in zlarfg) is zhetd2:
+    same d, e, tau and reflectors to rounding.  On the device the placement modes agree bit for bit and with numpy.linalg to 1e-12
+    (tests/test_gpu_parity.py::test_distributed_tridiagonalisation_modes_agree)."""
+    from oracle.subspace_music import householder_tridiag, householder_tridiag_distributed
+    rng = np.random.default_rng(n)
+    m = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    h = m @ m.conj().T / n + np.diag(rng.uniform(0, 3, n))
+    if n == 8:                                        # a column that needs no reflector (tau = 0) in the middle of the walk
+        h[4:, 2] = 0.0; h[2, 4:] = 0.0
+        h[3, 2] = h[2, 3] = 0.7
+    d0, e0, v0, t0 = householder_tridiag(h)
+    d1, e1, v1, t1 = householder_tridiag_distributed(h, cols_per_owner=4 if n > 8 else 3)
+    s = np.abs(h).max()
+    assert np.abs(d0 - d1).max() < 1e-12 * s and np.abs(e0 - e1).max() < 1e-12 * s
+    assert np.abs(t0 - t1).max() < 1e-12 and np.abs(v0 - v1).max() < 1e-11
