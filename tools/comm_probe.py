@@ -9,7 +9,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
-ap = argparse.ArgumentParser(); ap.add_argument("--ues", type=int, default=10); ap.add_argument("--reps", type=int, default=10)
+ap = argparse.ArgumentParser(); ap.add_argument("--ues", type=int, default=10); ap.add_argument("--reps", type=int, default=10); ap.add_argument("--batch-only", action="store_true", help="downlink batches only (kernel traces: nothing but the batched launches)")
 args = ap.parse_args()
 pkg = importlib.import_module(bench.PKG)
 CM = pkg.communication.channelModels
@@ -22,13 +22,13 @@ def timed(fn, reps=args.reps):
     for _ in range(reps):
         ctx.sync(); ctx.timer_start(); t0 = time.perf_counter(); fn(); w.append(1e3 * (time.perf_counter() - t0)); g.append(ctx.timer_stop_ms())
     return float(np.min(g)), float(np.median(g)), float(np.median(w))
-for name, txs, rxs in (("DL 64 -> 2", (4, 8, 2, 1, 1), (1, 1, 2, 1, 1)), ("UL 2 -> 64", (1, 1, 2, 1, 1), (4, 8, 2, 1, 1))):
+for name, txs, rxs in (("DL 64 -> 2", (4, 8, 2, 1, 1), (1, 1, 2, 1, 1)), ("UL 2 -> 64", (1, 1, 2, 1, 1), (4, 8, 2, 1, 1)))[:1 if args.batch_only else 2]:
     nt, nr = int(np.prod(txs)), int(np.prod(rxs))
     x = ctx.to_device(np.asfortranarray(rng.standard_normal((T, nt)) + 1j * rng.standard_normal((T, nt))))
     for prof in ("CDL-D", "CDL-A"):
         ch = CM.CDLChannel(DelayProfile=prof, TransmitAntennaArraySize=txs, ReceiveAntennaArraySize=rxs)
         n_paths = ch.path_delays().size
-        mn, med, wall = timed(lambda: CM.applyCDL(ch, x, ctx=ctx))
+        mn, med, wall = (0.0, 0.0, 0.0) if args.batch_only else timed(lambda: CM.applyCDL(ch, x, ctx=ctx))
         chans = [CM.CDLChannel(DelayProfile=prof, TransmitAntennaArraySize=txs, ReceiveAntennaArraySize=rxs) for _ in range(args.ues)]
         outs = [ctx.empty((T, nr)) for _ in chans]
         bmn, bmed, bwall = timed(lambda: CM.applyCDLBatch(chans, [x] * args.ues, ctx=ctx, outs=outs))
