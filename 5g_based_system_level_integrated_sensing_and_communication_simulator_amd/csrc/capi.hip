@@ -13,15 +13,15 @@ using namespace isac;
 int isac_rdm_power_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, const c64* d_rx, const c64* d_tx,
                           int K, int L, int A, int* nr_out, int* nc_out, bool use_cached_range);
 int isac_cfar_window(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cf, int nr, int nc, int A, int cap);
-int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st);
+int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st, bool live_replay = true);
 // status word the device eigensolver leaves behind the eigenvalues (ctx->eig_w [A] | info[0..5]): negative = the QL
 // recurrence ran out of rotation storage (-1) or a replay block gave up waiting (-2).  Call after the stream is idle.
 int isac_eigh_replay_recover(isac_ctx* ctx, int n, hipStream_t st);   // music.hip
-static int eig_status(isac_ctx* ctx, int A) {
+static int eig_status(isac_ctx* ctx, int A, bool ql_ran = true /* false: the signal-subspace kernel delivered, the QL pipeline returned at once */) {
   int sweeps = 0;
   ISAC_HIP(hipMemcpy(&sweeps, (const char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(int), hipMemcpyDeviceToHost));
   static const bool force = std::getenv("ISAC_EIG_FORCE_REPLAY_TIMEOUT") != nullptr;   // test hook: take the recovery path on every call ...
-  if (force && sweeps >= 0 && A > 16 && ctx->eig_scratch.p) {
+  if (force && ql_ran && sweeps >= 0 && A > 16 && ctx->eig_scratch.p) {
     ISAC_HIP(hipMemset(ctx->eig_v.p, 0xFF, sizeof(c64) * (size_t)A * A));               // ... with the eigenvectors destroyed first
     sweeps = -2;
   }
@@ -32,6 +32,7 @@ static int eig_status(isac_ctx* ctx, int A) {
   }
   if (sweeps < 0) return isac::fail(ctx, ISAC_ERR_HIP, sweeps == -1 ? "eigensolver: QL recurrence exceeded its rotation storage (no convergence)"
                                                      : sweeps == -3 ? "eigensolver: the signal-subspace vectors are not finite (NaN / Inf in the covariance)"
+                                                     : sweeps == -4 ? "eigensolver: the distributed tridiagonalisation saw no progress for 2 s (its workgroups were not resident together)"
                                                                      : "eigensolver: a replay block timed out waiting for the recurrence");
   return ISAC_OK;
 }
@@ -568,7 +569,7 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
   auto eig_first_half = [&]() -> int {                                                           // music.m:19
     if (upa) return ISAC_OK;
     if (sub) return isac_music_tridiag_bisect_dev(ctx, (const c64*)ctx->cov.p, A, s2);           // reflectors + eigenvalues: independent of numDets
-    return isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, s2);
+    return isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, s2, /*live_replay=*/false);   // (collect cannot run the replay time-out recovery before the scan)
   };
   // (wide order: the many-workgroup narrow kernels -- Doppler, CFAR panels, merge -- first, while the next CPI's beam-sum holds the main stream and
   // leaves registers free; the one-workgroup eigensolver kernels then sit under the next fused kernel, where they cost one CU each)
@@ -653,7 +654,7 @@ extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
   const int* hdr = (const int*)h;
   const int total = hdr[0];
   const int num_dets_dev = hdr[1];
-  if (hdr[2] & 2) return fail(ctx, ISAC_ERR_HIP, "eigensolver did not finish (non-finite covariance, rotation storage exceeded or a replay block timed out)");
+  if (hdr[2] & 2) return fail(ctx, ISAC_ERR_HIP, "eigensolver did not finish (non-finite covariance, rotation storage exceeded, or an in-launch exchange of the eigensolver timed out)");
   if (hdr[2] & 1) return fail(ctx, ISAC_ERR_CAPACITY, "an antenna produced more CFAR detections than the per-antenna capacity (256 MB of scratch / 12 B / antennas)");
   std::vector<int> cut((size_t)total);
   std::vector<double> pw((size_t)total);
@@ -894,7 +895,7 @@ extern "C" int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_
   int ctl[2] = {0, 0};
   ISAC_HIP(hipMemcpyAsync(ctl, isac_music_ctl(ctx), sizeof(ctl), hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
-  ISAC_TRY(eig_status(ctx, A));
+  ISAC_TRY(eig_status(ctx, A, ctl[0] != 1));
   if (std::getenv("ISAC_DEBUG")) {
     int inf[15] = {0};
     ISAC_HIP(hipMemcpy(inf, (char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(inf), hipMemcpyDeviceToHost));

@@ -1376,7 +1376,7 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_fused_kernel(const c64* __r
 // no fence, no reset between launches; the consumer re-reads the 64 bytes of each of its rows (p_i and the next column's entry) with sc1 loads until
 // all tags match.  Two parities of the area alternate: a wavefront can overwrite parity k & 1 at step k + 2 only after it has consumed every other
 // wavefront's step k + 1, which they publish after reading step k.  A wavefront returns after the step that consumed its last column; a poll that
-// sees no progress for ~2 s gives up with info[0] = -3.
+// sees no progress for ~2 s gives up with info[0] = -4.
 //   History (n = 256, profiles/r04_tridiag_dist.txt): 16 workgroups of 256 threads, agent-scope atomics + one step stamp per workgroup behind
 // s_waitcnt 1.0 ms (with __threadfence() instead 2.8 ms); tagged granules 0.9 ms -- 58 % of it the O(n) vector work, a chain of ~550 dependent
 // instructions through two workgroup-wide sums per reflector; this form: the sums stay inside the wavefront (DPP), four independent rows per lane.
@@ -1456,7 +1456,7 @@ __global__ __launch_bounds__(256) void eigh_tridiag_dist_kernel(const c64* __res
     }
     for (int o = 32; o > 0; o >>= 1) t = fmax(t, __shfl_xor(t, o));
     __syncthreads();
-    if (s_abort) { if (threadIdx.x == 0 && info) info[0] = -3; return; }
+    if (s_abort) { if (threadIdx.x == 0 && info) info[0] = -4; return; }
     if (t > 0.0 && t < 1.7976931348623157e308) {                     // (eigh_safe_scale's rule)
       const int ex = ilogb(t);
       if (ex < -400 || ex > 400) scl = ldexp(1.0, -ex);
@@ -1562,7 +1562,7 @@ __global__ __launch_bounds__(256) void eigh_tridiag_dist_kernel(const c64* __res
       sc[par][i] = cr;
     }
     __syncthreads();
-    if (s_abort) { if (threadIdx.x == 0 && info) info[0] = -3; return; }
+    if (s_abort) { if (threadIdx.x == 0 && info) info[0] = -4; return; }
     c64 pi[4], ci[4];
     bool live[4];
 #pragma unroll
@@ -2683,7 +2683,7 @@ static int launch_replay_offline(isac_ctx* ctx, int n, hipStream_t st, int* info
   return ISAC_OK;
 }
 
-static int launch_ql(isac_ctx* ctx, int n, hipStream_t st, int* info, const int* ctl) {
+static int launch_ql(isac_ctx* ctx, int n, hipStream_t st, int* info, const int* ctl, bool allow_live = true) {
   void* gs = ctx->eig_scratch.p;
   // (forcing the zungtr block and the lone recurrence wavefront onto different CUs with an oversized LDS request made no
   // difference to the recurrence -- 345 vs 350 cycles per rotation at the time -- and cost CU capacity in pipelined runs)
@@ -2697,7 +2697,7 @@ static int launch_ql(isac_ctx* ctx, int n, hipStream_t st, int* info, const int*
   // Replay blocks ride along with zungtr and the recurrence (they spin on flags of the same launch: co-resident workgroups are a speed
   // assumption, a bounded spin turns a violation into an error) -- except when this is the in-stream fallback of the subspace route
   // (ctl != null): there the replay is its own launch behind the recurrence, so the rare large-numDets CPI cannot fail on a spin time-out
-  const bool live = lds_replay && !no_overlap && ctl == nullptr;
+  const bool live = lds_replay && !no_overlap && ctl == nullptr && allow_live;
   const int n_replay = (2 * n + bt - 1) / bt;
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(eigh_formq_ql_kernel), (size_t)(160 * 1024)));
   // (as the in-stream fallback it almost always returns at its first instruction: 256 threads then -- a 1024-thread workgroup of ~110 VGPRs needs a
@@ -2766,7 +2766,9 @@ int isac_music_subspace_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num
 const int* isac_music_ctl(isac_ctx* ctx) { return music_ctl(ctx); }
 
 // device eig: H [A x A] (device) -> ctx->eig_w [A], ctx->eig_v [A x A] (unsorted)
-int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
+// live_replay = false: the recorded rotations are applied by a launch of their own behind the recurrence instead of by blocks that spin on its progress inside the
+// same launch -- for callers that cannot run the time-out recovery (isac_eigh_replay_recover) before the result is consumed on the device: the fft2D pipeline
+int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st, bool live_replay) {
   if (!st) st = ctx->stream;
   if (A > 1024) return fail(ctx, ISAC_ERR_UNSUPPORTED, "device eigensolver supports up to 1024 antennas");
   // measured host-call times (tools/_eig_sizes.py): Jacobi 0.10 / 0.16 / 0.26 / 0.35 / 0.78 / 1.41 ms at A = 8 / 16 / 24 / 32 / 48 /
@@ -2782,7 +2784,7 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st) {
   static const bool force_ql = std::getenv("ISAC_EIG_QL") != nullptr;             // development switch: A <= 64 through the pipeline
   if (A >= 3 && (big || force_ql)) {
     ISAC_TRY(launch_tridiag(ctx, d_H, A, st, info));
-    return launch_ql(ctx, A, st, info, nullptr);
+    return launch_ql(ctx, A, st, info, nullptr, live_replay);
   }
   const int n = (A + 1) & ~1;
   size_t lds = sizeof(c64) * ((size_t)2 * n * n + n / 2) + sizeof(double) * (n / 2) + sizeof(int) * (n + 1) + 64;
