@@ -87,6 +87,7 @@ for name, label in (("bench_driver_invocation.json", "driver invocation (`--gpus
                     ("bench_blocking_full_eig.json", "`--inflight 1`, full eigendecomposition route (`ISAC_MUSIC_FULL_EIG=1`: the round-2 eigensolver)"),
                     ("bench_default_100steps_old_cfar.json", "100 steps, per-antenna CFAR + memset + count (`ISAC_TAIL_UNFUSED=1`)"),
                     ("bench_7cells_per_gpu.json", "7 cells per GPU"), ("bench_a256.json", "`--ants 256 --inflight 3`"),
+                    ("bench_a256_inflight6.json", "`--ants 256 --inflight 6`"),
                     ("bench_a256_blocking.json", "`--ants 256 --inflight 1`"), ("bench_a16.json", "`--ants 16`"), ("bench_traced_pipelined.json", "under rocprofv3, 300 steps, `--trace-only`")):
     d = jline(name)
     if d:
@@ -115,4 +116,21 @@ for name in ("pipeline_overlap.txt", "pipeline_gaps.txt"):
     if os.path.exists(f):
         lines = open(f).read().splitlines()
         out.append(f"* `{tag}_{name}`: " + " | ".join(lines[:2]))
+a256 = rows("kernel_stats_single_stream_a256.csv")
+if a256:
+    out.append(f"* A = 256 single-stream kernel trace (`{tag}_kernel_stats_single_stream_a256.csv`): " + "; ".join(f"`{short(r['kernel'])}` {float(r['avg_us']):.1f} us x {r['calls']} ({float(r['pct']):.1f} %)" for r in a256[:6]) + ".")
+f = os.path.join(P, f"{tag}_tridiag_dist_probe.txt")
+if os.path.exists(f):
+    ln = [l for l in open(f).read().splitlines() if "distributed tridiagonalisation" in l]
+    if ln:
+        out.append(f"* `{tag}_tridiag_dist_probe.txt` (n = 256, in-kernel clocks of the last wavefront): " + ln[-1].split("phases(x64 clk): ")[-1] + ".")
 print("\n".join(out))
+# the generated block of profiles/README.md is replaced in place (from its title line to the next "---")
+readme = os.path.join(P, "README.md")
+if os.path.exists(readme) and "--no-write" not in sys.argv:
+    txt = open(readme).read()
+    title = f"Headline readings (generated: `python tools/profiles_readme.py {tag}`)"
+    if title in txt:
+        a = txt.index(title)
+        b = txt.index("\n---", a)
+        open(readme, "w").write(txt[:a] + title + "\n" + "\n".join(out) + "\n" + txt[b:])

@@ -22,6 +22,7 @@ $B --no-cpu-baseline --inflight 1 2>/dev/null | tail -1 > $OUT/${TAG}_bench_bloc
 $B --no-cpu-baseline --cells-per-gpu 7 --steps 20 --warmup 3 2>/dev/null | tail -1 > $OUT/${TAG}_bench_7cells_per_gpu.json
 $B --no-cpu-baseline --ants 256 --inflight 1 --steps 5 --warmup 1 2>/dev/null | tail -1 > $OUT/${TAG}_bench_a256_blocking.json
 $B --no-cpu-baseline --ants 256 --inflight 3 --steps 12 --warmup 3 2>/dev/null | tail -1 > $OUT/${TAG}_bench_a256.json
+$B --no-cpu-baseline --ants 256 --inflight 6 --steps 24 --warmup 6 2>/dev/null | tail -1 > $OUT/${TAG}_bench_a256_inflight6.json
 $B --no-cpu-baseline --ants 16 2>/dev/null | tail -1 > $OUT/${TAG}_bench_a16.json
 ISAC_MUSIC_FULL_EIG=1 $B --no-cpu-baseline --inflight 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/${TAG}_bench_blocking_full_eig.json
 $B --no-cpu-baseline --schedule ordered 2>/dev/null | tail -1 > $OUT/${TAG}_bench_default_100steps_ordered.json
@@ -68,4 +69,5 @@ $ROOT/tests/_build/abi_host time 64 3 2>/dev/null | tail -1 > $OUT/${TAG}_abi_ho
 rm -rf /tmp/p9 && rocprofv3 --kernel-trace --stats -d /tmp/p9 -- $B --workload config5 --steps 1 --warmup 1 > /dev/null 2>&1
 $PS $(db /tmp/p9) --csv $OUT/${TAG}_kernel_stats_config5.csv > $OUT/${TAG}_kernel_stats_config5.txt
 python $ROOT/tools/cov_probe.py 2>/dev/null | grep -v amdgpu.ids > $OUT/${TAG}_cov_probe.txt; python $ROOT/tools/cov_probe.py --ants 256 --reps 10 2>/dev/null | grep -v amdgpu.ids >> $OUT/${TAG}_cov_probe.txt
+(cd $ROOT && bash tools/tridiag_dist_probe.sh > /dev/null 2>&1; cp gpurun_out/tridiag_dist_probe.txt $OUT/${TAG}_tridiag_dist_probe.txt)
 ls -la $OUT
