@@ -148,6 +148,18 @@ def test_covariance_staged_kernel_is_pipelined_inside_the_wave(music_co):
         assert any(asm[j].startswith("v_mfma") for j in range(i - 3, i)) and any(asm[j].startswith("v_mfma") for j in range(i + 1, i + 4)), asm[i - 3:i + 4]
 
 
+def test_covariance_block_kernel_is_pipelined_inside_the_wave(music_co):
+    """cov_mfma_block_pl_kernel (A > 64): no scratch, <= 256 registers (two workgroups per CU), and the operand reads / staging writes / staging loads of a unit
+    sit in the gaps of its MFMA stream -- at most a handful of instructions between two MFMAs except at the unit / diagonal-vs-off-diagonal seams."""
+    name, meta, asm = music_co.find("cov_mfma_block_pl_kernel")
+    assert meta["private_segment_fixed_size"] == 0 and meta["vgpr_count"] <= 256, meta
+    mf = [i for i, ln in enumerate(asm) if ln.startswith("v_mfma_f64_16x16x4")]
+    assert len(mf) >= 200
+    gaps = [b - a - 1 for a, b in zip(mf, mf[1:])]
+    assert sum(1 for g in gaps if g <= 4) >= 0.9 * len(gaps), sorted(gaps)[-12:]
+    assert sum(1 for g in gaps if g > 16) <= 2, sorted(gaps)[-6:]       # (the two code paths: diagonal and off-diagonal block pairs)
+
+
 def test_one_pass_householder_kernel_budget(music_co):
     """1024-thread workgroup: 128 VGPRs is all a wave gets; the fused pass keeps four matrix loads in flight per thread (eight spilled)."""
     name, meta, asm = music_co.find("eigh_tridiag_fused_kernel")
