@@ -1,5 +1,5 @@
-// Development micro-benchmark (not part of the product): HBM WRITE rate of a streaming kernel -- what bounds echo_range_sl_kernel, which writes 1.50 GB per
-// launch (the receive grid and the range-transformed grids, 16 B per lane, 52 KB contiguous per (symbol, antenna) column) and reads 0.19 GB.
+// Development micro-benchmark (not part of the product): HBM WRITE rate of a streaming kernel, beside tools/gbench.hip's read rate -- echo_range_sl_kernel reads
+// 0.83 GB (transmit grid, D columns) and writes 0.83 GB (receive grid, range rows) per launch, 16 B per lane, 52 KB contiguous per (symbol, antenna) column.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wbench.hip -o tools/wbench && tools/wbench
 // Each workgroup writes `chunk` contiguous bytes per trip (256 threads x 16 B x UNROLL), trips interleaved over the workgroups; MODE 0 plain stores, 1 nontemporal,
 // 2 plain stores + a streaming read of 1/8 of the bytes (the echo kernel's read share).
@@ -44,7 +44,7 @@ int run(c64* out, const c64* in, long long n, int n_wg, const char* what) {
   return 0;
 }
 int main() {
-  const long long n = 3276ll * 224 * 64 * 2;            // 1.503 GB: the echo kernel's two output sets at A = 64
+  const long long n = 3276ll * 224 * 64 * 2;            // 1.503 GB = the echo kernel's algorithmic bytes at A = 64
   c64 *out, *in;
   CK(hipMalloc(&out, sizeof(c64) * n)); CK(hipMalloc(&in, sizeof(c64) * n)); CK(hipMemset(in, 0, sizeof(c64) * n));
   for (int wg : {512, 1024, 2048, 4096}) {
