@@ -23,6 +23,7 @@ committed PMC passes (profiles/rNN_pmc_*.csv).  `cpu_baseline` is the un-tuned C
 from __future__ import annotations
 
 import argparse
+import gc
 import ctypes as C
 import importlib
 import json
@@ -724,6 +725,11 @@ def main():
     # tens of milliseconds below its sustained clocks -- 20 timed steps behind 5 warm-up steps measured 35 % under the
     # steady-state rate, behind 100 warm-up steps they measure the steady state (profiles/r02_warmup_sensitivity.txt).  The
     # timed region below is still exactly K steps of the full hot path between two barriers.
+    # (the host interpreter's collector is switched off from here to the end of the timed region: a pause inside 16 ms of timed steps would be the
+    #  measurement, and a collection BETWEEN warm-up and the timed steps idles the GPU long enough for its clocks to drop: 18.2 k instead of 19.5-20.3 k)
+    if os.environ.get("ISAC_BENCH_GC", "off") == "off":
+        gc.collect()
+        gc.disable()
     prime_steps, t_prime = 0, time.perf_counter()
     stamps, unpaced_ms = [], None                            # auto pacing: un-paced period over the last CPIs before 60 % of the priming phase
     n_win = max(3 * args.inflight, 16)                       # (the first tens of ms run at low clocks and hold the first-call allocations)
@@ -780,6 +786,7 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     # one line per rank on stderr: which device it ran on, how many cells it held, its own timed region (the first multi-GPU run must be diagnosable)
     os.write(2, (f"bench.py: rank {rank}/{world}: device {local_rank} ({torch.cuda.get_device_name(local_rank) if torch.cuda.is_available() else 'no GPU'}), "
                  f"{len(cells)} cell(s) {my_cells}, timed region {1e3 * dt:.3f} ms for {args.steps} step(s), backend {dist.get_backend() if dist is not None else 'none'}\n").encode())   # (one write: lines of different ranks do not interleave)
