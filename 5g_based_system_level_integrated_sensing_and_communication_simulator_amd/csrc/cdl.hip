@@ -230,6 +230,82 @@ __global__ __launch_bounds__(256) void cdl_fir_kernel(const CdlSeg* __restrict__
   if (t < sg.o1) (UL ? sg.C : sg.Y)[t + ld_out * (long long)oc] = acc * scale;
 }
 
+// The same filters with FOUR consecutive outputs per thread (n_taps = 16, the model's filter length).  cdl_fir_kernel reads one 16-byte window sample from LDS
+// per tap and output -- 16 x n_paths ds_read_b128 per output: at 13-23 paths the LDS pipe, not HBM, sets its time (the Z columns stream at 3.5 TB/s).  Here a
+// thread keeps the 19 window samples of its four outputs in registers (4.75 reads per output) and applies the taps from scalar registers; the additions of an
+// output run in the same order (terms ascending, taps ascending): same bits.  Measured (profiles/r04_negative_results.txt): 62.7 -> 58.7 us per launch mix --
+// the kernel turned out to be bound by its Z reads (with the tap arithmetic and the LDS reads REMOVED it still takes 90 of 95 us = 4.2 TB/s on Z that the
+// contraction has just written, 10 loads per thread in flight), not by LDS: kept for the 6 %, the downlink only.  One workgroup = 1024 consecutive outputs of one column; window index s lives at
+// s ^ ((s >> 4) & 3): with lane i reading sample 4 i + m every ds_read_b128 touches each bank once (plain layout: 16-way conflicts -- bank model of the guide).
+template <bool UL>
+__global__ __launch_bounds__(256) void cdl_fir4_kernel(const CdlSeg* __restrict__ segs, long long ld_in, long long ld_out, int Nt, int Nr, int n_paths,
+                                                       const double* __restrict__ taps, const int* __restrict__ shift, double scale) {
+  constexpr int NTAPS = 16, R = 4, W = 256 * R, WIN = W + 64;
+  __shared__ __attribute__((aligned(16))) c64 s_win[2][WIN];
+  const CdlSeg sg = segs[blockIdx.z];
+  const long long t0 = sg.o0 + (long long)blockIdx.x * W;
+  if (t0 >= sg.o1) return;                                            // (uniform)
+  const int tid = threadIdx.x;
+  const int oc = blockIdx.y;                                          // DL: receive antenna u;  UL: filtered signal n Nt + s
+  const c64* in = UL ? sg.A : sg.C;
+  const int n_terms = UL ? 1 : n_paths;
+  auto swz = [](int s_) { return s_ ^ ((s_ >> 4) & 3); };
+  auto term_n = [&](int j) { return UL ? oc / Nt : j; };
+  // window of term j: rows base_j .. base_j + W + 14, base_j = t0 - shift - 15; thread tid fetches rows base_j + tid + 256 q (q = 0..3) and (tid < 15) row base_j + W + tid
+  auto fetch = [&](int j, c64 (&v)[R + 1]) {
+    const int n = term_n(j);
+    const c64* col = in + ld_in * (long long)(UL ? oc % Nt : n * Nr + oc);
+    const long long base = t0 - shift[n] - (NTAPS - 1);
+#pragma unroll
+    for (int q = 0; q <= R; ++q) {
+      const long long i = base + 256 * q + tid;
+      const long long cl = i < 0 ? 0 : (i < ld_in ? i : ld_in - 1);
+      const c64 a = col[cl];                                          // unconditional load (clamped), select afterwards
+      v[q] = i >= 0 ? a : mk(0.0, 0.0);
+    }
+  };
+  c64 acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = mk(0.0, 0.0);
+  // two register sets: while term j is consumed, the windows of terms j + 1 AND j + 2 are in flight (one term ahead the loads return while their consumer
+  // already waits: the filter then streams Z at the rate of the one-output kernel, 3.6 TB/s, whatever the LDS traffic)
+  c64 vs[2][R + 1];
+  fetch(0, vs[0]);
+  if (n_terms > 1) fetch(1, vs[1]);
+  auto term = [&](auto par_c, int j) __attribute__((always_inline)) {
+    constexpr int PAR = decltype(par_c)::value;
+    c64 (&v)[R + 1] = vs[PAR];
+    c64* w = s_win[PAR];
+#pragma unroll
+    for (int q = 0; q < R; ++q) w[swz(tid + 256 * q)] = v[q];
+    if (tid < NTAPS - 1) w[swz(W + tid)] = v[R];
+    if (j + 2 < n_terms) fetch(j + 2, v);
+    __syncthreads();                                                  // (one barrier per term: this buffer was last read two terms ago)
+    const double* g = taps + term_n(j) * NTAPS;
+    c64 x[NTAPS + R - 1];
+#pragma unroll
+    for (int m = 0; m < NTAPS + R - 1; ++m) x[m] = w[swz(R * tid + m)];
+    // output r = row t0 + 4 tid + r needs rows .. - shift - k  <->  window index 4 tid + r + 15 - k
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < NTAPS; ++k) {
+        acc[r].re = ::fma(g[k], x[r + NTAPS - 1 - k].re, acc[r].re);
+        acc[r].im = ::fma(g[k], x[r + NTAPS - 1 - k].im, acc[r].im);
+      }
+  };
+  for (int j = 0; j < n_terms; j += 2) {
+    term(std::integral_constant<int, 0>{}, j);
+    if (j + 1 < n_terms) term(std::integral_constant<int, 1>{}, j + 1);
+  }
+  c64* out = (UL ? sg.C : sg.Y) + ld_out * (long long)oc;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const long long t = t0 + R * tid + r;
+    if (t < sg.o1) out[t] = acc[r] * scale;
+  }
+}
+
 // H[snap][n][s][u] = sum_m base[n][m][s][u] exp(j rate[n][m] t_snap) (+ los[s][u] exp(j los_rate t_snap) on path 0): the sample-and-hold path gains
 // of TR 38.901 eq. 7.5-22 / 7.5-29 from the time-independent per-ray terms (the Python mirror's CDLChannel._static()).
 __global__ __launch_bounds__(256) void cdl_path_gains_kernel(const c64* __restrict__ base, const double* __restrict__ rate, int n_paths, int n_rays, int nsu,
@@ -358,9 +434,13 @@ int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long lon
   char* dm = (char*)ctx->stage_c.p;
   ISAC_TRY(stage_upload(ctx, dm, host.data(), meta));
   const CdlSeg* d_segs = (const CdlSeg*)dm;
+  static const bool fir1 = std::getenv("ISAC_CDL_FIR1") != nullptr;     // development switch: the one-output-per-thread filter kernel for every tap count
+  const bool fir4 = n_taps == 16 && !fir1;
   const double* d_taps = (const double*)(dm + seg_bytes);
   const int* d_shift = (const int*)(dm + seg_bytes + tap_bytes);
   if (ul) {
+    // (the uplink prefilter is ONE term per output column: nothing to pipeline across terms, the one-output kernel's 4x finer grid hides the latency better --
+    //  cdl_fir4_kernel<true> measured 71 vs 54 us)
     hipLaunchKernelGGL(cdl_fir_kernel<true>, dim3((unsigned)cdiv(T, 256), (unsigned)Kc, (unsigned)n_jobs), dim3(256), 0, ctx->stream, d_segs + n_gemm, (long long)T,
                        (long long)T, Nt, Nr, n_paths, n_taps, d_taps, d_shift, 1.0);
     ISAC_HIP(hipGetLastError());
@@ -375,8 +455,10 @@ int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long lon
   long long max_out = 0;
   for (size_t i = 0; i < n_gemm; ++i) max_out = std::max(max_out, segs[i].o1 - segs[i].o0);
   if (max_out > 0) {
-    hipLaunchKernelGGL(cdl_fir_kernel<false>, dim3((unsigned)cdiv(max_out, 256), (unsigned)Nr, (unsigned)n_gemm), dim3(256), 0, ctx->stream, d_segs, (long long)T,
-                       (long long)T, Nt, Nr, n_paths, n_taps, d_taps, d_shift, out_scale);
+    if (fir4) hipLaunchKernelGGL(cdl_fir4_kernel<false>, dim3((unsigned)cdiv(max_out, 1024), (unsigned)Nr, (unsigned)n_gemm), dim3(256), 0, ctx->stream, d_segs, (long long)T,
+                                 (long long)T, Nt, Nr, n_paths, d_taps, d_shift, out_scale);
+    else hipLaunchKernelGGL(cdl_fir_kernel<false>, dim3((unsigned)cdiv(max_out, 256), (unsigned)Nr, (unsigned)n_gemm), dim3(256), 0, ctx->stream, d_segs, (long long)T,
+                            (long long)T, Nt, Nr, n_paths, n_taps, d_taps, d_shift, out_scale);
     ISAC_HIP(hipGetLastError());
   }
   return ISAC_OK;

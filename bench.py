@@ -370,7 +370,7 @@ class CommCell:
             c_.sync()
         ctx_csi.sync()
 
-    SLOTS_PER_CALL = 4
+    SLOTS_PER_CALL = int(os.environ.get("ISAC_C5_SLOTS_PER_CALL", "8"))   # slots of the frame per library call (1 / 2 / 4 / 8 / 16: 137 / 131.6 / 125-127 / 121-123 / 122-123 ms per frame)
 
     def enqueue_frame(self):
         """All downlink slots of the frame through every UE's channel: one library call per delay profile and SLOTS_PER_CALL consecutive slots (every UE of

@@ -568,6 +568,39 @@ def test_cdl_batch_apply_matches_oracle(pkg, ctx, profile, tx_size, rx_size):
     assert chans[2].time == pytest.approx(t_now + 2 * t_len / fs)
 
 
+_CDL_FIR_SNIPPET = """
+import hashlib, importlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module(%r)
+ctx = pkg._lib.Context(0)
+CM = pkg.communication.channelModels
+fs, t_len = 15.36e6, 5003
+for profile, tx, rx in (("CDL-D", (4, 8, 2, 1, 1), (1, 1, 2, 1, 1)), ("CDL-A", (2, 4, 2, 1, 1), (1, 1, 2, 1, 1)), ("CDL-A", (1, 1, 2, 1, 1), (2, 4, 2, 1, 1))):
+    nt = int(np.prod(tx))
+    rng = np.random.default_rng(nt)
+    xs = [ctx.to_device(np.asfortranarray(rng.standard_normal((t_len, nt)) + 1j * rng.standard_normal((t_len, nt)))) for _ in range(2)]
+    chans = [CM.CDLChannel(profile, 300e-9, 3.5e9, tx, rx, fs, Seed=70 + u) for u in range(4)]
+    chans[3].time = 1.0 / 640 - 2000 / fs                # one job crosses a path-gain refresh: two segments with their own output rows
+    outs = CM.applyCDLBatch(chans, [xs[0], xs[0], xs[1], xs[1]], ctx=ctx)
+    print("digest", profile, nt, hashlib.sha256(b"".join(o.numpy().tobytes() for o in outs)).hexdigest())
+"""
+
+
+def test_cdl_delay_filter_forms_same_bits():
+    """cdl_fir4_kernel (four outputs per thread, window samples in registers; the model's 16-tap filters) against cdl_fir_kernel (ISAC_CDL_FIR1, read once per
+    process, hence the subprocesses): downlink contract-then-filter and uplink filter-then-contract, ragged lengths, a job split at a path-gain refresh -- the
+    additions of every output run in the same order: the same bits."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for extra in ({}, {"ISAC_CDL_FIR1": "1"}):
+        r = subprocess.run([sys.executable, "-c", _CDL_FIR_SNIPPET % (root, PKG_NAME)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")])
+    assert len(out[0]) == 3 and out[0] == out[1]
+
+
 # ------------------------------------------------------------------ SINR -> CQI
 @pytest.mark.parametrize("nr,p,nl", [(2, 4, 1), (2, 4, 2), (4, 8, 4), (8, 32, 8)])
 def test_precoded_sinr_and_cqi(pkg, ctx, nr, p, nl):
