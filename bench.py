@@ -44,6 +44,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "5g_based_system_level_integrated_sensing_and_communication_simulator_amd"
 
+COPY_RATE_GBS = 5450.0          # what a plain device-to-device copy of the dominant kernel's bytes reaches on an MI355X (profiles/r04_wbench_write_rate.txt)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix (= vector) dense peak
 DOMINANT_KERNEL = "echo_range_"          # echo_range_sl_kernel<Q, NZ> (one / two LoS targets) or echo_range_kernel<Q, NZ>
@@ -471,7 +472,7 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
                                   f"({CommCell.DL_SLOTS * args.ues} applies), {CommCell.CSI_OCCASIONS} CSI reports per UE (Type-I PMI search + subband CQI, 546 CSI-RS REs x 32 entries)",
                       "parallelism": f"cells sharded over {world} GPU(s)"},
            "per_frame_and_rank": {"cells": len(mine), "cdl_applies": n_applies, "csi_reports": len(mine) * args.ues * CommCell.CSI_OCCASIONS, "sensing_cpis": len(mine)},
-           "roofline": {"bound": "mfma", "kernel": "cdl_gemm_kernel<3,false> (DL contraction of a batch: X [T x Nt] against the path gains of n UEs, 3M form on v_mfma_f64_16x16x4_f64)",
+           "roofline": {"bound": "mfma", "kernel": "cdl_gemm_kernel<NCT,false> (DL contraction of a batch: X [T x Nt] against the path gains of n UEs, 3M form on v_mfma_f64_16x16x4_f64)",
                         "achieved": round(flops / 1e12 / (ms_k / 1e3), 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / 1e12 / (ms_k / 1e3) / FP64_MFMA_PEAK_TFLOPS, 4),
                         "traffic": None, "avg_launch_ms": round(ms_k, 4), "launches_averaged": 10, "jobs_per_launch": n_jobs, "paths": n_paths,
                         "issued_flops_per_launch": flops, "flops_note": "3 real MFMAs x 2 flops per complex multiply-add, padded to 16-column tiles: 6 T cols Nt per job",
@@ -617,6 +618,10 @@ def roofline_entry(cell, args, ms_timed, ms_iso, n_launches, stages, cpi_bytes, 
                       "device to itself (10 launches right after the timed region; this is what rocprofv3 reports for the single-stream run, "
                       "profiles/rNN_kernel_stats_single_stream.csv), `..._in_timed_region` with the other in-flight CPIs' kernels sharing the GPU",
             "algorithmic_bytes_per_launch": nb, "algorithmic_bytes_note": "txGrid read once + echoGrid written once = 2 K L A 16 B; echoGrid is not re-read by the range stage",
+            # the same bytes moved by a plain copy kernel / hipMemcpyAsync on this part (1 : 1 read / write mix): measured 5.35-5.53 TB/s, tools/wbench.hip
+            "copy_rate_reference": {"GBps": COPY_RATE_GBS, "frac_of_copy_rate": round(nb / 1e9 / (ms / 1e3) / COPY_RATE_GBS, 4),
+                                    "source": "profiles/r04_wbench_write_rate.txt: copying 0.75 GB -> 0.75 GB takes 272-281 us (hipMemcpyAsync device to device 281 us); "
+                                              "`frac` above prices the same launch against the 8 TB/s specification"},
             "other_stages": stages, "whole_cpi": whole}
 
 

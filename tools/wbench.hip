@@ -27,6 +27,24 @@ __global__ __launch_bounds__(256) void write_stream(c64* __restrict__ out, const
     }
   }
 }
+// copy: reads n/2 elements, writes n/2 elements (the fused kernel's 1 : 1 read / write mix)
+template <int UNROLL, bool NT>
+__global__ __launch_bounds__(256) void copy_stream(c64* __restrict__ out, const c64* __restrict__ in, long long n) {
+  const long long per_trip = 256ll * UNROLL, stride = per_trip * gridDim.x;
+  for (long long base = (long long)blockIdx.x * per_trip; base < n; base += stride) {
+    c64 v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) { const long long i = base + 256 * u + threadIdx.x; v[u] = in[i < n ? i : n - 1]; }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const long long i = base + 256 * u + threadIdx.x;
+      if (i < n) {
+        if (NT) { __builtin_nontemporal_store(v[u].re, &out[i].re); __builtin_nontemporal_store(v[u].im, &out[i].im); }
+        else out[i] = v[u];
+      }
+    }
+  }
+}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 template <int MODE, int UNROLL>
 int run(c64* out, const c64* in, long long n, int n_wg, const char* what) {
@@ -52,6 +70,27 @@ int main() {
     if (run<0, 16>(out, in, n, wg, "plain 16-B stores")) return 1;
     if (run<1, 4>(out, in, n, wg, "nontemporal stores")) return 1;
     if (run<2, 4>(out, in, n, wg, "plain stores + echo's read share")) return 1;
+  }
+  {
+    const long long h = n / 2;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timeit = [&](auto launch, const char* what) {
+      float best = 1e30f;
+      for (int rep = 0; rep < 6; ++rep) {
+        (void)hipEventRecord(e0); launch(); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+      }
+      printf("%-58s %8.1f us  %5.2f TB/s (read + written)\n", what, best * 1e3, 32.0 * h / 1e9 / best);
+    };
+    for (int wg : {1024, 2048, 4096}) {
+      char nm[96];
+      snprintf(nm, sizeof nm, "copy 0.75 GB -> 0.75 GB, unroll 8, %d workgroups", wg);
+      timeit([&] { hipLaunchKernelGGL((copy_stream<8, false>), dim3(wg), dim3(256), 0, 0, out, in, h); }, nm);
+      snprintf(nm, sizeof nm, "copy, nontemporal stores, unroll 8, %d workgroups", wg);
+      timeit([&] { hipLaunchKernelGGL((copy_stream<8, true>), dim3(wg), dim3(256), 0, 0, out, in, h); }, nm);
+    }
+    timeit([&] { (void)hipMemcpyAsync(out, in, sizeof(c64) * h, hipMemcpyDeviceToDevice, 0); }, "hipMemcpyAsync device to device, 0.75 GB");
   }
   // memset as the runtime does it
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
