@@ -620,6 +620,7 @@ def roofline_entry(cell, args, ms_timed, ms_iso, n_launches, stages, cpi_bytes, 
             "algorithmic_bytes_per_launch": nb, "algorithmic_bytes_note": "txGrid read once + echoGrid written once = 2 K L A 16 B; echoGrid is not re-read by the range stage",
             # the same bytes moved by a plain copy kernel / hipMemcpyAsync on this part (1 : 1 read / write mix): measured 5.35-5.53 TB/s, tools/wbench.hip
             "copy_rate_reference": {"GBps": COPY_RATE_GBS, "frac_of_copy_rate": round(nb / 1e9 / (ms / 1e3) / COPY_RATE_GBS, 4),
+                                    "frac_of_copy_rate_on_counter_traffic": round(facts["traffic"] / 1e9 / (ms / 1e3) / COPY_RATE_GBS, 4) if (at_shape and facts["traffic"]) else None,
                                     "source": "profiles/r04_wbench_write_rate.txt: copying 0.75 GB -> 0.75 GB takes 272-281 us (hipMemcpyAsync device to device 281 us); "
                                               "`frac` above prices the same launch against the 8 TB/s specification"},
             "other_stages": stages, "whole_cpi": whole}
