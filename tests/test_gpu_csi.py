@@ -74,6 +74,34 @@ def test_csi_report_matches_oracle(pkg, nrb, ports, panel, layers, mode, sbsize,
     assert not np.all(np.isnan(got_cqi)) and got_cqi[0] >= 1
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_csi_report_irregular_re_sets(pkg, seed):
+    """The subband reduction walks host-built per-subband RE lists: REs in SHUFFLED order, on three different symbols with unequal counts per (subband, symbol),
+    a ragged subset of the RBs -- PMI / CQI integers exact, subband SINRs <= 1e-10 against the oracle (mean over symbols of the per-symbol means)."""
+    rng = np.random.default_rng(100 + seed)
+    nrb, ports, layers = 52, 4, 1 + seed % 2
+    carrier = SimpleNamespace(NSizeGrid=nrb, NStartGrid=0, SymbolsPerSlot=14)
+    rep = SimpleNamespace(NSizeBWP=nrb, NStartBWP=3, PanelDimensions=(2, 1), CodebookMode=1, PMIMode="Subband", CQIMode="Subband", SubbandSize=8)
+    k_all = 12 * rng.choice(nrb, size=nrb - 7, replace=False) + rng.integers(1, 12, nrb - 7)       # one RE in most RBs, seven RBs without CSI-RS
+    k = np.concatenate([k_all, k_all[: nrb // 2] + 1, k_all[: nrb // 4]])                             # unequal counts per symbol
+    l = np.concatenate([np.full(k_all.size, 2), np.full(nrb // 2, 6), np.full(nrb // 4, 11)])
+    perm = rng.permutation(k.size)
+    k, l = k[perm], l[perm]
+    h = np.ascontiguousarray(channel(rng, nrb, 2, ports) * (1.0 + 0.3 * rng.standard_normal((1, 14, 1, 1))))   # symbol-dependent gain: the symbol means differ
+    nvar = 0.05
+    want_cqi, want_pmi, want_ci, want_pi = OP.cqi_select(rep, layers, h, k, l, nvar, OQ.DOWNLINK_SINR90PC)
+    tot = np.nansum(want_pi.SINRPerRE, axis=(0, 1, 2)).reshape(-1, order="F")
+    got_cqi, got_pmi, got_ci, got_pi = pkg.communication.phyLayer.cqiSelect(carrier, SimpleNamespace(k=k, l=l), rep, layers, h, nvar, OQ.DOWNLINK_SINR90PC)
+    got_tot = got_pi.TotalSINR.reshape(-1, order="F")
+    assert np.abs(got_tot - tot).max() <= 1e-10 * np.abs(tot).max()
+    if not np.array_equal(OP.matlab_round4(got_tot), OP.matlab_round4(tot)):
+        pytest.skip("a total SINR sits on a rounding boundary of round(., 4): the PMI is rounding-defined")
+    assert same(got_pmi.i1, want_pmi.i1) and same(got_pmi.i2, want_pmi.i2), (got_pmi, want_pmi)
+    assert same(got_cqi, want_cqi), (got_cqi, want_cqi)
+    a, b = got_ci.SINRPerSubbandPerCW, want_ci.SINRPerSubbandPerCW
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.abs(a[~np.isnan(a)] - b[~np.isnan(b)]).max() <= 1e-10 * np.nanmax(np.abs(b))
+
+
 def test_csi_report_batch_equals_single_reports(pkg):
     """isac_csi_report_batch_dev: six UEs of one cell (different channels and noise variances, one of them with an all-NaN-prone tiny channel) in one
     call -- every field of every UE's report equals the single-UE call's (same kernels, same host half, one synchronisation instead of six)."""
