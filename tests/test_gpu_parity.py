@@ -404,6 +404,40 @@ def test_distributed_tridiagonalisation_modes_agree():
     assert out["0"] != out[""]                              # (the switch did switch)
 
 
+def test_distributed_tridiagonalisation_concurrent_contexts(pkg):
+    """Twelve host threads, each with its own context, run isac_eigh at n = 256 / 200 at the same time: up to twelve distributed reductions in flight, each of
+    which needs its 13-16 workgroups resident together (consecutive launches go to consecutive XCDs).  No exchange may time out (status -4) and every result must
+    be the single-context result."""
+    import threading
+    rng = np.random.default_rng(5)
+    mats = {}
+    for a in (256, 200):
+        m = rng.standard_normal((a, a)) + 1j * rng.standard_normal((a, a))
+        mats[a] = np.asfortranarray(m @ m.conj().T / a + np.diag(rng.uniform(0, 3, a)))
+    ref = {a: np.linalg.eigvalsh(h) for a, h in mats.items()}
+    errors = []
+
+    def worker(tid):
+        try:
+            c = pkg._lib.Context(0)
+            for rep in range(6):
+                a = 256 if (tid + rep) % 2 == 0 else 200
+                h = mats[a]
+                w = np.zeros(a); v = np.zeros((a, a), dtype=np.complex128, order="F")
+                c.check(c.lib.isac_eigh(c.handle, h.ctypes.data_as(C.c_void_p), C.c_int32(a), w.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
+                if not (np.abs(w - ref[a]).max() < 1e-12 * np.abs(ref[a]).max() and np.abs(h @ v - v * w).max() < 1e-11 * np.abs(ref[a]).max()):
+                    errors.append((tid, rep, "wrong result"))
+        except Exception as e:                                # noqa: BLE001 -- collected and reported by the main thread
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(12)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:4]
+
+
 @pytest.mark.parametrize("kind,a", [("identity", 100), ("rank2", 130), ("diag_repeated", 96), ("tiny", 72), ("huge", 65),
                                     ("clustered", 200), ("tridiag_zero_blocks", 128),
                                     ("identity", 12), ("rank2", 40), ("tiny", 33), ("huge", 64), ("clustered", 48), ("zero", 20), ("zero", 80)])
