@@ -741,26 +741,48 @@ __device__ __forceinline__ void cov_lds_body(const c64* __restrict__ G, long lon
     step(std::integral_constant<int, 1>{}, slab + 1, rd, wr);
     rot();
   }
+  // the two sample phases of a tile group are summed inside the workgroup (through the now idle slab images) before anything goes to memory: one partial per
+  // workgroup and tile instead of two -- half the partial-sum traffic of this kernel and of the reducers behind it (20 instead of 41 MB per launch at A = 64)
+  double* x = reinterpret_cast<double*>(lds) + GRP * (P::kPerGroup * 2 * 256);
+  static_assert(sizeof(c64) * kCovLdsBufs * kBuf >= sizeof(double) * 2 * P::kPerGroup * 2 * 256, "the phase exchange fits the slab images");
+  double o0[NT][4], o1[NT][4];
   static_for<0, NT>([&](auto uc) {
     constexpr int u = decltype(uc)::value;
     constexpr bool diag = cov_tile_i(NB, T0 + u) == cov_tile_j(NB, T0 + u);
-    double* o = part + (((long long)part_index * P::kTiles + (T0 + u)) * 2) * 256;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if constexpr (!diag) {
-        o[0 * 256 + r * 64 + lane] = re[u][r] + im[u][r];
-        o[1 * 256 + r * 64 + lane] = (s3[u][r] - re[u][r]) + im[u][r];
+        o0[u][r] = re[u][r] + im[u][r];
+        o1[u][r] = (s3[u][r] - re[u][r]) + im[u][r];
       } else {
-        o[0 * 256 + r * 64 + lane] = re[u][r];
-        o[1 * 256 + r * 64 + lane] = im[u][r];             // diagonal tile: M, antisymmetrised by cov_reduce_kernel
+        o0[u][r] = re[u][r];
+        o1[u][r] = im[u][r];                                 // diagonal tile: M, antisymmetrised by cov_reduce_kernel
       }
     }
   });
+  if (phase == 1) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { x[(u * 2 + 0) * 256 + r * 64 + lane] = o0[u][r]; x[(u * 2 + 1) * 256 + r * 64 + lane] = o1[u][r]; }
+  }
+  __syncthreads();
+  if (phase == 0) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      double* o = part + (((long long)part_index * P::kTiles + (T0 + u)) * 2) * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[0 * 256 + r * 64 + lane] = o0[u][r] + x[(u * 2 + 0) * 256 + r * 64 + lane];
+        o[1 * 256 + r * 64 + lane] = o1[u][r] + x[(u * 2 + 1) * 256 + r * 64 + lane];
+      }
+    }
+  }
 }
 
 template <int NB>
 __global__ __launch_bounds__(256, 2) void cov_mfma_lds_kernel(const c64* __restrict__ G, long long N, int A, long long slabs_per_wg,
-                                                              double* __restrict__ part /* [gridX*2][kTiles][2][256] */) {
+                                                              double* __restrict__ part /* [gridX][kTiles][2][256] */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);      // [kCovLdsBufs][NB * 16 * kCovPitch]
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -769,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_lds_kernel(const c64* __restr
   const long long s_begin = (long long)blockIdx.x * slabs_per_wg;
   long long s_end = s_begin + slabs_per_wg;
   if (s_end > total) s_end = total;
-  const int pidx = blockIdx.x * 2 + phase;
+  const int pidx = blockIdx.x;                       // (one partial per workgroup: the phases are summed in the kernel)
   if (grp == 0) cov_lds_body<NB, 0>(G, N, A, phase, s_begin, s_end, pidx, part, lds);
   else cov_lds_body<NB, 1>(G, N, A, phase, s_begin, s_end, pidx, part, lds);
 }
@@ -2529,7 +2551,7 @@ static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long lo
   const bool staged = (NB >= 3) && !reg_operands && N * 256 < (1ll << 31);           // two tile groups: fetch each slab once per workgroup, through LDS
   if (staged) { gx = 512 < total ? 512 : total; per = (total + gx - 1) / gx; per = (per + 1) & ~1ll; }   // (the staged kernel walks slabs in pairs)
   gx = (total + per - 1) / per;
-  const int n_part = (int)gx * P::kPhases;
+  const int n_part = (int)gx * (staged ? 1 : P::kPhases);       // (the staged kernel sums its two sample phases itself)
   ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * ((size_t)n_part + 32) * P::kTiles * 2 * 256));
   if constexpr (NB >= 3) {
     if (staged) {
