@@ -306,6 +306,245 @@ __global__ __launch_bounds__(256) void cdl_fir4_kernel(const CdlSeg* __restrict_
   }
 }
 
+// ---------------------------------------------------------------- fused downlink apply (round 5): contraction + delay filters, Z never leaves the CU
+// One persistent workgroup per CU (four waves, one per SIMD) walks consecutive 128-row tiles of a (job, gain block) segment:
+//   1. contraction of the tile on fp64 MFMA (3M form) against the LDS image of the segment's path gains, built ONCE per segment ([k-step][column tile]
+//      [hr, hi, hr + hi][lane]: every B operand one conflict-free ds_read_b64); x streams from HBM straight into A-operand order, requested kFzPf k-steps
+//      ahead and across the tile boundary (the next tile's first k-steps are in flight under the filter phases: a lone wave per SIMD has nothing else to hide latency);
+//   then, per 16-column tile (= the paths whose reduced signals it holds):
+//   2. Z -> LDS: [column][16 history rows | 128 tile rows]; the history rows are the previous tile's last 16 rows (kept per column in `hist`);
+//   3. the 16-tap fractional-delay filters in Z space, f_n[t] = sum_k g_n[k] Z_n[t - k]: task = (column, 4 consecutive rows), 19 window samples in
+//      registers (rows XOR-swizzled inside aligned groups of four: conflict-free ds_read_b128), perfectly balanced whatever the delay profile; f overwrites Z in place;
+//   4. integer delays as a gather: thread (rho, u) owns the output rows = rho (mod 128) -- for every path exactly ONE row of the tile lands on one of its rows
+//      (row t + d_n, d_n = 128 q_n + m_n: slot q_n if rho >= m_n, else q_n + 1) -- so the "y ring" of the scatter form is NSLOT registers per thread: no atomics,
+//      no conflicts; slot 0 is final after every tile and is stored (1 KB runs), the others shift down.
+// The sums of an output row run tile-major (tiles ascending; inside a tile column tiles ascending, paths in delay order): a fixed order that does not depend on
+// how the tile sequence is cut into workgroup ranges -- a range that starts inside a segment first walks W = ceil((max delay + 15) / 128) warm-up tiles without
+// storing, which reproduces exactly the partial sums its predecessor holds at that point.  batch == single, run to run, bit for bit; against the unfused
+// kernels (path-major sums) the results differ in the last bits.  Reference seam: uePhy.m:724-731, cdl.m:57-64.
+struct CdlWork { int seg, tile0, tile1, store_tile; };   // tiles [tile0, tile1) of segment `seg`; tiles below store_tile are warm-up
+constexpr int kFzRows = 128;       // rows per tile (4 waves x 2 x 16)
+constexpr int kFzHist = 16;        // history rows in front of the tile rows
+constexpr int kFzLd = 145;         // column pitch in elements (16 + 128 + one pad row: 8 lanes writing 8 columns touch 8 bank quads)
+constexpr int kFzLdF = 129;        // column pitch of the filtered tile
+constexpr int kFzPf = 4;           // k-steps of x in flight
+constexpr int kFzTaps = 16;
+constexpr int kFzPpt = 8;          // paths per 16-column tile (two receive antennas)
+
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// rows are XOR-swizzled inside aligned groups of eight: the 16 lanes of a filter task column read rows 8 g + m -- (g & 1, (g >> 1) ^ m) is a different bank quad for every g
+__device__ __forceinline__ int fz_swz(int p) { return p ^ ((p >> 4) & 7); }
+
+template <int NCT, int NSLOT, bool PROF = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void cdl_fused_kernel(const CdlSeg* __restrict__ segs, const CdlWork* __restrict__ works, const int* __restrict__ wg_first, long long lda, long long ldy, int Nt,
+                      int n_paths, const double* __restrict__ taps16 /* [n_paths][16], zero padded */,
+                      const int* __restrict__ pmeta /* [NCT][8]: per column tile its paths in delay order, packed local path | (delay & 127) << 8 | (delay >> 7) << 16 | valid << 24 */,
+                      double scale, long long* __restrict__ prof /* PROF: [workgroup][8] cycles per phase (development: ISAC_CDL_FUSED_PROF) */) {
+  long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = 0;
+  auto stamp = [&](int i) { if constexpr (PROF) { const long long t = (long long)__builtin_readcyclecounter(); pc[i] += t - pt; pt = t; } };
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int RT = 2, KS = 16, Nr = 2;
+  const int Nc = n_paths * Nr;
+  c64* zbuf = reinterpret_cast<c64*>(smem_raw);                              // [16][kFzLd]: Z of one column tile, history rows in front
+  c64* fbuf = zbuf + 16 * kFzLd;                                             // [16][kFzLdF]: the filtered tile
+  double* bimg = reinterpret_cast<double*>(fbuf + 16 * kFzLdF);              // [KS][NCT][3][64]: hr, hi, hr + hi in B-operand order
+  double* s_taps = bimg + KS * NCT * 3 * 64;                                 // [NCT * 8][16]
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  for (int i = tid; i < NCT * kFzPpt * kFzTaps; i += 256) s_taps[i] = i < n_paths * kFzTaps ? taps16[i] : 0.0;
+  const int w_begin = wg_first[blockIdx.x], w_end = wg_first[blockIdx.x + 1];
+  for (int wi = w_begin; wi < w_end; ++wi) {
+    const CdlWork wk = works[wi];
+    const CdlSeg sg = segs[wk.seg];
+    const __amdgpu_buffer_rsrc_t rs_a = buffer_of(sg.A, (unsigned)(lda * Nt * (long long)sizeof(c64)));
+    const __amdgpu_buffer_rsrc_t rs_y = buffer_of(sg.Y, (unsigned)(ldy * Nr * (long long)sizeof(c64)));
+    lds_barrier();                                                           // the previous item's last reads of the image are done
+    for (int i = tid; i < KS * NCT * 64; i += 256) {
+      const int ks = i / (NCT * 64), ct = (i >> 6) % NCT, ln = i & 63;
+      const int k = 4 * ks + (ln >> 4), col = 16 * ct + (ln & 15);
+      const bool ok = k < Nt && col < Nc;
+      const int kk = ok ? k : 0, cc = ok ? col : 0;
+      const c64 h = sg.H[((long long)(cc / Nr) * Nt + kk) * Nr + (cc % Nr)];   // unconditional load, select afterwards
+      double* d = bimg + ((ks * NCT + ct) * 3) * 64 + ln;
+      d[0] = ok ? h.re : 0.0;
+      d[64] = ok ? h.im : 0.0;
+      d[128] = ok ? h.re + h.im : 0.0;
+    }
+    c64 hk[NCT];                                                             // thread (column tid >> 4, row tid & 15): the history rows it carries from tile to tile
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) hk[ct] = mk(0.0, 0.0);                  // samples in front of the first tile are zero
+    c64 slot[NSLOT];
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) slot[j] = mk(0.0, 0.0);
+    lds_barrier();
+    const long long last = sg.r1 - 1;
+    auto row_off = [&](long long row0, unsigned (&ro)[RT]) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) { const long long r = row0 + 32 * wid + 16 * rt + li; ro[rt] = (unsigned)((r < last ? r : last) * (long long)sizeof(c64)); }
+    };
+    const unsigned col_step = (unsigned)(4 * lda * (long long)sizeof(c64));
+    const unsigned col0 = (unsigned)((long long)kq * lda * (long long)sizeof(c64)), col_last = (unsigned)((long long)(Nt - 1) * lda * (long long)sizeof(c64));
+    const int k_last = Nt - 1 - kq;                                          // (k-steps whose column >= Nt re-read column Nt - 1: B is zero there)
+    auto load_a = [&](const unsigned (&ro)[RT], int ks, c64 (&x)[RT]) {
+      const unsigned co = 4 * ks <= k_last ? col0 + (unsigned)ks * col_step : col_last;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) x[rt] = buffer_load_c64(rs_a, ro[rt] + co);
+    };
+    auto load_b = [&](int ks, double (&h)[NCT][3]) {
+      const double* bp = bimg + (ks * NCT * 3) * 64 + lane;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int fm = 0; fm < 3; ++fm) h[ct][fm] = bp[(ct * 3 + fm) * 64];
+    };
+    c64 xq[kFzPf][RT];
+    unsigned ro_cur[RT], ro_nxt[RT];
+    row_off(sg.r0 + (long long)wk.tile0 * kFzRows, ro_cur);
+#pragma unroll
+    for (int s_ = 0; s_ < kFzPf; ++s_) load_a(ro_cur, s_, xq[s_]);
+    stamp(6);                                                                // (bucket 6: everything outside the tile loop, incl. the first reading)
+    for (int tile = wk.tile0; tile < wk.tile1; ++tile) {
+      const long long row0 = sg.r0 + (long long)tile * kFzRows;
+      row_off(row0 + kFzRows, ro_nxt);
+      stamp(7);
+      // ---- 1. contraction: 16 k-steps x (2 row tiles x NCT column tiles x 3 forms) MFMAs
+      v4f64 p1[RT][NCT], p2[RT][NCT], p3[RT][NCT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) p1[rt][ct] = p2[rt][ct] = p3[rt][ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+      double hb[2][NCT][3];
+      load_b(0, hb[0]);
+      static_for<0, KS>([&](auto ksc) {
+        constexpr int ks = decltype(ksc)::value, cur = ks & 1, sl = ks % kFzPf;
+        double xr[RT], xi[RT], xs[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) { xr[rt] = xq[sl][rt].re; xi[rt] = xq[sl][rt].im; }
+        if constexpr (ks + kFzPf < KS) load_a(ro_cur, ks + kFzPf, xq[sl]);
+        else load_a(ro_nxt, ks + kFzPf - KS, xq[sl]);
+        if constexpr (ks + 1 < KS) load_b(ks + 1, hb[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) xs[rt] = xr[rt] + xi[rt];
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) p1[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[rt], hb[cur][ct][0], p1[rt][ct], 0, 0, 0);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) p2[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xi[rt], hb[cur][ct][1], p2[rt][ct], 0, 0, 0);
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) p3[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[rt], hb[cur][ct][2], p3[rt][ct], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) ro_cur[rt] = ro_nxt[rt];
+      stamp(0);
+      const int rho = tid & 127, u = tid >> 7;                               // gather phase: output rows = rho (mod 128) of receive antenna u
+      const int fc = tid >> 4, fg = tid & 15;                                // filter phase: column fc of the tile, rows 8 fg .. 8 fg + 7
+      static_for<0, NCT>([&](auto ctc) {
+        constexpr int ct = decltype(ctc)::value;
+        // ---- 2. Z of this column tile -> LDS (f64 MFMA C/D layout: lane (li, kq) holds rows kq + 4 r of column li), history rows in front.
+        //      (No barrier in front: every wave's window reads of the previous column tile precede the barrier behind ITS f rows.)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int p = kFzHist + 32 * wid + 16 * rt + kq + 4 * r;
+            zbuf[li * kFzLd + fz_swz(p)] = mk(p1[rt][ct][r] - p2[rt][ct][r], (p3[rt][ct][r] - p1[rt][ct][r]) - p2[rt][ct][r]);
+          }
+        zbuf[fc * kFzLd + fz_swz(fg)] = hk[ct];
+        lds_barrier();
+        stamp(1);
+        // ---- 3. delay filters in Z space: thread = (column fc, rows 8 fg .. 8 fg + 7), 23 window samples in registers
+        {
+          const c64* zc = zbuf + fc * kFzLd;
+          c64 w[24];                                                         // logical rows 8 fg - 16 .. 8 fg + 7  <->  positions 8 fg .. 8 fg + 23 (w[0] unused)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int p = 8 * (fg + j), x = (p >> 4) & 7;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+              if (8 * j + i > 0) w[8 * j + i] = zc[p + (i ^ x)];
+          }
+          hk[ct] = zbuf[fc * kFzLd + fz_swz(kFzRows + fg)];                  // the tile's last 16 rows: the next tile's history
+          const double* tp = s_taps + (ct * kFzPpt + (fc >> 1)) * kFzTaps;
+          double gk[kFzTaps];
+#pragma unroll
+          for (int k = 0; k < kFzTaps; ++k) gk[k] = tp[k];
+          c64* fo = fbuf + fc * kFzLdF;
+          const int po = 8 * fg, xo = (po >> 4) & 7;
+          // 16 independent accumulation chains (8 rows x re / im), taps outermost: a lone wave per SIMD has nobody to fill the latency of a dependent fp64 FMA
+          c64 a[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) a[r] = mk(0.0, 0.0);
+#pragma unroll
+          for (int k = 0; k < kFzTaps; ++k)                                  // f[t] = sum_k g[k] z[t - k]: row 8 fg + r - k  <->  w[16 + r - k]
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              a[r].re = ::fma(gk[k], w[16 + r - k].re, a[r].re);
+              a[r].im = ::fma(gk[k], w[16 + r - k].im, a[r].im);
+            }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) fo[po + (r ^ xo)] = a[r];              // (the previous tile's gather of fbuf lies in front of the barrier above)
+        }
+        stamp(2);
+        lds_barrier();
+        stamp(3);
+        // ---- 4. integer delays: for every path of this column tile, the one row of the tile that lands on a row = rho (mod 128)
+        {
+          int pm[kFzPpt], h0[kFzPpt], h1[kFzPpt];
+          c64 v[kFzPpt];
+#pragma unroll
+          for (int e = 0; e < kFzPpt; ++e) {
+            pm[e] = __builtin_amdgcn_readfirstlane(pmeta[ct * kFzPpt + e]);
+            int zr = rho - ((pm[e] >> 8) & 127);
+            const bool lt = zr < 0, on = (pm[e] >> 24) != 0;
+            zr += lt ? kFzRows : 0;
+            v[e] = fbuf[(2 * (pm[e] & 15) + u) * kFzLdF + fz_swz(zr)];
+            h0[e] = on && !lt ? 0x3ff00000 : 0;                              // high word of 1.0 / 0.0: the row lands in slot q (rho >= delay mod 128) ...
+            h1[e] = on && lt ? 0x3ff00000 : 0;                               // ... or in slot q + 1
+          }
+          // Branch-free: slot j takes the row with coefficient 1.0 or 0.0 (fma(v, 1, s) = s + v and fma(v, 0, s) = s exactly); the delay class q is
+          // wave-uniform, its comparisons are scalar masks.  (A switch over q made the compiler index `slot` dynamically -- a scratch array; selects on
+          // the lane condition made it split the wave into exec-masked branches.)
+#pragma unroll
+          for (int e = 0; e < kFzPpt; ++e) {
+            const int q = (pm[e] >> 16) & 7;
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) {
+              const int hi = (j + 1 < NSLOT ? (h0[e] & (q == j ? -1 : 0)) : 0) | (j > 0 ? (h1[e] & (q == j - 1 ? -1 : 0)) : 0);
+              const double cf = __hiloint2double(hi, 0);
+              slot[j].re = ::fma(v[e].re, cf, slot[j].re);
+              slot[j].im = ::fma(v[e].im, cf, slot[j].im);
+            }
+          }
+        }
+        stamp(4);
+      });
+      {
+        const long long row = row0 + rho;
+        const bool st = tile >= wk.store_tile && row >= sg.o0 && row < sg.o1;
+        const unsigned off = st ? (unsigned)((row + ldy * (long long)u) * (long long)sizeof(c64)) : 0xfffffff0u;   // (masked: out of range, dropped by the hardware)
+        buffer_store_c64_nt(rs_y, off, slot[0] * scale);
+#pragma unroll
+        for (int j = 0; j + 1 < NSLOT; ++j) slot[j] = slot[j + 1];
+        slot[NSLOT - 1] = mk(0.0, 0.0);
+      }
+      stamp(5);
+    }
+  }
+  if constexpr (PROF) {
+    if (tid == 0)
+      for (int i = 0; i < 8; ++i) prof[blockIdx.x * 8 + i] = pc[i];
+  }
+}
+
 // H[snap][n][s][u] = sum_m base[n][m][s][u] exp(j rate[n][m] t_snap) (+ los[s][u] exp(j los_rate t_snap) on path 0): the sample-and-hold path gains
 // of TR 38.901 eq. 7.5-22 / 7.5-29 from the time-independent per-ray terms (the Python mirror's CDLChannel._static()).
 __global__ __launch_bounds__(256) void cdl_path_gains_kernel(const c64* __restrict__ base, const double* __restrict__ rate, int n_paths, int n_rays, int nsu,
@@ -382,6 +621,110 @@ int launch_gemm(isac_ctx* ctx, const CdlSeg* d_segs, int n_segs, long long max_r
   return ISAC_OK;
 }
 
+// Fused downlink apply: does the shape fit the kernel's envelope?  (Everything else -- uplink, more than 64 transmit elements, more than two receive
+// antennas (or one), more than 24 paths, filters longer than 16 taps, delays beyond 895 samples -- takes the unfused kernels.)
+bool cdl_fused_ok(long long T, int Nt, int Nr, int n_paths, int n_taps, int max_shift) {
+  static const bool off = std::getenv("ISAC_CDL_UNFUSED") != nullptr;        // development switch: contraction + filter as separate launches (Z through HBM)
+  return !off && Nr == 2 && Nt >= 2 && Nt <= 64 && n_paths <= 3 * kFzPpt && n_taps <= kFzTaps && max_shift < 128 * 7 && (long long)T * Nr < (1ll << 28);
+}
+
+int launch_fused(isac_ctx* ctx, const std::vector<CdlSeg>& segs, long long T, int Nt, int Nr, int n_paths, const double* taps, int n_taps, const int32_t* shift,
+                 int max_shift, double out_scale) {
+  const int Nc = n_paths * Nr, nct = (Nc + 15) / 16, nslot = max_shift < 128 * 3 ? 4 : 8;
+  // ---- tables: taps padded to 16, paths in delay order, first entry of every 128-sample delay class
+  std::vector<double> taps16((size_t)n_paths * kFzTaps, 0.0);
+  for (int n = 0; n < n_paths; ++n) std::memcpy(&taps16[(size_t)n * kFzTaps], taps + (size_t)n * n_taps, sizeof(double) * (size_t)n_taps);
+  // delay table: per 16-column tile its (up to 8) paths in delay order, packed  local path | (delay & 127) << 8 | (delay >> 7) << 16 | valid << 24
+  std::vector<int> pmeta((size_t)nct * kFzPpt, 0);
+  for (int ct = 0; ct < nct; ++ct) {
+    const int lo = std::min(n_paths, ct * kFzPpt), hi = std::min(n_paths, (ct + 1) * kFzPpt);
+    std::vector<int> order;
+    for (int n = lo; n < hi; ++n) order.push_back(n);
+    std::stable_sort(order.begin(), order.end(), [&](int a_, int b_) { return shift[a_] < shift[b_]; });
+    for (size_t e = 0; e < order.size(); ++e) pmeta[(size_t)ct * kFzPpt + e] = (order[e] - lo) | ((shift[order[e]] & 127) << 8) | ((shift[order[e]] >> 7) << 16) | (1 << 24);
+  }
+  // ---- work list: the tile sequence of all segments cut into one contiguous range per workgroup; a range that starts inside a segment walks W warm-up tiles first
+  if (ctx->n_cus <= 0) {
+    int v = 0;
+    ISAC_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    ctx->n_cus = v > 0 ? v : 256;
+  }
+  const int warm = (max_shift + (kFzTaps - 1) + kFzRows - 1) / kFzRows;
+  std::vector<long long> seg_tiles(segs.size());
+  long long total = 0;
+  for (size_t i = 0; i < segs.size(); ++i) { seg_tiles[i] = segs[i].o1 > segs[i].o0 ? (segs[i].r1 - segs[i].r0 + kFzRows - 1) / kFzRows : 0; total += seg_tiles[i]; }
+  if (total == 0) return ISAC_OK;
+  static const int wgs_env = std::getenv("ISAC_CDL_FUSED_WGS") ? std::atoi(std::getenv("ISAC_CDL_FUSED_WGS")) : 0;   // development switch: workgroups of the persistent grid
+  const int n_wg = (int)std::min<long long>(wgs_env > 0 ? wgs_env : ctx->n_cus, total);
+  std::vector<CdlWork> works;
+  std::vector<int> wg_first(n_wg + 1, 0);
+  {
+    size_t si = 0;
+    long long seg_lo = 0;                                                    // global index of the first tile of segment si
+    for (int w = 0; w < n_wg; ++w) {
+      const long long g0 = total * w / n_wg, g1 = total * (w + 1) / n_wg;
+      wg_first[w] = (int)works.size();
+      long long g = g0;
+      while (g < g1) {
+        while (g >= seg_lo + seg_tiles[si]) { seg_lo += seg_tiles[si]; ++si; }
+        const long long t0 = g - seg_lo, t1 = std::min(seg_tiles[si], g1 - seg_lo);
+        works.push_back(CdlWork{(int)si, (int)std::max<long long>(0, t0 - warm), (int)t1, (int)t0});
+        g = seg_lo + t1;
+      }
+    }
+    wg_first[n_wg] = (int)works.size();
+  }
+  // ---- one upload: segments | taps | delay table | class starts | work items | ranges
+  auto pad = [](size_t b) { return (b + 63) & ~(size_t)63; };
+  const size_t o_seg = 0, o_tap = o_seg + pad(sizeof(CdlSeg) * segs.size()), o_pm = o_tap + pad(sizeof(double) * taps16.size()), o_wk = o_pm + pad(sizeof(int) * pmeta.size()),
+               o_wf = o_wk + pad(sizeof(CdlWork) * works.size()), meta = o_wf + pad(sizeof(int) * wg_first.size());
+  std::vector<char> host(meta);
+  std::memcpy(host.data() + o_seg, segs.data(), sizeof(CdlSeg) * segs.size());
+  std::memcpy(host.data() + o_tap, taps16.data(), sizeof(double) * taps16.size());
+  std::memcpy(host.data() + o_pm, pmeta.data(), sizeof(int) * pmeta.size());
+  std::memcpy(host.data() + o_wk, works.data(), sizeof(CdlWork) * works.size());
+  std::memcpy(host.data() + o_wf, wg_first.data(), sizeof(int) * wg_first.size());
+  ISAC_TRY(ensure(ctx, ctx->stage_c, meta + 64));
+  char* dm = (char*)ctx->stage_c.p;
+  ISAC_TRY(stage_upload(ctx, dm, host.data(), meta));
+  const size_t lds_bytes = sizeof(c64) * 16 * (size_t)(kFzLd + kFzLdF) + sizeof(double) * 16 * (size_t)nct * 3 * 64 + sizeof(double) * (size_t)nct * kFzPpt * kFzTaps;
+  if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));       // isac_profile_*: brackets exactly the fused launch
+#define ISAC_CDL_FUSED(NCT, NSLOT)                                                                                                                          \
+  do {                                                                                                                                                      \
+    auto kern = cdl_fused_kernel<NCT, NSLOT>;                                                                                                               \
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds_bytes));                                                                               \
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), lds_bytes, ctx->stream, (const CdlSeg*)(dm + o_seg), (const CdlWork*)(dm + o_wk),            \
+                       (const int*)(dm + o_wf), (long long)T, (long long)T, Nt, n_paths, (const double*)(dm + o_tap), (const int*)(dm + o_pm), out_scale,  \
+                       (long long*)nullptr);                                                                                                                \
+  } while (0)
+  static const bool prof_on = std::getenv("ISAC_CDL_FUSED_PROF") != nullptr;   // development switch: cycles per phase of every workgroup on stderr (synchronises)
+  if (prof_on && nslot == 4 && nct >= 2) {
+    ISAC_TRY(ensure(ctx, ctx->misc, sizeof(long long) * 8 * (size_t)n_wg));
+    auto launch = [&](auto kern) -> int {
+      ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds_bytes));
+      hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), lds_bytes, ctx->stream, (const CdlSeg*)(dm + o_seg), (const CdlWork*)(dm + o_wk), (const int*)(dm + o_wf), (long long)T,
+                         (long long)T, Nt, n_paths, (const double*)(dm + o_tap), (const int*)(dm + o_pm), out_scale, (long long*)ctx->misc.p);
+      return ISAC_OK;
+    };
+    if (nct == 2) ISAC_TRY(launch(cdl_fused_kernel<2, 4, true>)); else ISAC_TRY(launch(cdl_fused_kernel<3, 4, true>));
+    std::vector<long long> h(8 * (size_t)n_wg);
+    ISAC_HIP(hipMemcpyAsync(h.data(), ctx->misc.p, sizeof(long long) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+    ISAC_HIP(hipStreamSynchronize(ctx->stream));
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < n_wg; ++w) for (int i = 0; i < 8; ++i) sum[i] += (double)h[8 * (size_t)w + i];
+    const double tiles_wg = (double)total / n_wg;
+    std::fprintf(stderr, "CDLPROF wgs %d tiles/wg %.1f (+%d warm-up) | cycles per workgroup: mfma %.0f  z-write+barrier %.0f  filter+f-write %.0f  barrier %.0f  gather %.0f  store %.0f  tile-head %.0f\n", n_wg, tiles_wg, warm,
+                 sum[0] / n_wg, sum[1] / n_wg, sum[2] / n_wg, sum[3] / n_wg, sum[4] / n_wg, sum[5] / n_wg, sum[7] / n_wg);
+    return ISAC_OK;
+  }
+  if (nslot == 4) { switch (nct) { case 1: ISAC_CDL_FUSED(1, 4); break; case 2: ISAC_CDL_FUSED(2, 4); break; default: ISAC_CDL_FUSED(3, 4); break; } }
+  else { switch (nct) { case 1: ISAC_CDL_FUSED(1, 8); break; case 2: ISAC_CDL_FUSED(2, 8); break; default: ISAC_CDL_FUSED(3, 8); break; } }
+#undef ISAC_CDL_FUSED
+  ISAC_HIP(hipGetLastError());
+  if (ctx->profile) { ISAC_HIP(hipEventRecord(ctx->ev_k1, ctx->stream)); ctx->profile_recorded = true; }
+  return ISAC_OK;
+}
+
 int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long T, int Nt, int Nr, int n_paths, const double* taps, int n_taps,
                    const int32_t* shift, double out_scale) {
   if (!jobs || !taps || !shift) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
@@ -405,9 +748,10 @@ int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long lon
     ctx->range_cache.touch(jobs[j].d_y, sizeof(c64) * (size_t)T * Nr);   // an output that overlaps a cached grid drops the cached range rows
   }
   if (n_seg_total > 65535) return fail(ctx, ISAC_ERR_CAPACITY, "more than 65535 (job, gain block) segments in one batch");
-  // workspace: DL: Z [T x Ncp] per segment;  UL: prefiltered signals [T x Kc] per job
-  const size_t ws_elems = ul ? (size_t)n_jobs * (size_t)T * Kc : n_seg_total * (size_t)T * Ncp;
-  ISAC_TRY(ensure(ctx, ctx->stage_b, sizeof(c64) * ws_elems));
+  // workspace: DL (unfused kernels only): Z [T x Ncp] per segment;  UL: prefiltered signals [T x Kc] per job;  fused DL: none
+  const bool fused = !ul && cdl_fused_ok(T, Nt, Nr, n_paths, n_taps, max_shift);
+  const size_t ws_elems = fused ? 0 : ul ? (size_t)n_jobs * (size_t)T * Kc : n_seg_total * (size_t)T * Ncp;
+  if (ws_elems) ISAC_TRY(ensure(ctx, ctx->stage_b, sizeof(c64) * ws_elems));
   c64* ws = (c64*)ctx->stage_b.p;
   segs.reserve(n_seg_total + (size_t)n_jobs);
   size_t si = 0;
@@ -435,6 +779,7 @@ int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long lon
     }
   }
   const size_t n_gemm = segs.size();
+  if (fused) return launch_fused(ctx, segs, T, Nt, Nr, n_paths, taps, n_taps, shift, max_shift, out_scale);
   if (ul)
     for (int j = 0; j < n_jobs; ++j) {                                // prefilter segments: one per job, all rows
       CdlSeg s{};

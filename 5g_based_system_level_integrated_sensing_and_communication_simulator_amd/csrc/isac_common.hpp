@@ -108,6 +108,7 @@ struct Fft2dPending {  // state between isac_fft2d_submit_dev and isac_fft2d_col
 
 struct isac_ctx {
   int device = 0;
+  int n_cus = 0;                   // compute units of the device (queried on first use: persistent-grid launches)
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // MUSIC branch (covariance/eig) overlaps the RDM branch
   hipStream_t own_stream = nullptr, own_stream2 = nullptr;   // the streams this context created (stream / stream2 may alias another context's: isac_ctx_share_streams)

@@ -628,11 +628,56 @@ def test_cdl_delay_filter_forms_same_bits():
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = []
-    for extra in ({}, {"ISAC_CDL_FIR1": "1"}):
+    for extra in ({"ISAC_CDL_UNFUSED": "1"}, {"ISAC_CDL_UNFUSED": "1", "ISAC_CDL_FIR1": "1"}):
         r = subprocess.run([sys.executable, "-c", _CDL_FIR_SNIPPET % (root, PKG_NAME)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")])
     assert len(out[0]) == 3 and out[0] == out[1]
+
+
+_CDL_FUSED_SNIPPET = """
+import hashlib, importlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+pkg = importlib.import_module(%r)
+ctx = pkg._lib.Context(0)
+CM = pkg.communication.channelModels
+fs = 122.88e6
+for profile, tx, t_len in (("CDL-A", (4, 8, 2, 1, 1), 20011), ("CDL-D", (1, 8, 2, 1, 1), 9000), ("CDL-A", (1, 3, 2, 1, 1), 1531)):
+    nt = int(np.prod(tx))
+    rng = np.random.default_rng(nt)
+    xs = [ctx.to_device(np.asfortranarray(rng.standard_normal((t_len, nt)) + 1j * rng.standard_normal((t_len, nt)))) for _ in range(2)]
+    def chans():
+        c = [CM.CDLChannel(profile, 300e-9, 3.5e9, tx, (1, 1, 2, 1, 1), fs, Seed=70 + u) for u in range(4)]
+        c[3].time = 1.0 / 640 - (t_len // 2) / fs            # one job crosses a path-gain refresh: two segments, the second starts inside the waveform
+        return c
+    outs = CM.applyCDLBatch(chans(), [xs[0], xs[0], xs[1], xs[1]], ctx=ctx)
+    print("digest batch", profile, nt, hashlib.sha256(b"".join(o.numpy().tobytes() for o in outs)).hexdigest())
+    single = [CM.applyCDLBatch([c], [x], ctx=ctx)[0] for c, x in zip(chans(), [xs[0], xs[0], xs[1], xs[1]])]
+    print("digest single", profile, nt, hashlib.sha256(b"".join(o.numpy().tobytes() for o in single)).hexdigest())
+    np.save(sys.argv[1] + "_%%s_%%d.npy" %% (profile, nt), np.stack([o.numpy() for o in outs]))
+"""
+
+
+def test_cdl_fused_apply_bits_do_not_depend_on_the_grid(tmp_path):
+    """cdl_fused_kernel (downlink: contraction + delay filters in one persistent launch, Z never in HBM): the same bits whether the tile sequence is walked by
+    1, 7 or one-per-CU workgroups (ranges that start inside a segment re-create their predecessor's partial sums with warm-up tiles), the same bits for a job
+    alone or in a batch; against the unfused kernels (other summation order) <= 1e-12 relative.  122.88 MHz sampling: delays up to 355 samples (three tiles back)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for tag, extra in (("cu", {}), ("one", {"ISAC_CDL_FUSED_WGS": "1"}), ("seven", {"ISAC_CDL_FUSED_WGS": "7"}), ("unfused", {"ISAC_CDL_UNFUSED": "1"})):
+        r = subprocess.run([sys.executable, "-c", _CDL_FUSED_SNIPPET % (root, PKG_NAME), str(tmp_path / tag)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        runs[tag] = [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("digest")]
+    assert len(runs["cu"]) == 6
+    assert runs["cu"] == runs["one"] == runs["seven"]
+    for i in range(0, 6, 2):
+        assert runs["cu"][i][1:] == runs["cu"][i + 1][1:], runs["cu"][i]                  # batch == single
+    for f in sorted(os.listdir(tmp_path)):
+        if f.startswith("cu_"):
+            a, b = np.load(tmp_path / f), np.load(tmp_path / f.replace("cu_", "unfused_"))
+            assert rel(a, b) < 1e-12, f
 
 
 # ------------------------------------------------------------------ SINR -> CQI
