@@ -25,6 +25,7 @@
 namespace isac {
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
 template <int U, int NT, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -340,7 +341,7 @@ __device__ __forceinline__ void lds_barrier() {
 __device__ __forceinline__ int fz_swz(int p) { return p ^ ((p >> 4) & 7); }
 
 template <int NCT, int NSLOT, bool PROF = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void cdl_fused_kernel(const CdlSeg* __restrict__ segs, const CdlWork* __restrict__ works, const int* __restrict__ wg_first, long long lda, long long ldy, int Nt,
                       int n_paths, const double* __restrict__ taps16 /* [n_paths][16], zero padded */,
                       const int* __restrict__ pmeta /* [NCT][8]: per column tile its paths in delay order, packed local path | (delay & 127) << 8 | (delay >> 7) << 16 | valid << 24 */,
@@ -348,150 +349,133 @@ void cdl_fused_kernel(const CdlSeg* __restrict__ segs, const CdlWork* __restrict
   long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pt = 0;
   auto stamp = [&](int i) { if constexpr (PROF) { const long long t = (long long)__builtin_readcyclecounter(); pc[i] += t - pt; pt = t; } };
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int RT = 2, KS = 16, Nr = 2;
+  constexpr int KS = 16, Nr = 2;
   const int Nc = n_paths * Nr;
   c64* zbuf = reinterpret_cast<c64*>(smem_raw);                              // [16][kFzLd]: Z of one column tile, history rows in front
   c64* fbuf = zbuf + 16 * kFzLd;                                             // [16][kFzLdF]: the filtered tile
-  double* bimg = reinterpret_cast<double*>(fbuf + 16 * kFzLdF);              // [KS][NCT][3][64]: hr, hi, hr + hi in B-operand order
-  double* s_taps = bimg + KS * NCT * 3 * 64;                                 // [NCT * 8][16]
+  c64* bpair = fbuf + 16 * kFzLdF;                                           // [KS][NCT][64]: (hr, hi) in B-operand order
+  double* bsum = reinterpret_cast<double*>(bpair + KS * NCT * 64);           // [KS][NCT][64]: hr + hi
+  double* s_taps = bsum + KS * NCT * 64;                                     // [NCT * 8][16]
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
-  for (int i = tid; i < NCT * kFzPpt * kFzTaps; i += 256) s_taps[i] = i < n_paths * kFzTaps ? taps16[i] : 0.0;
+  for (int i = tid; i < NCT * kFzPpt * kFzTaps; i += 512) s_taps[i] = i < n_paths * kFzTaps ? taps16[i] : 0.0;
   const int w_begin = wg_first[blockIdx.x], w_end = wg_first[blockIdx.x + 1];
+  // filter phase: a thread pair shares a task (column fc of the tile, rows 8 fg .. 8 fg + 7): one takes the real parts, one the imaginary parts;
+  // gather phase: a pair shares the output rows = rho (mod 128) of receive antenna u the same way
+  const int part = tid & 1, fc = tid >> 5, fg = (tid >> 1) & 15, rho = (tid >> 1) & 127, u = tid >> 8;
+  const double* zre = reinterpret_cast<const double*>(zbuf) + part;
+  double* fwr = reinterpret_cast<double*>(fbuf) + part;
   for (int wi = w_begin; wi < w_end; ++wi) {
     const CdlWork wk = works[wi];
     const CdlSeg sg = segs[wk.seg];
     const __amdgpu_buffer_rsrc_t rs_a = buffer_of(sg.A, (unsigned)(lda * Nt * (long long)sizeof(c64)));
     const __amdgpu_buffer_rsrc_t rs_y = buffer_of(sg.Y, (unsigned)(ldy * Nr * (long long)sizeof(c64)));
     lds_barrier();                                                           // the previous item's last reads of the image are done
-    for (int i = tid; i < KS * NCT * 64; i += 256) {
+    for (int i = tid; i < KS * NCT * 64; i += 512) {
       const int ks = i / (NCT * 64), ct = (i >> 6) % NCT, ln = i & 63;
       const int k = 4 * ks + (ln >> 4), col = 16 * ct + (ln & 15);
       const bool ok = k < Nt && col < Nc;
       const int kk = ok ? k : 0, cc = ok ? col : 0;
       const c64 h = sg.H[((long long)(cc / Nr) * Nt + kk) * Nr + (cc % Nr)];   // unconditional load, select afterwards
-      double* d = bimg + ((ks * NCT + ct) * 3) * 64 + ln;
-      d[0] = ok ? h.re : 0.0;
-      d[64] = ok ? h.im : 0.0;
-      d[128] = ok ? h.re + h.im : 0.0;
+      bpair[i] = ok ? h : mk(0.0, 0.0);
+      bsum[i] = ok ? h.re + h.im : 0.0;
     }
-    c64 hk[NCT];                                                             // thread (column tid >> 4, row tid & 15): the history rows it carries from tile to tile
+    c64 hk[NCT];                                                             // threads 0..255 (column tid >> 4, row tid & 15): the history rows carried from tile to tile
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) hk[ct] = mk(0.0, 0.0);                  // samples in front of the first tile are zero
-    c64 slot[NSLOT];
+    double slot[NSLOT];
 #pragma unroll
-    for (int j = 0; j < NSLOT; ++j) slot[j] = mk(0.0, 0.0);
+    for (int j = 0; j < NSLOT; ++j) slot[j] = 0.0;
     lds_barrier();
     const long long last = sg.r1 - 1;
-    auto row_off = [&](long long row0, unsigned (&ro)[RT]) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) { const long long r = row0 + 32 * wid + 16 * rt + li; ro[rt] = (unsigned)((r < last ? r : last) * (long long)sizeof(c64)); }
+    auto row_off = [&](long long row0) {
+      const long long r = row0 + 16 * wid + li;
+      return (unsigned)((r < last ? r : last) * (long long)sizeof(c64));
     };
     const unsigned col_step = (unsigned)(4 * lda * (long long)sizeof(c64));
     const unsigned col0 = (unsigned)((long long)kq * lda * (long long)sizeof(c64)), col_last = (unsigned)((long long)(Nt - 1) * lda * (long long)sizeof(c64));
     const int k_last = Nt - 1 - kq;                                          // (k-steps whose column >= Nt re-read column Nt - 1: B is zero there)
-    auto load_a = [&](const unsigned (&ro)[RT], int ks, c64 (&x)[RT]) {
+    auto load_a = [&](unsigned ro, int ks) {
       const unsigned co = 4 * ks <= k_last ? col0 + (unsigned)ks * col_step : col_last;
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) x[rt] = buffer_load_c64(rs_a, ro[rt] + co);
+      return buffer_load_c64(rs_a, ro + co);
     };
-    auto load_b = [&](int ks, double (&h)[NCT][3]) {
-      const double* bp = bimg + (ks * NCT * 3) * 64 + lane;
+    auto load_b = [&](int ks, c64 (&hp)[NCT], double (&hs)[NCT]) {
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-        for (int fm = 0; fm < 3; ++fm) h[ct][fm] = bp[(ct * 3 + fm) * 64];
+      for (int ct = 0; ct < NCT; ++ct) { hp[ct] = bpair[(ks * NCT + ct) * 64 + lane]; hs[ct] = bsum[(ks * NCT + ct) * 64 + lane]; }
     };
-    c64 xq[kFzPf][RT];
-    unsigned ro_cur[RT], ro_nxt[RT];
-    row_off(sg.r0 + (long long)wk.tile0 * kFzRows, ro_cur);
+    c64 xq[kFzPf];
+    unsigned ro_cur = row_off(sg.r0 + (long long)wk.tile0 * kFzRows), ro_nxt;
 #pragma unroll
-    for (int s_ = 0; s_ < kFzPf; ++s_) load_a(ro_cur, s_, xq[s_]);
+    for (int s_ = 0; s_ < kFzPf; ++s_) xq[s_] = load_a(ro_cur, s_);
     stamp(6);                                                                // (bucket 6: everything outside the tile loop, incl. the first reading)
     for (int tile = wk.tile0; tile < wk.tile1; ++tile) {
       const long long row0 = sg.r0 + (long long)tile * kFzRows;
-      row_off(row0 + kFzRows, ro_nxt);
+      ro_nxt = row_off(row0 + kFzRows);
       stamp(7);
-      // ---- 1. contraction: 16 k-steps x (2 row tiles x NCT column tiles x 3 forms) MFMAs
-      v4f64 p1[RT][NCT], p2[RT][NCT], p3[RT][NCT];
+      // ---- 1. contraction: 16 k-steps x (NCT column tiles x 3 forms) MFMAs on this wave's 16 rows
+      v4f64 p1[NCT], p2[NCT], p3[NCT];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) p1[rt][ct] = p2[rt][ct] = p3[rt][ct] = v4f64{0.0, 0.0, 0.0, 0.0};
-      double hb[2][NCT][3];
-      load_b(0, hb[0]);
+      for (int ct = 0; ct < NCT; ++ct) p1[ct] = p2[ct] = p3[ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+      c64 hp[2][NCT];
+      double hs[2][NCT];
+      load_b(0, hp[0], hs[0]);
       static_for<0, KS>([&](auto ksc) {
         constexpr int ks = decltype(ksc)::value, cur = ks & 1, sl = ks % kFzPf;
-        double xr[RT], xi[RT], xs[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) { xr[rt] = xq[sl][rt].re; xi[rt] = xq[sl][rt].im; }
-        if constexpr (ks + kFzPf < KS) load_a(ro_cur, ks + kFzPf, xq[sl]);
-        else load_a(ro_nxt, ks + kFzPf - KS, xq[sl]);
-        if constexpr (ks + 1 < KS) load_b(ks + 1, hb[cur ^ 1]);
+        const double xr = xq[sl].re, xi = xq[sl].im;
+        if constexpr (ks + kFzPf < KS) xq[sl] = load_a(ro_cur, ks + kFzPf);
+        else xq[sl] = load_a(ro_nxt, ks + kFzPf - KS);
+        if constexpr (ks + 1 < KS) load_b(ks + 1, hp[cur ^ 1], hs[cur ^ 1]);
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) xs[rt] = xr[rt] + xi[rt];
+        const double xs = xr + xi;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) p1[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr[rt], hb[cur][ct][0], p1[rt][ct], 0, 0, 0);
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) p2[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xi[rt], hb[cur][ct][1], p2[rt][ct], 0, 0, 0);
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) p3[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs[rt], hb[cur][ct][2], p3[rt][ct], 0, 0, 0);
+          p1[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, hp[cur][ct].re, p1[ct], 0, 0, 0);
+          p2[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, hp[cur][ct].im, p2[ct], 0, 0, 0);
+          p3[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs, hs[cur][ct], p3[ct], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
       });
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) ro_cur[rt] = ro_nxt[rt];
+      ro_cur = ro_nxt;
       stamp(0);
-      const int rho = tid & 127, u = tid >> 7;                               // gather phase: output rows = rho (mod 128) of receive antenna u
-      const int fc = tid >> 4, fg = tid & 15;                                // filter phase: column fc of the tile, rows 8 fg .. 8 fg + 7
       static_for<0, NCT>([&](auto ctc) {
         constexpr int ct = decltype(ctc)::value;
         // ---- 2. Z of this column tile -> LDS (f64 MFMA C/D layout: lane (li, kq) holds rows kq + 4 r of column li), history rows in front.
         //      (No barrier in front: every wave's window reads of the previous column tile precede the barrier behind ITS f rows.)
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int p = kFzHist + 32 * wid + 16 * rt + kq + 4 * r;
-            zbuf[li * kFzLd + fz_swz(p)] = mk(p1[rt][ct][r] - p2[rt][ct][r], (p3[rt][ct][r] - p1[rt][ct][r]) - p2[rt][ct][r]);
-          }
-        zbuf[fc * kFzLd + fz_swz(fg)] = hk[ct];
+        for (int r = 0; r < 4; ++r) {
+          const int p = kFzHist + 16 * wid + kq + 4 * r;
+          zbuf[li * kFzLd + fz_swz(p)] = mk(p1[ct][r] - p2[ct][r], (p3[ct][r] - p1[ct][r]) - p2[ct][r]);
+        }
+        if (tid < 256) zbuf[(tid >> 4) * kFzLd + fz_swz(tid & 15)] = hk[ct];
         lds_barrier();
         stamp(1);
-        // ---- 3. delay filters in Z space: thread = (column fc, rows 8 fg .. 8 fg + 7), 23 window samples in registers
+        // ---- 3. delay filters in Z space: 23 window samples (one component) in registers, 8 independent accumulation chains
         {
-          const c64* zc = zbuf + fc * kFzLd;
-          c64 w[24];                                                         // logical rows 8 fg - 16 .. 8 fg + 7  <->  positions 8 fg .. 8 fg + 23 (w[0] unused)
+          const double* zc = zre + 2 * (fc * kFzLd);
+          double w[24];                                                      // logical rows 8 fg - 16 .. 8 fg + 7  <->  positions 8 fg .. 8 fg + 23 (w[0] unused)
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const int p = 8 * (fg + j), x = (p >> 4) & 7;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-              if (8 * j + i > 0) w[8 * j + i] = zc[p + (i ^ x)];
+              if (8 * j + i > 0) w[8 * j + i] = zc[2 * (p + (i ^ x))];
           }
-          hk[ct] = zbuf[fc * kFzLd + fz_swz(kFzRows + fg)];                  // the tile's last 16 rows: the next tile's history
+          if (tid < 256) hk[ct] = zbuf[(tid >> 4) * kFzLd + fz_swz(kFzRows + (tid & 15))];   // the tile's last 16 rows: the next tile's history
           const double* tp = s_taps + (ct * kFzPpt + (fc >> 1)) * kFzTaps;
           double gk[kFzTaps];
 #pragma unroll
           for (int k = 0; k < kFzTaps; ++k) gk[k] = tp[k];
-          c64* fo = fbuf + fc * kFzLdF;
-          const int po = 8 * fg, xo = (po >> 4) & 7;
-          // 16 independent accumulation chains (8 rows x re / im), taps outermost: a lone wave per SIMD has nobody to fill the latency of a dependent fp64 FMA
-          c64 a[8];
+          double a[8];
 #pragma unroll
-          for (int r = 0; r < 8; ++r) a[r] = mk(0.0, 0.0);
+          for (int r = 0; r < 8; ++r) a[r] = 0.0;
 #pragma unroll
           for (int k = 0; k < kFzTaps; ++k)                                  // f[t] = sum_k g[k] z[t - k]: row 8 fg + r - k  <->  w[16 + r - k]
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-              a[r].re = ::fma(gk[k], w[16 + r - k].re, a[r].re);
-              a[r].im = ::fma(gk[k], w[16 + r - k].im, a[r].im);
-            }
+            for (int r = 0; r < 8; ++r) a[r] = ::fma(gk[k], w[16 + r - k], a[r]);
+          double* fo = fwr + 2 * (fc * kFzLdF);
+          const int po = 8 * fg, xo = (po >> 4) & 7;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) fo[po + (r ^ xo)] = a[r];              // (the previous tile's gather of fbuf lies in front of the barrier above)
+          for (int r = 0; r < 8; ++r) fo[2 * (po + (r ^ xo))] = a[r];         // (the previous tile's gather of fbuf lies in front of the barrier above)
         }
         stamp(2);
         lds_barrier();
@@ -499,14 +483,15 @@ void cdl_fused_kernel(const CdlSeg* __restrict__ segs, const CdlWork* __restrict
         // ---- 4. integer delays: for every path of this column tile, the one row of the tile that lands on a row = rho (mod 128)
         {
           int pm[kFzPpt], h0[kFzPpt], h1[kFzPpt];
-          c64 v[kFzPpt];
+          double v[kFzPpt];
+          const double* fr = reinterpret_cast<const double*>(fbuf) + part;
 #pragma unroll
           for (int e = 0; e < kFzPpt; ++e) {
             pm[e] = __builtin_amdgcn_readfirstlane(pmeta[ct * kFzPpt + e]);
             int zr = rho - ((pm[e] >> 8) & 127);
             const bool lt = zr < 0, on = (pm[e] >> 24) != 0;
             zr += lt ? kFzRows : 0;
-            v[e] = fbuf[(2 * (pm[e] & 15) + u) * kFzLdF + fz_swz(zr)];
+            v[e] = fr[2 * ((2 * (pm[e] & 15) + u) * kFzLdF + fz_swz(zr))];
             h0[e] = on && !lt ? 0x3ff00000 : 0;                              // high word of 1.0 / 0.0: the row lands in slot q (rho >= delay mod 128) ...
             h1[e] = on && lt ? 0x3ff00000 : 0;                               // ... or in slot q + 1
           }
@@ -519,9 +504,7 @@ void cdl_fused_kernel(const CdlSeg* __restrict__ segs, const CdlWork* __restrict
 #pragma unroll
             for (int j = 0; j < NSLOT; ++j) {
               const int hi = (j + 1 < NSLOT ? (h0[e] & (q == j ? -1 : 0)) : 0) | (j > 0 ? (h1[e] & (q == j - 1 ? -1 : 0)) : 0);
-              const double cf = __hiloint2double(hi, 0);
-              slot[j].re = ::fma(v[e].re, cf, slot[j].re);
-              slot[j].im = ::fma(v[e].im, cf, slot[j].im);
+              slot[j] = ::fma(v[e], __hiloint2double(hi, 0), slot[j]);
             }
           }
         }
@@ -530,11 +513,11 @@ void cdl_fused_kernel(const CdlSeg* __restrict__ segs, const CdlWork* __restrict
       {
         const long long row = row0 + rho;
         const bool st = tile >= wk.store_tile && row >= sg.o0 && row < sg.o1;
-        const unsigned off = st ? (unsigned)((row + ldy * (long long)u) * (long long)sizeof(c64)) : 0xfffffff0u;   // (masked: out of range, dropped by the hardware)
-        buffer_store_c64_nt(rs_y, off, slot[0] * scale);
+        const unsigned off = st ? (unsigned)((row + ldy * (long long)u) * (long long)sizeof(c64)) + 8u * (unsigned)part : 0xfffffff0u;   // (masked: out of range, dropped by the hardware)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, slot[0] * scale), rs_y, (int)off, 0, /*nt*/ 2);
 #pragma unroll
         for (int j = 0; j + 1 < NSLOT; ++j) slot[j] = slot[j + 1];
-        slot[NSLOT - 1] = mk(0.0, 0.0);
+        slot[NSLOT - 1] = 0.0;
       }
       stamp(5);
     }
@@ -693,7 +676,7 @@ int launch_fused(isac_ctx* ctx, const std::vector<CdlSeg>& segs, long long T, in
   do {                                                                                                                                                      \
     auto kern = cdl_fused_kernel<NCT, NSLOT>;                                                                                                               \
     ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds_bytes));                                                                               \
-    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), lds_bytes, ctx->stream, (const CdlSeg*)(dm + o_seg), (const CdlWork*)(dm + o_wk),            \
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), lds_bytes, ctx->stream, (const CdlSeg*)(dm + o_seg), (const CdlWork*)(dm + o_wk),            \
                        (const int*)(dm + o_wf), (long long)T, (long long)T, Nt, n_paths, (const double*)(dm + o_tap), (const int*)(dm + o_pm), out_scale,  \
                        (long long*)nullptr);                                                                                                                \
   } while (0)
@@ -702,7 +685,7 @@ int launch_fused(isac_ctx* ctx, const std::vector<CdlSeg>& segs, long long T, in
     ISAC_TRY(ensure(ctx, ctx->misc, sizeof(long long) * 8 * (size_t)n_wg));
     auto launch = [&](auto kern) -> int {
       ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds_bytes));
-      hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(256), lds_bytes, ctx->stream, (const CdlSeg*)(dm + o_seg), (const CdlWork*)(dm + o_wk), (const int*)(dm + o_wf), (long long)T,
+      hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), lds_bytes, ctx->stream, (const CdlSeg*)(dm + o_seg), (const CdlWork*)(dm + o_wk), (const int*)(dm + o_wf), (long long)T,
                          (long long)T, Nt, n_paths, (const double*)(dm + o_tap), (const int*)(dm + o_pm), out_scale, (long long*)ctx->misc.p);
       return ISAC_OK;
     };

@@ -452,9 +452,14 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
     gi, n_jobs, flops, n_paths = cc.gemm_launch()
     ctx_cdl.check(ctx_cdl.lib.isac_profile_enable(ctx_cdl.handle, 1))
     ms_k, ms_call = [], []
+    # (the batch the frame loop issues: SLOTS_PER_CALL consecutive slots x the UEs of the group -- the persistent grid of the fused kernel is priced on the
+    #  launch shape it actually runs with; a one-slot batch would spend a quarter of its tiles on warm-up)
+    n_slots = min(CommCell.SLOTS_PER_CALL, CommCell.DL_SLOTS)
+    n_jobs, flops = n_jobs * n_slots, flops * n_slots
     for i in range(11):
         ctx_cdl.sync(); ctx_cdl.timer_start()
-        cc.CM.applyCDLBatch([cc.chans[u] for u in cc.groups[gi]], [cc.waves[i % cc.DL_SLOTS]] * n_jobs, ctx=ctx_cdl, outs=cc.rx[gi][:n_jobs], gains=cc.gains[gi])
+        cc.CM.applyCDLBatch([cc.chans[u] for s_ in range(n_slots) for u in cc.groups[gi]], [cc.waves[(i + s_) % cc.DL_SLOTS] for s_ in range(n_slots) for u in cc.groups[gi]],
+                            ctx=ctx_cdl, outs=cc.rx[gi][:n_jobs], gains=cc.gains[gi])
         v = C.c_double(0.0)
         ctx_cdl.check(ctx_cdl.lib.isac_profile_last_kernel_ms(ctx_cdl.handle, C.byref(v)))
         ms_call.append(ctx_cdl.timer_stop_ms()); ms_k.append(v.value)
@@ -472,12 +477,14 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
                                   f"({CommCell.DL_SLOTS * args.ues} applies), {CommCell.CSI_OCCASIONS} CSI reports per UE (Type-I PMI search + subband CQI, 546 CSI-RS REs x 32 entries)",
                       "parallelism": f"cells sharded over {world} GPU(s)"},
            "per_frame_and_rank": {"cells": len(mine), "cdl_applies": n_applies, "csi_reports": len(mine) * args.ues * CommCell.CSI_OCCASIONS, "sensing_cpis": len(mine)},
-           "roofline": {"bound": "mfma", "kernel": "cdl_gemm_kernel<NCT,false> (DL contraction of a batch: X [T x Nt] against the path gains of n UEs, 3M form on v_mfma_f64_16x16x4_f64)",
+           "roofline": {"bound": "mfma", "kernel": "cdl_fused_kernel<NCT,NSLOT> (DL apply of a batch in one persistent launch: contraction X [T x Nt] against the path gains of every job, 3M form on "
+                                                    "v_mfma_f64_16x16x4_f64, + 16-tap delay filters + integer delays on the CU; Z never in HBM)" if not os.environ.get("ISAC_CDL_UNFUSED") else
+                                                    "cdl_gemm_kernel<NCT,false> (DL contraction of a batch; ISAC_CDL_UNFUSED: the delay filter is a second launch, Z through HBM)",
                         "achieved": round(flops / 1e12 / (ms_k / 1e3), 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / 1e12 / (ms_k / 1e3) / FP64_MFMA_PEAK_TFLOPS, 4),
                         "traffic": None, "avg_launch_ms": round(ms_k, 4), "launches_averaged": 10, "jobs_per_launch": n_jobs, "paths": n_paths,
-                        "issued_flops_per_launch": flops, "flops_note": "3 real MFMAs x 2 flops per complex multiply-add, padded to 16-column tiles: 6 T cols Nt per job",
-                        "whole_batch_call_ms": round(ms_call, 4), "whole_batch_note": "path gains + contraction + delay filter of the same batch, HIP events around the call",
-                        "timing": "HIP events recorded by the library around every contraction launch (isac_profile_*), device otherwise idle"},
+                        "issued_flops_per_launch": flops, "flops_note": "contraction only (the launch also runs the delay filters on the VALU: + 16 % flops, not counted): 3 real MFMAs x 2 flops per complex multiply-add, padded to 16-column tiles: 6 T cols Nt per job",
+                        "whole_batch_call_ms": round(ms_call, 4), "whole_batch_note": "path gains + apply of the same batch, HIP events around the call",
+                        "timing": "HIP events recorded by the library around the apply launch (isac_profile_*), device otherwise idle"},
            "comm_seams": {"cdl_apply_ms_per_job": round(ms_call / n_jobs, 4), "csi_report_ms_per_ue": round(ms_csi, 4),
                           "csi_note": "host wall per UE of the batched report (one synchronisation per cell and occasion), device otherwise idle"},
            "cells": [{"cell": int(r[0]), "nRng": None if np.isnan(r[1]) else int(r[1]), "rngEst0": None if np.isnan(r[2]) else round(float(r[2]), 6),
