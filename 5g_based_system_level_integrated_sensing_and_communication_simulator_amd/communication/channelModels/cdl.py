@@ -176,7 +176,9 @@ class CDLChannel:
         shift = np.floor(d).astype(np.int32)
         x = np.arange(FILTER_TAPS, dtype=np.float64)[None, :] - FILTER_DELAY - (d - shift)[:, None]
         g = np.sinc(x) * np.where(np.abs(x) < FILTER_TAPS / 2, 0.5 + 0.5 * np.cos(np.pi * x / (FILTER_TAPS / 2)), 0.0)
-        _TAPS_CACHE[key] = (np.ascontiguousarray(g), shift)
+        g = np.ascontiguousarray(g)
+        g.setflags(write=False); shift.setflags(write=False)              # shared between channels: read-only
+        _TAPS_CACHE[key] = (g, shift)
         return _TAPS_CACHE[key]
 
     def __call__(self, waveform, *, ctx=None):
@@ -187,19 +189,23 @@ class CDLChannel:
     def _device_static(self, ctx):
         """(d_base [n][m][s][u], d_rate [n][m], d_los [s][u] | None, los_rate) on `ctx`'s device; cached per context and channel configuration."""
         st = self._static()
-        cache = st.__dict__.setdefault("_dev", {})
-        key = id(ctx)
-        if key not in cache:
+        cache = st.__dict__.get("_dev")
+        if cache is None:
+            import weakref
+            cache = st.__dict__["_dev"] = weakref.WeakKeyDictionary()     # keyed weakly by the context: a closed / collected context takes its device copies along
+        if ctx not in cache:
             d_base = ctx.to_device(np.ascontiguousarray(st.base).reshape(-1))
             d_rate = ctx.to_device(np.ascontiguousarray(st.rate, dtype=np.float64).reshape(-1))
             d_los = ctx.to_device(np.ascontiguousarray(st.los).reshape(-1)) if st.los is not None else None
-            cache[key] = (ctx, d_base, d_rate, d_los, float(getattr(st, "los_rate", 0.0)))
-        return cache[key][1:]
+            cache[ctx] = (d_base, d_rate, d_los, float(getattr(st, "los_rate", 0.0)))
+        return cache[ctx]
 
     def block_plan(self, T: int):
         """Gain blocks that the next T samples touch: (snapshot times, first output sample of each block) -- plain Python scalars (this runs once
         per (UE, slot) job in front of every batched apply)."""
         rate = 2.0 * self.SampleDensity * self.MaximumDopplerShift
+        if not rate > 0.0:                                                # static channel (MaximumDopplerShift = 0, valid for nrCDLChannel): one block at the current time
+            return [self.time], [0]
         b0 = math.floor(self.time * rate + 1e-9)
         b1 = math.floor((self.time + (T - 1) / self.SampleRate) * rate + 1e-9)
         # first output sample of each block: smallest t with floor((time + t/fs) rate + 1e-9) >= b

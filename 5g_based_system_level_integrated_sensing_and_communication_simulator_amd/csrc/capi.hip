@@ -1,6 +1,7 @@
 // C ABI of libisac_hip.so: context, tables, host glue of the fft2D pipeline (gfx950 only).
 // Declarations and the reference functions each entry point replaces: include/isac.h.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -305,7 +306,6 @@ extern "C" int isac_ctx_create(int device, isac_ctx** out) {
       hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_cfar, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->ev_h2d, hipEventDisableTiming) != hipSuccess ||
       hipEventCreate(&ctx->ev_t0) != hipSuccess || hipEventCreate(&ctx->ev_t1) != hipSuccess ||
       hipEventCreate(&ctx->ev_k0) != hipSuccess || hipEventCreate(&ctx->ev_k1) != hipSuccess) {
     delete ctx;
@@ -337,12 +337,15 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->pinned_csi) (void)hipHostFree(ctx->pinned_csi);
   (void)hipEventDestroy(ctx->ev_fork);
   (void)hipEventDestroy(ctx->ev_join);
   (void)hipEventDestroy(ctx->ev_cfar);
   (void)hipEventDestroy(ctx->ev_done);
-  (void)hipEventDestroy(ctx->ev_h2d);
-  if (ctx->pinned_in) (void)hipHostFree(ctx->pinned_in);
+  for (auto& sl : ctx->stage_ring) {
+    if (sl.ev) (void)hipEventDestroy(sl.ev);
+    if (sl.p) (void)hipHostFree(sl.p);
+  }
   (void)hipEventDestroy(ctx->ev_t0);
   (void)hipEventDestroy(ctx->ev_t1);
   (void)hipEventDestroy(ctx->ev_k0);
@@ -919,6 +922,52 @@ extern "C" int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](int p, int q) { return wv[(size_t)p] > wv[(size_t)q]; });
   for (int i = 0; i < n_top; ++i) std::memcpy(U + (size_t)A * i, vv.data() + (size_t)A * order[(size_t)i], sizeof(c64) * (size_t)A);
+  return ISAC_OK;
+}
+
+extern "C" int isac_ctx_reserve(isac_ctx* ctx, int64_t T, int32_t tx_dim_l, const isac_carrier* carrier, const isac_radar_channel_params* rp,
+                                const isac_est_params* ep, const isac_cfar_config* cfar, double warm_ms, double* elapsed_ms) {
+  ISAC_ENTER(ctx);
+  if (!carrier || !rp || !ep || !cfar || T <= 0 || tx_dim_l < 0 || rp->n_ants <= 0 || rp->n_targets <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "isac_ctx_reserve: NULL / empty argument");
+  const auto t0 = std::chrono::steady_clock::now();
+  auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+  int32_t l_whole = 0;
+  ISAC_TRY(isac_ofdm_symbol_count(carrier, T, &l_whole));
+  const int K = carrier->n_sc, A = rp->n_ants, L = std::max<int>(l_whole, tx_dim_l);
+  if (L <= 0) return fail(ctx, ISAC_ERR_SHORT_WAVEFORM, "isac_ctx_reserve: waveform shorter than one OFDM symbol");
+  const size_t g_bytes = sizeof(c64) * (size_t)K * L * A, w_bytes = sizeof(c64) * (size_t)T * A;
+  void *d_grid = nullptr, *d_wave = nullptr, *d_echo = nullptr;
+  auto release = [&]() { if (d_grid) (void)hipFree(d_grid); if (d_wave) (void)hipFree(d_wave); if (d_echo) (void)hipFree(d_echo); };
+  if (hipMalloc(&d_grid, g_bytes) != hipSuccess || hipMalloc(&d_wave, w_bytes) != hipSuccess || hipMalloc(&d_echo, g_bytes) != hipSuccess) {
+    release();
+    return fail(ctx, ISAC_ERR_HIP, "isac_ctx_reserve: no device memory for the dry run's grids (T A + 2 K L A elements)");
+  }
+  std::vector<uint8_t> los((size_t)rp->n_targets, 1);
+  int st = isac_synth_qpsk_grid_dev(ctx, (isac_c64*)d_grid, K, L, A, 0x5EEDull, 0);
+  if (st == ISAC_OK) st = isac_memset_dev(ctx, d_wave, 0, w_bytes);                     // (rows past the whole symbols stay zero)
+  if (st == ISAC_OK && l_whole > 0) st = isac_ofdm_modulate_dev(ctx, (const isac_c64*)d_grid, std::min<int>(l_whole, L), A, carrier, 1.0, (isac_c64*)d_wave, T);
+  int n_dry = 0;
+  while (st == ISAC_OK) {
+    int32_t lo = 0;
+    st = isac_mono_static_sensing_fused_dev(ctx, (const isac_c64*)d_wave, T, tx_dim_l, carrier, rp, los.data(), ISAC_NOISE_PHILOX_SPECTRAL, nullptr, 0x5EED0000ull + (uint64_t)n_dry,
+                                            (isac_c64*)d_echo, &lo, ep, cfar, (const isac_c64*)d_grid);
+    if (st != ISAC_OK) break;
+    st = isac_fft2d_submit_cached_dev(ctx, ep, cfar, (const isac_c64*)d_echo, (const isac_c64*)d_grid, K, L, A);
+    if (st == ISAC_ERR_INVALID_ARG) st = isac_fft2d_submit_dev(ctx, ep, cfar, (const isac_c64*)d_echo, (const isac_c64*)d_grid, K, L, A);   // (nothing cached: the CUT window left the map)
+    if (st != ISAC_OK) break;
+    static thread_local isac_est_result res;                                               // (128 KB: not on the stack)
+    st = isac_fft2d_collect(ctx, &res);
+    if (st == ISAC_ERR_NO_DETECTION || st == ISAC_ERR_CFAR_WINDOW) st = ISAC_OK;          // a dry CPI without estimates has still prepared everything
+    ++n_dry;
+    if (ms_since() >= warm_ms) break;
+  }
+  const std::string keep = ctx->err;
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipStreamSynchronize(ctx->stream2);
+  ctx->range_cache.valid = false;                                                          // the cached rows belong to grids that are about to be freed
+  release();
+  if (elapsed_ms) *elapsed_ms = ms_since();
+  if (st != ISAC_OK) { ctx->err = keep; return st; }
   return ISAC_OK;
 }
 

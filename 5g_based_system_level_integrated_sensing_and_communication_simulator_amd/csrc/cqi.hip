@@ -523,6 +523,7 @@ static int csi_report_batch(isac_ctx* ctx, int n_ue, const isac_c64* const* d_H_
                             const isac_c64* W, int32_t n_layers, const int32_t dims[4], const double* nvar, const double* sinr_table_db, int32_t n_table,
                             isac_csi_report* out, double* total_sinr_out, double* d_sinr_per_re_out) {
   if (!out || n_ue <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (n_ue > 65535) return fail(ctx, ISAC_ERR_CAPACITY, "more than 65535 UEs in one CSI batch (grid dimension)");
   for (int u = 0; u < n_ue; ++u) std::memset(&out[u], 0, sizeof(out[u]));
   if (!W || !dims || !nvar || n_re < 0 || Nr <= 0 || Nr > kMaxRx || P <= 0 || n_layers < 1 || n_layers > 4 || n_size_bwp <= 0 || subband_size <= 0 ||
       (n_re > 0 && (!d_H_list || !re_k || !re_l)))
@@ -611,10 +612,10 @@ static int csi_report_batch(isac_ctx* ctx, int n_ue, const isac_c64* const* d_H_
   ISAC_HIP(hipGetLastError());
   // ---- ONE copy back, ONE synchronisation for the whole batch
   const size_t res_bytes = sizeof(double) * res_stride * (size_t)n_ue;
-  ISAC_TRY(ensure_pinned(ctx, res_bytes));
-  ISAC_HIP(hipMemcpyAsync(ctx->pinned, d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_TRY(ensure_pinned_buf(ctx, ctx->pinned_csi, ctx->pinned_csi_cap, res_bytes));   // (its own buffer: ctx->pinned may hold a submitted CPI that has not been collected)
+  ISAC_HIP(hipMemcpyAsync(ctx->pinned_csi, d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
-  const double* res = (const double*)ctx->pinned;
+  const double* res = (const double*)ctx->pinned_csi;
   for (int u = 0; u < n_ue; ++u) {
     const double* r = res + res_stride * (size_t)u;
     if (total_sinr_out) std::memcpy(total_sinr_out + (size_t)u * nE, r, sizeof(double) * (size_t)nE);

@@ -596,20 +596,13 @@ static int prepare_echo(isac_ctx* ctx, const c64* d_tx, long long T, const isac_
   ISAC_TRY(ensure(ctx, ctx->phase_rx, sizeof(c64) * (size_t)T));
   c64* d_steer_aq = (c64*)ctx->steer.p;
   {
-    // pinned staging so the upload is truly asynchronous; the event guards reuse of the staging buffer
+    // pinned staging ring: the upload is truly asynchronous
     const size_t bytes = sizeof(c64) * (size_t)A * Q * 2;
-    if (ctx->pinned_in_cap < bytes) {
-      if (ctx->pinned_in) { ISAC_HIP(hipEventSynchronize(ctx->ev_h2d)); ISAC_HIP(hipHostFree(ctx->pinned_in)); }
-      ctx->pinned_in = nullptr; ctx->pinned_in_cap = 0;
-      ISAC_HIP(hipHostMalloc(&ctx->pinned_in, bytes < 4096 ? 4096 : bytes, hipHostMallocDefault));
-      ctx->pinned_in_cap = bytes < 4096 ? 4096 : bytes;
-    } else {
-      ISAC_HIP(hipEventSynchronize(ctx->ev_h2d));
-    }
-    std::memcpy(ctx->pinned_in, steer_aq.data(), bytes / 2);
-    std::memcpy((char*)ctx->pinned_in + bytes / 2, steer_rq.data(), bytes / 2);
-    ISAC_HIP(hipMemcpyAsync(d_steer_aq, ctx->pinned_in, bytes, hipMemcpyHostToDevice, ctx->stream));
-    ISAC_HIP(hipEventRecord(ctx->ev_h2d, ctx->stream));
+    void* hst = nullptr;
+    ISAC_TRY(stage_acquire(ctx, bytes, &hst));
+    std::memcpy(hst, steer_aq.data(), bytes / 2);
+    std::memcpy((char*)hst + bytes / 2, steer_rq.data(), bytes / 2);
+    ISAC_TRY(stage_commit(ctx, d_steer_aq, bytes));
   }
   // beam-sums in tiles of up to 8 targets (tx is re-read only when Q > 8)
   static const int bs_wgs = std::getenv("ISAC_BEAMSUM_WGS") ? std::atoi(std::getenv("ISAC_BEAMSUM_WGS")) : 1024;   // development switch: workgroups of the launch

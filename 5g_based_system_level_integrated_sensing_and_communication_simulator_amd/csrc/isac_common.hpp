@@ -94,6 +94,16 @@ struct RangeCache {  // range rows pre-computed by the fused monoStaticSensing c
   }
 };
 
+// pinned host -> device parameter staging: a small ring of slots, each guarded by its own event, so that a call's uploads do not wait for the
+// previous call's kernels to drain (one slot + one event did: every upload sat in stream order behind whatever was queued before it)
+struct StageSlot {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipEvent_t ev = nullptr;
+  bool busy = false;
+};
+constexpr int kStageSlots = 8;
+
 struct Fft2dPending {  // state between isac_fft2d_submit_dev and isac_fft2d_collect
   bool active = false;
   isac_est_params ep{};
@@ -134,12 +144,13 @@ struct isac_ctx {
   // scratch
   isac::DevBuf beam, coef, phase_rx, steer, dgrid, ymid, pwin, flags, det_cut, det_pow, det_cnt, cov_part, cov,
       eig_w, eig_v, eig_scratch, spec, misc, stage_a, stage_b, stage_c, sind_tab, seg, cdl_h;
-  void* pinned = nullptr; size_t pinned_cap = 0;
+  void* pinned = nullptr; size_t pinned_cap = 0;                       // results of isac_fft2d_submit* (read by isac_fft2d_collect) -- no other entry point may touch it
+  void* pinned_csi = nullptr; size_t pinned_csi_cap = 0;               // results of isac_csi_report*: its own buffer, so a CSI call between submit and collect cannot clobber a pending CPI
   isac::Fft2dLast last;
   isac::Fft2dPending pending;
   isac::RangeCache range_cache;
-  hipEvent_t ev_h2d = nullptr;       // completion of the last pinned->device parameter upload
-  void* pinned_in = nullptr; size_t pinned_in_cap = 0;
+  isac::StageSlot stage_ring[isac::kStageSlots];   // pinned->device parameter uploads (stage_acquire / stage_commit)
+  int stage_next = 0;
 };
 
 namespace isac {
@@ -222,31 +233,50 @@ inline int ensure(isac_ctx* ctx, DevBuf& b, size_t bytes) {
   return ISAC_OK;
 }
 
-inline int ensure_pinned(isac_ctx* ctx, size_t bytes) {
-  if (ctx->pinned_cap >= bytes) return ISAC_OK;
-  if (ctx->pinned) ISAC_HIP(hipHostFree(ctx->pinned));
-  ctx->pinned = nullptr;
-  ctx->pinned_cap = 0;
-  ISAC_HIP(hipHostMalloc(&ctx->pinned, bytes, hipHostMallocDefault));
-  ctx->pinned_cap = bytes;
+inline int ensure_pinned_buf(isac_ctx* ctx, void*& p, size_t& cap, size_t bytes) {
+  if (cap >= bytes) return ISAC_OK;
+  if (p) ISAC_HIP(hipHostFree(p));
+  p = nullptr;
+  cap = 0;
+  ISAC_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+  cap = bytes;
   return ISAC_OK;
 }
+inline int ensure_pinned(isac_ctx* ctx, size_t bytes) {
+  if (ctx->pinned_cap >= bytes) return ISAC_OK;
+  if (ctx->pinned && ctx->ev_done) ISAC_HIP(hipEventSynchronize(ctx->ev_done));   // a submitted CPI's D2H copy may still be writing the old buffer
+  return ensure_pinned_buf(ctx, ctx->pinned, ctx->pinned_cap, bytes);
+}
 
-// Small host block -> device scratch through the context's pinned staging buffer: asynchronous, no stream synchronisation; the event guards reuse.
-inline int stage_upload(isac_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
-  if (ctx->pinned_in_cap < bytes) {
-    if (ctx->pinned_in) { ISAC_HIP(hipEventSynchronize(ctx->ev_h2d)); ISAC_HIP(hipHostFree(ctx->pinned_in)); }
-    ctx->pinned_in = nullptr; ctx->pinned_in_cap = 0;
+// Small host block -> device scratch through the context's pinned staging ring: asynchronous, no stream synchronisation; the host waits only when the
+// ring wraps onto a slot whose copy has not left it yet.  stage_acquire hands out the next slot's host memory, stage_commit enqueues its copy.
+inline int stage_acquire(isac_ctx* ctx, size_t bytes, void** host) {
+  StageSlot& sl = ctx->stage_ring[ctx->stage_next];
+  if (!sl.ev) ISAC_HIP(hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+  if (sl.busy) { ISAC_HIP(hipEventSynchronize(sl.ev)); sl.busy = false; }    // the slot's previous upload has left it
+  if (sl.cap < bytes) {
+    if (sl.p) ISAC_HIP(hipHostFree(sl.p));
+    sl.p = nullptr; sl.cap = 0;
     const size_t want = bytes < 65536 ? 65536 : bytes;
-    ISAC_HIP(hipHostMalloc(&ctx->pinned_in, want, hipHostMallocDefault));
-    ctx->pinned_in_cap = want;
-  } else {
-    ISAC_HIP(hipEventSynchronize(ctx->ev_h2d));                        // the previous upload has left the staging buffer
+    ISAC_HIP(hipHostMalloc(&sl.p, want, hipHostMallocDefault));
+    sl.cap = want;
   }
-  std::memcpy(ctx->pinned_in, src, bytes);
-  ISAC_HIP(hipMemcpyAsync(d_dst, ctx->pinned_in, bytes, hipMemcpyHostToDevice, ctx->stream));
-  ISAC_HIP(hipEventRecord(ctx->ev_h2d, ctx->stream));
+  *host = sl.p;
   return ISAC_OK;
+}
+inline int stage_commit(isac_ctx* ctx, void* d_dst, size_t bytes) {
+  StageSlot& sl = ctx->stage_ring[ctx->stage_next];
+  ISAC_HIP(hipMemcpyAsync(d_dst, sl.p, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_HIP(hipEventRecord(sl.ev, ctx->stream));
+  sl.busy = true;
+  ctx->stage_next = (ctx->stage_next + 1) % kStageSlots;
+  return ISAC_OK;
+}
+inline int stage_upload(isac_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+  void* h = nullptr;
+  ISAC_TRY(stage_acquire(ctx, bytes, &h));
+  std::memcpy(h, src, bytes);
+  return stage_commit(ctx, d_dst, bytes);
 }
 
 // ---------------------------------------------------------------- OFDM numerology (TS 38.211 5.3.1)

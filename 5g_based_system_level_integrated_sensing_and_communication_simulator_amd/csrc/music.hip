@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_kernel(const c64* __restric
   }
   if (tid == 0) {
     S.d[n - 1] = M[n - 1 + n * (n - 1)].re; S.e[n - 1] = 0.0;
-    if (info) info[1] = (int)((clock64() - t_start) >> 6);
+    if (info) { info[1] = (int)((clock64() - t_start) >> 6); info[6] = 0; }
   }
 }
 
@@ -1380,7 +1380,7 @@ __global__ __launch_bounds__(1024) void eigh_tridiag_fused_kernel(const c64* __r
   if (tid == 0) {
     const c64 c = M[n - 1 + n * (n - 1)] - mul_conj(sv[n - 1], sw[n - 1]) - mul_conj(sw[n - 1], sv[n - 1]);   // the last pending update
     S.d[n - 1] = c.re; S.e[n - 1] = 0.0;
-    if (info) info[1] = (int)((clock64() - t_start) >> 6);
+    if (info) { info[1] = (int)((clock64() - t_start) >> 6); info[6] = 0; }
   }
 }
 
@@ -1423,8 +1423,9 @@ __device__ __forceinline__ double row16_sum_dpp(double x) {      // every lane: 
   return x;
 }
 __global__ __launch_bounds__(256) void eigh_tridiag_dist_kernel(const c64* __restrict__ Hin, int n, void* scratch, int* __restrict__ info, unsigned base,
-                                                                      int stride, int slot, int far_only) {
+                                                                      int stride, int slot, int far_only, int force_abort) {
   if ((int)(blockIdx.x % (unsigned)stride) != slot) return;
+  if (force_abort) { if (threadIdx.x == 0 && info) info[0] = info[6] = -4; return; }   // test hook (ISAC_EIG_FORCE_TRIDIAG_TIMEOUT): behave like an exchange that timed out
   __shared__ __attribute__((aligned(16))) c64 sv[2][kTdMaxN];      // the reflector of the step, by parity   (sv, sw: every wavefront writes the same bits)
   __shared__ __attribute__((aligned(16))) c64 sw[kTdMaxN];         // w of the step
   __shared__ __attribute__((aligned(16))) c64 scol4[4][kTdMaxN];   // per wavefront: the owner's next column, row by row
@@ -1478,7 +1479,7 @@ __global__ __launch_bounds__(256) void eigh_tridiag_dist_kernel(const c64* __res
     }
     for (int o = 32; o > 0; o >>= 1) t = fmax(t, __shfl_xor(t, o));
     __syncthreads();
-    if (s_abort) { if (threadIdx.x == 0 && info) info[0] = -4; return; }
+    if (s_abort) { if (threadIdx.x == 0 && info) info[0] = info[6] = -4; return; }   // (info[6]: sticky -- the kernels behind overwrite info[0])
     if (t > 0.0 && t < 1.7976931348623157e308) {                     // (eigh_safe_scale's rule)
       const int ex = ilogb(t);
       if (ex < -400 || ex > 400) scl = ldexp(1.0, -ex);
@@ -1584,7 +1585,7 @@ __global__ __launch_bounds__(256) void eigh_tridiag_dist_kernel(const c64* __res
       sc[par][i] = cr;
     }
     __syncthreads();
-    if (s_abort) { if (threadIdx.x == 0 && info) info[0] = -4; return; }
+    if (s_abort) { if (threadIdx.x == 0 && info) info[0] = info[6] = -4; return; }   // (info[6]: sticky -- the kernels behind overwrite info[0])
     c64 pi[4], ci[4];
     bool live[4];
 #pragma unroll
@@ -1735,7 +1736,7 @@ __global__ __launch_bounds__(64 * kTriWaves) void eigh_tridiag_small_kernel(cons
   }
   if (tid == 0) {
     S.d[n - 1] = M[n - 1 + n * (n - 1)].re; S.e[n - 1] = 0.0;
-    if (info) { info[1] = (int)((clock64() - t_start) >> 6); info[12] = (int)(c_refl >> 6); info[13] = (int)(c_mv >> 6); info[14] = (int)(c_upd >> 6); }
+    if (info) { info[1] = (int)((clock64() - t_start) >> 6); info[6] = 0; info[12] = (int)(c_refl >> 6); info[13] = (int)(c_mv >> 6); info[14] = (int)(c_upd >> 6); }
   }
 }
 
@@ -1927,7 +1928,7 @@ __global__ __launch_bounds__(1024) void eigh_formq_ql_kernel(int n, void* scratc
     S.cnt[1] = (int)nrot; S.cnt[2] = overflow;
     __hip_atomic_store(&S.cnt[0], sweeps, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&S.cnt[4], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    if (info) { info[0] = overflow ? -1 : sweeps; info[3] = (int)((clock64() - t0) >> 6); info[5] = (int)nrot; }
+    if (info) { info[0] = info[6] == -4 ? -4 : overflow ? -1 : sweeps; info[3] = (int)((clock64() - t0) >> 6); info[5] = (int)nrot; }   // (a timed-out tridiagonalisation stays reported)
   }
 }
 
@@ -2075,7 +2076,7 @@ __device__ __forceinline__ void eigh_replay_body(int n, const EighScratch& S, c6
     double* Vd = reinterpret_cast<double*>(V_out) + item;
     for (int c = 0; c < n; ++c) Vd[gs * c] = Zd[cs * c];
   }
-  if (gid == 0 && info) { info[4] = (int)((clock64() - t0) >> 6); if (timeout) info[0] = -2; }
+  if (gid == 0 && info) { info[4] = (int)((clock64() - t0) >> 6); if (timeout && info[6] != -4) info[0] = -2; }
 }
 
 template <bool LDS>
@@ -2183,7 +2184,7 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
       const bool done = L <= 0 || L >= n;
       ctl[MusicCtl::kRoute] = done ? 1 : 0;
       ctl[MusicCtl::kLsub] = L <= 0 ? 0 : L;
-      if (done && info) { info[0] = 0; info[5] = -3; }
+      if (done && info) { info[0] = info[6] == -4 ? -4 : 0; info[5] = -3; }
     }
     return;
   }
@@ -2392,7 +2393,7 @@ __global__ __launch_bounds__(1024) void music_subspace_kernel(int n, void* scrat
     ctl[MusicCtl::kRoute] = 1;
     ctl[MusicCtl::kLsub] = L;
     if (info) {
-      info[0] = s_bad ? -3 : 0; info[5] = -3;
+      info[0] = info[6] == -4 ? -4 : s_bad ? -3 : 0; info[5] = -3;
       info[8] = (int)((t_k1 - t_k0) >> 6); info[9] = (int)(t_solve >> 6); info[10] = (int)(t_mgs >> 6); info[11] = (int)((clock64() - t_k2) >> 6);
     }
   }
@@ -2674,8 +2675,10 @@ static int launch_tridiag(isac_ctx* ctx, const c64* d_H, int n, hipStream_t st, 
       }
       // every 8th workgroup of the grid works (the others return at once): the dispatcher deals workgroups round-robin to the 8 XCDs, so the working ones share
       // an L2 and the exchange can stay in it -- verified by the kernel (XCC ids in its first exchange), never assumed
+      static const bool force_to = std::getenv("ISAC_EIG_FORCE_TRIDIAG_TIMEOUT") != nullptr;   // test hook: every distributed reduction reports a time-out
+      ISAC_HIP(hipMemsetAsync(info + 6, 0, sizeof(int), st));                        // the sticky time-out word (the one-workgroup kernels clear it themselves)
       hipLaunchKernelGGL(eigh_tridiag_dist_kernel, dim3((unsigned)(((n + 15) / 16) * td_stride)), dim3(256), 0, st, d_H, n, gs, info,
-                         (unsigned)((ctx->eig_epoch & 0xFFFFF) << 12), td_stride, (int)(td_launches.fetch_add(1) % (unsigned)td_stride), td_far);
+                         (unsigned)((ctx->eig_epoch & 0xFFFFF) << 12), td_stride, (int)(td_launches.fetch_add(1) % (unsigned)td_stride), td_far, force_to ? 1 : 0);
     } else if (unfused) hipLaunchKernelGGL(eigh_tridiag_kernel<false>, dim3(1), dim3(1024), lds1, st, d_H, n, gs, info);
     else {
       const size_t ldsf = sizeof(c64) * 7 * (size_t)n + sizeof(double) * 32 + 64;

@@ -32,10 +32,10 @@ extern "C" {
 #endif
 
 /* Bumped on EVERY change of a struct layout, enum value or entry-point signature below (1: round 1; 2: ISAC_MAX_EST 1024 -> 4096,
- * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev).  A host must
+ * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve).  A host must
  * compare isac_abi_version() with the ISAC_ABI_VERSION it was compiled against AND isac_abi_sizeof() with its own sizeof of every
  * struct it passes: the library writes whole structs (isac_est_result is 128 KB) into caller memory. */
-#define ISAC_ABI_VERSION 5
+#define ISAC_ABI_VERSION 6
 #define ISAC_MAX_EST 4096 /* capacity of the estimate vectors in isac_est_result: unique range bins <= nIFFT (<= 4096 for every
                              * NR numerology), unique velocity bins <= nFFT, azimuth peaks <= 180 -- never the binding limit */
 
@@ -325,6 +325,17 @@ int isac_ctx_set_option(isac_ctx* ctx, int32_t option, int32_t value);
  * stream.  isac_fft2d_collect waits for its own CPI only.  owner = NULL (or ctx itself) restores the context's own streams.  `owner`
  * must outlive the sharing; both contexts must be idle (no pending submit) and on the same device. */
 int isac_ctx_share_streams(isac_ctx* ctx, isac_ctx* owner);
+/* Prepare the context for the sensing chain the caller is about to run, OUTSIDE the part of its run that matters: the reference calls
+ * monoStaticSensing -> fft2D ONCE per cell and simulation (+simulation/cellSimulation.m:189-202, one worker per cell: networkSimulation.m:47-60), so
+ * the first call of a process would otherwise pay for loading seven code objects, sizing every scratch buffer, building the twiddle / Kaiser / sind
+ * tables, enabling the large-LDS kernels, allocating pinned staging -- and run at the clocks of an idle device.  The call runs the REAL chain
+ * (isac_mono_static_sensing_fused_dev with Philox spectral noise -> isac_fft2d_submit_cached_dev -> isac_fft2d_collect) on QPSK grids it generates
+ * itself in temporary device memory (T x A + 2 K L A elements, freed before it returns) with the caller's own parameter blocks, so every buffer,
+ * table and kernel the real call touches is the one that gets prepared; it repeats the dry CPI until warm_ms of wall time have passed (0: once)
+ * -- 50-300 ms bring the clocks of an idle MI355X up.  The estimates of the dry runs are discarded; a dry CPI without detections is not an
+ * error.  *elapsed_ms (optional) receives the wall time of the call. */
+int isac_ctx_reserve(isac_ctx* ctx, int64_t T, int32_t tx_dim_l, const isac_carrier* carrier, const isac_radar_channel_params* rp,
+                     const isac_est_params* ep, const isac_cfar_config* cfar, double warm_ms, double* elapsed_ms);
 
 /* sensing.estimation.doaEstimation.music(numDets, radarEstParams, Ra) (music.m:1), ULA branch.
  * num_dets < 0 means [] (model order from determineNumTargets, music.m:109-125). */

@@ -187,6 +187,20 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     const uint64_t h = *mxGetUint64s(prhs[1]);
     auto it = g_arrays.find(h);
     if (it != g_arrays.end()) { check(isac_dev_free(ctx(), it->second.p)); g_arrays.erase(it); }
+  // ------------------------------------------------------------------ context preparation
+  } else if (fn == "reserve") {
+    // ms = isac_mex('reserve', waveformLength, txDimension, carrierInfo, radarParams, radarEstParams, cfar [, warm_ms])
+    // One or more dry runs of monoStaticSensing -> fft2D at the caller's shape (isac_ctx_reserve): the reference calls that chain once per cell and
+    // simulation (cellSimulation.m:189-202) -- call this from the scenario set-up (networkSimulation.m:44-60, in front of the cell loop) and the one
+    // call that matters finds code objects, scratch, tables and clocks ready.
+    if (nrhs < 7) mexErrMsgIdAndTxt("isac:INVALID_ARG", "usage: isac_mex('reserve', T, txDimension, carrierInfo, radarParams, radarEstParams, cfar [, warm_ms])");
+    isac_carrier c = carrier_block(prhs[3]);
+    isac_radar_channel_params p = channel_block(prhs[4]);
+    isac_est_params e = est_block(prhs[5]);
+    isac_cfar_config cf = cfar_block(prhs[6]);
+    double ms = 0.0;
+    check(isac_ctx_reserve(ctx(), (int64_t)mxGetScalar(prhs[1]), (int)mxGetDoubles(prhs[2])[1], &c, &p, &e, &cf, nrhs > 7 && !mxIsEmpty(prhs[7]) ? mxGetScalar(prhs[7]) : 0.0, &ms));
+    plhs[0] = mxCreateDoubleScalar(ms);
   // ------------------------------------------------------------------ echo synthesis
   } else if (fn == "monoStaticSensing" || fn == "basicRadarChannel" || fn == "monoStaticSensingFused") {
     // (txWaveform | handle, txDimension | [], carrierInfo | [], radarParams, uint8(LoS), noise | [] , seed | [], noiseDomain 'time'|'spectral'

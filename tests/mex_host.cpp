@@ -140,6 +140,11 @@ int chain(const char* in, const char* out) {
 
   FILE* o = std::fopen(out, "wb");
   if (!o) { std::perror(out); return 1; }
+  // (0) context preparation at the caller's shape (isac.reserve -> isac_ctx_reserve): dry runs of the chain below; must not disturb what follows
+  {
+    mxArray* ms = call("reserve", {scalar((double)h.T), dim, car, rp, rp, cfar, scalar(0.0)})[0];
+    if (!(mxGetScalar(ms) > 0.0)) { std::fprintf(stderr, "reserve reported no elapsed time\n"); return 5; }
+  }
   // (1) the reference's own calling convention: MATLAB arrays in, MATLAB arrays out                 monoStaticSensing.m:1, fft2D.m:1
   mxArray* echo1 = call("monoStaticSensing", {m_wave, dim, car, rp, m_los, m_noise, none, s_time})[0];
   mxArray* est1 = call("fft2D", {rp, cfar, echo1, m_grid})[0];

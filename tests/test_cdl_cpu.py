@@ -74,6 +74,24 @@ def test_host_mirror_matches_oracle(profile):
         pkg.communication.channelModels.CDLChannel("CDL-B")
 
 
+def test_block_plan_of_a_static_channel_and_shared_taps():
+    """Host mirror: MaximumDopplerShift = 0 (a valid nrCDLChannel configuration) is ONE gain block at the current channel time, not a division by zero;
+    the filter taps shared between channels of one delay profile are read-only."""
+    pkg = load_pkg()
+    CM = pkg.communication.channelModels
+    ch = CM.CDLChannel("CDL-A", 300e-9, 3.5e9, (1, 4, 2, 1, 1), (1, 1, 2, 1, 1), 15.36e6, MaximumDopplerShift=0.0)
+    ch.time = 0.37
+    assert ch.block_plan(7680) == ([0.37], [0])
+    mv = CM.CDLChannel("CDL-A", 300e-9, 3.5e9, (1, 4, 2, 1, 1), (1, 1, 2, 1, 1), 15.36e6)
+    t_snap, starts = mv.block_plan(7680)
+    assert starts[0] == 0 and len(t_snap) == len(starts) >= 1
+    g, sh = mv.filter_taps()
+    with pytest.raises(ValueError):
+        g[0, 0] = 1.0
+    with pytest.raises(ValueError):
+        sh[0] = 1
+
+
 def test_apply_cdl_is_linear_and_causal():
     cfg = OC.cdl_config("CDL-D", 3.5e9, (1, 2, 2, 1, 1), (1, 1, 2, 1, 1), 15.36e6)
     rng = np.random.default_rng(0)

@@ -23,11 +23,21 @@ def pkg():
     return load_pkg()
 
 
-def _scene(seed):
+# antenna counts that reach every covariance / eigensolver kernel: cov_mfma_small (<= 32), cov_mfma_lds<3> (33-48), <4> (49-64: the bench's own),
+# cov_mfma_block_pl + eigh_tridiag_dist (65-256); scenes with them stay small (24-51 PRB, 2-4 slots) so that the oracle stays cheap
+WIDE_ANTS = (64, 200, 56, 96, 33, 256, 48, 130, 16, 65)
+
+
+def _scene(seed, wide=None):
     rng = np.random.default_rng(1000 + seed)
     nrb = int(rng.choice([24, 51, 106, 133, 273]))
     n_ants = int(rng.choice([1, 2, 3, 4, 5, 8]))
     n_slots = int(rng.choice([2, 3, 4, 6]))
+    if wide is None:
+        wide = seed % 4 >= 2                 # half of the seeds are wide-array scenes; the default 16 cover 64, 200, 56, 96, 33, 256, 48, 130 antennas
+    if wide:
+        nrb, n_slots = int(rng.choice([24, 51])), int(rng.choice([2, 3, 4]))
+        n_ants = int(WIDE_ANTS[(2 * (seed // 4) + seed % 4 - 2) % len(WIDE_ANTS)])
     q = int(rng.integers(1, 4))
     r = rng.uniform(60.0, 400.0, q)
     az = np.deg2rad(rng.uniform(-70.0, 70.0, q))
@@ -176,8 +186,8 @@ def test_spectral_fused_path_on_random_scene(pkg, seed):
     from conftest import spectral_to_time_noise
     rng = np.random.default_rng(9000 + seed)
     q = int(rng.integers(1, 7))
-    n_ants = int(rng.choice([1, 2, 3, 5, 8, 17, 40]))
-    n_slots = int(rng.choice([2, 4] if n_ants > 8 else [2, 3, 4]))
+    n_ants = int(rng.choice([1, 2, 3, 5, 8, 17, 40, 56, 64, 72]))    # (56 / 64: cov_mfma_lds_kernel<4>, the bench's own instantiation; 72: the block kernel + the distributed tridiagonalisation)
+    n_slots = int(rng.choice([2, 4] if n_ants > 8 else [2, 3, 4])) if n_ants <= 40 else 2
     r = rng.uniform(60.0, 300.0, q)
     az = np.deg2rad(rng.uniform(-70.0, 70.0, q))
     targets = tuple((float(r[i] * np.cos(az[i])), float(r[i] * np.sin(az[i])), 1.5) for i in range(q))
@@ -225,3 +235,36 @@ def test_spectral_fused_path_on_random_scene(pkg, seed):
     if n_sig >= 1 and (ev[n_sig - 1] - ev[n_sig]) < 1e-9 * ev[0]:
         pytest.skip("signal/noise split inside a degenerate eigenvalue cluster: MUSIC peaks undefined")
     assert np.array_equal(got.aziEst, want.aziEst)
+
+
+N_EIG = max(12, N_CASES)
+
+
+@pytest.mark.parametrize("seed", range(N_EIG))
+def test_eigh_top_on_random_spectrum(pkg, seed):
+    """isac_eigh_top fuzzed over 65 <= n <= 256 (eigh_tridiag_dist_kernel -> bisection -> subspace kernel; every third seed 17 <= n <= 64: the one-workgroup
+    reduction) on Hermitian matrices with a PRESCRIBED spectrum: k leading eigenvalues separated by random relative gaps between 1e-9 and 1 (tight pairs,
+    well-separated ones, random dynamic range up to 1e12), a noise floor with its own spread, a random unitary basis.  Eigenvalues to 1e-13 ||H||; the returned
+    vectors span an invariant subspace (residual 1e-11 ||H||, orthonormal to 1e-12) -- inside a tight cluster any rotation of the basis is right.  music.m:19-29."""
+    ctx = pkg.default_context()
+    rng = np.random.default_rng(31000 + seed)
+    n = int(rng.integers(17, 65)) if seed % 3 == 2 else int(rng.integers(65, 257))
+    lmax = max(1, min(32 if n <= 128 else 16, 122880 // (32 * n)))
+    k = int(rng.integers(1, min(lmax, 8) + 1))
+    top = [10.0 ** rng.uniform(0, 6)]
+    for _ in range(k - 1):
+        top.append(top[-1] * (1.0 - 10.0 ** rng.uniform(-9, -0.05)))
+    floor_hi = top[-1] * 10.0 ** rng.uniform(-6, -0.3)
+    floor = np.sort(floor_hi * 10.0 ** (-rng.uniform(0, rng.choice([0.0, 0.5, 6.0]), n - k)))[::-1]
+    lam = np.concatenate([top, floor])
+    q_, _ = np.linalg.qr(rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+    h = (q_ * lam) @ q_.conj().T
+    h = np.asfortranarray(0.5 * (h + h.conj().T))
+    wr = np.linalg.eigvalsh(h)
+    scale = np.abs(wr).max()
+    for n_top in sorted({k, min(k + 1, n - 1), 1}):
+        w, u = ctx.eigh_top(h, n_top)
+        assert np.abs(w - wr).max() < 1e-13 * scale, (seed, n, k, n_top)
+        assert np.abs(u.conj().T @ u - np.eye(n_top)).max() < 1e-12, (seed, n, k, n_top)
+        # invariant subspace: H U = U (U^H H U)
+        assert np.abs(h @ u - u @ (u.conj().T @ h @ u)).max() < 1e-11 * scale, (seed, n, k, n_top)

@@ -367,6 +367,60 @@ def test_eigh_live_replay_timeout_is_recovered():
     assert r.returncode == 0 and "recovered" in r.stdout, r.stdout + r.stderr
 
 
+_TRIDIAG_TIMEOUT_SNIPPET = """
+import ctypes as C, importlib, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r + "/tests")
+pkg = importlib.import_module(%r)
+from conftest import make_scene
+ctx = pkg._lib.Context(0)
+def herm(a):
+    rng = np.random.default_rng(a)
+    m = rng.standard_normal((a, a)) + 1j * rng.standard_normal((a, a))
+    return np.asfortranarray(m @ m.conj().T / a + np.diag(rng.uniform(0, 3, a)))
+def eigh(a):
+    h = herm(a); w = np.zeros(a); v = np.zeros((a, a), dtype=np.complex128, order="F")
+    ctx.check(ctx.lib.isac_eigh(ctx.handle, h.ctypes.data_as(C.c_void_p), C.c_int32(a), w.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
+    return h, w, v
+def eigh_top(a, k):
+    h = herm(a); w = np.zeros(k); v = np.zeros((a, k), dtype=np.complex128, order="F")
+    ctx.check(ctx.lib.isac_eigh_top(ctx.handle, h.ctypes.data_as(C.c_void_p), C.c_int32(a), C.c_int32(k), w.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
+n_err = 0
+for call in (lambda: eigh(100), lambda: eigh_top(100, 3), lambda: eigh(256)):
+    try:
+        call()
+    except pkg.IsacError as e:
+        assert "tridiagonalisation" in str(e), str(e)
+        n_err += 1
+assert n_err == 3, n_err
+# the one-workgroup route (A <= 64) of the same context is untouched by the stale status
+h, w, v = eigh(48)
+assert np.abs(w - np.linalg.eigvalsh(h)).max() < 1e-12 * np.abs(w).max()
+# the whole chain at 72 antennas: the CPI must fail, not return azimuths computed from a half-written tridiagonal form
+sc = make_scene(n_ants=72, n_slots=2, nrb=24, targets=((120.0, 60.0, 1.5),), velocity=(5.0,), seed=3)
+rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+cf = pkg.sensing.detection.cfar2D(rp)
+echo = pkg.sensing.monoStaticSensing(sc.tx_wave, sc.tx_grid.shape, sc.carrier, rp, np.ones(1, np.uint8), noise=sc.noise, nfft=sc.wave.Nfft)
+try:
+    pkg.sensing.estimation.fft2D(rp, cf, echo, sc.tx_grid)
+    raise SystemExit("fft2D returned estimates after a timed-out tridiagonalisation")
+except pkg.IsacError as e:
+    assert e.name != "NO_DETECTION", str(e)
+print("surfaced")
+"""
+
+
+def test_distributed_tridiagonalisation_timeout_surfaces():
+    """eigh_tridiag_dist_kernel reports an exchange time-out in info[0] AND in the sticky word info[6]: the kernels that follow on the stream (QL pipeline,
+    subspace kernel, replay) overwrite info[0] and must keep the -4.  ISAC_EIG_FORCE_TRIDIAG_TIMEOUT (read once per process, hence the subprocess) makes
+    every distributed reduction report one: isac_eigh, isac_eigh_top and the fft2D chain at A > 64 must fail; A <= 64 on the same context must not."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ISAC_EIG_FORCE_TRIDIAG_TIMEOUT="1")
+    r = subprocess.run([sys.executable, "-c", _TRIDIAG_TIMEOUT_SNIPPET % (root, root, PKG_NAME)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "surfaced" in r.stdout, r.stdout + r.stderr
+
+
 _TRIDIAG_SNIPPET = """
 import ctypes as C, hashlib, importlib, sys
 import numpy as np

@@ -110,3 +110,53 @@ def test_share_streams_refuses_a_pending_context(pkg):
     pkg.sensing.estimation.fft2D_collect(b)
     b.share_streams(a)
     b.share_streams(None)
+
+
+def test_csi_report_between_submit_and_collect_keeps_the_pending_cpi(pkg):
+    """isac_csi_report[_batch]_dev on a context with a submitted, not yet collected CPI used to copy its results into the very pinned buffer
+    the submit's D2H copy fills and isac_fft2d_collect parses.  The CSI path has its own result buffer now: the collect that follows returns the CPI's
+    own estimates, and the report equals the one computed on an idle context."""
+    from types import SimpleNamespace
+    import oracle.cqi as OQ
+    c = pkg.Context()
+    sc = _scene(2)
+    rx, want = _oracle(sc)
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    cf = pkg.sensing.detection.cfar2D(rp)
+    rng = np.random.default_rng(5)
+    nrb = 52
+    k = np.concatenate([[12 * r + 1, 12 * r + 2] for r in range(nrb)])
+    l = np.ones_like(k)
+    carrier = SimpleNamespace(NSizeGrid=nrb, NStartGrid=0, SymbolsPerSlot=14)
+    rep = SimpleNamespace(NSizeBWP=nrb, NStartBWP=0, PanelDimensions=(2, 1), CodebookMode=1, PMIMode="Subband", CQIMode="Subband", SubbandSize=8)
+    hs = [c.to_device(np.asfortranarray((rng.standard_normal((k.size, 2, 4)) + 1j * rng.standard_normal((k.size, 2, 4))) * 2.0)) for _ in range(12)]
+    nv = [0.05 * (1 + u) for u in range(12)]
+    idle = pkg.communication.phyLayer.cqiSelectBatch(carrier, SimpleNamespace(k=k, l=l), rep, 1, hs, nv, OQ.DOWNLINK_SINR90PC, ctx=c)
+    d_rx, d_tx = c.to_device(rx), c.to_device(sc.tx_grid)
+    for _ in range(3):
+        pkg.sensing.estimation.fft2D_submit(rp, cf, d_rx, d_tx, ctx=c)
+        busy = pkg.communication.phyLayer.cqiSelectBatch(carrier, SimpleNamespace(k=k, l=l), rep, 1, hs, nv, OQ.DOWNLINK_SINR90PC, ctx=c)
+        assert _same(pkg.sensing.estimation.fft2D_collect(c), want)
+        for a, b in zip(idle, busy):
+            assert np.array_equal(np.nan_to_num(a[0], nan=-1.0), np.nan_to_num(b[0], nan=-1.0))
+
+
+def test_reserve_prepares_the_context_and_leaves_no_state_behind(pkg):
+    """isac_ctx_reserve: dry runs of monoStaticSensing -> fft2D at the caller's shape on grids the library makes itself.  Afterwards the real
+    chain gives the oracle's estimates, nothing of the dry run is cached (a cached fft2D without a preceding fused call is still an error), and a second
+    reserve with a wall-clock budget keeps running dry CPIs for about that long."""
+    c = pkg.Context()
+    sc = _scene(4)
+    rx, want = _oracle(sc)
+    rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
+    cf = pkg.sensing.detection.cfar2D(rp)
+    ms = pkg.sensing.reserve(sc.T, sc.tx_grid.shape, sc.carrier, rp, cf, nfft=sc.wave.Nfft, ctx=c)
+    assert ms > 0.0
+    d_rx, d_tx = c.to_device(rx), c.to_device(sc.tx_grid)
+    with pytest.raises(pkg.IsacError):
+        pkg.sensing.estimation.fft2D(rp, cf, d_rx, d_tx, ctx=c, reuse_range=True)
+    assert _same(pkg.sensing.estimation.fft2D(rp, cf, d_rx, d_tx, ctx=c), want)
+    echo = pkg.sensing.monoStaticSensing(c.to_device(sc.tx_wave), sc.tx_grid.shape, sc.carrier, rp, sc.los, noise=c.to_device(sc.noise), nfft=sc.wave.Nfft, ctx=c)
+    assert _same(pkg.sensing.estimation.fft2D(rp, cf, echo, d_tx, ctx=c), want)
+    ms2 = pkg.sensing.reserve(sc.T, sc.tx_grid.shape, sc.carrier, rp, cf, nfft=sc.wave.Nfft, warm_ms=60.0, ctx=c)
+    assert 60.0 <= ms2 < 2000.0
