@@ -653,10 +653,12 @@ def cold_probe(args, pkg):
         out["reserve_warm_ms_requested"] = args.cold_warm_ms
         out["reserve_ms_library_clock"] = round(lib_ms, 2)
     per = []
+    gc.collect(); gc.disable()                                # (the caller of the drop-in is MATLAB: no Python collector pauses in its figures)
     for _ in range(21):
         t0 = time.perf_counter()
         cell.step()
         per.append(1e3 * (time.perf_counter() - t0))
+    gc.enable()
     out.update({"first_cpi_ms": round(per[0], 3), "cpi_2_21_ms": {"median": round(float(np.median(per[1:])), 3), "max": round(float(np.max(per[1:])), 3)},
                 "wall_21_blocking_cpis_ms": round(float(np.sum(per)), 2), "per_cpi_ms": [round(v, 3) for v in per]})
     # the steady blocking CPI of the same process (clocks up): the yardstick for the figures above

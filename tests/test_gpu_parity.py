@@ -383,19 +383,22 @@ def eigh(a):
     ctx.check(ctx.lib.isac_eigh(ctx.handle, h.ctypes.data_as(C.c_void_p), C.c_int32(a), w.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
     return h, w, v
 def eigh_top(a, k):
-    h = herm(a); w = np.zeros(k); v = np.zeros((a, k), dtype=np.complex128, order="F")
+    h = herm(a); w = np.zeros(a); v = np.zeros((a, k), dtype=np.complex128, order="F")     # (w: ALL eigenvalues)
     ctx.check(ctx.lib.isac_eigh_top(ctx.handle, h.ctypes.data_as(C.c_void_p), C.c_int32(a), C.c_int32(k), w.ctypes.data_as(C.c_void_p), v.ctypes.data_as(C.c_void_p)))
 n_err = 0
-for call in (lambda: eigh(100), lambda: eigh_top(100, 3), lambda: eigh(256)):
+for i, call in enumerate((lambda: eigh(100), lambda: eigh_top(100, 3), lambda: eigh(256))):
+    print("call", i, flush=True)
     try:
         call()
     except pkg.IsacError as e:
         assert "tridiagonalisation" in str(e), str(e)
         n_err += 1
 assert n_err == 3, n_err
+print("eigh calls failed as they must", flush=True)
 # the one-workgroup route (A <= 64) of the same context is untouched by the stale status
 h, w, v = eigh(48)
 assert np.abs(w - np.linalg.eigvalsh(h)).max() < 1e-12 * np.abs(w).max()
+print("A = 48 fine", flush=True)
 # the whole chain at 72 antennas: the CPI must fail, not return azimuths computed from a half-written tridiagonal form
 sc = make_scene(n_ants=72, n_slots=2, nrb=24, targets=((120.0, 60.0, 1.5),), velocity=(5.0,), seed=3)
 rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
