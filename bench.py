@@ -367,6 +367,7 @@ class CommCell:
         self.nvar = 10.0 ** (-(46.0 - pl_db - (-174.0 + 10.0 * np.log10(100e6) + 7.0)) / 10.0)
         self.h_est = [ctx_csi.to_device(freq_response(ch, self.csi_k, K, 30e3, 4)) for ch in self.chans]
         self.last_cqi = None
+        self.last_reports = None
         for c_ in self.ctxs:
             c_.sync()
         ctx_csi.sync()
@@ -389,6 +390,7 @@ class CommCell:
             rep = self.PL.cqiSelectBatch(self.carrier, SimpleNamespace(k=self.csi_k, l=self.csi_l), self.report, 1, self.h_est, self.nvar, DOWNLINK_SINR90PC,
                                          ctx=self.ctx_csi, codebook=self.codebook)
         self.last_cqi = [None if np.isnan(c[0][0]) else int(c[0][0]) for c in rep]
+        self.last_reports = rep                              # (cqi, pmi, info) per UE of the frame's last occasion: what the per-cell record carries to rank 0
 
     def gemm_launch(self):
         """(jobs, issued 3M flops, bytes) of one contraction launch of the larger delay-profile group: what `roofline` prices."""
@@ -441,7 +443,7 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
     barrier()
     dt = time.perf_counter() - t0
     os.write(2, f"bench.py: rank {rank}/{world}: device {local_rank}, {len(mine)} cell(s) {mine}, timed region {1e3 * dt:.3f} ms for {args.steps} frame(s), config5\n".encode())
-    recs = np.array([d.make_record(cid, sc.last, dt) for cid, sc in zip(mine, sense)]).reshape(-1, d.RECORD_LEN)
+    recs = np.array([d.make_record(cid, sc.last, dt, ue_reports=cc.last_reports) for cid, sc, cc in zip(mine, sense, comm)]).reshape(-1, d.RECORD_LEN)
     on_gpu = dist is not None and dist.get_backend() == "nccl"
     allr = d.gather_records(recs, dist, torch.device("cuda", local_rank) if on_gpu else None)
     dt_max = float(np.nanmax(allr[:, 6])) if allr.size else dt
@@ -487,9 +489,9 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
                         "timing": "HIP events recorded by the library around the apply launch (isac_profile_*), device otherwise idle"},
            "comm_seams": {"cdl_apply_ms_per_job": round(ms_call / n_jobs, 4), "csi_report_ms_per_ue": round(ms_csi, 4),
                           "csi_note": "host wall per UE of the batched report (one synchronisation per cell and occasion), device otherwise idle"},
-           "cells": [{"cell": int(r[0]), "nRng": None if np.isnan(r[1]) else int(r[1]), "rngEst0": None if np.isnan(r[2]) else round(float(r[2]), 6),
-                      "aziEst0": None if np.isnan(r[4]) else float(r[4])} for r in allr[:64]],
-           "rank0_cqi": [c_.last_cqi for c_ in comm[:4]]}
+           "cells": [d.record_json(r) for r in allr[:64]],
+           "cells_note": "gathered from every rank (one all_gather of fixed-size records, _dist.py): every cell's whole estResults (fft2D.m:102,114-115) and every UE's last "
+                         "CSI report of the frame (wideband CQI, subband CQIs, PMI i1 / i2: networkSimulation.m:173-232)"}
     print(json.dumps(res))
 
 
@@ -921,9 +923,7 @@ def main():
                        "parallelism": f"cells sharded over {world} GPU(s)"},
             "roofline": roofline_entry(cells[0], args, dom_ms_timed, dom_ms_iso, len(sink or []), stages, echo_b + rdm_b, per_cpi_ms),
         }
-        res["cells"] = [{"cell": int(r[0]), "nRng": None if np.isnan(r[1]) else int(r[1]), "rngEst0": None if np.isnan(r[2]) else round(float(r[2]), 6),
-                         "velEst0": None if np.isnan(r[3]) else round(float(r[3]), 6), "aziEst0": None if np.isnan(r[4]) else float(r[4])}
-                        for r in allr[:64]]
+        res["cells"] = [d.record_json(r) for r in allr[:64]]                      # every cell's whole estResults, gathered from every rank
         if world > 1:
             n1 = n1_in_run if n1_in_run is not None else args.n1_value
             per_gpu = "the same per-GPU workload" if args.cells == 0 else "rank 0's share of the cells"

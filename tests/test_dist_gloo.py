@@ -32,7 +32,10 @@ def _worker(rank, world, port, n_cells, q):
     recs = []
     for c in mine:
         est = SimpleNamespace(rngEst=np.array([100.0 + c, 5.0]), velEst=np.array([float(c)]), aziEst=np.array([-c * 1.0]))
-        recs.append(d.make_record(c, est if c != 3 else None, elapsed_s=0.1 * c))
+        # per-UE CSI reports as cqiSelect returns them: cqi [1 + nSB x 1] (row 0 wideband), pmi.i1 (3), pmi.i2 [1 + nSB]; UE 1 of cell 2 has none
+        ues = [None if (c == 2 and u == 1) else (np.array([[7 + u], [6], [8 + c % 3], [5]], dtype=float), SimpleNamespace(i1=np.array([1 + u, 1, 1]), i2=np.array([2, 1, 2, 1 + c % 2])), None)
+               for u in range(3)]
+        recs.append(d.make_record(c, est if c != 3 else None, elapsed_s=0.1 * c, ue_reports=ues if c % 2 == 0 else None))
     allr = d.gather_records(np.array(recs).reshape(-1, d.RECORD_LEN), dist)
     q.put((rank, mine, allr))
     dist.barrier()
@@ -56,12 +59,26 @@ def test_shard_and_gather_world2(n_cells):
     assert sorted(got[0][1] + got[1][1]) == list(range(n_cells))          # every cell exactly once
     assert got[0][1] == [c for c in range(n_cells) if c % 2 == 0]
     for _, _, allr in got:                                                 # every rank sees every record, in cell order
-        assert allr.shape == (n_cells, 8) and allr[:, 0].tolist() == list(range(n_cells))
+        d = __import__("importlib").import_module(load_pkg().__name__ + "._dist")
+        assert allr.shape == (n_cells, d.RECORD_LEN) and allr[:, 0].tolist() == list(range(n_cells))
         for c in range(n_cells):
+            u = d.unpack_record(allr[c])
             if c == 3:
-                assert allr[c, 7] == 0.0 and np.isnan(allr[c, 2])            # senResults = NaN cell
+                assert allr[c, 7] == 0.0 and np.isnan(allr[c, 2]) and not u.valid and u.rngEst.size == 0   # senResults = NaN cell
             else:
                 assert allr[c, 1] == 2 and allr[c, 2] == 100.0 + c and allr[c, 3] == c and allr[c, 4] == -c
+                # the WHOLE estimate lists arrive on every rank (fft2D.m:102,114-115), not the first entries only
+                assert u.valid and u.rngEst.tolist() == [100.0 + c, 5.0] and u.velEst.tolist() == [float(c)] and u.aziEst.tolist() == [-c * 1.0]
+            if c % 2 == 0:                                                # and every UE's report of the cells that carry them (networkSimulation.m:173-232)
+                assert u.nUE == 3 and [x.ue for x in u.ues] == [0, 1, 2]
+                for x in u.ues:
+                    if c == 2 and x.ue == 1:
+                        assert x.cqi is None and x.sbCQI == []
+                    else:
+                        assert x.cqi == 7 + x.ue and x.sbCQI == [6, 8 + c % 3, 5] and x.i1 == [1 + x.ue, 1, 1] and x.sbI2 == [1, 2, 1 + c % 2]
+            else:
+                assert u.nUE == 0 and u.ues == []
+            assert d.record_json(allr[c])["cell"] == c
 
 
 def test_shard_cells_round_robin():
@@ -70,3 +87,14 @@ def test_shard_cells_round_robin():
     assert sum(len(d.shard_cells(21, r, 8)) for r in range(8)) == 21
     r = d.gather_records(np.array([d.make_record(2, None), d.make_record(0, None)]))
     assert r[:, 0].tolist() == [0, 2]
+
+
+def test_record_truncation_keeps_true_counts():
+    """More estimates / UEs / subbands than the record keeps: the counts in front stay the true ones, the lists are cut at the capacity."""
+    d = __import__("importlib").import_module(load_pkg().__name__ + "._dist")
+    est = SimpleNamespace(rngEst=np.arange(100.0), velEst=np.arange(3.0), aziEst=np.arange(70.0))
+    ues = [(np.arange(1.0 + 40).reshape(-1, 1), SimpleNamespace(i1=[1, 1, 1], i2=np.arange(41)), None) for _ in range(20)]
+    u = d.unpack_record(d.make_record(5, est, 0.0, ues))
+    assert (u.nRng, u.nVel, u.nAzi, u.nUE) == (100, 3, 70, 20)
+    assert u.rngEst.size == d.EST_CAP and u.velEst.size == 3 and u.aziEst.size == d.EST_CAP and len(u.ues) == d.UE_CAP
+    assert len(u.ues[0].sbCQI) == d.SB_CAP and u.ues[0].sbCQI[:3] == [1, 2, 3] and u.ues[0].sbI2[:2] == [1, 2]

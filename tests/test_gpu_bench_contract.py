@@ -65,4 +65,10 @@ def test_config5_workload_line():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6 and 0.0 < rf["frac"] < 1.0
     assert abs(rf["achieved"] - rf["issued_flops_per_launch"] / 1e12 / (rf["avg_launch_ms"] / 1e3)) <= 1e-2 * rf["achieved"]
     assert d["comm_seams"]["cdl_apply_ms_per_job"] > 0 and d["comm_seams"]["csi_report_ms_per_ue"] > 0
-    assert len(d["cells"]) == 2 and all(c is None or 0 <= c <= 15 for ue in d["rank0_cqi"] for c in ue)
+    # the gathered per-cell records: whole estimate lists + every UE's last CSI report (wideband CQI, 18 subband CQIs at 273 PRB / 16-PRB subbands, PMI)
+    assert len(d["cells"]) == 2
+    for c in d["cells"]:
+        assert len(c["ues"]) == 4 and all(u["cqi"] is None or 0 <= u["cqi"] <= 15 for u in c["ues"])
+        assert all(len(u["sbCQI"]) == 18 and len(u["sbI2"]) == 18 and len(u["i1"]) == 3 for u in c["ues"])
+        if c["valid"]:
+            assert len(c["rngEst"]) == c["nRng"] >= 1 and len(c["velEst"]) == c["nVel"] and len(c["aziEst"]) == c["nAzi"]
