@@ -225,6 +225,29 @@ class CDLChannel:
         return d_h
 
 
+    def freq_response_device(self, k_sub, n_sc, scs_hz, ports, ctx, *, t=None, out=None, gains=None):
+        """Perfect channel estimate Hf [n_re x Nr x ports] ON THE DEVICE at the 1-based subcarriers `k_sub` of an n_sc-subcarrier grid, for the channel time
+        `t` (default: the current one, snapped to its sample-and-hold gain block as the apply does): path gains of that block from isac_cdl_path_gains_dev,
+        then Hf[i, u, p] = sum_n h[n, p, u] exp(-2 pi j f_i tau_n) (isac_cdl_freq_response_dev) -- nothing is evaluated on the host.  What the CSI report of a
+        CSI-RS occasion works on (uePhy.m:901-908); the estimator itself is out of scope."""
+        st = self._static()
+        n_paths, _, nt, nr = st.base.shape
+        t_snap = self.block_plan(1)[0][0] if t is None else float(t)
+        d_h = self.path_gains_device([t_snap], ctx, out=gains)
+        key = (id(ctx), tuple(np.asarray(k_sub).tolist()) if np.size(k_sub) < 64 else (int(np.size(k_sub)), int(np.sum(k_sub))), int(n_sc), float(scs_hz))
+        cache = st.__dict__.setdefault("_fr", {})
+        if key not in cache or cache[key][0]() is not ctx:
+            import weakref
+            f = ((np.asarray(k_sub, dtype=np.float64) - 1.0) - n_sc / 2.0) * float(scs_hz)
+            cache[key] = (weakref.ref(ctx), ctx.to_device(np.ascontiguousarray(self.path_delays(), dtype=np.float64)), ctx.to_device(np.ascontiguousarray(f)), f.size)
+        _, d_tau, d_f, n_re = cache[key]
+        if out is None:
+            out = ctx.empty((n_re, nr, int(ports)))
+        ctx.check(ctx.lib.isac_cdl_freq_response_dev(ctx.handle, C.c_void_p(d_h.ptr), C.c_int32(n_paths), C.c_int32(nt), C.c_int32(nr), C.c_int32(int(ports)),
+                                                     C.c_void_p(d_tau.ptr), C.c_void_p(d_f.ptr), C.c_int64(n_re), C.c_void_p(out.ptr)))
+        return out
+
+
 def applyCDLBatch(channels, waveforms, *, ctx=None, outs=None, gains=None):
     """rxWaveform_i = channel_i(waveform_i) for many (UE, slot) pairs in ONE library call (isac_cdl_apply_batch_dev): uePhy.m:729-731 inside the
     per-UE loop of a cell, or the slots of a frame.  All channels must share antenna counts, sample rate, delay profile length and filter taps

@@ -571,6 +571,32 @@ __global__ __launch_bounds__(256) void cdl_path_gains_kernel(const c64* __restri
   H[(long long)blockIdx.y * n_paths * nsu + e] = acc;
 }
 
+// Perfect channel estimate at given subcarrier frequencies from the path gains of ONE snapshot:  Hf[i, u, p] = sum_n H[n][p][u] exp(-2 pi j f_i tau_n),
+// p < ports (the CSI-RS ports = the first transmit elements).  One thread per (i, u, p); a workgroup covers 64 frequencies and forms their rotations once (LDS).
+__global__ __launch_bounds__(256) void cdl_freq_response_kernel(const c64* __restrict__ H, int n_paths, int Nt, int Nr, int ports, const double* __restrict__ tau,
+                                                                const double* __restrict__ freq, long long n_re, c64* __restrict__ Hf) {
+  constexpr int kF = 64, kMaxPaths = 64;
+  __shared__ __attribute__((aligned(16))) c64 s_rot[kF * kMaxPaths];
+  const long long i0 = (long long)blockIdx.x * kF;
+  for (int j = threadIdx.x; j < kF * n_paths; j += blockDim.x) {
+    const int fi = j / n_paths, n = j % n_paths;
+    const long long i = i0 + fi;
+    double sn, cs;
+    sincospi(-2.0 * (i < n_re ? freq[i] : 0.0) * tau[n], &sn, &cs);
+    s_rot[fi * kMaxPaths + n] = mk(cs, sn);
+  }
+  __syncthreads();
+  const int per = Nr * ports;
+  for (int e = threadIdx.x; e < kF * per; e += blockDim.x) {
+    const int fi = e % kF, up = e / kF, u = up % Nr, pp = up / Nr;
+    const long long i = i0 + fi;
+    if (i >= n_re) continue;
+    c64 acc = mk(0.0, 0.0);
+    for (int n = 0; n < n_paths; ++n) acc = fma(H[((long long)n * Nt + pp) * Nr + u], s_rot[fi * kMaxPaths + n], acc);
+    Hf[i + n_re * (u + (long long)Nr * pp)] = acc;
+  }
+}
+
 }  // namespace isac
 
 using namespace isac;
@@ -845,6 +871,18 @@ extern "C" int isac_cdl_path_gains_dev(isac_ctx* ctx, const isac_c64* d_base, co
   const int nsu = Nt * Nr;
   hipLaunchKernelGGL(cdl_path_gains_kernel, dim3((unsigned)cdiv((long long)n_paths * nsu, 256), (unsigned)n_snap), dim3(256), 0, ctx->stream, (const c64*)d_base,
                      d_rate, n_paths, n_rays, nsu, (const c64*)d_los, los_rate, (const double*)ctx->sind_tab.p, (c64*)d_H);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+extern "C" int isac_cdl_freq_response_dev(isac_ctx* ctx, const isac_c64* d_H, int32_t n_paths, int32_t Nt, int32_t Nr, int32_t ports, const double* d_tau,
+                                          const double* d_freq, int64_t n_re, isac_c64* d_Hf) {
+  ISAC_ENTER(ctx);
+  if (!d_H || !d_tau || !d_freq || !d_Hf) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (n_paths <= 0 || n_paths > 64 || Nt <= 0 || Nr <= 0 || ports <= 0 || ports > Nt || n_re <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad dimensions (1 <= n_paths <= 64, ports <= Nt)");
+  ctx->range_cache.touch(d_Hf, sizeof(c64) * (size_t)n_re * Nr * ports);
+  hipLaunchKernelGGL(cdl_freq_response_kernel, dim3(cdiv(n_re, 64)), dim3(256), 0, ctx->stream, (const c64*)d_H, n_paths, Nt, Nr, ports, d_tau, d_freq, (long long)n_re,
+                     (c64*)d_Hf);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }

@@ -238,6 +238,44 @@ static int launch_sinr(isac_ctx* ctx, const c64* H, long long n_re, int Nr, int 
   return ISAC_OK;
 }
 
+namespace isac {
+// prgPrecode.m:53-134 in its dense form: grid[k, l, p] = sum_v layers[k, l, v] F[v, p, prg(k)].  One thread per (k, l) x 4 consecutive antennas: the nu layer
+// symbols of its RE stay in registers, F of the RE's PRG comes from L1 / L2 (nu x P x n_prg complex: a few hundred KB at most).
+__global__ __launch_bounds__(256) void prg_precode_kernel(const c64* __restrict__ layers, int n_sc, int L, int nu, const c64* __restrict__ F, int P, int n_prg, int n_start_grid,
+                                                          int pd_bwp, c64* __restrict__ grid) {
+  const long long kl = (long long)blockIdx.x * blockDim.x + threadIdx.x, n_kl = (long long)n_sc * L;
+  if (kl >= n_kl) return;
+  const int k = (int)(kl % n_sc);
+  int prg = (n_start_grid + k / 12) / pd_bwp;                       // getPRGSet (:93-99), 0-based
+  prg = prg < n_prg ? prg : n_prg - 1;
+  c64 sym[8];
+  for (int v = 0; v < nu; ++v) sym[v] = layers[kl + n_kl * v];
+  const c64* Fp = F + (long long)prg * nu * P;
+  for (int p = blockIdx.y * 4; p < min(P, (int)blockIdx.y * 4 + 4); ++p) {
+    c64 acc = mk(0.0, 0.0);
+    for (int v = 0; v < nu; ++v) acc = fma(sym[v], Fp[v + (long long)nu * p], acc);
+    grid[kl + n_kl * p] = acc;
+  }
+}
+}  // namespace isac
+
+extern "C" int isac_prg_precode_dev(isac_ctx* ctx, const isac_c64* d_layers, int32_t n_sc, int32_t L, int32_t nu, const isac_c64* F, int32_t P, int32_t n_prg,
+                                    int32_t n_start_grid, isac_c64* d_grid) {
+  ISAC_ENTER(ctx);
+  if (!d_layers || !F || !d_grid) return isac::fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (n_sc <= 0 || n_sc % 12 != 0 || L <= 0 || nu <= 0 || nu > 8 || P <= 0 || n_prg <= 0 || n_start_grid < 0)
+    return isac::fail(ctx, ISAC_ERR_INVALID_ARG, "bad dimensions (n_sc a multiple of 12, 1 <= nu <= 8)");
+  const size_t f_bytes = sizeof(isac::c64) * (size_t)nu * P * n_prg;
+  ISAC_TRY(isac::ensure(ctx, ctx->seg, f_bytes));
+  ISAC_TRY(isac::stage_upload(ctx, ctx->seg.p, F, f_bytes));
+  ctx->range_cache.touch(d_grid, sizeof(isac::c64) * (size_t)n_sc * L * P);
+  const int nrb = n_sc / 12, pd_bwp = (nrb + n_start_grid + n_prg - 1) / n_prg;
+  hipLaunchKernelGGL(isac::prg_precode_kernel, dim3(isac::cdiv((long long)n_sc * L, 256), (unsigned)((P + 3) / 4)), dim3(256), 0, ctx->stream, (const isac::c64*)d_layers,
+                     n_sc, L, nu, (const isac::c64*)ctx->seg.p, P, n_prg, n_start_grid, pd_bwp, (isac::c64*)d_grid);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
 extern "C" int isac_precoded_sinr_cqi_dev(isac_ctx* ctx, const isac_c64* d_H, int64_t n_re, int32_t Nr, int32_t P,
                                           const isac_c64* W, int32_t n_layers, double sigma, const double* sinr_table_db,
                                           int32_t n_table, double* d_sinr_per_re, double* mean_sinr, int32_t* cqi) {

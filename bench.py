@@ -327,10 +327,16 @@ class CommCell:
       * every slot that carries downlink symbols (12 'D' + 4 'S' of DDDSU x 4): the slot waveform (+ MaxChannelDelay zero rows) through EVERY UE's
         nrCDLChannel (uePhy.m:724-731: applyChannelModel on each gNB packet; CDL-D for LoS UEs, CDL-A otherwise, updateCDLModels.m:9-14);
       * every CSI-RS occasion (setupCSIRS.m:11: period 5 slots -> 4 per frame): every UE's Type-I PMI search + subband CQI (uePhy.m:901-908).
-    Inputs are synthetic and resident in HBM before the timed region: the 16 slot waveforms (QPSK grids through the OFDM modulator), one channel
-    estimate per UE at the CSI-RS REs (the channel's own frequency response -- the estimator is out of scope).  Channel time advances from slot to
-    slot and from frame to frame (path gains formed on the device per gain block)."""
-    DL_SLOTS, CSI_OCCASIONS, SLOT_T = 16, 4, 61440
+      * every 'U' slot (4 per frame): every UE's uplink packet [T x 2] through its UL channel into the 64-element gNB array (gNBPhy.m:833-864: applyChannelModel
+        on each UE packet; cdl.m:78-85), one batched call per slot and delay-profile group   (round 5; ISAC_C5_NO_UL=1 leaves it out: the round-4 workload).
+    Inputs are synthetic and resident in HBM before the timed region: the 16 DL slot waveforms -- since round 5 the PRECODED PDSCH: QPSK layers [K x 14 x nu]
+    through prgPrecode (a rank-nu precoder per 4-PRB PRG, prgPrecode.m:107-134, isac_prg_precode_dev) and the OFDM modulator -- and one UL waveform per UE.
+    The CSI-RS channel estimate of every occasion is formed ON THE DEVICE from that occasion's path gains (isac_cdl_path_gains_dev +
+    isac_cdl_freq_response_dev; the estimator itself is out of scope; ISAC_C5_HOST_CSI=1: one host evaluation at set-up as in round 4).  Channel time advances
+    from slot to slot and from frame to frame (path gains formed on the device per gain block)."""
+    DL_SLOTS, UL_SLOTS, CSI_OCCASIONS, SLOT_T, LAYERS, PRG_PRBS = 16, 4, 4, 61440, 2, 4
+    WITH_UL = os.environ.get("ISAC_C5_NO_UL") is None
+    DEVICE_CSI = os.environ.get("ISAC_C5_HOST_CSI") is None
 
     def __init__(self, pkg, ctxs_cdl, ctx_csi, cell_id, n_ants, n_ues):
         CM, self.PL, L = pkg.communication.channelModels, pkg.communication.phyLayer, pkg._lib
@@ -344,10 +350,17 @@ class CommCell:
         K = 3276
         car = L.Carrier(K, 4096, 30, 0)
         self.waves = []
-        grid = ctx_cdl.empty((K, 14, n_ants))
+        grid, layers = ctx_cdl.empty((K, 14, n_ants)), ctx_cdl.empty((K, 14, self.LAYERS))
+        n_prg = -(-273 // self.PRG_PRBS)
+        dft = np.exp(-2j * np.pi * np.outer(np.arange(n_ants), np.arange(n_ants)) / n_ants) / np.sqrt(n_ants)
         for s_ in range(self.DL_SLOTS):
             w = ctx_cdl.empty((self.T, n_ants))
-            ctx_cdl.check(ctx_cdl.lib.isac_synth_qpsk_grid_dev(ctx_cdl.handle, C.c_void_p(grid.ptr), K, 14, n_ants, C.c_uint64(0xD100 + 64 * cell_id + s_), 0))
+            # PDSCH layers (QPSK) x the slot's precoders: one rank-nu matrix per PRG, rows of the DFT beam set picked per (cell, slot, PRG) -- shape-true stand-in
+            # for the W of the scheduled UE's PMI (gNBPhy.m:803,822); the channel input is then nu beams per PRG on 64 antennas, not i.i.d. QPSK per antenna
+            ctx_cdl.check(ctx_cdl.lib.isac_synth_qpsk_grid_dev(ctx_cdl.handle, C.c_void_p(layers.ptr), K, 14, self.LAYERS, C.c_uint64(0xD100 + 64 * cell_id + s_), 0))
+            beams = rng.integers(0, n_ants, (n_prg, self.LAYERS))
+            F = np.stack([dft[b, :] for b in beams], axis=2) * np.sqrt(n_ants / self.LAYERS)          # [nu x A x n_prg], unit power per antenna on average
+            self.PL.prgPrecodeGrid(layers, F, 0, ctx=ctx_cdl, out=grid)
             ctx_cdl.check(ctx_cdl.lib.isac_ofdm_modulate_dev(ctx_cdl.handle, C.c_void_p(grid.ptr), 14, n_ants, C.byref(car), C.c_double(1.0), C.c_void_p(w.ptr), C.c_int64(self.T)))
             self.waves.append(w)
         self.groups = [[u for u in range(n_ues) if self.los[u]], [u for u in range(n_ues) if not self.los[u]]]
@@ -366,6 +379,21 @@ class CommCell:
         pl_db = 32.4 + 20.0 * np.log10(3.5) + 30.0 * np.log10(np.maximum(r, 10.0))
         self.nvar = 10.0 ** (-(46.0 - pl_db - (-174.0 + 10.0 * np.log10(100e6) + 7.0)) / 10.0)
         self.h_est = [ctx_csi.to_device(freq_response(ch, self.csi_k, K, 30e3, 4)) for ch in self.chans]
+        self.csi_gains = [ctx_csi.empty((int(np.prod(ch._static().base.shape[:1] + ch._static().base.shape[2:])),)) for ch in self.chans]   # one snapshot's path gains per UE
+        # uplink: every UE's packet of a 'U' slot through its UL channel (UE 2 elements -> gNB array), cdl.m:78-85
+        self.ul_chans = [CM.CDLChannel(DelayProfile="CDL-D" if lo else "CDL-A", TransmitAntennaArraySize=(1, 1, 2, 1, 1), ReceiveAntennaArraySize=nt_shape, Seed=73) for lo in self.los]
+        self.ul_waves, self.ul_rx, self.ul_gains = [], [], []
+        if self.WITH_UL:
+            g2 = ctx_cdl.empty((K, 14, 2))
+            for u in range(n_ues):
+                w = ctx_cdl.empty((self.T, 2))
+                ctx_cdl.check(ctx_cdl.lib.isac_synth_qpsk_grid_dev(ctx_cdl.handle, C.c_void_p(g2.ptr), K, 14, 2, C.c_uint64(0xE100 + 64 * cell_id + u), 0))
+                ctx_cdl.check(ctx_cdl.lib.isac_ofdm_modulate_dev(ctx_cdl.handle, C.c_void_p(g2.ptr), 14, 2, C.byref(car), C.c_double(1.0), C.c_void_p(w.ptr), C.c_int64(self.T)))
+                self.ul_waves.append(w)
+            for g in self.groups:
+                st = self.ul_chans[g[0]]._static()
+                self.ul_rx.append([ctx_cdl.empty((self.T, n_ants)) for _ in g])
+                self.ul_gains.append(ctx_cdl.empty((len(g) * 4 * st.base.shape[0] * st.base.shape[2] * st.base.shape[3],)))
         self.last_cqi = None
         self.last_reports = None
         for c_ in self.ctxs:
@@ -383,10 +411,20 @@ class CommCell:
                 # (one context per delay-profile group: the filter launch of one group runs beside the contraction launch of the other)
                 self.CM.applyCDLBatch([self.chans[u] for s_ in slots for u in g], [self.waves[s_] for s_ in slots for u in g], ctx=self.ctxs[gi % len(self.ctxs)],
                                       outs=[rx[(s_ - s0) * len(g) + i] for s_ in slots for i in range(len(g))], gains=gn)
+        if self.WITH_UL:                                      # the frame's 'U' slots: every UE's packet into the gNB array, one call per slot and group
+            for _ in range(self.UL_SLOTS):
+                for gi, g in enumerate(self.groups):
+                    self.CM.applyCDLBatch([self.ul_chans[u] for u in g], [self.ul_waves[u] for u in g], ctx=self.ctxs[gi % len(self.ctxs)], outs=self.ul_rx[gi], gains=self.ul_gains[gi])
 
     def csi_reports(self):
         """The frame's CSI-RS occasions: every UE's report, one batched call (one synchronisation of the CSI context) per occasion."""
-        for _ in range(self.CSI_OCCASIONS):
+        t_frame = [ch.time - self.DL_SLOTS * self.T / ch.SampleRate for ch in self.chans]        # channel time at the frame's first DL slot (enqueue_frame has advanced it)
+        for o in range(self.CSI_OCCASIONS):
+            if self.DEVICE_CSI:                               # this occasion's channel estimate, formed on the device from this occasion's path gains (CSI-RS period 5 slots)
+                for u, ch in enumerate(self.chans):
+                    t_o = t_frame[u] + o * 5 * self.T / ch.SampleRate
+                    rate = 2.0 * ch.SampleDensity * ch.MaximumDopplerShift
+                    ch.freq_response_device(self.csi_k, 3276, 30e3, 4, self.ctx_csi, t=np.floor(t_o * rate + 1e-9) / rate, out=self.h_est[u], gains=self.csi_gains[u])
             rep = self.PL.cqiSelectBatch(self.carrier, SimpleNamespace(k=self.csi_k, l=self.csi_l), self.report, 1, self.h_est, self.nvar, DOWNLINK_SINR90PC,
                                          ctx=self.ctx_csi, codebook=self.codebook)
         self.last_cqi = [None if np.isnan(c[0][0]) else int(c[0][0]) for c in rep]
@@ -475,10 +513,15 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": f"BASELINE configs[4]: {n_cells} cells x {args.ues} UE, {args.ants}-antenna gNB; per 20-slot frame and cell: one sensing CPI ({args.slots} slots, "
-                                  f"echo -> 2D-FFT -> 2D-CFAR -> MUSIC), {CommCell.DL_SLOTS} DL slot waveforms [{cc.T} x {args.ants}] through every UE's CDL-D / CDL-A channel "
-                                  f"({CommCell.DL_SLOTS * args.ues} applies), {CommCell.CSI_OCCASIONS} CSI reports per UE (Type-I PMI search + subband CQI, 546 CSI-RS REs x 32 entries)",
+                                  f"echo -> 2D-FFT -> 2D-CFAR -> MUSIC), {CommCell.DL_SLOTS} DL slot waveforms [{cc.T} x {args.ants}] (precoded PDSCH: {CommCell.LAYERS} layers, one precoder per "
+                                  f"{CommCell.PRG_PRBS}-PRB PRG) through every UE's CDL-D / CDL-A channel ({CommCell.DL_SLOTS * args.ues} applies), "
+                                  + (f"{CommCell.UL_SLOTS} UL slots x every UE's packet [{cc.T} x 2] into the {args.ants}-element array ({CommCell.UL_SLOTS * args.ues} applies), " if CommCell.WITH_UL else "")
+                                  + f"{CommCell.CSI_OCCASIONS} CSI reports per UE (Type-I PMI search + subband CQI, 546 CSI-RS REs x 32 entries; channel estimate of each occasion "
+                                  f"{'formed on the device from its path gains' if CommCell.DEVICE_CSI else 'evaluated once on the host'})",
                       "parallelism": f"cells sharded over {world} GPU(s)"},
-           "per_frame_and_rank": {"cells": len(mine), "cdl_applies": n_applies, "csi_reports": len(mine) * args.ues * CommCell.CSI_OCCASIONS, "sensing_cpis": len(mine)},
+           "per_frame_and_rank": {"cells": len(mine), "cdl_applies": n_applies, "csi_reports": len(mine) * args.ues * CommCell.CSI_OCCASIONS, "sensing_cpis": len(mine),
+                                  "ul_applies": sum(c_.n_ues for c_ in comm) * CommCell.UL_SLOTS if CommCell.WITH_UL else 0, "precoded": True,
+                                  "csi_h": "device, per occasion" if CommCell.DEVICE_CSI else "host, once at set-up"},
            "roofline": {"bound": "mfma", "kernel": "cdl_fused_kernel<NCT,NSLOT> (DL apply of a batch in one persistent launch: contraction X [T x Nt] against the path gains of every job, 3M form on "
                                                     "v_mfma_f64_16x16x4_f64, + 16-tap delay filters + integer delays on the CU; Z never in HBM)" if not os.environ.get("ISAC_CDL_UNFUSED") else
                                                     "cdl_gemm_kernel<NCT,false> (DL contraction of a batch; ISAC_CDL_UNFUSED: the delay filter is a second launch, Z through HBM)",

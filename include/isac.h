@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 /* Bumped on EVERY change of a struct layout, enum value or entry-point signature below (1: round 1; 2: ISAC_MAX_EST 1024 -> 4096,
- * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve).  A host must
+ * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve, isac_prg_precode_dev, isac_cdl_freq_response_dev).  A host must
  * compare isac_abi_version() with the ISAC_ABI_VERSION it was compiled against AND isac_abi_sizeof() with its own sizeof of every
  * struct it passes: the library writes whole structs (isac_est_result is 128 KB) into caller memory. */
 #define ISAC_ABI_VERSION 6
@@ -404,6 +404,19 @@ int isac_cdl_apply_batch_dev(isac_ctx* ctx, const isac_cdl_job* jobs, int32_t n_
 int isac_cdl_path_gains_dev(isac_ctx* ctx, const isac_c64* d_base, const double* d_rate, int32_t n_paths, int32_t n_rays, int32_t Nt, int32_t Nr,
                             const isac_c64* d_los, double los_rate, const double* t_snap, int32_t n_snap, isac_c64* d_H);
 
+/* communication.phyLayer.prgPrecode(siz, nstartgrid, portsym, portind, F) (+communication/+phyLayer/prgPrecode.m:53-134; called for PDSCH and its DM-RS at
+ * gNBPhy.m:822-827) in its dense form: the layer grid [n_sc x L x nu] (zero where a layer carries nothing) times the precoder of each RE's PRG,
+ * F [nu x P x n_prg] (HOST, MATLAB layout: F(:,:,prg), nu fastest):  grid[k, l, p] = sum_v layers[k, l, v] F[v, p, prg(k)],
+ * prg(k) = floor((n_start_grid + floor(k / 12)) / ceil((NRB + n_start_grid) / n_prg))  (getPRGSet, :93-99).  d_grid [n_sc x L x P] is the txSlotGrid the
+ * OFDM modulator takes next. */
+int isac_prg_precode_dev(isac_ctx* ctx, const isac_c64* d_layers, int32_t n_sc, int32_t L, int32_t nu, const isac_c64* F, int32_t P, int32_t n_prg,
+                         int32_t n_start_grid, isac_c64* d_grid);
+/* Perfect channel estimate at the frequencies d_freq [n_re] (Hz, relative to the carrier centre; DEVICE) from the path gains of one snapshot
+ * d_H [n_paths][Nt][Nr] (isac_cdl_path_gains_dev) and the path delays d_tau [n_paths] (s; DEVICE):  Hf[i, u, p] = sum_n H[n][p][u] exp(-2 pi j f_i tau_n)
+ * for the first `ports` transmit elements -- the H the CSI report takes ([n_re x Nr x ports], uePhy.m:901-908 works on the channel estimate at the CSI-RS REs;
+ * the estimator itself is out of scope). */
+int isac_cdl_freq_response_dev(isac_ctx* ctx, const isac_c64* d_H, int32_t n_paths, int32_t Nt, int32_t Nr, int32_t ports, const double* d_tau,
+                               const double* d_freq, int64_t n_re, isac_c64* d_Hf);
 /* ------------------------------------------------------------------ SINR -> CQI (config 5)
  * precodedSINR(H, sigma, W) (+communication/+phyLayer/precodedSINR.m:11-17) for every resource element of a
  * channel estimate, its mean, and getCQI (+communication/+phyLayer/cqiSelect.m:697-722) against a SINR table

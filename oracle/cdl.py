@@ -222,3 +222,15 @@ def apply_cdl(cfg, waveform, t0=0.0):
     if cfg.NormalizeChannelOutputs:
         y = y / math.sqrt(nr)
     return y
+
+
+def freq_response(cfg, t, k_sub, n_sc, scs_hz, ports):
+    """Perfect channel estimate at the 1-based subcarriers k_sub: Hf[i, u, p] = sum_n h[n, p, u](t_blk) exp(-2 pi j f_i tau_n), f_i = (k_i - 1 - n_sc / 2) scs, with the
+    sample-and-hold path gains of the gain block that holds t (TR 38.901 7.5-22 evaluated in the frequency domain; what nrPerfectChannelEstimate returns for a
+    channel whose filters are ideal delays).  [n_re x Nr x ports]."""
+    blk, rate = snapshot_index(cfg, np.array([t]))
+    h = path_gains(cfg, float(blk[0]) / rate)[:, :ports, :]                # [n, p, u]
+    tau = path_delays(cfg)
+    f = ((np.asarray(k_sub, dtype=np.float64) - 1.0) - n_sc / 2.0) * float(scs_hz)
+    e = np.exp(-2j * np.pi * f[:, None] * tau[None, :])                    # [i, n]
+    return np.einsum("kn,npu->kup", e, h)

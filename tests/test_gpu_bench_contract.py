@@ -59,7 +59,8 @@ def test_config5_workload_line():
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["dtype"] == "f64" and d["data"] == "synthetic" and "configs[4]" in d["config"]["workload"]
-    assert d["per_frame_and_rank"] == {"cells": 2, "cdl_applies": 2 * 4 * 16, "csi_reports": 2 * 4 * 4, "sensing_cpis": 2}
+    assert d["per_frame_and_rank"] == {"cells": 2, "cdl_applies": 2 * 4 * 16, "csi_reports": 2 * 4 * 4, "sensing_cpis": 2, "ul_applies": 2 * 4 * 4, "precoded": True,
+                                       "csi_h": "device, per occasion"}                # (round 5: 'U' slots, precoded PDSCH input, per-occasion device CSI)
     assert abs(d["value"] - 2 * 20 / (d["ms_per_step"] / 1e3)) <= 1e-3 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6 and 0.0 < rf["frac"] < 1.0

@@ -53,3 +53,21 @@ def test_oracle_pmi_known_answers():
     # no CSI-RS in the BWP -> everything NaN
     cqi, pmi, _, _ = OP.cqi_select(rep, 1, h, np.zeros(0, int), np.zeros(0, int), 0.01, OQ.DOWNLINK_SINR90PC)
     assert np.all(np.isnan(cqi)) and np.all(np.isnan(pmi.i1)) and np.all(np.isnan(pmi.i2))
+
+
+def test_prg_precode_restatement_equals_dense_formula():
+    """oracle/precode.py (prgPrecode.m:53-144 loop for loop) against the closed form grid[k, l, :] = layers[k, l, :] F(:, :, prg(k)), prg from getPRGSet."""
+    import oracle.precode as OPR
+    rng = np.random.default_rng(3)
+    for nrb, L, nu, P, nprg, nstart in ((24, 4, 2, 8, 5, 3), (52, 3, 1, 4, 1, 0), (10, 2, 4, 16, 10, 0)):
+        K = 12 * nrb
+        re = np.sort(rng.choice(K * L, size=K * L // 2, replace=False))
+        portind = re[:, None] + K * L * np.arange(nu)[None, :] + 1
+        portsym = rng.standard_normal(portind.shape) + 1j * rng.standard_normal(portind.shape)
+        F = rng.standard_normal((nu, P, nprg)) + 1j * rng.standard_normal((nu, P, nprg))
+        sym, ind = OPR.prg_precode((K, L), nstart, portsym, portind, F)
+        prg = OPR.get_prg_set(nrb, nstart, nprg)
+        assert prg.min() >= 1 and prg.max() <= nprg and np.all(np.diff(prg) >= 0)
+        want = np.stack([portsym[i] @ F[:, :, prg[(re[i] % K) // 12] - 1] for i in range(re.size)])
+        assert np.abs(sym - want).max() <= 1e-13 * np.abs(want).max()
+        assert np.array_equal(ind, re[:, None] + K * L * np.arange(P)[None, :] + 1)
