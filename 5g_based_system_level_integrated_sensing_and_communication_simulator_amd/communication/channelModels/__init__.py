@@ -1,2 +1,2 @@
 from .updateCDLModels import updateCDLModels  # noqa: F401
-from .cdl import CDLChannel, applyCDL, applyCDLBatch  # noqa: F401
+from .cdl import CDLChannel, applyCDL, applyCDLBatch, csiEstimateBatch  # noqa: F401

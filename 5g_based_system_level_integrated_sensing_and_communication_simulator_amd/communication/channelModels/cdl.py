@@ -225,6 +225,24 @@ class CDLChannel:
         return d_h
 
 
+    def _fr_tables(self, ctx, k_sub, n_sc, scs_hz):
+        """(d_tau [n_paths], d_freq [n_re], n_re) on `ctx`'s device for the 1-based subcarriers k_sub; cached per context and subcarrier set."""
+        st = self._static()
+        key = (id(ctx), tuple(np.asarray(k_sub).tolist()) if np.size(k_sub) < 64 else (int(np.size(k_sub)), int(np.sum(k_sub))), int(n_sc), float(scs_hz))
+        cache = st.__dict__.setdefault("_fr", {})
+        if key not in cache or cache[key][0]() is not ctx:
+            import weakref
+            f = ((np.asarray(k_sub, dtype=np.float64) - 1.0) - n_sc / 2.0) * float(scs_hz)
+            cache[key] = (weakref.ref(ctx), ctx.to_device(np.ascontiguousarray(self.path_delays(), dtype=np.float64)), ctx.to_device(np.ascontiguousarray(f)), f.size)
+        return cache[key][1:]
+
+    def snap_time(self, t=None):
+        """The sample-and-hold gain-block time that holds channel time t (default: now) -- what the apply uses for a sample at t."""
+        if t is None:
+            t = self.time
+        rate = 2.0 * self.SampleDensity * self.MaximumDopplerShift
+        return float(t) if not rate > 0.0 else math.floor(float(t) * rate + 1e-9) / rate
+
     def freq_response_device(self, k_sub, n_sc, scs_hz, ports, ctx, *, t=None, out=None, gains=None):
         """Perfect channel estimate Hf [n_re x Nr x ports] ON THE DEVICE at the 1-based subcarriers `k_sub` of an n_sc-subcarrier grid, for the channel time
         `t` (default: the current one, snapped to its sample-and-hold gain block as the apply does): path gains of that block from isac_cdl_path_gains_dev,
@@ -234,18 +252,44 @@ class CDLChannel:
         n_paths, _, nt, nr = st.base.shape
         t_snap = self.block_plan(1)[0][0] if t is None else float(t)
         d_h = self.path_gains_device([t_snap], ctx, out=gains)
-        key = (id(ctx), tuple(np.asarray(k_sub).tolist()) if np.size(k_sub) < 64 else (int(np.size(k_sub)), int(np.sum(k_sub))), int(n_sc), float(scs_hz))
-        cache = st.__dict__.setdefault("_fr", {})
-        if key not in cache or cache[key][0]() is not ctx:
-            import weakref
-            f = ((np.asarray(k_sub, dtype=np.float64) - 1.0) - n_sc / 2.0) * float(scs_hz)
-            cache[key] = (weakref.ref(ctx), ctx.to_device(np.ascontiguousarray(self.path_delays(), dtype=np.float64)), ctx.to_device(np.ascontiguousarray(f)), f.size)
-        _, d_tau, d_f, n_re = cache[key]
+        d_tau, d_f, n_re = self._fr_tables(ctx, k_sub, n_sc, scs_hz)
         if out is None:
             out = ctx.empty((n_re, nr, int(ports)))
         ctx.check(ctx.lib.isac_cdl_freq_response_dev(ctx.handle, C.c_void_p(d_h.ptr), C.c_int32(n_paths), C.c_int32(nt), C.c_int32(nr), C.c_int32(int(ports)),
                                                      C.c_void_p(d_tau.ptr), C.c_void_p(d_f.ptr), C.c_int64(n_re), C.c_void_p(out.ptr)))
         return out
+
+
+def csiEstimateBatch(channels, k_sub, n_sc, scs_hz, ports, *, ctx, times=None, outs=None):
+    """The perfect CSI-RS channel estimates Hf_j [n_re x Nr x ports] of MANY UEs of one delay profile at their own channel times in ONE library call
+    (isac_cdl_csi_estimate_batch_dev): per UE the sample-and-hold path gains of `times[j]` (default: its current channel time) and their response at the
+    1-based subcarriers k_sub, formed on the device without the gains leaving the CU.  A cell's CSI-RS occasion (uePhy.m:901-908 works on these estimates)
+    is one call per delay profile.  Returns the list of DeviceArrays (`outs` if given)."""
+    channels = list(channels)
+    if not channels:
+        return []
+    ch0 = channels[0]
+    st0 = ch0._static()
+    n_paths, n_rays, nt, nr = st0.base.shape
+    tau0 = ch0.path_delays()
+    for ch in channels[1:]:
+        if ch._static().base.shape != st0.base.shape or not np.array_equal(ch.path_delays(), tau0):
+            raise ValueError("csiEstimateBatch: all channels must share the delay profile, delay spread and antenna counts")
+    d_tau, d_f, n_re = ch0._fr_tables(ctx, k_sub, n_sc, scs_hz)
+    n = len(channels)
+    if outs is None:
+        outs = [ctx.empty((n_re, nr, int(ports))) for _ in range(n)]
+    statics = [ch._device_static(ctx) for ch in channels]
+    vp = C.c_void_p * n
+    base = vp(*[st[0].ptr for st in statics])
+    rate = vp(*[st[1].ptr for st in statics])
+    los = vp(*[(st[2].ptr if st[2] is not None else None) for st in statics])
+    los_rate = (C.c_double * n)(*[st[3] for st in statics])
+    t = (C.c_double * n)(*[ch.snap_time(None if times is None else times[j]) for j, ch in enumerate(channels)])
+    hf = vp(*[o.ptr for o in outs])
+    ctx.check(ctx.lib.isac_cdl_csi_estimate_batch_dev(ctx.handle, C.c_int32(n), base, rate, los, los_rate, t, C.c_int32(n_paths), C.c_int32(n_rays), C.c_int32(nt), C.c_int32(nr),
+                                                      C.c_int32(int(ports)), C.c_void_p(d_tau.ptr), C.c_void_p(d_f.ptr), C.c_int64(n_re), hf))
+    return outs
 
 
 def applyCDLBatch(channels, waveforms, *, ctx=None, outs=None, gains=None):

@@ -597,6 +597,54 @@ __global__ __launch_bounds__(256) void cdl_freq_response_kernel(const c64* __res
   }
 }
 
+// The CSI-RS channel estimates of MANY UEs at one occasion in ONE launch: for UE j (blockIdx.y) the sample-and-hold path gains of its channel time t[j] for the
+// first `ports` transmit elements (TR 38.901 7.5-22 / 7.5-29, as cdl_path_gains_kernel) and their frequency response at the n_re frequencies (as
+// cdl_freq_response_kernel), without the path gains ever leaving the CU.  All UEs share the delay profile (n_paths, n_rays, delays); each has its own per-ray terms.
+struct CdlCsiUe { const c64* base; const double* rate; const c64* los; double los_rate; double t; c64* Hf; };
+__global__ __launch_bounds__(256) void cdl_csi_estimate_kernel(const CdlCsiUe* __restrict__ ues, int n_paths, int n_rays, int Nt, int Nr, int ports, const double* __restrict__ tau,
+                                                               const double* __restrict__ freq, long long n_re) {
+  constexpr int kF = 32;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* s_rot = reinterpret_cast<c64*>(smem_raw);            // [n_paths * n_rays]  Doppler rotation of every ray at t
+  c64* s_h = s_rot + n_paths * n_rays;                      // [n_paths][ports * Nr]
+  c64* s_fr = s_h + n_paths * ports * Nr;                   // [kF][n_paths]       delay rotation of every path at this block's frequencies
+  const CdlCsiUe ue = ues[blockIdx.y];
+  const long long i0 = (long long)blockIdx.x * kF;
+  const int nsu = Nt * Nr, per = ports * Nr;
+  for (int j = threadIdx.x; j < n_paths * n_rays; j += blockDim.x) {
+    double sn, cs;
+    sincos(ue.rate[j] * ue.t, &sn, &cs);
+    s_rot[j] = mk(cs, sn);
+  }
+  for (int j = threadIdx.x; j < kF * n_paths; j += blockDim.x) {
+    const int fi = j / n_paths, n = j % n_paths;
+    double sn, cs;
+    sincospi(-2.0 * (i0 + fi < n_re ? freq[i0 + fi] : 0.0) * tau[n], &sn, &cs);
+    s_fr[j] = mk(cs, sn);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n_paths * per; j += blockDim.x) {
+    const int n = j / per, pu = j % per;                    // pu = p Nr + u: the element order of base's [s][u] block for s < ports
+    c64 acc = mk(0.0, 0.0);
+    for (int m = 0; m < n_rays; ++m) acc = fma(ue.base[((long long)n * n_rays + m) * nsu + pu], s_rot[n * n_rays + m], acc);
+    if (ue.los && n == 0) {
+      double sn, cs;
+      sincos(ue.los_rate * ue.t, &sn, &cs);
+      acc = fma(ue.los[pu], mk(cs, sn), acc);
+    }
+    s_h[j] = acc;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kF * per; e += blockDim.x) {
+    const int fi = e % kF, pu = e / kF, u = pu % Nr, pp = pu / Nr;
+    const long long i = i0 + fi;
+    if (i >= n_re) continue;
+    c64 acc = mk(0.0, 0.0);
+    for (int n = 0; n < n_paths; ++n) acc = fma(s_h[n * per + pu], s_fr[fi * n_paths + n], acc);
+    ue.Hf[i + n_re * (u + (long long)Nr * pp)] = acc;
+  }
+}
+
 }  // namespace isac
 
 using namespace isac;
@@ -883,6 +931,29 @@ extern "C" int isac_cdl_freq_response_dev(isac_ctx* ctx, const isac_c64* d_H, in
   ctx->range_cache.touch(d_Hf, sizeof(c64) * (size_t)n_re * Nr * ports);
   hipLaunchKernelGGL(cdl_freq_response_kernel, dim3(cdiv(n_re, 64)), dim3(256), 0, ctx->stream, (const c64*)d_H, n_paths, Nt, Nr, ports, d_tau, d_freq, (long long)n_re,
                      (c64*)d_Hf);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+extern "C" int isac_cdl_csi_estimate_batch_dev(isac_ctx* ctx, int32_t n_ue, const isac_c64* const* d_base, const double* const* d_rate, const isac_c64* const* d_los,
+                                               const double* los_rate, const double* t, int32_t n_paths, int32_t n_rays, int32_t Nt, int32_t Nr, int32_t ports,
+                                               const double* d_tau, const double* d_freq, int64_t n_re, isac_c64* const* d_Hf) {
+  ISAC_ENTER(ctx);
+  if (!d_base || !d_rate || !t || !d_tau || !d_freq || !d_Hf) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (n_ue <= 0 || n_paths <= 0 || n_rays <= 0 || Nt <= 0 || Nr <= 0 || ports <= 0 || ports > Nt || n_re <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad dimensions (ports <= Nt)");
+  if (n_ue > 65535) return fail(ctx, ISAC_ERR_CAPACITY, "more than 65535 UEs in one batch (grid dimension)");
+  const size_t lds = sizeof(c64) * ((size_t)n_paths * n_rays + (size_t)n_paths * ports * Nr + 32 * (size_t)n_paths);
+  if (lds > 64 * 1024) return fail(ctx, ISAC_ERR_UNSUPPORTED, "CSI estimate: n_paths x (n_rays + ports Nr + 32) complex values must fit 64 KB of LDS");
+  std::vector<CdlCsiUe> tab((size_t)n_ue);
+  for (int j = 0; j < n_ue; ++j) {
+    if (!d_base[j] || !d_rate[j] || !d_Hf[j]) return fail(ctx, ISAC_ERR_INVALID_ARG, "incomplete UE entry");
+    tab[j] = CdlCsiUe{(const c64*)d_base[j], d_rate[j], d_los ? (const c64*)d_los[j] : nullptr, los_rate ? los_rate[j] : 0.0, t[j], (c64*)d_Hf[j]};
+    ctx->range_cache.touch(d_Hf[j], sizeof(c64) * (size_t)n_re * Nr * ports);
+  }
+  ISAC_TRY(ensure(ctx, ctx->sind_tab, sizeof(CdlCsiUe) * tab.size()));     // (scratch of the CDL parameter entry points; stream order protects reuse)
+  ISAC_TRY(stage_upload(ctx, ctx->sind_tab.p, tab.data(), sizeof(CdlCsiUe) * tab.size()));
+  hipLaunchKernelGGL(cdl_csi_estimate_kernel, dim3(cdiv(n_re, 32), (unsigned)n_ue), dim3(256), lds, ctx->stream, (const CdlCsiUe*)ctx->sind_tab.p, n_paths, n_rays, Nt, Nr, ports,
+                     d_tau, d_freq, (long long)n_re);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }

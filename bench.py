@@ -82,7 +82,7 @@ def profile_facts():
             out["top_by_time"] = {"kernel": short(top["kernel"]), "share": round(float(top["pct"]) / 100.0, 4), "avg_us": float(top["avg_us"]),
                                   "dominant_hbm_kernel_share": round(float(dom[0]["pct"]) / 100.0, 4) if dom else None,
                                   "dominant_hbm_kernel_avg_us": float(dom[0]["avg_us"]) if dom else None,
-                                  "source": "profiles/" + os.path.basename(f)}
+                                  "source": "profiles/" + os.path.basename(f), "from_committed_profile": True}
         ff, fw = newest("pmc_fetch_size.csv"), newest("pmc_write_size.csv")
         if ff and fw:
             def kb(path, counter):
@@ -379,7 +379,6 @@ class CommCell:
         pl_db = 32.4 + 20.0 * np.log10(3.5) + 30.0 * np.log10(np.maximum(r, 10.0))
         self.nvar = 10.0 ** (-(46.0 - pl_db - (-174.0 + 10.0 * np.log10(100e6) + 7.0)) / 10.0)
         self.h_est = [ctx_csi.to_device(freq_response(ch, self.csi_k, K, 30e3, 4)) for ch in self.chans]
-        self.csi_gains = [ctx_csi.empty((int(np.prod(ch._static().base.shape[:1] + ch._static().base.shape[2:])),)) for ch in self.chans]   # one snapshot's path gains per UE
         # uplink: every UE's packet of a 'U' slot through its UL channel (UE 2 elements -> gNB array), cdl.m:78-85
         self.ul_chans = [CM.CDLChannel(DelayProfile="CDL-D" if lo else "CDL-A", TransmitAntennaArraySize=(1, 1, 2, 1, 1), ReceiveAntennaArraySize=nt_shape, Seed=73) for lo in self.los]
         self.ul_waves, self.ul_rx, self.ul_gains = [], [], []
@@ -420,11 +419,10 @@ class CommCell:
         """The frame's CSI-RS occasions: every UE's report, one batched call (one synchronisation of the CSI context) per occasion."""
         t_frame = [ch.time - self.DL_SLOTS * self.T / ch.SampleRate for ch in self.chans]        # channel time at the frame's first DL slot (enqueue_frame has advanced it)
         for o in range(self.CSI_OCCASIONS):
-            if self.DEVICE_CSI:                               # this occasion's channel estimate, formed on the device from this occasion's path gains (CSI-RS period 5 slots)
-                for u, ch in enumerate(self.chans):
-                    t_o = t_frame[u] + o * 5 * self.T / ch.SampleRate
-                    rate = 2.0 * ch.SampleDensity * ch.MaximumDopplerShift
-                    ch.freq_response_device(self.csi_k, 3276, 30e3, 4, self.ctx_csi, t=np.floor(t_o * rate + 1e-9) / rate, out=self.h_est[u], gains=self.csi_gains[u])
+            if self.DEVICE_CSI:                               # this occasion's channel estimates, formed on the device from this occasion's path gains (CSI-RS period
+                for g in self.groups:                         # 5 slots): one library call per delay-profile group
+                    self.CM.csiEstimateBatch([self.chans[u] for u in g], self.csi_k, 3276, 30e3, 4, ctx=self.ctx_csi,
+                                             times=[t_frame[u] + o * 5 * self.T / self.chans[u].SampleRate for u in g], outs=[self.h_est[u] for u in g])
             rep = self.PL.cqiSelectBatch(self.carrier, SimpleNamespace(k=self.csi_k, l=self.csi_l), self.report, 1, self.h_est, self.nvar, DOWNLINK_SINR90PC,
                                          ctx=self.ctx_csi, codebook=self.codebook)
         self.last_cqi = [None if np.isnan(c[0][0]) else int(c[0][0]) for c in rep]
@@ -630,10 +628,18 @@ def cpu_baseline(cell, budget_s=12.0):
         est_o = None
     np_s = time.perf_counter() - t0
     oracle_leg = {"value": round(n_slots / np_s, 3), "unit": "sensing slots/sec", "kind": "port", "language": "NumPy / SciPy oracle (oracle/*.py: scipy.fft with workers = all cores, OpenBLAS)",
-                  "cpi_s": round(np_s, 3), "n": 1, "cores": os.cpu_count(),
+                  "cpi_s": round(np_s, 3), "n": 1, "cores": os.cpu_count(),   # (`cores` everywhere in this object = the THREADS the leg actually ran on)
                   "first_estimates": None if est_o is None else {"rng": np.round(est_o.rngEst[:2], 3).tolist(), "azi": est_o.aziEst[:2].tolist()}}
     best = port if port["value"] >= oracle_leg["value"] else dict(oracle_leg, tuning="NumPy / SciPy restatement", sample=f"one whole CPI through the NumPy / SciPy oracle, {np_s:.2f} s", note=port["note"])
     best = dict(best)
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+    except Exception:                                        # noqa: BLE001
+        phys = None
+    best["host"] = {"logical_cpus": os.cpu_count(), "physical_cores": phys,
+                    "cores_convention": "`cores` = threads the timed leg used: the OpenMP port runs one thread per PHYSICAL core (OMP default under the container's "
+                                        "affinity mask), the NumPy / SciPy leg hands every LOGICAL cpu to scipy.fft workers / OpenBLAS"}
     best["implementations"] = {"cpp_openmp_port": {k: port[k] for k in ("value", "cores", "cpi_s", "language")}, "numpy_scipy_oracle": oracle_leg,
                                "note": "BASELINE.md section 2: both CPU implementations timed on this host in this run; `value` is the faster one"}
     return best
@@ -961,7 +967,7 @@ def main():
                         "why": "idle GPU ramps to sustained clocks; timed region = exactly `steps` CPIs between barriers"},
             "config": {"workload": f"{(str(args.cells) + ' cells round-robin over the ranks') if args.cells > 0 else (str(args.cells_per_gpu) + ' cell(s)/GPU')}, {args.ants}-antenna ULA echo -> 2D-FFT -> 2D-CFAR -> MUSIC, "
                                    f"100 MHz / 273 PRB, K=3276 L={14 * args.slots} T={cells[0].T} nIFFT=4096 nFFT=256, "
-                                   f"{args.targets} target(s), Philox AWGN drawn on the {'demodulated grid' if args.noise_domain == 'spectral' else 'time samples'}, "
+                                   f"{args.targets} target(s), Philox AWGN drawn on the {'demodulated grid (Philox4x32-10 + SINGLE-precision hardware Box-Muller: the field is defined to float32 accuracy, echo_dev.hpp box_muller32_hw; all signal arithmetic fp64)' if args.noise_domain == 'spectral' else 'time samples (fp64 Box-Muller)'}, "
                                    f"{'fused synthesis + range kernel' if args.fuse else 'separate echo / range kernels'}, {args.inflight} CPIs in flight",
                        "parallelism": f"cells sharded over {world} GPU(s)"},
             "roofline": roofline_entry(cells[0], args, dom_ms_timed, dom_ms_iso, len(sink or []), stages, echo_b + rdm_b, per_cpi_ms),

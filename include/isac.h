@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 /* Bumped on EVERY change of a struct layout, enum value or entry-point signature below (1: round 1; 2: ISAC_MAX_EST 1024 -> 4096,
- * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve, isac_prg_precode_dev, isac_cdl_freq_response_dev).  A host must
+ * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve, isac_prg_precode_dev, isac_cdl_freq_response_dev, isac_cdl_csi_estimate_batch_dev).  A host must
  * compare isac_abi_version() with the ISAC_ABI_VERSION it was compiled against AND isac_abi_sizeof() with its own sizeof of every
  * struct it passes: the library writes whole structs (isac_est_result is 128 KB) into caller memory. */
 #define ISAC_ABI_VERSION 6
@@ -417,6 +417,13 @@ int isac_prg_precode_dev(isac_ctx* ctx, const isac_c64* d_layers, int32_t n_sc, 
  * the estimator itself is out of scope). */
 int isac_cdl_freq_response_dev(isac_ctx* ctx, const isac_c64* d_H, int32_t n_paths, int32_t Nt, int32_t Nr, int32_t ports, const double* d_tau,
                                const double* d_freq, int64_t n_re, isac_c64* d_Hf);
+/* The same estimate for MANY UEs of one delay profile at their own channel times in ONE launch, straight from the time-independent per-ray terms (the
+ * inputs of isac_cdl_path_gains_dev): Hf_j = freq_response(path_gains_j(t[j])) -- the path gains never leave the CU.  HOST arrays of n_ue device pointers
+ * (d_base [n_paths][n_rays][Nt][Nr], d_rate [n_paths][n_rays], d_los [Nt][Nr] or NULL entries / NULL array, d_Hf [n_re x Nr x ports]); los_rate / t: HOST [n_ue].
+ * One CSI-RS occasion of a cell is one or two calls (one per delay profile) instead of two calls per UE. */
+int isac_cdl_csi_estimate_batch_dev(isac_ctx* ctx, int32_t n_ue, const isac_c64* const* d_base, const double* const* d_rate, const isac_c64* const* d_los,
+                                    const double* los_rate, const double* t, int32_t n_paths, int32_t n_rays, int32_t Nt, int32_t Nr, int32_t ports,
+                                    const double* d_tau, const double* d_freq, int64_t n_re, isac_c64* const* d_Hf);
 /* ------------------------------------------------------------------ SINR -> CQI (config 5)
  * precodedSINR(H, sigma, W) (+communication/+phyLayer/precodedSINR.m:11-17) for every resource element of a
  * channel estimate, its mean, and getCQI (+communication/+phyLayer/cqiSelect.m:697-722) against a SINR table

@@ -59,3 +59,26 @@ def test_cdl_freq_response_on_device_matches_oracle(pkg, profile, tx_size, t0):
     ch.time = t0 + 0.01
     got2 = ch.freq_response_device(k, 12 * nrb, 30e3, 4, ctx).numpy()
     assert np.abs(got2 - OC.freq_response(cfg, t0 + 0.01, k, 12 * nrb, 30e3, 4)).max() <= 1e-10 * np.abs(want).max()
+
+
+def test_csi_estimate_batch_equals_single_calls_and_oracle(pkg):
+    """isac_cdl_csi_estimate_batch_dev: six UEs of one delay profile (different seeds, channel times in different gain blocks) in one launch -- each estimate
+    equals the two-step single-UE evaluation (path gains, then frequency response) to rounding and the oracle to 1e-10."""
+    import oracle.cdl as OC
+    ctx = pkg.default_context()
+    CM = pkg.communication.channelModels
+    fs, nrb = 122.88e6, 273
+    k = np.concatenate([[12 * r + 1, 12 * r + 2] for r in range(nrb)])
+    for profile in ("CDL-A", "CDL-D"):
+        chans = [CM.CDLChannel(profile, 300e-9, 3.5e9, (4, 8, 2, 1, 1), (1, 1, 2, 1, 1), fs, Seed=70 + u) for u in range(6)]
+        times = [0.0, 0.0031, 0.2, 1.0 / 640 + 1e-7, 0.05, 0.9]
+        outs = CM.csiEstimateBatch(chans, k, 12 * nrb, 30e3, 4, ctx=ctx, times=times)
+        for u, (ch, t) in enumerate(zip(chans, times)):
+            single = ch.freq_response_device(k, 12 * nrb, 30e3, 4, ctx, t=ch.snap_time(t)).numpy()
+            got = outs[u].numpy()
+            assert np.abs(got - single).max() <= 1e-13 * np.abs(single).max()
+            cfg = OC.cdl_config(profile, 3.5e9, (4, 8, 2, 1, 1), (1, 1, 2, 1, 1), fs, seed=70 + u)
+            want = OC.freq_response(cfg, t, k, 12 * nrb, 30e3, 4)
+            assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max(), (profile, u)
+    with pytest.raises(ValueError):
+        CM.csiEstimateBatch([chans[0], CM.CDLChannel("CDL-A", 300e-9, 3.5e9, (4, 8, 2, 1, 1), (1, 1, 2, 1, 1), fs)], k, 12 * nrb, 30e3, 4, ctx=ctx)
