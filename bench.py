@@ -44,7 +44,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "5g_based_system_level_integrated_sensing_and_communication_simulator_amd"
 
-COPY_RATE_GBS = 5450.0          # what a plain device-to-device copy of the dominant kernel's bytes reaches on an MI355X (profiles/r04_wbench_write_rate.txt)
+COPY_RATE_GBS = 6260.0        # flat float4 copy of the fused kernel's 2 x 0.75 GB on this part (the guide's form: 6.26-6.32 TB/s, profiles/r05_cbench_copy_rate.txt)
+COPY_RATE_COLUMNS_GBS = 5730.0  # the same bytes copied in the fused kernel's own shape: one workgroup per 52 416-byte column
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured-achievable)
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix (= vector) dense peak
 DOMINANT_KERNEL = "echo_range_"          # echo_range_sl_kernel<Q, NZ> (one / two LoS targets) or echo_range_kernel<Q, NZ>
@@ -676,11 +677,15 @@ def roofline_entry(cell, args, ms_timed, ms_iso, n_launches, stages, cpi_bytes, 
                       "device to itself (10 launches right after the timed region; this is what rocprofv3 reports for the single-stream run, "
                       "profiles/rNN_kernel_stats_single_stream.csv), `..._in_timed_region` with the other in-flight CPIs' kernels sharing the GPU",
             "algorithmic_bytes_per_launch": nb, "algorithmic_bytes_note": "txGrid read once + echoGrid written once = 2 K L A 16 B; echoGrid is not re-read by the range stage",
-            # the same bytes moved by a plain copy kernel / hipMemcpyAsync on this part (1 : 1 read / write mix): measured 5.35-5.53 TB/s, tools/wbench.hip
+            # the same bytes moved by plain copy kernels on this part (1 : 1 read / write mix), tools/cbench.hip: the guide's flat form (one float4 per thread) and the
+            # kernel's own column shape.  Round 4 quoted a persistent grid-stride probe (5.35-5.53 TB/s) -- that was the probe's shape, not the part's limit.
             "copy_rate_reference": {"GBps": COPY_RATE_GBS, "frac_of_copy_rate": round(nb / 1e9 / (ms / 1e3) / COPY_RATE_GBS, 4),
                                     "frac_of_copy_rate_on_counter_traffic": round(facts["traffic"] / 1e9 / (ms / 1e3) / COPY_RATE_GBS, 4) if (at_shape and facts["traffic"]) else None,
-                                    "source": "profiles/r04_wbench_write_rate.txt: copying 0.75 GB -> 0.75 GB takes 272-281 us (hipMemcpyAsync device to device 281 us); "
-                                              "`frac` above prices the same launch against the 8 TB/s specification"},
+                                    "column_shaped_copy_GBps": COPY_RATE_COLUMNS_GBS,
+                                    "frac_of_column_shaped_copy_on_counter_traffic": round(facts["traffic"] / 1e9 / (ms / 1e3) / COPY_RATE_COLUMNS_GBS, 4) if (at_shape and facts["traffic"]) else None,
+                                    "source": "profiles/r05_cbench_copy_rate.txt: a flat float4 copy (n / 256 short-lived workgroups: MI355X_MICROARCH.md's 6.29 TB/s form) moves the "
+                                              "kernel's 0.75 GB -> 0.75 GB at 6.26 TB/s; one workgroup per 52 416-byte column -- the shape a per-column transform must have -- at 5.73; "
+                                              "persistent grid-stride copies and hipMemcpyAsync at 5.0-5.9.  `frac` above prices the same launch against the 8 TB/s specification"},
             "other_stages": stages, "whole_cpi": whole}
 
 
