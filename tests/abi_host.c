@@ -65,6 +65,12 @@ static int chain(const char* in, const char* out) {
   isac_cfar_config cf = {h.pfa, {h.guard[0], h.guard[1]}, {h.train[0], h.train[1]}, h.row0, h.row1, h.col0, h.col1};
   FILE* o = fopen(out, "wb");
   if (!o) { perror(out); return 1; }
+  /* ---- (0) 'reserve': dry runs of the chain at this shape (isac_ctx_reserve); must leave nothing behind that changes the results below */
+  {
+    double ms = 0.0;
+    CHECK(isac_ctx_reserve(ctx, h.T, h.L, &car, &rp, &ep, &cf, 0.0, &ms));
+    if (!(ms > 0.0)) { fprintf(stderr, "reserve reported no elapsed time\n"); return 6; }
+  }
   /* ---- (1) gateway 'monoStaticSensing' + 'fft2D' with MATLAB arrays: the host-pointer entry points stage through the context */
   int32_t l_out = 0;
   isac_est_result r1, r2;
