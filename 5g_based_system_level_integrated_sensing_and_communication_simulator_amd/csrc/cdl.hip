@@ -597,6 +597,139 @@ __global__ __launch_bounds__(256) void cdl_freq_response_kernel(const c64* __res
   }
 }
 
+// ---------------------------------------------------------------- fused UPLINK apply (round 5): delay filters + contraction in one persistent launch
+// Uplink (two transmit elements -> the gNB array): y[t, u] = sum_n sum_s h[n][s][u] XF[t, 2 n + s],  XF[t, 2 n + s] = sum_k g_n[k] x[t - d_n - k, s].  The unfused path
+// writes XF [T x 2 n_paths] to HBM and contracts from there.  Here a 512-thread workgroup per CU walks 128-row tiles; per tile
+//   1. the x rows the tile reaches back to ([t0 - H, t0 + 128) x 2, H = max delay + 15 rounded up to 8: 16-33 KB) go to LDS in EIGHT ROW PHASES (row r at [r & 7][r >> 3]):
+//      the 16 filter tasks of a column read rows 8 g + c + j -- for every j one phase, 16 consecutive entries: conflict-free for any delay, and the phase / entry of j
+//      are wave-uniform scalars (a wave's 64 lanes = one path, both transmit elements);
+//   2. per chunk of 8 paths (16 contraction columns = 4 k-steps): the filters exactly as in the downlink kernel's filter phase (thread pair = (column, 8 rows), real / imaginary
+//      parts; 23 window samples in registers) write XF into the swizzled LDS tile in A-operand order, then 4 k-steps x NCT column tiles x 3 (3M) MFMAs per wave accumulate;
+//   3. y is stored straight from the accumulators (the eight waves of a column tile complete 2 KB runs per column together).
+// Tiles are independent (the filter is a gather on x, which is in memory): no ring, no warm-up; sums of an output run chunk-major, k ascending -- a fixed order.
+template <int NCT, bool PROF = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void cdl_fused_ul_kernel(const CdlSeg* __restrict__ segs, const CdlWork* __restrict__ works, const int* __restrict__ wg_first, long long ldx, long long ldy, int Nr, int n_paths,
+                         const double* __restrict__ taps16 /* [n_paths][16], zero padded */, const int* __restrict__ shift, int hist /* H */, double scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int Nt = 2, KSC = 4;                                             // k-steps per chunk (16 contraction columns = 8 paths x 2 transmit elements)
+  const int n_chunks = (n_paths + kFzPpt - 1) / kFzPpt, KS = KSC * n_chunks;
+  const int xs_len = (hist + kFzRows) / 8 + 1, xs_pitch = (xs_len + 15) / 16 * 16 + 1;   // entries per row phase; pitch = 1 (mod 16): the eight phases of 8 consecutive rows hit 8 bank quads
+  c64* fbuf = reinterpret_cast<c64*>(smem_raw);                              // [16][kFzLdF]: XF of one chunk
+  c64* bpair = fbuf + 16 * kFzLdF;                                           // [KS][NCT][64]: (hr, hi) in B-operand order
+  double* bsum = reinterpret_cast<double*>(bpair + KS * NCT * 64);           // [KS][NCT][64]: hr + hi
+  double* s_taps = bsum + KS * NCT * 64;                                     // [n_chunks * 8][16]
+  c64* xwin = reinterpret_cast<c64*>(s_taps + n_chunks * kFzPpt * kFzTaps);  // [2][8][xs_pitch]
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  for (int i = tid; i < n_chunks * kFzPpt * kFzTaps; i += 512) s_taps[i] = i < n_paths * kFzTaps ? taps16[i] : 0.0;
+  const int part = tid & 1, fc = tid >> 5, fg = (tid >> 1) & 15;             // filter task: column fc of the chunk (path fc >> 1 = wid, element fc & 1), rows 8 fg .. 8 fg + 7
+  const int Nc = Nr;
+  const int w_begin = wg_first[blockIdx.x], w_end = wg_first[blockIdx.x + 1];
+  for (int wi = w_begin; wi < w_end; ++wi) {
+    const CdlWork wk = works[wi];
+    const CdlSeg sg = segs[wk.seg];
+    const __amdgpu_buffer_rsrc_t rs_x = buffer_of(sg.A, (unsigned)(ldx * Nt * (long long)sizeof(c64)));
+    const __amdgpu_buffer_rsrc_t rs_y = buffer_of(sg.Y, (unsigned)(ldy * Nr * (long long)sizeof(c64)));
+    lds_barrier();                                                           // the previous item's last reads of the image are done
+    for (int i = tid; i < KS * NCT * 64; i += 512) {
+      const int ks = i / (NCT * 64), ct = (i >> 6) % NCT, ln = i & 63;
+      const int k = 4 * ks + (ln >> 4), col = 16 * ct + (ln & 15);          // contraction index k = 2 n + s
+      const bool ok = k < Nt * n_paths && col < Nc;
+      const int kk = ok ? k : 0, cc = ok ? col : 0;
+      const c64 h = sg.H[((long long)(kk >> 1) * Nt + (kk & 1)) * Nr + cc];  // unconditional load, select afterwards
+      bpair[i] = ok ? h : mk(0.0, 0.0);
+      bsum[i] = ok ? h.re + h.im : 0.0;
+    }
+    for (int tile = wk.tile0; tile < wk.tile1; ++tile) {
+      const long long t0 = sg.o0 + (long long)tile * kFzRows;
+      lds_barrier();                                                         // the previous tile's window reads are done (and the image is in place)
+      // ---- 1. x rows t0 - hist .. t0 + 127 of both transmit elements -> LDS in eight row phases; rows in front of the waveform are zero
+      for (int i = tid; i < (hist + kFzRows) * Nt; i += 512) {
+        const int s_ = i / (hist + kFzRows), r = i - s_ * (hist + kFzRows);
+        const long long row = t0 - hist + r;
+        const long long rc = row < 0 ? 0 : (row < ldx ? row : ldx - 1);
+        const c64 v = buffer_load_c64(rs_x, (unsigned)((rc + ldx * s_) * (long long)sizeof(c64)));
+        xwin[(s_ * 8 + (r & 7)) * xs_pitch + (r >> 3)] = (row >= 0 && row < ldx) ? v : mk(0.0, 0.0);
+      }
+      v4f64 p1[NCT], p2[NCT], p3[NCT];
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) p1[ct] = p2[ct] = p3[ct] = v4f64{0.0, 0.0, 0.0, 0.0};
+      lds_barrier();
+      for (int ch = 0; ch < n_chunks; ++ch) {
+        // ---- 2a. XF of this chunk's 16 contraction columns: the wave's path n = 8 ch + wid (both transmit elements), 23 window samples of one component in registers
+        {
+          const int n = ch * kFzPpt + wid;
+          const int nn = n < n_paths ? n : 0;
+          const int base = hist - (kFzTaps - 1) - __builtin_amdgcn_readfirstlane(shift[nn]);   // (wave-uniform) window row of (fg = 0, j = 0)
+          const double* xc = reinterpret_cast<const double*>(xwin + ((fc & 1) * 8) * xs_pitch + fg) + part;
+          double w[23];
+#pragma unroll
+          for (int j = 0; j < 23; ++j) {
+            const int r = base + j;                                          // (scalar) row of task 0; task fg reads row r + 8 fg: phase r & 7, entry (r >> 3) + fg
+            w[j] = xc[2 * ((r & 7) * xs_pitch + (r >> 3))];
+          }
+          const double* tp = s_taps + (ch * kFzPpt + wid) * kFzTaps;
+          double gk[kFzTaps];
+#pragma unroll
+          for (int k = 0; k < kFzTaps; ++k) gk[k] = n < n_paths ? tp[k] : 0.0;
+          double a[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) a[r] = 0.0;
+#pragma unroll
+          for (int k = 0; k < kFzTaps; ++k)                                  // XF[t] = sum_k g[k] x[t - d - k]: row 8 fg + r - d - k  <->  w[15 + r - k]
+#pragma unroll
+            for (int r = 0; r < 8; ++r) a[r] = ::fma(gk[k], w[15 + r - k], a[r]);
+          double* fo = reinterpret_cast<double*>(fbuf) + part + 2 * (fc * kFzLdF);
+          const int po = 8 * fg, xo = (po >> 4) & 7;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) fo[2 * (po + (r ^ xo))] = a[r];
+        }
+        lds_barrier();
+        // ---- 2b. four k-steps of the contraction: A operands from the XF tile (lane (li, kq): row 16 wid + li, column 4 ksl + kq), B from the image
+        {
+          const c64* ap = fbuf + fz_swz(16 * wid + li);
+          c64 xa[2], hp[2][NCT];
+          double hs[2][NCT];
+          auto load_ops = [&](int ksl, c64& x, c64 (&h)[NCT], double (&hsv)[NCT]) {
+            x = ap[(4 * ksl + kq) * kFzLdF];
+            const int ks = ch * KSC + ksl;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) { h[ct] = bpair[(ks * NCT + ct) * 64 + lane]; hsv[ct] = bsum[(ks * NCT + ct) * 64 + lane]; }
+          };
+          load_ops(0, xa[0], hp[0], hs[0]);
+          static_for<0, KSC>([&](auto kc) {
+            constexpr int ksl = decltype(kc)::value, cur = ksl & 1;
+            if constexpr (ksl + 1 < KSC) load_ops(ksl + 1, xa[cur ^ 1], hp[cur ^ 1], hs[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const double xr = xa[cur].re, xi = xa[cur].im, xs = xr + xi;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+              p1[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xr, hp[cur][ct].re, p1[ct], 0, 0, 0);
+              p2[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xi, hp[cur][ct].im, p2[ct], 0, 0, 0);
+              p3[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs, hs[cur][ct], p3[ct], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
+        if (ch + 1 < n_chunks) lds_barrier();                                // (uniform) the next chunk's XF overwrites the tile
+      }
+      // ---- 3. y rows of this wave straight from the accumulators (f64 MFMA C/D layout: lane (li, kq) holds rows kq + 4 r of column 16 ct + li)
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int col = 16 * ct + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long long row = t0 + 16 * wid + kq + 4 * r;
+          const bool st = col < Nc && row < sg.o1;
+          const unsigned off = st ? (unsigned)((row + ldy * (long long)col) * (long long)sizeof(c64)) : 0xfffffff0u;
+          buffer_store_c64_nt(rs_y, off, mk((p1[ct][r] - p2[ct][r]) * scale, ((p3[ct][r] - p1[ct][r]) - p2[ct][r]) * scale));
+        }
+      }
+    }
+  }
+}
+
 // The CSI-RS channel estimates of MANY UEs at one occasion in ONE launch: for UE j (blockIdx.y) the sample-and-hold path gains of its channel time t[j] for the
 // first `ports` transmit elements (TR 38.901 7.5-22 / 7.5-29, as cdl_path_gains_kernel) and their frequency response at the n_re frequencies (as
 // cdl_freq_response_kernel), without the path gains ever leaving the CU.  All UEs share the delay profile (n_paths, n_rays, delays); each has its own per-ray terms.
@@ -685,6 +818,25 @@ bool cdl_fused_ok(long long T, int Nt, int Nr, int n_paths, int n_taps, int max_
   return !off && Nr == 2 && Nt >= 2 && Nt <= 64 && n_paths <= 3 * kFzPpt && n_taps <= kFzTaps && max_shift < 128 * 7 && (long long)T * Nr < (1ll << 28);
 }
 
+// The tile sequence of all segments cut into one contiguous range per workgroup; a range that starts inside a segment walks `warm` warm-up tiles first.
+void cdl_work_list(const std::vector<long long>& seg_tiles, long long total, int n_wg, int warm, std::vector<CdlWork>& works, std::vector<int>& wg_first) {
+  wg_first.assign((size_t)n_wg + 1, 0);
+  size_t si = 0;
+  long long seg_lo = 0;                                                      // global index of the first tile of segment si
+  for (int w = 0; w < n_wg; ++w) {
+    const long long g0 = total * w / n_wg, g1 = total * (w + 1) / n_wg;
+    wg_first[w] = (int)works.size();
+    long long g = g0;
+    while (g < g1) {
+      while (g >= seg_lo + seg_tiles[si]) { seg_lo += seg_tiles[si]; ++si; }
+      const long long t0 = g - seg_lo, t1 = std::min(seg_tiles[si], g1 - seg_lo);
+      works.push_back(CdlWork{(int)si, (int)std::max<long long>(0, t0 - warm), (int)t1, (int)t0});
+      g = seg_lo + t1;
+    }
+  }
+  wg_first[n_wg] = (int)works.size();
+}
+
 int launch_fused(isac_ctx* ctx, const std::vector<CdlSeg>& segs, long long T, int Nt, int Nr, int n_paths, const double* taps, int n_taps, const int32_t* shift,
                  int max_shift, double out_scale) {
   const int Nc = n_paths * Nr, nct = (Nc + 15) / 16, nslot = max_shift < 128 * 3 ? 4 : 8;
@@ -714,23 +866,8 @@ int launch_fused(isac_ctx* ctx, const std::vector<CdlSeg>& segs, long long T, in
   static const int wgs_env = std::getenv("ISAC_CDL_FUSED_WGS") ? std::atoi(std::getenv("ISAC_CDL_FUSED_WGS")) : 0;   // development switch: workgroups of the persistent grid
   const int n_wg = (int)std::min<long long>(wgs_env > 0 ? wgs_env : ctx->n_cus, total);
   std::vector<CdlWork> works;
-  std::vector<int> wg_first(n_wg + 1, 0);
-  {
-    size_t si = 0;
-    long long seg_lo = 0;                                                    // global index of the first tile of segment si
-    for (int w = 0; w < n_wg; ++w) {
-      const long long g0 = total * w / n_wg, g1 = total * (w + 1) / n_wg;
-      wg_first[w] = (int)works.size();
-      long long g = g0;
-      while (g < g1) {
-        while (g >= seg_lo + seg_tiles[si]) { seg_lo += seg_tiles[si]; ++si; }
-        const long long t0 = g - seg_lo, t1 = std::min(seg_tiles[si], g1 - seg_lo);
-        works.push_back(CdlWork{(int)si, (int)std::max<long long>(0, t0 - warm), (int)t1, (int)t0});
-        g = seg_lo + t1;
-      }
-    }
-    wg_first[n_wg] = (int)works.size();
-  }
+  std::vector<int> wg_first;
+  cdl_work_list(seg_tiles, total, n_wg, warm, works, wg_first);
   // ---- one upload: segments | taps | delay table | class starts | work items | ranges
   auto pad = [](size_t b) { return (b + 63) & ~(size_t)63; };
   const size_t o_seg = 0, o_tap = o_seg + pad(sizeof(CdlSeg) * segs.size()), o_pm = o_tap + pad(sizeof(double) * taps16.size()), o_wk = o_pm + pad(sizeof(int) * pmeta.size()),
@@ -782,6 +919,61 @@ int launch_fused(isac_ctx* ctx, const std::vector<CdlSeg>& segs, long long T, in
   return ISAC_OK;
 }
 
+// Fused uplink apply: two transmit elements into an array of up to 64 elements, <= 24 paths, <= 16 taps, delays that keep the x window within LDS.
+bool cdl_fused_ul_ok(long long T, int Nt, int Nr, int n_paths, int n_taps, int max_shift) {
+  static const bool off = std::getenv("ISAC_CDL_UNFUSED") != nullptr;
+  return !off && Nt == 2 && Nr > Nt && Nr <= 64 && n_paths <= 3 * kFzPpt && n_taps <= kFzTaps && max_shift + kFzTaps <= 896 && (long long)T * Nr < (1ll << 28);
+}
+
+int launch_fused_ul(isac_ctx* ctx, const std::vector<CdlSeg>& segs, long long T, int Nr, int n_paths, const double* taps, int n_taps, const int32_t* shift, int max_shift,
+                    double out_scale) {
+  const int nct = (Nr + 15) / 16, n_chunks = (n_paths + kFzPpt - 1) / kFzPpt, KS = 4 * n_chunks;
+  const int hist = (max_shift + (kFzTaps - 1) + 7) / 8 * 8;
+  std::vector<double> taps16((size_t)n_paths * kFzTaps, 0.0);
+  for (int n = 0; n < n_paths; ++n) std::memcpy(&taps16[(size_t)n * kFzTaps], taps + (size_t)n * n_taps, sizeof(double) * (size_t)n_taps);
+  if (ctx->n_cus <= 0) {
+    int v = 0;
+    ISAC_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    ctx->n_cus = v > 0 ? v : 256;
+  }
+  std::vector<long long> seg_tiles(segs.size());
+  long long total = 0;
+  for (size_t i = 0; i < segs.size(); ++i) { seg_tiles[i] = segs[i].o1 > segs[i].o0 ? (segs[i].o1 - segs[i].o0 + kFzRows - 1) / kFzRows : 0; total += seg_tiles[i]; }
+  if (total == 0) return ISAC_OK;
+  static const int wgs_env = std::getenv("ISAC_CDL_FUSED_WGS") ? std::atoi(std::getenv("ISAC_CDL_FUSED_WGS")) : 0;
+  const int n_wg = (int)std::min<long long>(wgs_env > 0 ? wgs_env : ctx->n_cus, total);
+  std::vector<CdlWork> works;
+  std::vector<int> wg_first;
+  cdl_work_list(seg_tiles, total, n_wg, 0, works, wg_first);                 // tiles are independent: no warm-up
+  auto pad = [](size_t b) { return (b + 63) & ~(size_t)63; };
+  const size_t o_seg = 0, o_tap = o_seg + pad(sizeof(CdlSeg) * segs.size()), o_sh = o_tap + pad(sizeof(double) * taps16.size()), o_wk = o_sh + pad(sizeof(int) * (size_t)n_paths),
+               o_wf = o_wk + pad(sizeof(CdlWork) * works.size()), meta = o_wf + pad(sizeof(int) * wg_first.size());
+  std::vector<char> host(meta);
+  std::memcpy(host.data() + o_seg, segs.data(), sizeof(CdlSeg) * segs.size());
+  std::memcpy(host.data() + o_tap, taps16.data(), sizeof(double) * taps16.size());
+  std::memcpy(host.data() + o_sh, shift, sizeof(int) * (size_t)n_paths);
+  std::memcpy(host.data() + o_wk, works.data(), sizeof(CdlWork) * works.size());
+  std::memcpy(host.data() + o_wf, wg_first.data(), sizeof(int) * wg_first.size());
+  ISAC_TRY(ensure(ctx, ctx->stage_c, meta + 64));
+  char* dm = (char*)ctx->stage_c.p;
+  ISAC_TRY(stage_upload(ctx, dm, host.data(), meta));
+  const int xs_len = (hist + kFzRows) / 8 + 1, xs_pitch = (xs_len + 15) / 16 * 16 + 1;
+  const size_t lds_bytes = sizeof(c64) * (16 * (size_t)kFzLdF + (size_t)KS * nct * 64 + 2 * 8 * (size_t)xs_pitch) + sizeof(double) * ((size_t)KS * nct * 64 + (size_t)n_chunks * kFzPpt * kFzTaps);
+  if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));
+#define ISAC_CDL_FUSED_UL(NCT)                                                                                                                                     \
+  do {                                                                                                                                                             \
+    auto kern = cdl_fused_ul_kernel<NCT>;                                                                                                                          \
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds_bytes));                                                                                      \
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg), dim3(512), lds_bytes, ctx->stream, (const CdlSeg*)(dm + o_seg), (const CdlWork*)(dm + o_wk), (const int*)(dm + o_wf), \
+                       (long long)T, (long long)T, Nr, n_paths, (const double*)(dm + o_tap), (const int*)(dm + o_sh), hist, out_scale);                            \
+  } while (0)
+  switch (nct) { case 1: ISAC_CDL_FUSED_UL(1); break; case 2: ISAC_CDL_FUSED_UL(2); break; case 3: ISAC_CDL_FUSED_UL(3); break; default: ISAC_CDL_FUSED_UL(4); break; }
+#undef ISAC_CDL_FUSED_UL
+  ISAC_HIP(hipGetLastError());
+  if (ctx->profile) { ISAC_HIP(hipEventRecord(ctx->ev_k1, ctx->stream)); ctx->profile_recorded = true; }
+  return ISAC_OK;
+}
+
 int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long T, int Nt, int Nr, int n_paths, const double* taps, int n_taps,
                    const int32_t* shift, double out_scale) {
   if (!jobs || !taps || !shift) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
@@ -806,8 +998,8 @@ int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long lon
   }
   if (n_seg_total > 65535) return fail(ctx, ISAC_ERR_CAPACITY, "more than 65535 (job, gain block) segments in one batch");
   // workspace: DL (unfused kernels only): Z [T x Ncp] per segment;  UL: prefiltered signals [T x Kc] per job;  fused DL: none
-  const bool fused = !ul && cdl_fused_ok(T, Nt, Nr, n_paths, n_taps, max_shift);
-  const size_t ws_elems = fused ? 0 : ul ? (size_t)n_jobs * (size_t)T * Kc : n_seg_total * (size_t)T * Ncp;
+  const bool fused = !ul && cdl_fused_ok(T, Nt, Nr, n_paths, n_taps, max_shift), fused_ul = ul && cdl_fused_ul_ok(T, Nt, Nr, n_paths, n_taps, max_shift);
+  const size_t ws_elems = (fused || fused_ul) ? 0 : ul ? (size_t)n_jobs * (size_t)T * Kc : n_seg_total * (size_t)T * Ncp;
   if (ws_elems) ISAC_TRY(ensure(ctx, ctx->stage_b, sizeof(c64) * ws_elems));
   c64* ws = (c64*)ctx->stage_b.p;
   segs.reserve(n_seg_total + (size_t)n_jobs);
@@ -821,8 +1013,8 @@ int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long lon
       s.H = (const c64*)jb.d_H + (size_t)b * n_paths * Nt * Nr;
       s.o0 = o0; s.o1 = o1 > o0 ? o1 : o0;
       s.Y = (c64*)jb.d_y;
-      if (ul) {                                                       // rows of y that use this block: contraction of the job's prefiltered signals
-        s.A = ws + (size_t)j * (size_t)T * Kc;
+      if (ul) {                                                       // rows of y that use this block: contraction of the job's prefiltered signals (fused: straight from x)
+        s.A = fused_ul ? (const c64*)jb.d_x : ws + (size_t)j * (size_t)T * Kc;
         s.C = (c64*)jb.d_y;
         s.r0 = s.o0; s.r1 = s.o1;
       } else {                                                        // Z of this block: the rows its outputs reach back to
@@ -837,6 +1029,7 @@ int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long lon
   }
   const size_t n_gemm = segs.size();
   if (fused) return launch_fused(ctx, segs, T, Nt, Nr, n_paths, taps, n_taps, shift, max_shift, out_scale);
+  if (fused_ul) return launch_fused_ul(ctx, segs, T, Nr, n_paths, taps, n_taps, shift, max_shift, out_scale);
   if (ul)
     for (int j = 0; j < n_jobs; ++j) {                                // prefilter segments: one per job, all rows
       CdlSeg s{};

@@ -700,12 +700,14 @@ pkg = importlib.import_module(%r)
 ctx = pkg._lib.Context(0)
 CM = pkg.communication.channelModels
 fs = 122.88e6
-for profile, tx, t_len in (("CDL-A", (4, 8, 2, 1, 1), 20011), ("CDL-D", (1, 8, 2, 1, 1), 9000), ("CDL-A", (1, 3, 2, 1, 1), 1531)):
-    nt = int(np.prod(tx))
+UE = (1, 1, 2, 1, 1)
+for profile, tx, rx, t_len in (("CDL-A", (4, 8, 2, 1, 1), UE, 20011), ("CDL-D", (1, 8, 2, 1, 1), UE, 9000), ("CDL-A", (1, 3, 2, 1, 1), UE, 1531),
+                               ("CDL-A", UE, (4, 8, 2, 1, 1), 9001), ("CDL-D", UE, (1, 12, 2, 1, 1), 4000)):        # (the last two: uplink, 2 -> 64 and 2 -> 24 elements)
+    nt = int(np.prod(tx)) + 100 * int(np.prod(rx))
     rng = np.random.default_rng(nt)
-    xs = [ctx.to_device(np.asfortranarray(rng.standard_normal((t_len, nt)) + 1j * rng.standard_normal((t_len, nt)))) for _ in range(2)]
+    xs = [ctx.to_device(np.asfortranarray(rng.standard_normal((t_len, int(np.prod(tx)))) + 1j * rng.standard_normal((t_len, int(np.prod(tx)))))) for _ in range(2)]
     def chans():
-        c = [CM.CDLChannel(profile, 300e-9, 3.5e9, tx, (1, 1, 2, 1, 1), fs, Seed=70 + u) for u in range(4)]
+        c = [CM.CDLChannel(profile, 300e-9, 3.5e9, tx, rx, fs, Seed=70 + u) for u in range(4)]
         c[3].time = 1.0 / 640 - (t_len // 2) / fs            # one job crosses a path-gain refresh: two segments, the second starts inside the waveform
         return c
     outs = CM.applyCDLBatch(chans(), [xs[0], xs[0], xs[1], xs[1]], ctx=ctx)
@@ -717,7 +719,8 @@ for profile, tx, t_len in (("CDL-A", (4, 8, 2, 1, 1), 20011), ("CDL-D", (1, 8, 2
 
 
 def test_cdl_fused_apply_bits_do_not_depend_on_the_grid(tmp_path):
-    """cdl_fused_kernel (downlink: contraction + delay filters in one persistent launch, Z never in HBM): the same bits whether the tile sequence is walked by
+    """cdl_fused_kernel (downlink: contraction + delay filters in one persistent launch, Z never in HBM) and cdl_fused_ul_kernel (uplink: filters + contraction, the
+    filtered signals never in HBM): the same bits whether the tile sequence is walked by
     1, 7 or one-per-CU workgroups (ranges that start inside a segment re-create their predecessor's partial sums with warm-up tiles), the same bits for a job
     alone or in a batch; against the unfused kernels (other summation order) <= 1e-12 relative.  122.88 MHz sampling: delays up to 355 samples (three tiles back)."""
     import subprocess, sys
@@ -727,9 +730,9 @@ def test_cdl_fused_apply_bits_do_not_depend_on_the_grid(tmp_path):
         r = subprocess.run([sys.executable, "-c", _CDL_FUSED_SNIPPET % (root, PKG_NAME), str(tmp_path / tag)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         runs[tag] = [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("digest")]
-    assert len(runs["cu"]) == 6
+    assert len(runs["cu"]) == 10
     assert runs["cu"] == runs["one"] == runs["seven"]
-    for i in range(0, 6, 2):
+    for i in range(0, 10, 2):
         assert runs["cu"][i][1:] == runs["cu"][i + 1][1:], runs["cu"][i]                  # batch == single
     for f in sorted(os.listdir(tmp_path)):
         if f.startswith("cu_"):
