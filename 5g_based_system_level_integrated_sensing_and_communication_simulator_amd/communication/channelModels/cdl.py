@@ -86,6 +86,7 @@ class CDLChannel:
         self.TxElement, self.RxElement = "38.901", "isotropic"
         self.NormalizePathGains = self.NormalizeChannelOutputs = True
         self.time = 0.0                                                 # InitialTime
+        self.n_tx, self.n_rx = int(np.prod(self.TransmitAntennaArraySize)), int(np.prod(self.ReceiveAntennaArraySize))
         self._rays = None
         self._st = None
 
@@ -307,13 +308,17 @@ def applyCDLBatch(channels, waveforms, *, ctx=None, outs=None, gains=None):
     ctx = ctx or waveforms[0].ctx
     c0 = channels[0]
     T, nt = waveforms[0].shape
-    nr = int(np.prod(c0.ReceiveAntennaArraySize))
+    nr = c0.n_rx
     g, shift = c0.filter_taps()
     n_paths = g.shape[0]
+    checked = set()                                                       # (a channel that appears many times -- the slots of a frame -- is validated once)
     for ch, w in zip(channels, waveforms):
         if not isinstance(w, L.DeviceArray) or tuple(w.shape) != (T, nt):
             raise ValueError("applyCDLBatch: waveforms must be DeviceArrays of one shape [T x Nt]")
-        if int(np.prod(ch.TransmitAntennaArraySize)) != nt or int(np.prod(ch.ReceiveAntennaArraySize)) != nr:
+        if id(ch) in checked:
+            continue
+        checked.add(id(ch))
+        if ch.n_tx != nt or ch.n_rx != nr:
             raise ValueError("applyCDLBatch: channels must share the antenna counts")
         g2, s2 = ch.filter_taps()
         if g2 is not g and (g2.shape != g.shape or not np.array_equal(s2, shift) or not np.array_equal(g2, g)):
@@ -335,7 +340,7 @@ def applyCDLBatch(channels, waveforms, *, ctx=None, outs=None, gains=None):
     for i, ch in enumerate(channels):
         groups.setdefault(id(ch._static()), []).append(i)
     n_blk_total = sum(len(p[0]) for p in plans)
-    if gains is not None and int(np.prod(gains.shape)) < n_blk_total * per_block:
+    if gains is not None and math.prod(gains.shape) < n_blk_total * per_block:
         raise ValueError("applyCDLBatch: `gains` scratch too small for this batch's gain blocks")
     d_h_all = gains if gains is not None else ctx.empty((n_blk_total * per_block,))
     off = 0

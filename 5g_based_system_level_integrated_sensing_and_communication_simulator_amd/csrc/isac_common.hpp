@@ -102,7 +102,7 @@ struct StageSlot {
   hipEvent_t ev = nullptr;
   bool busy = false;
 };
-constexpr int kStageSlots = 8;
+constexpr int kStageSlots = 32;     // (a batched CDL call stages two blocks: with 8 slots the host could run only 4 calls ahead of the device and short launches starved it)
 
 struct Fft2dPending {  // state between isac_fft2d_submit_dev and isac_fft2d_collect
   bool active = false;

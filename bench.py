@@ -390,10 +390,10 @@ class CommCell:
                 ctx_cdl.check(ctx_cdl.lib.isac_synth_qpsk_grid_dev(ctx_cdl.handle, C.c_void_p(g2.ptr), K, 14, 2, C.c_uint64(0xE100 + 64 * cell_id + u), 0))
                 ctx_cdl.check(ctx_cdl.lib.isac_ofdm_modulate_dev(ctx_cdl.handle, C.c_void_p(g2.ptr), 14, 2, C.byref(car), C.c_double(1.0), C.c_void_p(w.ptr), C.c_int64(self.T)))
                 self.ul_waves.append(w)
-            for g in self.groups:
+            for g in self.groups:                         # (one output per (U slot, UE): the frame's four U slots of a group go out in ONE library call)
                 st = self.ul_chans[g[0]]._static()
-                self.ul_rx.append([ctx_cdl.empty((self.T, n_ants)) for _ in g])
-                self.ul_gains.append(ctx_cdl.empty((len(g) * 4 * st.base.shape[0] * st.base.shape[2] * st.base.shape[3],)))
+                self.ul_rx.append([ctx_cdl.empty((self.T, n_ants)) for _ in range(self.UL_SLOTS * len(g))])
+                self.ul_gains.append(ctx_cdl.empty((self.UL_SLOTS * len(g) * 4 * st.base.shape[0] * st.base.shape[2] * st.base.shape[3],)))
         self.last_cqi = None
         self.last_reports = None
         for c_ in self.ctxs:
@@ -411,10 +411,10 @@ class CommCell:
                 # (one context per delay-profile group: the filter launch of one group runs beside the contraction launch of the other)
                 self.CM.applyCDLBatch([self.chans[u] for s_ in slots for u in g], [self.waves[s_] for s_ in slots for u in g], ctx=self.ctxs[gi % len(self.ctxs)],
                                       outs=[rx[(s_ - s0) * len(g) + i] for s_ in slots for i in range(len(g))], gains=gn)
-        if self.WITH_UL:                                      # the frame's 'U' slots: every UE's packet into the gNB array, one call per slot and group
-            for _ in range(self.UL_SLOTS):
-                for gi, g in enumerate(self.groups):
-                    self.CM.applyCDLBatch([self.ul_chans[u] for u in g], [self.ul_waves[u] for u in g], ctx=self.ctxs[gi % len(self.ctxs)], outs=self.ul_rx[gi], gains=self.ul_gains[gi])
+        if self.WITH_UL:                                      # the frame's four 'U' slots: every UE's packet into the gNB array, one call per group (a channel that
+            for gi, g in enumerate(self.groups):              # appears four times advances its time from slot to slot)
+                self.CM.applyCDLBatch([self.ul_chans[u] for _ in range(self.UL_SLOTS) for u in g], [self.ul_waves[u] for _ in range(self.UL_SLOTS) for u in g],
+                                      ctx=self.ctxs[gi % len(self.ctxs)], outs=self.ul_rx[gi], gains=self.ul_gains[gi])
 
     def csi_reports(self):
         """The frame's CSI-RS occasions: every UE's report, one batched call (one synchronisation of the CSI context) per occasion."""
