@@ -189,3 +189,32 @@ def test_scratch_users_are_the_known_ones(echo_co, music_co):
         for n, m in co.meta.items():
             if m.get("private_segment_fixed_size", 0) > 0:
                 assert any(k in n for k in known), f"{n} uses {m['private_segment_fixed_size']} B of scratch"
+
+
+@pytest.fixture(scope="module")
+def cdl_co(tmp_path_factory):
+    return CodeObject(str(tmp_path_factory.mktemp("cdl_co")), "cdl")
+
+
+def test_fused_cdl_kernels_code_generation(cdl_co):
+    """cdl_fused_kernel / cdl_fused_ul_kernel: two waves per SIMD (<= 256 registers), no scratch inside the tile loop (the compiler once turned
+    the gather's slot array into a dynamically indexed scratch array and its lane selects into exec-masked branches: 2.6 k -> 7.9 k cycles per column tile), and the
+    contraction as one straight-line run of MFMAs per tile / chunk."""
+    # downlink, CDL-A shape: 3 column tiles, 4 delay slots
+    name, meta, asm = cdl_co.find("cdl_fused_kernel", "ILi3ELi4ELb0E")
+    assert meta["vgpr_count"] <= 256 and meta["agpr_count"] == 0
+    assert meta["private_segment_fixed_size"] <= 64, "more than a handful of prologue spills"        # (a few registers of the per-range prologue)
+    mf = [i for i, ln in enumerate(asm) if ln.startswith("v_mfma_f64_16x16x4")]
+    assert len(mf) == 16 * 3 * 3, len(mf)                                  # 16 k-steps x 3 column tiles x 3 forms, unrolled once
+    body = asm[mf[0]:mf[-1] + 1]
+    assert not any(ln.startswith("scratch_") for ln in body), "scratch traffic inside the contraction"
+    after = asm[mf[-1]:]
+    assert sum(ln.startswith("scratch_") for ln in after) == 0, "scratch traffic in the filter / gather phases"
+    assert sum(ln.startswith("s_barrier") for ln in after) <= 2 * 3 + 2, "more than two barriers per column tile"
+    # the gather is branch-free: no exec-mask manipulation behind the MFMAs except loop control
+    assert sum(ln.startswith("s_and_saveexec") or ln.startswith("s_or_saveexec") for ln in after) <= 6
+    # uplink, 64 receive elements: 4 column tiles
+    name, meta, asm = cdl_co.find("cdl_fused_ul_kernel", "ILi4ELb0E")
+    assert meta["vgpr_count"] <= 256 and meta["private_segment_fixed_size"] == 0
+    assert sum(ln.startswith("v_mfma_f64_16x16x4") for ln in asm) == 4 * 4 * 3       # one chunk: 4 k-steps x 4 column tiles x 3 forms
+    assert not any(ln.startswith("scratch_") for ln in asm)

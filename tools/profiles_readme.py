@@ -99,8 +99,28 @@ c5 = jline("bench_config5_21x10.json")
 if c5:
     rf = c5["roofline"]
     out.append(f"* bench, `--workload config5` (21 cells x 10 UE on ONE GPU; per 20-slot frame: {c5['per_frame_and_rank']['sensing_cpis']} sensing CPIs + {c5['per_frame_and_rank']['cdl_applies']} CDL applies + "
-               f"{c5['per_frame_and_rank']['csi_reports']} CSI reports): **{c5['value']:,.0f} slots/s**, {c5['ms_per_step']:.1f} ms per frame; `cdl_gemm_kernel` {rf['avg_launch_ms']} ms per {rf['jobs_per_launch']}-job launch = "
+               f"{c5['per_frame_and_rank']['csi_reports']} CSI reports): **{c5['value']:,.0f} slots/s**, {c5['ms_per_step']:.1f} ms per frame; `{rf.get('kernel', 'cdl_gemm_kernel').split('<')[0].split(' ')[0]}` {rf['avg_launch_ms']} ms per {rf['jobs_per_launch']}-job launch = "
                f"{rf['achieved']} TFLOP/s issued = `roofline.frac` {rf['frac']} of the fp64 MFMA peak; CDL apply {c5['comm_seams']['cdl_apply_ms_per_job']} ms per job, CSI report {c5['comm_seams']['csi_report_ms_per_ue']} ms per UE.")
+for name, label in (("bench_config5_21x10_no_ul.json", "without the 'U' slots' uplink applies (`ISAC_C5_NO_UL=1`)"),
+                    ("bench_config5_21x10_r04_workload.json", "the round-4 workload shape (`ISAC_C5_NO_UL=1 ISAC_C5_HOST_CSI=1`: no uplink, CSI estimate evaluated once on the host)"),
+                    ("bench_config5_21x10_r04_workload_unfused_cdl.json", "the round-4 workload shape through the UNFUSED CDL kernels (`+ ISAC_CDL_UNFUSED=1`: Z through HBM)")):
+    d = jline(name)
+    if d:
+        rf = d["roofline"]
+        out.append(f"* config 5, {label}: **{d['ms_per_step']:.1f} ms per frame** ({d['value']:,.0f} slots/s); priced launch {rf['avg_launch_ms']} ms per {rf['jobs_per_launch']} jobs = `roofline.frac` {rf['frac']}; "
+                   f"per frame and rank {d['per_frame_and_rank']}.")
+cold = os.path.join(P, f"{tag}_cold_probe_lines.json")
+if os.path.exists(cold):
+    for ln in open(cold):
+        if ln.startswith("{"):
+            d = json.loads(ln)
+            out.append(f"* cold probe, mode `{d['mode']}`" + (f" (isac_ctx_reserve {d.get('reserve_ms')} ms, warm_ms {d.get('reserve_warm_ms_requested')})" if d['mode'] == 'reserve' else "") +
+                       f": first blocking CPI {d['first_cpi_ms']} ms, CPIs 2..21 median {d['cpi_2_21_ms']['median']} / max {d['cpi_2_21_ms']['max']} ms, steady blocking CPI {d['steady_blocking_cpi_ms']} ms (fresh process, inputs resident, device idle 1 s).")
+d0c = jline("bench_driver_invocation.json")
+if d0c and d0c.get("cold"):
+    c = d0c["cold"]
+    if "first_cpi_ms" in c.get("reserve", {}) and "first_cpi_ms" in c.get("noreserve", {}):
+        out.append(f"* `cold` block of the driver's line: first CPI {c['noreserve']['first_cpi_ms']} ms straight in, {c['reserve']['first_cpi_ms']} ms after isac_ctx_reserve ({c['reserve'].get('reserve_ms')} ms).")
 c5k = rows("kernel_stats_config5.csv")
 if c5k:
     out.append(f"* config 5 under rocprofv3 (`{tag}_kernel_stats_config5.csv`, warm-up + one frame): " + "; ".join(f"`{short(r['kernel'])}` {float(r['avg_us']):.1f} us x {r['calls']} ({float(r['pct']):.1f} %)" for r in c5k[:8]) + ".")
