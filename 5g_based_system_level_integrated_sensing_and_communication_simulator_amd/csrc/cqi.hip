@@ -306,9 +306,12 @@ extern "C" int isac_precoded_sinr_cqi_dev(isac_ctx* ctx, const isac_c64* d_H, in
     double* d_mean = (double*)((char*)ctx->misc.p + 64);
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, ctx->stream, (const double*)out, (long long)n_re, d_mean);
     ISAC_HIP(hipGetLastError());
-    double m = 0.0;
-    ISAC_HIP(hipMemcpyAsync(&m, d_mean, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    // (through pinned memory: an asynchronous copy into a pageable stack variable goes through the runtime's own staging -- one mean of ~1 900 fuzz cases under 16
+    //  concurrent processes came back wrong once, unreproduced, profiles/r05_fuzz_campaigns.txt; pinned memory takes the runtime's staging out of the picture)
+    ISAC_TRY(ensure_pinned_buf(ctx, ctx->pinned_csi, ctx->pinned_csi_cap, 64));
+    ISAC_HIP(hipMemcpyAsync(ctx->pinned_csi, d_mean, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ISAC_HIP(hipStreamSynchronize(ctx->stream));
+    const double m = *(const double*)ctx->pinned_csi;
     if (mean_sinr) *mean_sinr = m;
     if (cqi) {                                           // cqiSelect.m:705-721 getCQI
       int c = 0;

@@ -2,7 +2,7 @@
 pattern, noise) through monoStaticSensing -> fft2D on the GPU against the oracle.  Same tolerances as test_gpu_parity.py:
 fields <= 1e-10 relative, CFAR detections / range-velocity bins / integer azimuths exact.  Scenes in which some CUT lies
 within 1e-9 (relative) of its CFAR threshold are skipped -- there a rounding-level difference may legitimately flip a
-detection.  ISAC_FUZZ_N=<n> runs more seeds."""
+detection.  ISAC_FUZZ_N=<n> runs more seeds, ISAC_FUZZ_SEED0=<s> starts every test's window at seed s."""
 from __future__ import annotations
 
 import os
@@ -16,6 +16,7 @@ from test_gpu_parity import RTOL, _guard_band_ok, rel
 
 pytestmark = pytest.mark.gpu
 N_CASES = int(os.environ.get("ISAC_FUZZ_N", "16"))
+SEED0 = int(os.environ.get("ISAC_FUZZ_SEED0", "0"))       # first seed of every test's window: a campaign can walk fresh windows (profiles/r05_fuzz_campaigns.txt)
 
 
 @pytest.fixture(scope="module")
@@ -52,7 +53,7 @@ def _scene(seed, wide=None):
     return sc, los
 
 
-@pytest.mark.parametrize("seed", range(N_CASES))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + N_CASES))
 def test_chain_matches_oracle_on_random_scene(pkg, seed):
     sc, los = _scene(seed)
     rp = pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave)
@@ -74,7 +75,16 @@ def test_chain_matches_oracle_on_random_scene(pkg, seed):
     got, gd = pkg.sensing.estimation.fft2D(rp, cf, ref_echo, sc.tx_grid, return_debug=True)
     r0, c0 = gd.first_row - 1, gd.first_col - 1
     nr, nc, _ = gd.power_window.shape
-    assert rel(gd.power_window, np.abs(dbg.rdm[r0:r0 + nr, c0:c0 + nc, :]) ** 2) < RTOL
+    if not rel(gd.power_window, np.abs(dbg.rdm[r0:r0 + nr, c0:c0 + nc, :]) ** 2) < RTOL:
+        # self-diagnosis (one such mismatch was seen once in ~1 900 cases under 16 concurrent processes and never reproduced, profiles/r05_fuzz_campaigns.txt):
+        # repeat BOTH sides and say which one moved -- a device-side race, a host-side one, or a genuine disagreement
+        got2, gd2 = pkg.sensing.estimation.fft2D(rp, cf, ref_echo, sc.tx_grid, return_debug=True)
+        _, dbg2 = O.fft2d(sc.rp, ocf, ref_echo, sc.tx_grid, return_debug=True)
+        ref1, ref2 = (np.abs(d.rdm[r0:r0 + nr, c0:c0 + nc, :]) ** 2 for d in (dbg, dbg2))
+        bad = np.argwhere(np.abs(gd.power_window - ref1) > 1e-8 * ref1.max())
+        pytest.fail(f"power window: device call 1 vs oracle call 1 {rel(gd.power_window, ref1):.3e}; device call 2 vs oracle call 1 {rel(gd2.power_window, ref1):.3e}; "
+                    f"device 1 vs device 2 {rel(gd.power_window, gd2.power_window):.3e}; oracle 1 vs oracle 2 {rel(ref1, ref2):.3e}; {len(bad)} entries off in call 1, "
+                    f"rows {sorted(set(bad[:, 0].tolist()))[:8]} cols {sorted(set(bad[:, 1].tolist()))[:8]} antennas {sorted(set(bad[:, 2].tolist()))}")
     assert rel(gd.Ra, dbg.Ra) < RTOL
     for a in range(sc.A):
         assert np.array_equal(gd.detections[a], dbg.detections[a]), f"antenna {a}"
@@ -90,7 +100,7 @@ def test_chain_matches_oracle_on_random_scene(pkg, seed):
     assert np.array_equal(got.aziEst, want.aziEst)
 
 
-@pytest.mark.parametrize("seed", range(max(6, N_CASES // 4)))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + max(6, N_CASES // 4)))
 def test_fused_and_philox_paths_on_random_scene(pkg, seed):
     """Full-size numerology (Nfft = nIFFT = 4096): (a) the fused monoStaticSensing+range path is bit-identical to the
     unfused call sequence for injected, Philox and no noise and 1..6 targets (the compile-time target-count kernels
@@ -133,7 +143,7 @@ def test_fused_and_philox_paths_on_random_scene(pkg, seed):
     assert np.array_equal(est0.rngEst, est1.rngEst) and np.array_equal(est0.velEst, est1.velEst) and np.array_equal(est0.aziEst, est1.aziEst)
 
 
-@pytest.mark.parametrize("seed", range(max(8, N_CASES // 4)))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + max(8, N_CASES // 4)))
 def test_cdl_apply_on_random_configuration(pkg, seed):
     import oracle.cdl as OC
     rng = np.random.default_rng(9000 + seed)
@@ -151,7 +161,7 @@ def test_cdl_apply_on_random_configuration(pkg, seed):
     assert got.shape == (t_len, 2) and rel(got, OC.apply_cdl(cfg, x, t0)) < RTOL
 
 
-@pytest.mark.parametrize("seed", range(max(8, N_CASES // 4)))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + max(8, N_CASES // 4)))
 def test_sinr_cqi_on_random_configuration(pkg, seed):
     import oracle.cqi as OQ
     rng = np.random.default_rng(9500 + seed)
@@ -176,7 +186,7 @@ def test_sinr_cqi_on_random_configuration(pkg, seed):
 N_SPECTRAL = max(8, N_CASES // 2)
 
 
-@pytest.mark.parametrize("seed", range(N_SPECTRAL))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + N_SPECTRAL))
 def test_spectral_fused_path_on_random_scene(pkg, seed):
     """The route bench.py times, fuzzed: per-target demodulation -> fused synthesis + range kernel with the AWGN on the demodulated grid ->
     cached fft2D, for random antenna counts (incl. the 33..64 range), 1..6 targets (compile-time kernels 1..4 and the run-time one),
@@ -240,7 +250,7 @@ def test_spectral_fused_path_on_random_scene(pkg, seed):
 N_EIG = max(12, N_CASES)
 
 
-@pytest.mark.parametrize("seed", range(N_EIG))
+@pytest.mark.parametrize("seed", range(SEED0, SEED0 + N_EIG))
 def test_eigh_top_on_random_spectrum(pkg, seed):
     """isac_eigh_top fuzzed over 65 <= n <= 256 (eigh_tridiag_dist_kernel -> bisection -> subspace kernel; every third seed 17 <= n <= 64: the one-workgroup
     reduction) on Hermitian matrices with a PRESCRIBED spectrum: k leading eigenvalues separated by random relative gaps between 1e-9 and 1 (tight pairs,
