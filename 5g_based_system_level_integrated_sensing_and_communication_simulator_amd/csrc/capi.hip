@@ -129,7 +129,7 @@ int determine_num_targets(const std::vector<double>& v_ascending) {  // music.m:
 
 int upload(isac_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
   ISAC_TRY(ensure(ctx, b, bytes));
-  ISAC_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+  ISAC_TRY(upload_now(ctx, b.p, src, bytes));         // (not hipMemcpy: see upload_now)
   return ISAC_OK;
 }
 
@@ -745,8 +745,7 @@ extern "C" int isac_fft2d(isac_ctx* ctx, const isac_est_params* ep, const isac_c
   ISAC_HIP(hipMalloc(&d_rx, bytes));
   if (hipMalloc(&d_tx, bytes) != hipSuccess) { (void)hipFree(d_rx); return fail(ctx, ISAC_ERR_HIP, "hipMalloc failed"); }
   int st = ISAC_OK;
-  if (hipMemcpy(d_rx, rx_grid, bytes, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(d_tx, tx_grid, bytes, hipMemcpyHostToDevice) != hipSuccess)
+  if (upload_now(ctx, d_rx, rx_grid, bytes) != ISAC_OK || upload_now(ctx, d_tx, tx_grid, bytes) != ISAC_OK)      // (on the context's stream and waited for: see upload_now)
     st = fail(ctx, ISAC_ERR_HIP, "host->device copy failed");
   if (st == ISAC_OK) st = isac_fft2d_dev(ctx, ep, cfar, (const isac_c64*)d_rx, (const isac_c64*)d_tx, K, L, A, out);
   (void)hipStreamSynchronize(ctx->stream);
@@ -1119,10 +1118,10 @@ extern "C" int isac_basic_radar_channel(isac_ctx* ctx, const isac_c64* tx_wave, 
   int st = ISAC_OK;
   if (hipMalloc(&d_tx, bytes) != hipSuccess || hipMalloc(&d_rx, bytes) != hipSuccess) st = fail(ctx, ISAC_ERR_HIP, "hipMalloc failed");
   if (st == ISAC_OK && noise_mode == ISAC_NOISE_INJECTED && noise_unit) {
-    if (hipMalloc(&d_nz, bytes) != hipSuccess || hipMemcpy(d_nz, noise_unit, bytes, hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMalloc(&d_nz, bytes) != hipSuccess || upload_now(ctx, d_nz, noise_unit, bytes) != ISAC_OK)
       st = fail(ctx, ISAC_ERR_HIP, "noise upload failed");
   }
-  if (st == ISAC_OK && hipMemcpy(d_tx, tx_wave, bytes, hipMemcpyHostToDevice) != hipSuccess) st = fail(ctx, ISAC_ERR_HIP, "upload failed");
+  if (st == ISAC_OK && upload_now(ctx, d_tx, tx_wave, bytes) != ISAC_OK) st = fail(ctx, ISAC_ERR_HIP, "upload failed");
   if (st == ISAC_OK)
     st = isac_basic_radar_channel_dev(ctx, (const isac_c64*)d_tx, T, rp, los, noise_mode, (const isac_c64*)d_nz, seed, (isac_c64*)d_rx);
   if (st == ISAC_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(rx_wave, d_rx, bytes, hipMemcpyDeviceToHost) != hipSuccess))
@@ -1147,10 +1146,10 @@ extern "C" int isac_mono_static_sensing(isac_ctx* ctx, const isac_c64* tx_wave, 
   if (hipMalloc(&d_tx, wbytes) != hipSuccess || hipMalloc(&d_g, gbytes) != hipSuccess) st = fail(ctx, ISAC_ERR_HIP, "hipMalloc failed");
   if (st == ISAC_OK && (noise_mode == ISAC_NOISE_INJECTED || noise_mode == ISAC_NOISE_INJECTED_SPECTRAL) && noise_unit) {
     const size_t nbytes = noise_mode == ISAC_NOISE_INJECTED ? wbytes : gbytes;   // [T x A] samples or [n_sc x L_out x A] grid elements
-    if (hipMalloc(&d_nz, nbytes) != hipSuccess || hipMemcpy(d_nz, noise_unit, nbytes, hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMalloc(&d_nz, nbytes) != hipSuccess || upload_now(ctx, d_nz, noise_unit, nbytes) != ISAC_OK)
       st = fail(ctx, ISAC_ERR_HIP, "noise upload failed");
   }
-  if (st == ISAC_OK && hipMemcpy(d_tx, tx_wave, wbytes, hipMemcpyHostToDevice) != hipSuccess) st = fail(ctx, ISAC_ERR_HIP, "upload failed");
+  if (st == ISAC_OK && upload_now(ctx, d_tx, tx_wave, wbytes) != ISAC_OK) st = fail(ctx, ISAC_ERR_HIP, "upload failed");
   if (st == ISAC_OK)
     st = isac_mono_static_sensing_dev(ctx, (const isac_c64*)d_tx, T, tx_dim_l, carrier, rp, los, noise_mode,
                                       (const isac_c64*)d_nz, seed, (isac_c64*)d_g, l_out);

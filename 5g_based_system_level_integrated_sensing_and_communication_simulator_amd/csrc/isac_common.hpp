@@ -248,6 +248,16 @@ inline int ensure_pinned(isac_ctx* ctx, size_t bytes) {
   return ensure_pinned_buf(ctx, ctx->pinned, ctx->pinned_cap, bytes);
 }
 
+// Host -> device copy that is COMPLETE when it returns and ordered in front of everything enqueued on the context's streams afterwards.  hipMemcpy on the NULL stream
+// returns once a PAGEABLE source has been staged -- its DMA may still be in flight -- and the context's streams are non-blocking (no implicit synchronisation with the NULL
+// stream): a kernel launched on them right away could read the destination before the data has landed.  Seen once in ~4 700 fuzz cases under 16 concurrent processes
+// (the |rdm|^2 window of a host-array fft2D call off by 1e-2, profiles/r05_fuzz_campaigns.txt); the copy therefore runs ON the context's stream and is waited for.
+inline int upload_now(isac_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  ISAC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  return ISAC_OK;
+}
+
 // Small host block -> device scratch through the context's pinned staging ring: asynchronous, no stream synchronisation; the host waits only when the
 // ring wraps onto a slot whose copy has not left it yet.  stage_acquire hands out the next slot's host memory, stage_commit enqueues its copy.
 inline int stage_acquire(isac_ctx* ctx, size_t bytes, void** host) {
