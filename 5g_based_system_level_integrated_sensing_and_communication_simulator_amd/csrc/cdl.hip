@@ -1019,7 +1019,7 @@ int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long lon
         s.r0 = s.o0; s.r1 = s.o1;
       } else {                                                        // Z of this block: the rows its outputs reach back to
         s.A = (const c64*)jb.d_x;
-        s.C = ws + si * (size_t)T * Ncp;
+        s.C = fused ? nullptr : ws + si * (size_t)T * Ncp;                 // (the fused kernel has no Z in memory)
         s.r0 = std::max<long long>(0, s.o0 - max_shift - (n_taps - 1)); s.r1 = s.o1;
       }
       max_rows = std::max(max_rows, s.r1 - s.r0);
