@@ -431,6 +431,49 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     double mean = 0.0;
     check(isac_precoded_sinr_cqi_dev(ctx(), d_h.p, 1, Nr, P, cplx(w), nl, sigma, nullptr, 0, nullptr, &mean, nullptr));
     plhs[0] = mxCreateDoubleScalar(mean);
+  } else if (fn == "prgPrecode") {
+    // [antsym, antind] = prgPrecode(siz, nstartgrid, portsym, portind, F)                         +communication/+phyLayer/prgPrecode.m:53-144 (gNBPhy.m:822-827)
+    // siz [K L (P)], portsym / portind [nRE x nu] (1-based linear indices into the [K x L x nu] port grid), F [nu x P x NPRG].  The symbols are scattered into the dense
+    // layer grid on the host, precoded on the device (isac_prg_precode_dev), and read back at the RE positions of the port indices on every antenna plane (nrExtractResources, :141).
+    const double* sz = mxGetDoubles(prhs[1]);
+    const int K = (int)sz[0], L = (int)sz[1], nstart = (int)mxGetScalar(prhs[2]);
+    const mxArray *psym = prhs[3], *pind = prhs[4], *F = prhs[5];
+    const mwSize n_re = mxGetM(pind), nu = mxGetN(pind);
+    mwSize fd[3];
+    dims3(F, fd);
+    if (fd[0] != nu || mxGetM(psym) != n_re || mxGetN(psym) != nu) mexErrMsgIdAndTxt("isac:INVALID_ARG", "prgPrecode: portsym / portind must be [nRE x nu] with nu = size(F, 1)");
+    const int P = (int)fd[1], n_prg = (int)fd[2];
+    const size_t n_kl = (size_t)K * L;
+    std::vector<isac_c64> layers(n_kl * nu, isac_c64{0.0, 0.0});
+    const double* ind = mxGetDoubles(pind);
+    const mxComplexDouble* sym = mxGetComplexDoubles(psym);
+    for (size_t i = 0; i < (size_t)n_re * nu; ++i) {
+      const size_t lin = (size_t)ind[i] - 1;
+      if (lin >= layers.size()) mexErrMsgIdAndTxt("isac:INVALID_ARG", "prgPrecode: port index outside the [K x L x nu] grid");
+      layers[lin] = isac_c64{sym[i].real, sym[i].imag};
+    }
+    void *d_l = nullptr, *d_g = nullptr;
+    check(isac_dev_alloc(ctx(), sizeof(isac_c64) * layers.size(), &d_l));
+    struct Guard2 { void* a; void* b; ~Guard2() { if (a) isac_dev_free(g_ctx, a); if (b) isac_dev_free(g_ctx, b); } } guard{d_l, nullptr};
+    check(isac_dev_alloc(ctx(), sizeof(isac_c64) * n_kl * P, &d_g));
+    guard.b = d_g;
+    check(isac_memcpy_h2d(ctx(), d_l, layers.data(), sizeof(isac_c64) * layers.size()));
+    check(isac_prg_precode_dev(ctx(), (const isac_c64*)d_l, K, L, (int)nu, cplx(F), P, n_prg, nstart, (isac_c64*)d_g));
+    std::vector<isac_c64> grid(n_kl * P);
+    check(isac_memcpy_d2h(ctx(), grid.data(), d_g, sizeof(isac_c64) * grid.size()));
+    plhs[0] = mxCreateDoubleMatrix(n_re, (mwSize)P, mxCOMPLEX);
+    mxArray* aind = mxCreateDoubleMatrix(n_re, (mwSize)P, mxREAL);
+    mxComplexDouble* os = mxGetComplexDoubles(plhs[0]);
+    double* oi = mxGetDoubles(aind);
+    for (mwSize i = 0; i < n_re; ++i) {
+      const size_t re = ((size_t)ind[i] - 1) % n_kl;                    // the RE of the (first) port plane, on every antenna plane
+      for (int p_ = 0; p_ < P; ++p_) {
+        const isac_c64 v = grid[re + n_kl * (size_t)p_];
+        os[i + n_re * (mwSize)p_] = mxComplexDouble{v.re, v.im};
+        oi[i + n_re * (mwSize)p_] = (double)(re + n_kl * (size_t)p_ + 1);
+      }
+    }
+    plhs[1] = aind;                                                  // (as the other multi-output entries: the shims always ask for every output)
   } else if (fn == "csiReport") {
     // [CQI, i1, i2, subbandCQI, sinrPerSubband] = (Hre [nRE x nRx x P] at the first CSI-RS port's REs, k, l (1-based, BWP relative), reportConfig struct
     //   {NSizeBWP, NStartBWP, PanelDimensions, CodebookMode, PMIMode, CQIMode, SubbandSize}, nLayers, nVar, SINRTable)      uePhy.m:901-908 -> cqiSelect.m

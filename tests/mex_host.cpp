@@ -394,6 +394,19 @@ int comm(const char* in, const char* out) {
     if (mxGetClassID(los) != mxLOGICAL_CLASS || (int)mxGetNumberOfElements(los) != n) { std::fprintf(stderr, "checkLoS output\n"); return 4; }
     std::fwrite(mxGetData(los), 1, (size_t)n, o);
   }
+  {   // ---- prgPrecode(siz, nstartgrid, portsym, portind, F)                                              prgPrecode.m:53-144, gNBPhy.m:822-827
+    int32_t d[7];
+    rd(d, sizeof(d), f);
+    const int K = d[0], L = d[1], nu = d[2], P = d[3], nprg = d[4], nstart = d[5], n_re = d[6];
+    auto ind = rdv<double>(f, (size_t)n_re * nu);
+    auto sym = rdv<isac_c64>(f, (size_t)n_re * nu);
+    auto Fv = rdv<isac_c64>(f, (size_t)nu * P * nprg);
+    std::vector<double> siz = {(double)K, (double)L};
+    std::vector<mxArray*> r = call("prgPrecode", {real_mat(siz, 1, 2), scalar(nstart), cplx_array(sym.data(), n_re, nu, 1), real_mat(ind, n_re, nu), cplx_array(Fv.data(), nu, P, nprg)}, 2);
+    if ((int)mxGetM(r[0]) != n_re || (int)mxGetN(r[0]) != P || (int)mxGetM(r[1]) != n_re || (int)mxGetN(r[1]) != P) { std::fprintf(stderr, "prgPrecode output shape\n"); return 4; }
+    write_cplx(o, r[0]);
+    std::fwrite(mxGetDoubles(r[1]), sizeof(double), (size_t)n_re * P, o);
+  }
   std::fclose(f);
   std::fclose(o);
   mxr_run_at_exit();

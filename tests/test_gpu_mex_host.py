@@ -187,6 +187,16 @@ def test_mex_gateway_communication_and_topology_entries(tmp_path):
         f.write(struct.pack("<3i", co.shape[1], off.size - 1, n_links))
         for a in (co, off, no, nd, ue, ant):
             f.write(np.asfortranarray(a).tobytes(order="F"))
+        # ---- prgPrecode: 24 PRB, 3 layers onto 16 antennas, 5 PRGs, carrier starting at CRB 3, a PDSCH-like RE set
+        import oracle.precode as OPR
+        Kp, Lp, nup, Pp, nprg, nstart = 288, 7, 3, 16, 5, 3
+        kk = np.arange(Kp)
+        re_p = np.concatenate([(kk if l_ % 3 else kk[kk % 2 == 0]) + Kp * l_ for l_ in range(1, Lp)])
+        pind = (re_p[:, None] + Kp * Lp * np.arange(nup)[None, :] + 1).astype(np.float64)
+        psym = cn(re_p.size, nup)
+        Fp = cn(nup, Pp, nprg) / 4
+        f.write(struct.pack("<7i", Kp, Lp, nup, Pp, nprg, nstart, re_p.size))
+        f.write(np.asfortranarray(pind).tobytes(order="F")); f.write(np.asfortranarray(psym).tobytes(order="F")); f.write(np.asfortranarray(Fp).tobytes(order="F"))
     r = subprocess.run([_exe(), "comm", str(fin), str(fout)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     buf = open(fout, "rb").read()
@@ -231,4 +241,10 @@ def test_mex_gateway_communication_and_topology_entries(tmp_path):
     los = np.frombuffer(buf, dtype=np.uint8, count=n_links, offset=off_b).astype(bool); off_b += n_links
     want_los = OL.check_los(list(zip(plans, heights)), ue.T, ant.T)
     assert np.array_equal(los, want_los) and 0 < los.sum() < n_links
+    # prgPrecode: [antsym, antind] against the loop-for-loop restatement of prgPrecode.m
+    (n,) = struct.unpack_from("<Q", buf, off_b); off_b += 8
+    antsym = np.frombuffer(buf, dtype=np.complex128, count=n, offset=off_b).reshape((re_p.size, Pp), order="F"); off_b += 16 * n
+    antind = np.frombuffer(buf, dtype=np.float64, count=re_p.size * Pp, offset=off_b).reshape((re_p.size, Pp), order="F"); off_b += 8 * re_p.size * Pp
+    want_sym, want_ind = OPR.prg_precode((Kp, Lp), nstart, psym, pind.astype(np.int64), Fp)
+    assert np.array_equal(antind, want_ind) and np.abs(antsym - want_sym).max() <= 1e-12 * np.abs(want_sym).max()
     assert off_b == len(buf)
