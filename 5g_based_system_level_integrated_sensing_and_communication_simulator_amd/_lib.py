@@ -188,9 +188,16 @@ class Context:
             raise IsacError(st, f"isac_ctx_create(device={device}) failed")
         self.handle = h
         self.device = device % n.value
+        self.device_cache = {}              # device-resident tables other modules keep per context (CDL per-ray terms, CSI frequency tables): dropped by close()
 
     def close(self):
         if getattr(self, "handle", None):
+            for ent in list(self.device_cache.values()):                 # free the cached DeviceArrays while the context still exists
+                for d in (ent if isinstance(ent, tuple) else (ent,)):
+                    for dd in (d if isinstance(d, tuple) else (d,)):
+                        if isinstance(dd, DeviceArray):
+                            dd.free()
+            self.device_cache.clear()
             self.lib.isac_ctx_destroy(self.handle)
             self.handle = None
 

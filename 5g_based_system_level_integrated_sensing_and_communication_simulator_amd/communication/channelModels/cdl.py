@@ -11,6 +11,7 @@ with the toolbox's documented defaults, so agreement with MATLAB is statistical 
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import math
 from types import SimpleNamespace
 
@@ -190,16 +191,16 @@ class CDLChannel:
     def _device_static(self, ctx):
         """(d_base [n][m][s][u], d_rate [n][m], d_los [s][u] | None, los_rate) on `ctx`'s device; cached per context and channel configuration."""
         st = self._static()
-        cache = st.__dict__.get("_dev")
-        if cache is None:
-            import weakref
-            cache = st.__dict__["_dev"] = weakref.WeakKeyDictionary()     # keyed weakly by the context: a closed / collected context takes its device copies along
-        if ctx not in cache:
+        # the device copies live in the CONTEXT's own registry (ctx.device_cache, emptied by Context.close()): a cache on the channel side whose values are
+        # DeviceArrays would keep the context alive through d.ctx and never release anything (ADVICE r5)
+        key = ("cdl_static", id(st))
+        ent = ctx.device_cache.get(key)
+        if ent is None or ent[0] is not st:
             d_base = ctx.to_device(np.ascontiguousarray(st.base).reshape(-1))
             d_rate = ctx.to_device(np.ascontiguousarray(st.rate, dtype=np.float64).reshape(-1))
             d_los = ctx.to_device(np.ascontiguousarray(st.los).reshape(-1)) if st.los is not None else None
-            cache[ctx] = (d_base, d_rate, d_los, float(getattr(st, "los_rate", 0.0)))
-        return cache[ctx]
+            ent = ctx.device_cache[key] = (st, (d_base, d_rate, d_los, float(getattr(st, "los_rate", 0.0))))
+        return ent[1]
 
     def block_plan(self, T: int):
         """Gain blocks that the next T samples touch: (snapshot times, first output sample of each block) -- plain Python scalars (this runs once
@@ -229,12 +230,11 @@ class CDLChannel:
     def _fr_tables(self, ctx, k_sub, n_sc, scs_hz):
         """(d_tau [n_paths], d_freq [n_re], n_re) on `ctx`'s device for the 1-based subcarriers k_sub; cached per context and subcarrier set."""
         st = self._static()
-        key = (id(ctx), tuple(np.asarray(k_sub).tolist()) if np.size(k_sub) < 64 else (int(np.size(k_sub)), int(np.sum(k_sub))), int(n_sc), float(scs_hz))
-        cache = st.__dict__.setdefault("_fr", {})
-        if key not in cache or cache[key][0]() is not ctx:
-            import weakref
+        key = ("cdl_fr", id(st), hashlib.sha1(np.ascontiguousarray(k_sub, dtype=np.int64).tobytes()).digest(), int(n_sc), float(scs_hz))   # keyed on the CONTENT of the subcarrier set
+        cache = ctx.device_cache                                           # (per context, released by Context.close())
+        if key not in cache or cache[key][0] is not st:
             f = ((np.asarray(k_sub, dtype=np.float64) - 1.0) - n_sc / 2.0) * float(scs_hz)
-            cache[key] = (weakref.ref(ctx), ctx.to_device(np.ascontiguousarray(self.path_delays(), dtype=np.float64)), ctx.to_device(np.ascontiguousarray(f)), f.size)
+            cache[key] = (st, ctx.to_device(np.ascontiguousarray(self.path_delays(), dtype=np.float64)), ctx.to_device(np.ascontiguousarray(f)), f.size)
         return cache[key][1:]
 
     def snap_time(self, t=None):
@@ -251,7 +251,7 @@ class CDLChannel:
         CSI-RS occasion works on (uePhy.m:901-908); the estimator itself is out of scope."""
         st = self._static()
         n_paths, _, nt, nr = st.base.shape
-        t_snap = self.block_plan(1)[0][0] if t is None else float(t)
+        t_snap = self.snap_time(t)                                       # an explicit t is snapped to its gain block too (as csiEstimateBatch and the apply do)
         d_h = self.path_gains_device([t_snap], ctx, out=gains)
         d_tau, d_f, n_re = self._fr_tables(ctx, k_sub, n_sc, scs_hz)
         if out is None:

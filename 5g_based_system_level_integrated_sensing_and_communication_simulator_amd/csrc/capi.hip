@@ -928,6 +928,9 @@ extern "C" int isac_ctx_reserve(isac_ctx* ctx, int64_t T, int32_t tx_dim_l, cons
                                 const isac_est_params* ep, const isac_cfar_config* cfar, double warm_ms, double* elapsed_ms) {
   ISAC_ENTER(ctx);
   if (!carrier || !rp || !ep || !cfar || T <= 0 || tx_dim_l < 0 || rp->n_ants <= 0 || rp->n_targets <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "isac_ctx_reserve: NULL / empty argument");
+  if (!std::isfinite(warm_ms) || warm_ms < 0.0) return fail(ctx, ISAC_ERR_INVALID_ARG, "isac_ctx_reserve: warm_ms must be finite and >= 0");   // (NaN / +inf: the dry-run loop would never end)
+  if (warm_ms > 5000.0) warm_ms = 5000.0;                                                  // a few seconds at most: 50-300 ms bring the clocks up
+  if (ctx->pending.active) return fail(ctx, ISAC_ERR_INVALID_ARG, "isac_ctx_reserve: a submitted fft2D is pending on this context (the dry run would discard it): collect it first");
   const auto t0 = std::chrono::steady_clock::now();
   auto ms_since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
   int32_t l_whole = 0;
@@ -964,6 +967,9 @@ extern "C" int isac_ctx_reserve(isac_ctx* ctx, int64_t T, int32_t tx_dim_l, cons
   (void)hipStreamSynchronize(ctx->stream);
   (void)hipStreamSynchronize(ctx->stream2);
   ctx->range_cache.valid = false;                                                          // the cached rows belong to grids that are about to be freed
+  ctx->last.valid = false;                                                                 // isac_fft2d_get_* must not hand out the dry run's detections / window / Ra
+  ctx->last.pow_on_device = false;
+  ctx->profile_recorded = false;                                                           // nor isac_profile_last_kernel_ms the dry run's kernel
   release();
   if (elapsed_ms) *elapsed_ms = ms_since();
   if (st != ISAC_OK) { ctx->err = keep; return st; }

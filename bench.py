@@ -350,7 +350,7 @@ class CommCell:
         self.T = self.SLOT_T + max(ch.info().MaxChannelDelay for ch in self.chans)            # uePhy.m:729: zero rows appended
         K = 3276
         car = L.Carrier(K, 4096, 30, 0)
-        self.waves = []
+        self.waves, self.precoders, self.layer_seeds = [], [], []          # (precoders / layer seeds kept for the oracle probe of tests/test_gpu_cdl_config5.py)
         grid, layers = ctx_cdl.empty((K, 14, n_ants)), ctx_cdl.empty((K, 14, self.LAYERS))
         n_prg = -(-273 // self.PRG_PRBS)
         dft = np.exp(-2j * np.pi * np.outer(np.arange(n_ants), np.arange(n_ants)) / n_ants) / np.sqrt(n_ants)
@@ -361,6 +361,7 @@ class CommCell:
             ctx_cdl.check(ctx_cdl.lib.isac_synth_qpsk_grid_dev(ctx_cdl.handle, C.c_void_p(layers.ptr), K, 14, self.LAYERS, C.c_uint64(0xD100 + 64 * cell_id + s_), 0))
             beams = rng.integers(0, n_ants, (n_prg, self.LAYERS))
             F = np.stack([dft[b, :] for b in beams], axis=2) * np.sqrt(n_ants / self.LAYERS)          # [nu x A x n_prg], unit power per antenna on average
+            self.precoders.append(F); self.layer_seeds.append(0xD100 + 64 * cell_id + s_)
             self.PL.prgPrecodeGrid(layers, F, 0, ctx=ctx_cdl, out=grid)
             ctx_cdl.check(ctx_cdl.lib.isac_ofdm_modulate_dev(ctx_cdl.handle, C.c_void_p(grid.ptr), 14, n_ants, C.byref(car), C.c_double(1.0), C.c_void_p(w.ptr), C.c_int64(self.T)))
             self.waves.append(w)

@@ -194,6 +194,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     // simulation (cellSimulation.m:189-202) -- call this from the scenario set-up (networkSimulation.m:44-60, in front of the cell loop) and the one
     // call that matters finds code objects, scratch, tables and clocks ready.
     if (nrhs < 7) mexErrMsgIdAndTxt("isac:INVALID_ARG", "usage: isac_mex('reserve', T, txDimension, carrierInfo, radarParams, radarEstParams, cfar [, warm_ms])");
+    if (mxGetClassID(prhs[2]) != mxDOUBLE_CLASS || mxGetNumberOfElements(prhs[2]) < 2) mexErrMsgIdAndTxt("isac:INVALID_ARG", "reserve: txDimension must be a double vector [nSc nSym (nAnts)]");
     isac_carrier c = carrier_block(prhs[3]);
     isac_radar_channel_params p = channel_block(prhs[4]);
     isac_est_params e = est_block(prhs[5]);
@@ -435,8 +436,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     // [antsym, antind] = prgPrecode(siz, nstartgrid, portsym, portind, F)                         +communication/+phyLayer/prgPrecode.m:53-144 (gNBPhy.m:822-827)
     // siz [K L (P)], portsym / portind [nRE x nu] (1-based linear indices into the [K x L x nu] port grid), F [nu x P x NPRG].  The symbols are scattered into the dense
     // layer grid on the host, precoded on the device (isac_prg_precode_dev), and read back at the RE positions of the port indices on every antenna plane (nrExtractResources, :141).
+    if (nrhs < 6) mexErrMsgIdAndTxt("isac:INVALID_ARG", "usage: isac_mex('prgPrecode', siz, nstartgrid, portsym, portind, F)");
+    if (mxGetClassID(prhs[1]) != mxDOUBLE_CLASS || mxGetNumberOfElements(prhs[1]) < 2) mexErrMsgIdAndTxt("isac:INVALID_ARG", "prgPrecode: siz must be a double vector [K L (P)]");
+    if (mxGetClassID(prhs[4]) != mxDOUBLE_CLASS || mxGetClassID(prhs[3]) != mxDOUBLE_CLASS || mxGetClassID(prhs[5]) != mxDOUBLE_CLASS)
+      mexErrMsgIdAndTxt("isac:INVALID_ARG", "prgPrecode: portsym, portind and F must be double arrays");
     const double* sz = mxGetDoubles(prhs[1]);
     const int K = (int)sz[0], L = (int)sz[1], nstart = (int)mxGetScalar(prhs[2]);
+    if (K <= 0 || L <= 0) mexErrMsgIdAndTxt("isac:INVALID_ARG", "prgPrecode: siz must hold positive dimensions");
     const mxArray *psym = prhs[3], *pind = prhs[4], *F = prhs[5];
     const mwSize n_re = mxGetM(pind), nu = mxGetN(pind);
     mwSize fd[3];

@@ -198,20 +198,36 @@ def snapshot_index(cfg, t):
     return np.floor(np.asarray(t) * rate + 1e-9).astype(np.int64), rate
 
 
-def apply_cdl(cfg, waveform, t0=0.0):
+def apply_cdl(cfg, waveform, t0=0.0, order=None):
     """y = channel(waveform):  waveform [T x Nt] -> [T x Nr]; t0 = channel time of the first sample [s].
-    y[t,u] = (1/sqrt(Nr)) sum_n sum_k g_n[k] sum_s H_n^{(b(t))}[s,u] x_s[t - shift_n - k]."""
+    y[t,u] = (1/sqrt(Nr)) sum_n sum_k g_n[k] sum_s H_n^{(b(t))}[s,u] x_s[t - shift_n - k].
+    ``order``: the two sums over k and s commute -- "contract_first" forms z = x H_n [T x Nr] and filters it (the literal reading of the line above),
+    "filter_first" filters x [T x Nt] and contracts the result; the same numbers to rounding (tests/test_cdl_cpu.py), 30x cheaper for the uplink's
+    2 -> 64 shape at config 5's 61 909 samples.  Default: whichever touches fewer elements."""
     x = np.asarray(waveform, dtype=np.complex128)
     t_len, nt = x.shape
     g, shift = filter_taps(cfg)
     tt = t0 + np.arange(t_len) / cfg.SampleRate
     blk, rate = snapshot_index(cfg, tt)
     nr = int(np.prod(cfg.RxSize))
+    if order is None:
+        order = "filter_first" if nr > nt else "contract_first"
     y = np.zeros((t_len, nr), dtype=np.complex128)
+    xf = None
+    if order == "filter_first":                              # the delayed / filtered transmit signals do not depend on the gain block
+        xf = np.zeros((g.shape[0], t_len, nt), dtype=np.complex128)
+        for n in range(g.shape[0]):
+            for k in range(FILTER_TAPS):
+                lag = int(shift[n]) + k
+                if lag < t_len:
+                    xf[n, lag:] += g[n, k] * x[: t_len - lag]
     for b in np.unique(blk):
         h = path_gains(cfg, b / rate)                        # [n, s, u]
         sel = blk == b
         for n in range(h.shape[0]):
+            if xf is not None:
+                y[sel] += xf[n][sel] @ h[n]
+                continue
             z = x @ h[n]                                     # [T x Nr] contraction over transmit antennas
             acc = np.zeros((t_len, nr), dtype=np.complex128)
             for k in range(FILTER_TAPS):
