@@ -14,7 +14,7 @@ _LIB_PATH = os.path.join(_HERE, "libisac_hip.so")
 _lib = None
 _lock = threading.Lock()
 
-ISAC_ABI_VERSION = 6          # include/isac.h ISAC_ABI_VERSION this binding was written against (checked at load)
+ISAC_ABI_VERSION = 7          # include/isac.h ISAC_ABI_VERSION this binding was written against (checked at load)
 ISAC_MAX_EST = 4096
 NOISE_NONE, NOISE_INJECTED, NOISE_PHILOX, NOISE_PHILOX_SPECTRAL, NOISE_INJECTED_SPECTRAL = 0, 1, 2, 3, 4
 
@@ -91,7 +91,7 @@ EXPORTS = [
     "isac_ctx_get_stream", "isac_sync", "isac_dev_alloc", "isac_dev_free", "isac_memcpy_h2d", "isac_memcpy_d2h", "isac_memcpy_d2d",
     "isac_memset_dev", "isac_timer_start", "isac_timer_stop_ms", "isac_profile_enable", "isac_profile_last_kernel_ms",
     "isac_basic_radar_channel_dev", "isac_basic_radar_channel", "isac_mono_static_sensing_dev",
-    "isac_mono_static_sensing", "isac_mono_static_sensing_fused_dev", "isac_ofdm_symbol_count", "isac_ofdm_demodulate_dev", "isac_ofdm_modulate_dev", "isac_ofdm_modulate_windowed_dev", "isac_sentx_append_dev",
+    "isac_mono_static_sensing", "isac_mono_static_sensing_fused_dev", "isac_echo_grid_materialize_dev", "isac_ofdm_symbol_count", "isac_ofdm_demodulate_dev", "isac_ofdm_modulate_dev", "isac_ofdm_modulate_windowed_dev", "isac_sentx_append_dev",
     "isac_ofdm_waveform_length", "isac_cfar2d_ca", "isac_fft2d_dev", "isac_fft2d", "isac_fft2d_submit_dev", "isac_fft2d_submit_cached_dev", "isac_fft2d_collect", "isac_fft2d_range_stage_dev", "isac_fft2d_get_detections",
     "isac_fft2d_get_power_window", "isac_fft2d_get_covariance", "isac_fft2d_get_music_spectrum",
     "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_ctx_set_option", "isac_ctx_share_streams", "isac_ctx_reserve", "isac_eigh_top", "isac_beamscan_doa", "isac_music2d_dev", "isac_eigh", "isac_cdl_apply_dev", "isac_cdl_apply_batch_dev", "isac_cdl_path_gains_dev", "isac_cdl_freq_response_dev", "isac_cdl_csi_estimate_batch_dev", "isac_prg_precode_dev", "isac_precoded_sinr_cqi_dev", "isac_type1sp_codebook", "isac_csi_report_dev", "isac_csi_report_batch_dev", "isac_los_check_dev", "isac_winding_number_dev", "isac_synth_qpsk_grid_dev",

@@ -45,6 +45,7 @@ int isac_music_tridiag_bisect_dev(isac_ctx* ctx, const c64* d_H, int A, hipStrea
 int isac_music_subspace_dev(isac_ctx* ctx, int A, const int* d_num_dets, int num_dets_host, hipStream_t st);
 const int* isac_music_ctl(isac_ctx* ctx);
 int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, int64_t N, int32_t A, isac_c64* d_Ra);
+int isac_covariance_lazy_on(isac_ctx* ctx, hipStream_t st, isac_c64* d_Ra);   // music.hip: Ra of the context's native lazy echo grid
 
 namespace {
 
@@ -333,7 +334,7 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->beam, &ctx->coef, &ctx->phase_rx, &ctx->steer, &ctx->dgrid,
                     &ctx->ymid, &ctx->pwin, &ctx->flags, &ctx->det_cut, &ctx->det_pow, &ctx->det_cnt, &ctx->cov_part,
                     &ctx->cov, &ctx->eig_w, &ctx->eig_v, &ctx->eig_scratch, &ctx->spec, &ctx->misc, &ctx->stage_a, &ctx->stage_b, &ctx->seg,
-                    &ctx->stage_c, &ctx->sind_tab, &ctx->cdl_h};
+                    &ctx->stage_c, &ctx->sind_tab, &ctx->cdl_h, &ctx->echo_own};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -523,7 +524,17 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
                         const isac_c64* d_tx_grid, int32_t K, int32_t L, int32_t A, bool use_cached_range) {
   ISAC_ENTER(ctx);
   ctx->pending.active = false;
-  if (!ep || !cfar || !d_rx_grid || !d_tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (!ep || !cfar || !d_tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  // d_rx_grid == NULL: the echo grid the preceding isac_mono_static_sensing_fused_dev call kept inside the context (d_echo_grid == NULL there): a descriptor the covariance
+  // kernel re-forms (LazyEcho::native), or the context's own buffer
+  bool lazy_native = false;
+  if (!d_rx_grid) {
+    const LazyEcho& lz = ctx->lazy;
+    if (!use_cached_range || !lz.valid || lz.K != K || lz.L_out != L || lz.A != A)
+      return fail(ctx, ISAC_ERR_INVALID_ARG, "rxGrid is NULL and no lazy echo grid of this shape is held by the context (isac_mono_static_sensing_fused_dev with d_echo_grid == NULL, then isac_fft2d_submit_cached_dev)");
+    lazy_native = lz.native;
+    if (!lazy_native) d_rx_grid = (const isac_c64*)ctx->echo_own.p;
+  }
   if (K <= 0 || L <= 0 || A <= 0 || A > 1024) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad grid dimensions");
   if (ep->n_ifft < K || (ep->n_ifft & (ep->n_ifft - 1)) || ep->n_fft <= 0 || (ep->n_fft & (ep->n_fft - 1)))
     return fail(ctx, ISAC_ERR_INVALID_ARG, "nIFFT/nFFT must be powers of two with nIFFT >= K");
@@ -557,7 +568,8 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
       rdm_done = true;
     }
     timeline_mark(ctx, 4, ctx->stream);
-    ISAC_TRY(isac_covariance_on(ctx, ctx->stream, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
+    if (lazy_native) ISAC_TRY(isac_covariance_lazy_on(ctx, ctx->stream, (isac_c64*)ctx->cov.p));
+    else ISAC_TRY(isac_covariance_on(ctx, ctx->stream, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
     timeline_mark(ctx, 5, ctx->stream);
     ISAC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
@@ -566,7 +578,8 @@ static int fft2d_submit(isac_ctx* ctx, const isac_est_params* ep, const isac_cfa
     ISAC_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
     ISAC_HIP(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
     timeline_mark(ctx, 4, s2);
-    ISAC_TRY(isac_covariance_on(ctx, s2, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
+    if (lazy_native) ISAC_TRY(isac_covariance_lazy_on(ctx, s2, (isac_c64*)ctx->cov.p));
+    else ISAC_TRY(isac_covariance_on(ctx, s2, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));   // fft2D.m:106-107
     timeline_mark(ctx, 5, s2);
   }
   auto eig_first_half = [&]() -> int {                                                           // music.m:19

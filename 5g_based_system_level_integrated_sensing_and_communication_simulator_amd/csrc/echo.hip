@@ -305,7 +305,9 @@ __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_ran
 // (Pointers that are loaded from between stores are NOT __restrict__: an invariant load may be sunk to its first use -- below the
 // stores of the group before -- and neither sched_barrier nor a compiler fence holds it.  With three or four targets the straight-line form
 // holds 2 x GROUP x (6 + 4 Q) load registers beside the generator and spills: those counts stay on the kernel above, as measured.)
-template <int QT, int NZ, int GROUP = (QT <= 1 ? 4 : 2)>
+// STORE = false (round 6, "lazy" echo grid: isac_mono_static_sensing_fused_dev with d_echo_grid == NULL): the echoGrid store is left out -- the grid is a function of (D, a, seed)
+// that the covariance kernel re-forms for itself (cov_lazy_kernel, music.hip), so that 0.75 GB written here and 0.75 GB read back there per CPI never cross the HBM.
+template <int QT, int NZ, bool STORE = true, int GROUP = (QT <= 1 ? 4 : 2)>
 __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_range_sl_kernel(int K, int L_whole, int L_out, int A, const c64* D,
                                                             const c64* __restrict__ steer_rq, double sig, uint64_t seed,
                                                             const c64* noise, const c64* __restrict__ tw,
@@ -371,12 +373,10 @@ __global__ __launch_bounds__(Fft4096W::NT, kEchoRangeWavesPerSimd) void echo_ran
     for (int u = 0; u < GROUP; ++u) {
       const int j = g * GROUP + u, k = tid + NT * j;
       const Ld& e = ld[b][u];
-      c64 v = mk(0.0, 0.0);
-#pragma unroll
-      for (int q = 0; q < QT; ++q) v = fma(e.d[q], s[q], v);
-      if constexpr (NZ == 1) v = v + fft.x[j] * sig;
-      if constexpr (NZ == 2) v = v + e.nz * sig;
-      buffer_store_c64_nt(rs_dst, (unsigned)k * (unsigned)sizeof(c64), v);   // echoGrid(k, l, r); k >= K: dropped by the bounds check
+      const c64 v = spectral_echo_value<QT, NZ != 0>(e.d, s, NZ == 2 ? e.nz : fft.x[j], sig);
+      if constexpr (STORE) buffer_store_c64_nt(rs_dst, (unsigned)k * (unsigned)sizeof(c64), v);   // echoGrid(k, l, r); k >= K: dropped by the bounds check
+      else asm volatile("" ::"v"(v.re), "v"(v.im) : "memory");          // (compiler-only: the element is complete HERE, as in the storing form -- without this anchor the scheduler
+                                                                        //  interleaves the eight elements and the two-target form spills 35 registers)
       c64 y = mul_conj(v, e.tx) * e.w;                                  // fft2D.m:37,:43 (same order as range_kernel)
       y = k < K ? y : mk(0.0, 0.0);                                     // ifft(., nIFFT, 1) zero-pads at the end
       live |= (y.re != 0.0) | (y.im != 0.0);
@@ -556,6 +556,7 @@ static int prepare_echo(isac_ctx* ctx, const c64* d_tx, long long T, const isac_
                         const uint8_t* los, int* q_out) {
   if (!d_tx || !rp || !los) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
   if (T <= 0 || rp->n_ants <= 0 || rp->n_targets < 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad T / n_ants / n_targets");
+  ctx->lazy.valid = false;                          // steer / coef / dgrid below are the inputs of a lazy echo grid of an earlier call: overwritten now
   if (!(rp->fs > 0)) return fail(ctx, ISAC_ERR_INVALID_ARG, "fs must be positive");
   const int A = rp->n_ants;
   const double c0 = 299792458.0;                    // physconst('Lightspeed')  basicRadarChannel.m:11
@@ -776,13 +777,38 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
                                                   const isac_c64* d_tx_grid) {
   ISAC_ENTER(ctx);
   ctx->range_cache.valid = false;
+  ctx->lazy.valid = false;
   ISAC_TRY(check_carrier(ctx, carrier));
-  if (!d_echo_grid || !ep || !cf || !d_tx_grid) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+  if (!ep || !cf || !d_tx_grid || !rp) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
   if (noise_mode == ISAC_NOISE_INJECTED && !d_noise_unit) return fail(ctx, ISAC_ERR_INVALID_ARG, "noise buffer missing");
   OfdmGeom g = geom_of(carrier);
   const int hr = cf->guard[0] + cf->train[0];
   const int row_lo = cf->row0 - 1 - hr, row_hi = cf->row1 - 1 + hr;
   const bool fusable = (g.nfft == 4096 && ep->n_ifft == g.nfft && row_lo >= 0 && row_hi < ep->n_ifft && cf->row1 >= cf->row0);
+  // d_echo_grid == NULL: the echo grid stays inside the context (LazyEcho, isac_common.hpp).  Where the kernels can re-form it -- the fused spectral route with Philox noise,
+  // 49..64 antennas, one or two LoS targets -- nothing is stored at all; every other shape gets a context-owned buffer and runs exactly as with a caller's array.
+  const bool lazy = d_echo_grid == nullptr;
+  bool lazy_native = false;
+  if (lazy) {
+    int n_los = 0;
+    if (!los) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
+    for (int i = 0; i < rp->n_targets; ++i) n_los += los[i] == 1;
+    static const bool no_native = std::getenv("ISAC_LAZY_OWNED") != nullptr;        // development switch: always the context-owned buffer
+    lazy_native = !no_native && fusable && noise_mode == ISAC_NOISE_PHILOX_SPECTRAL && rp->n_ants > 48 && rp->n_ants <= 64 && n_los >= 1 && n_los <= 2;
+    if (!lazy_native) {
+      int32_t lw = 0;
+      ISAC_TRY(isac_ofdm_symbol_count(carrier, T, &lw));
+      const int lo_ = lw < tx_dim_l ? tx_dim_l : lw;
+      if (lo_ <= 0) return fail(ctx, ISAC_ERR_SHORT_WAVEFORM, "waveform shorter than one OFDM symbol");
+      ISAC_TRY(ensure(ctx, ctx->echo_own, sizeof(c64) * (size_t)g.n_sc * lo_ * rp->n_ants));
+      d_echo_grid = (isac_c64*)ctx->echo_own.p;
+    }
+  }
+  auto lazy_owned_done = [&](int lo_) {                                            // the owned-buffer form: remember the shape, the data are in ctx->echo_own
+    if (!lazy) return;
+    LazyEcho& lz = ctx->lazy;
+    lz.valid = true; lz.native = false; lz.K = g.n_sc; lz.L_whole = lo_; lz.L_out = lo_; lz.A = rp->n_ants; lz.Q = 0; lz.sig = 0.0; lz.seed = 0;
+  };
   if (!fusable) {
     // other numerologies (Nfft != 4096 or nIFFT != Nfft): the plain synthesis, then the range stage of the following fft2D launched right
     // behind it -- the contract (stage results cached for isac_fft2d_submit_cached_dev) holds for every carrier.  A CUT window that
@@ -790,6 +816,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
     int32_t lo = 0;
     ISAC_TRY(isac_mono_static_sensing_dev(ctx, d_tx_wave, T, tx_dim_l, carrier, rp, los, noise_mode, d_noise_unit, seed, d_echo_grid, &lo));
     if (l_out) *l_out = lo;
+    lazy_owned_done(lo);
     const bool window_ok = row_lo >= 0 && row_hi < ep->n_ifft && cf->row1 >= cf->row0 && ep->n_ifft >= g.n_sc && (ep->n_ifft & (ep->n_ifft - 1)) == 0;
     if (!window_ok) return ISAC_OK;
     return isac_range_stage_into_cache(ctx, ep, cf, (const c64*)d_echo_grid, (const c64*)d_tx_grid, g.n_sc, lo, rp->n_ants);
@@ -805,6 +832,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
     int32_t lo = 0;
     ISAC_TRY(isac_mono_static_sensing_dev(ctx, d_tx_wave, T, tx_dim_l, carrier, rp, los, noise_mode, d_noise_unit, seed, d_echo_grid, &lo));
     if (l_out) *l_out = lo;
+    lazy_owned_done(lo);
     return isac_range_stage_into_cache(ctx, ep, cf, (const c64*)d_echo_grid, (const c64*)d_tx_grid, g.n_sc, lo, rp->n_ants);
   }
   int Q = 0, L_whole = 0;
@@ -816,7 +844,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
   const int nr = row_hi - row_lo + 1;
   ISAC_TRY(ensure(ctx, ctx->ymid, sizeof(c64) * (size_t)nr * L_out * A));
   if (L_out > L_whole) {
-    ISAC_HIP(hipMemsetAsync(d_echo_grid, 0, sizeof(c64) * (size_t)g.n_sc * L_out * A, ctx->stream));
+    if (!lazy_native) ISAC_HIP(hipMemsetAsync(d_echo_grid, 0, sizeof(c64) * (size_t)g.n_sc * L_out * A, ctx->stream));
     ISAC_HIP(hipMemsetAsync(ctx->ymid.p, 0, sizeof(c64) * (size_t)nr * L_out * A, ctx->stream));
   }
   const c64* tw = nullptr;
@@ -848,9 +876,18 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
                        (c64*)d_echo_grid, (const c64*)d_tx_grid, wk, wr, 1.0 / ep->n_ifft, std::sqrt((double)ep->n_ifft),   \
                        row_lo, nr, (c64*)ctx->ymid.p);                                                                               \
   } while (0)
+#define ISAC_SPEC_SL_LAZY(QT)                                                                                                        \
+  do {                                                                                                                               \
+    auto kern = echo_range_sl_kernel<QT, 1, false>;                                                                                  \
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));                                                              \
+    hipLaunchKernelGGL(kern, gr, bl, lds, ctx->stream, g.n_sc, L_whole, L_out, A, D, srq, sig, seed, (const c64*)nullptr, tw,        \
+                       (c64*)nullptr, (const c64*)d_tx_grid, wk, wr, 1.0 / ep->n_ifft, std::sqrt((double)ep->n_ifft),                \
+                       row_lo, nr, (c64*)ctx->ymid.p);                                                                               \
+  } while (0)
 #define ISAC_SPEC_Q(QT) do { if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL) ISAC_SPEC(QT, 1); else ISAC_SPEC(QT, 2); } while (0)
-#define ISAC_SPEC_SL_Q(QT) do { if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL) ISAC_SPEC_SL(QT, 1); else ISAC_SPEC_SL(QT, 2); } while (0)
+#define ISAC_SPEC_SL_Q(QT) do { if (lazy_native) ISAC_SPEC_SL_LAZY(QT); else if (noise_mode == ISAC_NOISE_PHILOX_SPECTRAL) ISAC_SPEC_SL(QT, 1); else ISAC_SPEC_SL(QT, 2); } while (0)
     switch (Q) { case 1: ISAC_SPEC_SL_Q(1); break; case 2: ISAC_SPEC_SL_Q(2); break; case 3: ISAC_SPEC_Q(3); break; case 4: ISAC_SPEC_Q(4); break; default: ISAC_SPEC_Q(0); break; }
+#undef ISAC_SPEC_SL_LAZY
 #undef ISAC_SPEC_SL_Q
 #undef ISAC_SPEC_SL
 #undef ISAC_SPEC_Q
@@ -860,9 +897,36 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
   if (ctx->profile) { ISAC_HIP(hipEventRecord(ctx->ev_k1, ctx->stream)); ctx->profile_recorded = true; }
   timeline_mark(ctx, 3, ctx->stream);
   RangeCache& rc = ctx->range_cache;
-  rc.rx = d_echo_grid; rc.tx = d_tx_grid; rc.K = g.n_sc; rc.L = L_out; rc.A = A; rc.n_ifft = ep->n_ifft; rc.row_lo = row_lo; rc.nr = nr;
+  rc.rx = d_echo_grid; rc.tx = d_tx_grid; rc.K = g.n_sc; rc.L = L_out; rc.A = A; rc.n_ifft = ep->n_ifft; rc.row_lo = row_lo; rc.nr = nr;   // (rc.rx == NULL: the native lazy grid)
   rc.valid = true;
+  if (lazy) {
+    LazyEcho& lz = ctx->lazy;
+    lz.valid = true; lz.native = lazy_native; lz.K = g.n_sc; lz.L_whole = lazy_native ? L_whole : L_out; lz.L_out = L_out; lz.A = A; lz.Q = Q;
+    lz.sig = n0s * std::sqrt((double)g.nfft); lz.seed = seed;
+  }
   return ISAC_OK;
+}
+
+// The lazy echo grid of the last fused call written out as an array (monoStaticSensing.m:1 returns echoGrid; cellSimulation.m:194-197 only ever hands it to fft2D, which is
+// why the fused call may keep it as a descriptor): the un-fused synthesis kernel on the descriptor's own inputs -- the same expression, the same bits as the fused kernel's
+// store would have been -- or a copy of the context-owned buffer.  d_echo_grid [n_sc x L_out x A].
+extern "C" int isac_echo_grid_materialize_dev(isac_ctx* ctx, isac_c64* d_echo_grid, int32_t* dims3) {
+  ISAC_ENTER(ctx);
+  const LazyEcho& lz = ctx->lazy;
+  if (!lz.valid) return fail(ctx, ISAC_ERR_INVALID_ARG, "no lazy echo grid on this context (isac_mono_static_sensing_fused_dev with d_echo_grid == NULL comes first)");
+  if (dims3) { dims3[0] = lz.K; dims3[1] = lz.L_out; dims3[2] = lz.A; }
+  if (!d_echo_grid) return ISAC_OK;                                  // size query
+  const size_t bytes = sizeof(c64) * (size_t)lz.K * lz.L_out * lz.A;
+  if (!lz.native) {
+    ISAC_HIP(hipMemcpyAsync(d_echo_grid, ctx->echo_own.p, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return ISAC_OK;
+  }
+  if (lz.L_out > lz.L_whole) ISAC_HIP(hipMemsetAsync(d_echo_grid, 0, bytes, ctx->stream));
+  OfdmGeom g{4096, lz.K, 0, 0, 0};
+  switch (lz.Q) {
+    case 1: return launch_echo_spectral<1>(ctx, g, lz.A, lz.L_whole, lz.L_out, lz.Q, ISAC_NOISE_PHILOX_SPECTRAL, nullptr, lz.sig, lz.seed, (c64*)d_echo_grid);
+    default: return launch_echo_spectral<2>(ctx, g, lz.A, lz.L_whole, lz.L_out, lz.Q, ISAC_NOISE_PHILOX_SPECTRAL, nullptr, lz.sig, lz.seed, (c64*)d_echo_grid);
+  }
 }
 
 extern "C" int isac_ofdm_demodulate_dev(isac_ctx* ctx, const isac_c64* d_wave, int64_t T, int32_t A,

@@ -148,6 +148,37 @@ __device__ __forceinline__ c64 box_muller32_hw(uint32_t ur, uint32_t ua) {
   return c64{(double)(rad * __builtin_amdgcn_cosf(turns)), (double)(rad * __builtin_amdgcn_sinf(turns))};
 }
 
+// The same transform with the two products still in single precision (what box_muller32_hw widens): the lazy covariance kernel (music.hip) keeps the unit noise of a slab in
+// flight as floats -- (double)re, (double)im are bit for bit box_muller32_hw's result.
+__device__ __forceinline__ void box_muller32_hw_f32(uint32_t ur, uint32_t ua, float& re, float& im) {
+  const float u = __builtin_fmaf((float)ur, 0x1.0p-32f, 0x1.0p-33f);
+  const float rad = __builtin_amdgcn_sqrtf(__builtin_amdgcn_logf(u) * -1.3862943611198906f);
+  const float turns = (float)ua * 0x1.0p-32f;
+  re = rad * __builtin_amdgcn_cosf(turns);
+  im = rad * __builtin_amdgcn_sinf(turns);
+}
+
+// One Philox4x32 round with the round's key pair (philox4x32_10 = rounds 0..9 with keys (k0 + r 0x9E3779B9, k1 + r 0xBB67AE85)): lets a kernel spread the ten rounds of a
+// call over its instruction stream (the lazy covariance kernel places one round per MFMA gap).
+__device__ __forceinline__ void philox4x32_round(uint32_t (&c)[4], uint32_t k0r, uint32_t k1r) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0r, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1r;
+  c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+}
+
+// echoGrid(k, l, r) = sum_q D_q[k, l] a_q[r] + sig W[k, l, r]: THE expression of the spectral synthesis, shared by every kernel that forms it (the fused synthesis + range kernel
+// stores it and feeds the range IFFT; the lazy covariance kernel re-forms it from the same D, a, seed instead of reading it back) -- same operations in the same order, so the
+// same bits.  w = unit noise (box_muller32_hw), NOISE = false: noiseless.
+template <int QT, bool NOISE>
+__device__ __forceinline__ c64 spectral_echo_value(const c64 (&d)[QT], const c64 (&s)[QT], c64 w, double sig) {
+  c64 v = mk(0.0, 0.0);
+#pragma unroll
+  for (int q = 0; q < QT; ++q) v = fma(d[q], s[q], v);
+  if constexpr (NOISE) v = v + w * sig;
+  return v;
+}
+
 // Workgroup -> (symbol l, antenna r) for the spectral synthesis kernels.  Every column (l, r) reads the per-target grids
 // D_q[:, l] (52 KB each at 273 PRB): in plain symbol-fastest order the 64 antennas that share a D column run ~224
 // workgroups apart, D (11.7 MB per target) does not survive in a 4 MB L2, and the kernel re-fetches as many bytes of D as it

@@ -94,6 +94,17 @@ struct RangeCache {  // range rows pre-computed by the fused monoStaticSensing c
   }
 };
 
+// Echo grid that stays inside the context (isac_mono_static_sensing_fused_dev with d_echo_grid == NULL, round 6).  native: the grid is NOT in memory -- it is the function
+//   echoGrid[k, l, r] = sum_q D_q[k, l] a_q[r] + sig philox(seed; k, l, r)      (D in ctx->dgrid, a in ctx->steer: the synthesis kernels' own inputs)
+// that the covariance kernel of the following isac_fft2d_submit_cached_dev re-forms tile by tile (cov_lazy_kernel) and isac_echo_grid_materialize_dev writes out on request.
+// !native: shapes the regenerating kernels do not cover (other carriers / noise modes, A outside 49..64, more than two LoS targets): the grid lives in ctx->echo_own.
+struct LazyEcho {
+  bool valid = false, native = false;
+  int K = 0, L_whole = 0, L_out = 0, A = 0, Q = 0;
+  double sig = 0.0;
+  unsigned long long seed = 0;
+};
+
 // pinned host -> device parameter staging: a small ring of slots, each guarded by its own event, so that a call's uploads do not wait for the
 // previous call's kernels to drain (one slot + one event did: every upload sat in stream order behind whatever was queued before it)
 struct StageSlot {
@@ -149,6 +160,8 @@ struct isac_ctx {
   isac::Fft2dLast last;
   isac::Fft2dPending pending;
   isac::RangeCache range_cache;
+  isac::LazyEcho lazy;               // the echo grid of the last fused monoStaticSensing call when the caller passed no array for it
+  isac::DevBuf echo_own;             // ... and its storage when it has to exist in memory (LazyEcho::native == false)
   isac::StageSlot stage_ring[isac::kStageSlots];   // pinned->device parameter uploads (stage_acquire / stage_commit)
   int stage_next = 0;
 };

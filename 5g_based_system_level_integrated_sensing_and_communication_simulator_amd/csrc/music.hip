@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <atomic>
 #include "isac_common.hpp"
+#include "echo_dev.hpp"
 
 namespace isac {
 
@@ -794,6 +795,259 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_lds_kernel(const c64* __restr
   const int pidx = blockIdx.x;                       // (one partial per workgroup: the phases are summed in the kernel)
   if (grp == 0) cov_lds_body<NB, 0>(G, N, A, phase, s_begin, s_end, pidx, part, lds);
   else cov_lds_body<NB, 1>(G, N, A, phase, s_begin, s_end, pidx, part, lds);
+}
+
+// ---------------------------------------------------------------- covariance of a LAZY echo grid (round 6)
+// The fused monoStaticSensing call wrote echoGrid (0.75 GB at the bench shape) only so that this stage could read it back.  With the spectral noise route the grid is a function
+// of 12 MB of inputs:   e[k, l, r] = sum_q D_q[k, l] a_q[r] + sig W(seed; k, l, r),   W = float32 Box-Muller of one Philox4x32-10 call per element PAIR (k, k + 512)
+// (echo_dev.hpp).  cov_lazy_kernel is cov_mfma_lds_kernel<4> with the slab staging (four 16-byte global loads per thread and slab) replaced by a generator that re-forms the
+// slab's 16 x 64 elements with THE expression of the synthesis kernel (spectral_echo_value: the same bits) and writes them into the same swizzled LDS image:
+//   * a slab is 8 PAIR rows of one symbol column: samples k0 + p and k0 + p + 512 (p = 0..7) occupy sample slots p and p + 8, so that both halves of every Philox call are
+//     used -- the slab order is therefore (symbol, 1024-subcarrier block pair, 8-row group), not the flat n = k + K l of the array form; the sum is the same, its rounding
+//     differs in the last bits (tests: <= 1e-13 of the array form; every estimate identical).  K is not a multiple of 1024: the partner half of the last block pair is masked
+//     (218 instead of 204.75 slabs per column at K = 3276: 6 % more MFMA issue than the array form);
+//   * thread (p = tid & 7, r0 = tid >> 3) makes TWO Philox calls per slab -- antennas r0 and r0 + 32 -- i.e. four elements, and two 16-byte loads of D (from L2: the lanes of a
+//     wave share 8 subcarriers) per target, issued two slabs ahead;
+//   * the generator is cut into 19 pieces (counter set-up + 10 Philox rounds, 4 Box-Muller transforms, 4 x (synthesis + mask + LDS store), the D loads) that sit in the gaps of the
+//     step's 30 MFMAs like the staging instructions did (SCHED picks the placement).
+// Bound: fp64 MFMA issue + the generator's VALU (v_mfma_f64 and VALU of one wave overlap only inside the 64-cycle shadow of the wave's own MFMA, section 3d of DESIGN.md).
+struct LazyCovArgs {
+  const c64* D;               // [K x L_whole x QT] per-target demodulated coefficient grids
+  const c64* steer_rq;        // [A x QT]: a_q[r] at r QT + q
+  double sig;
+  unsigned long long seed;
+  int K, L_whole, L_out, A;
+  int s_col;                  // slabs per symbol column
+};
+constexpr int kLazyPieces = 19;
+template <int SCHED>
+__host__ __device__ constexpr int lazy_piece_gap(int i) {       // MFMA gap (0..29) that carries generator piece i
+  return SCHED == 0 ? i : SCHED == 1 ? 8 + i : (i * 30) / kLazyPieces;
+}
+
+template <int GRP, int QT, int SCHED>
+__device__ __forceinline__ void cov_lazy_body(const LazyCovArgs& a, int phase, long long s_begin, long long s_end, int part_index, double* __restrict__ part,
+                                              c64* __restrict__ lds) {
+  constexpr int NB = 4;
+  using P = CovPlan<NB>;
+  constexpr int T0 = GRP * P::kPerGroup;
+  constexpr int NT = (T0 + P::kPerGroup <= P::kTiles) ? P::kPerGroup : (P::kTiles - T0);
+  constexpr int kBuf = NB * 16 * kCovPitch;         // one slab image
+  constexpr int kBlk = 16 * kCovPitch;              // one 16-antenna block of it
+  static_assert(6 * NT == 30, "30 MFMA gaps per slab step");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int li = lane & 15, kq = lane >> 4;
+  v4f64 re[NT], im[NT], s3[NT];
+#pragma unroll
+  for (int u = 0; u < NT; ++u) re[u] = im[u] = s3[u] = v4f64{0.0, 0.0, 0.0, 0.0};
+  // ---- generator: thread -> (pair row gp, antennas ga and ga + 32)
+  const int gp = tid & 7, ga = tid >> 3;
+  const int K = a.K;
+  const double sig = a.sig;
+  const uint32_t key0 = (uint32_t)a.seed, key1 = (uint32_t)(a.seed >> 32);
+  c64 st[2][QT];
+  bool ant_ok[2];
+  uint64_t colbase[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int ant = ga + 32 * j;
+    ant_ok[j] = ant < a.A;
+    colbase[j] = (uint64_t)a.L_out * (uint64_t)ant;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) st[j][q] = ant_ok[j] ? a.steer_rq[(long long)ant * QT + q] : mk(0.0, 0.0);
+  }
+  __amdgpu_buffer_rsrc_t rsD[QT];
+#pragma unroll
+  for (int q = 0; q < QT; ++q) rsD[q] = buffer_of(a.D + (long long)q * K * a.L_whole, (unsigned)((long long)K * a.L_whole * (long long)sizeof(c64)));
+  const int g_lds0 = (ga >> 4) * kBlk + gp * kCovPitch + ((ga & 15) ^ kCovSwizzle(gp));     // element (antenna ga, sample slot gp); + 2 j kBlk, + 8 h kCovPitch
+  // cursors (wave-uniform): the slab being generated and the slab whose D values are being fetched
+  struct Cur { int l, sc; long long g; };
+  auto cur_at = [&](long long g) { Cur c; c.g = g; c.l = (int)((unsigned)g / (unsigned)a.s_col); c.sc = (int)((unsigned)g - (unsigned)c.l * (unsigned)a.s_col); return c; };   // (slab counts fit 31 bits: checked by the launcher)
+  auto advance = [&](Cur& c) { ++c.g; if (++c.sc == a.s_col) { c.sc = 0; ++c.l; } };
+  auto k0_of = [&](const Cur& c) { return ((c.sc >> 6) << 10) + ((c.sc & 63) << 3) + gp; };      // subcarrier of half 0; half 1 = + 512
+  uint32_t pc[2][4];
+  float wf[2][2][2];
+  bool v_half[2];
+  c64 dl[2][QT][2];                                  // D values of two slabs in flight: dl[par][q][half]
+  auto gen_init = [&](const Cur& c) {
+    const int k0 = k0_of(c);
+    const bool in = c.g < s_end;
+    v_half[0] = in && k0 < K;
+    v_half[1] = in && k0 + 512 < K;
+    const uint32_t slot = (uint32_t)(((c.sc >> 6) << 9) + ((c.sc & 63) << 3) + gp);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const uint64_t ctr = (uint64_t)slot + (uint64_t)kSpectralSlotsPerColumn * ((uint64_t)c.l + colbase[j]);
+      pc[j][0] = (uint32_t)ctr; pc[j][1] = (uint32_t)(ctr >> 32); pc[j][2] = kSpectralStream; pc[j][3] = 0u;
+    }
+  };
+  auto gen_round = [&](auto rc) {
+    constexpr uint32_t r = (uint32_t)decltype(rc)::value;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) philox4x32_round(pc[j], key0 + r * 0x9E3779B9u, key1 + r * 0xBB67AE85u);
+  };
+  auto gen_bm = [&](auto jc, auto hc) {
+    constexpr int j = decltype(jc)::value, h = decltype(hc)::value;
+    box_muller32_hw_f32(pc[j][2 * h], pc[j][2 * h + 1], wf[j][h][0], wf[j][h][1]);
+  };
+  auto gen_emit = [&](auto jc, auto hc, const c64 (&dv)[QT][2], c64* img) {
+    constexpr int j = decltype(jc)::value, h = decltype(hc)::value;
+    c64 d[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) d[q] = dv[q][h];
+    c64 v = spectral_echo_value<QT, true>(d, st[j], mk((double)wf[j][h][0], (double)wf[j][h][1]), sig);
+    const bool ok = v_half[h] && ant_ok[j];
+    v = mk(ok ? v.re : 0.0, ok ? v.im : 0.0);
+    img[g_lds0 + 2 * j * kBlk + 8 * h * kCovPitch] = v;
+  };
+  auto gen_loads = [&](c64 (&dv)[QT][2], const Cur& c) {
+    const int k0 = k0_of(c);
+    const bool in = c.g < s_end;
+    const unsigned base = (unsigned)(((long long)K * c.l + k0) * (long long)sizeof(c64));
+    const unsigned o0 = (in && k0 < K) ? base : kCovOobOffset, o1 = (in && k0 + 512 < K) ? base + 512u * (unsigned)sizeof(c64) : kCovOobOffset;
+#pragma unroll
+    for (int q = 0; q < QT; ++q) { dv[q][0] = buffer_load_c64(rsD[q], o0); dv[q][1] = buffer_load_c64(rsD[q], o1); }
+  };
+  int r_off[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int smp = 4 * kq + 2 * phase + e;
+    r_off[e] = smp * kCovPitch + (li ^ kCovSwizzle(smp));
+  }
+  c64 ops[2][NB][2];                                 // operand sets: ops[s & 1] holds slab s
+  Cur cg = cur_at(s_begin), cd = cur_at(s_begin);
+  // One slab step.  PAR = parity of the step, rd / wr = LDS images of slab + 1 (complete) and slab + 2 (being generated here).
+  auto step = [&](auto par_c, int rd, int wr) {
+    constexpr int PAR = decltype(par_c)::value;
+    const c64 (&cur)[NB][2] = ops[PAR];
+    c64 (&nxt)[NB][2] = ops[PAR ^ 1];
+    const c64* img = lds + rd * kBuf;
+    c64* dst = lds + wr * kBuf;
+    double dm[2][NB], sp[2][NB];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { dm[e][b] = cur[b][e].re - cur[b][e].im; sp[e][b] = cur[b][e].re + cur[b][e].im; }
+    __builtin_amdgcn_sched_barrier(0);
+    auto piece = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i == 0) { gen_init(cg); gen_round(std::integral_constant<int, 0>{}); }
+      else if constexpr (i < 10) gen_round(std::integral_constant<int, i>{});
+      else if constexpr (i < 14) gen_bm(std::integral_constant<int, (i - 10) / 2>{}, std::integral_constant<int, (i - 10) % 2>{});
+      else if constexpr (i < 18) gen_emit(std::integral_constant<int, (i - 14) / 2>{}, std::integral_constant<int, (i - 14) % 2>{}, dl[PAR], dst);
+      else { gen_loads(dl[PAR], cd); advance(cg); advance(cd); }
+    };
+    auto filler = [&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k < 2 * NB) {
+        constexpr int e = k / NB, b = k % NB;
+        nxt[b][e] = img[b * kBlk + r_off[e]];        // (blocks no tile of this group touches: dead reads, dropped by the compiler)
+      }
+      static_for<0, kLazyPieces>([&](auto ic) {
+        if constexpr (lazy_piece_gap<SCHED>(decltype(ic)::value) == k) piece(ic);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    static_for<0, 2>([&](auto ec) {
+      constexpr int e = decltype(ec)::value;
+      static_for<0, NT>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);
+        re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].re, re[u], 0, 0, 0);
+        filler(std::integral_constant<int, e * 3 * NT + u>{});
+      });
+      static_for<0, NT>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);
+        if constexpr (I == J) im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].re, cur[J][e].im, im[u], 0, 0, 0);
+        else                  im[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].im, im[u], 0, 0, 0);
+        filler(std::integral_constant<int, e * 3 * NT + NT + u>{});
+      });
+      static_for<0, NT>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        constexpr int I = cov_tile_i(NB, T0 + u), J = cov_tile_j(NB, T0 + u);
+        if constexpr (I == J) re[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[I][e].im, cur[J][e].im, re[u], 0, 0, 0);
+        else                  s3[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(dm[e][I], sp[e][J], s3[u], 0, 0, 0);
+        filler(std::integral_constant<int, e * 3 * NT + 2 * NT + u>{});
+      });
+    });
+    __syncthreads();
+  };
+  // prologue: slabs 0 and 1 generated outright into images 0 and 1; the D values of slabs 2 and 3 in flight
+  auto gen_whole = [&](c64 (&dv)[QT][2], int buf) {
+    gen_loads(dv, cg);
+    gen_init(cg);
+    static_for<0, 10>([&](auto rc) { gen_round(rc); });
+    static_for<0, 4>([&](auto ic) { gen_bm(std::integral_constant<int, decltype(ic)::value / 2>{}, std::integral_constant<int, decltype(ic)::value % 2>{}); });
+    static_for<0, 4>([&](auto ic) { gen_emit(std::integral_constant<int, decltype(ic)::value / 2>{}, std::integral_constant<int, decltype(ic)::value % 2>{}, dv, lds + buf * kBuf); });
+    advance(cg);
+  };
+  gen_whole(dl[0], 0);
+  gen_whole(dl[1], 1);
+  cd = cg;                                           // slab s_begin + 2
+  gen_loads(dl[0], cd); advance(cd);
+  gen_loads(dl[1], cd); advance(cd);
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) ops[0][b][e] = lds[b * kBlk + r_off[e]];
+  int rd = 1, wr = 2;                                // (uniform) image of slab + 1, image for slab + 2
+  auto rot = [&]() { rd = wr; wr = wr == kCovLdsBufs - 1 ? 0 : wr + 1; };
+  for (long long slab = s_begin; slab < s_end; slab += 2) {       // (an odd slab count runs one all-zero slab: no exit in the middle)
+    step(std::integral_constant<int, 0>{}, rd, wr);
+    rot();
+    step(std::integral_constant<int, 1>{}, rd, wr);
+    rot();
+  }
+  // phase exchange + partial store: as cov_lds_body
+  double* x = reinterpret_cast<double*>(lds) + GRP * (P::kPerGroup * 2 * 256);
+  double o0[NT][4], o1[NT][4];
+  static_for<0, NT>([&](auto uc) {
+    constexpr int u = decltype(uc)::value;
+    constexpr bool diag = cov_tile_i(NB, T0 + u) == cov_tile_j(NB, T0 + u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if constexpr (!diag) {
+        o0[u][r] = re[u][r] + im[u][r];
+        o1[u][r] = (s3[u][r] - re[u][r]) + im[u][r];
+      } else {
+        o0[u][r] = re[u][r];
+        o1[u][r] = im[u][r];                                 // diagonal tile: M, antisymmetrised by cov_reduce_kernel
+      }
+    }
+  });
+  if (phase == 1) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { x[(u * 2 + 0) * 256 + r * 64 + lane] = o0[u][r]; x[(u * 2 + 1) * 256 + r * 64 + lane] = o1[u][r]; }
+  }
+  __syncthreads();
+  if (phase == 0) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      double* o = part + (((long long)part_index * P::kTiles + (T0 + u)) * 2) * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[0 * 256 + r * 64 + lane] = o0[u][r] + x[(u * 2 + 0) * 256 + r * 64 + lane];
+        o[1 * 256 + r * 64 + lane] = o1[u][r] + x[(u * 2 + 1) * 256 + r * 64 + lane];
+      }
+    }
+  }
+}
+
+template <int QT, int SCHED>
+__global__ __launch_bounds__(256, 2) void cov_lazy_kernel(LazyCovArgs a, long long n_slabs, long long slabs_per_wg, double* __restrict__ part /* [gridX][kTiles][2][256] */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* lds = reinterpret_cast<c64*>(smem_raw);      // [kCovLdsBufs][4 * 16 * kCovPitch]
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int grp = wid >> 1, phase = wid & 1;
+  const long long s_begin = (long long)blockIdx.x * slabs_per_wg;
+  long long s_end = s_begin + slabs_per_wg;
+  if (s_end > n_slabs) s_end = n_slabs;
+  if (grp == 0) cov_lazy_body<0, QT, SCHED>(a, phase, s_begin, s_end, blockIdx.x, part, lds);
+  else cov_lazy_body<1, QT, SCHED>(a, phase, s_begin, s_end, blockIdx.x, part, lds);
 }
 
 __global__ __launch_bounds__(256, 2) void cov_mfma_block_kernel(const c64* __restrict__ G, long long N, int A, int n_blk,
@@ -2596,6 +2850,52 @@ static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long lo
   ISAC_HIP(hipGetLastError());
   hipLaunchKernelGGL(cov_reduce_kernel, dim3(P::kTiles), dim3(256, 4), 0, st, (const double*)part2, S, P::kTiles, A,
                      1.0 / (double)N, Ra, 1);
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+// Ra of the context's NATIVE lazy echo grid (ctx->lazy: isac_mono_static_sensing_fused_dev with d_echo_grid == NULL) -- fft2D.m:106-107 without the array.
+template <int QT>
+static int launch_cov_lazy(isac_ctx* ctx, hipStream_t st, const LazyCovArgs& a, long long n_slabs, long long per, long long gx, double* part) {
+  static const int sched = std::getenv("ISAC_COV_LAZY_SCHED") ? std::atoi(std::getenv("ISAC_COV_LAZY_SCHED")) : 2;   // development switch: placement of the generator pieces
+  const size_t lds = sizeof(c64) * kCovLdsBufs * 4 * 16 * kCovPitch;
+#define ISAC_LAZY(S)                                                                                                       \
+  do {                                                                                                                     \
+    auto kern = cov_lazy_kernel<QT, S>;                                                                                    \
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));                                                    \
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, a, n_slabs, per, part);                               \
+  } while (0)
+  if (sched == 0) ISAC_LAZY(0); else if (sched == 1) ISAC_LAZY(1); else ISAC_LAZY(2);
+#undef ISAC_LAZY
+  ISAC_HIP(hipGetLastError());
+  return ISAC_OK;
+}
+
+int isac_covariance_lazy_on(isac_ctx* ctx, hipStream_t st, isac_c64* d_Ra) {
+  const LazyEcho& lz = ctx->lazy;
+  if (!lz.valid || !lz.native || !d_Ra) return fail(ctx, ISAC_ERR_INVALID_ARG, "no native lazy echo grid on this context");
+  if (lz.A <= 48 || lz.A > 64 || lz.Q < 1 || lz.Q > 2) return fail(ctx, ISAC_ERR_UNSUPPORTED, "lazy covariance: 49..64 antennas, one or two LoS targets");
+  if ((long long)lz.K * lz.L_whole * 16 >= (1ll << 31)) return fail(ctx, ISAC_ERR_UNSUPPORTED, "lazy covariance: per-target grid of 2 GB or more");
+  using P = CovPlan<4>;
+  int s_col = 0;
+  for (int k0 = 0; k0 < lz.K; k0 += 1024) s_col += (std::min(512, lz.K - k0) + 7) / 8;
+  const long long n_slabs = (long long)lz.L_whole * s_col;
+  if (n_slabs <= 0 || n_slabs >= (1ll << 31) - 4) return fail(ctx, ISAC_ERR_UNSUPPORTED, "lazy covariance: slab count out of range");
+  long long gx = 512 < n_slabs ? 512 : n_slabs;
+  long long per = (n_slabs + gx - 1) / gx;
+  per = (per + 1) & ~1ll;                             // the kernel walks slabs in pairs
+  gx = (n_slabs + per - 1) / per;
+  const int n_part = (int)gx;
+  ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * ((size_t)n_part + 32) * P::kTiles * 2 * 256));
+  LazyCovArgs a{(const c64*)ctx->dgrid.p, (const c64*)ctx->steer.p + (size_t)lz.A * lz.Q, lz.sig, lz.seed, lz.K, lz.L_whole, lz.L_out, lz.A, s_col};
+  if (lz.Q == 1) ISAC_TRY(launch_cov_lazy<1>(ctx, st, a, n_slabs, per, gx, (double*)ctx->cov_part.p));
+  else ISAC_TRY(launch_cov_lazy<2>(ctx, st, a, n_slabs, per, gx, (double*)ctx->cov_part.p));
+  const int S = 32;
+  double* part2 = (double*)ctx->cov_part.p + (size_t)n_part * P::kTiles * 2 * 256;
+  hipLaunchKernelGGL(cov_reduce_slice_kernel, dim3(P::kTiles, S), dim3(256), 0, st, (const double*)ctx->cov_part.p, n_part, P::kTiles, S, part2);
+  ISAC_HIP(hipGetLastError());
+  hipLaunchKernelGGL(cov_reduce_kernel, dim3(P::kTiles), dim3(256, 4), 0, st, (const double*)part2, S, P::kTiles, lz.A,
+                     1.0 / ((double)lz.K * (double)lz.L_out), (c64*)d_Ra, 1);
   ISAC_HIP(hipGetLastError());
   return ISAC_OK;
 }

@@ -45,7 +45,10 @@ def fft2D(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None, return_debug=False,
     Plotting (fft2D.m:119) is not part of the hot path.
     ``reuse_range=True`` (device grids): consume the range rows the preceding ``monoStaticSensing(..., fuse_fft2d=...)``
     call cached on this context (isac_fft2d_submit_cached_dev); an error if there are none."""
-    dev = isinstance(rxGrid, L.DeviceArray)
+    lazy = hasattr(rxGrid, "materialize")                 # LazyEchoGrid of monoStaticSensing(..., lazy=True): rxGrid goes to the library as NULL
+    if lazy and not reuse_range:
+        raise ValueError("a lazy echo grid is consumed with reuse_range=True (the fused call has already run its range stage)")
+    dev = isinstance(rxGrid, L.DeviceArray) or lazy
     if dev != isinstance(txGrid, L.DeviceArray):
         raise ValueError("rxGrid and txGrid must both be numpy arrays or both DeviceArrays")
     ctx = ctx or (rxGrid.ctx if dev else L.default_context())
@@ -57,7 +60,7 @@ def fft2D(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None, return_debug=False,
     res = L.EstResult()
     lib = ctx.lib
     if dev and reuse_range:
-        st = lib.isac_fft2d_submit_cached_dev(ctx.handle, C.byref(ep), C.byref(cf), C.c_void_p(rxGrid.ptr), C.c_void_p(txGrid.ptr),
+        st = lib.isac_fft2d_submit_cached_dev(ctx.handle, C.byref(ep), C.byref(cf), C.c_void_p(rxGrid.ptr or None), C.c_void_p(txGrid.ptr),
                                               C.c_int32(K), C.c_int32(Lsym), C.c_int32(A))
         if st == 0:
             st = lib.isac_fft2d_collect(ctx.handle, C.byref(res))
@@ -82,8 +85,8 @@ def fft2D_submit(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None, reuse_range=
     """Asynchronous half of fft2D for device-resident grids: enqueues every kernel and the result
     copy on ``ctx`` without waiting (isac_fft2d_submit_dev).  Pair with fft2D_collect(ctx).  Lets a
     host loop keep several cells / CPIs in flight on different contexts."""
-    if not (isinstance(rxGrid, L.DeviceArray) and isinstance(txGrid, L.DeviceArray)):
-        raise ValueError("fft2D_submit needs DeviceArray grids")
+    if not ((isinstance(rxGrid, L.DeviceArray) or (hasattr(rxGrid, "materialize") and reuse_range)) and isinstance(txGrid, L.DeviceArray)):
+        raise ValueError("fft2D_submit needs DeviceArray grids (or a LazyEchoGrid with reuse_range=True)")
     ctx = ctx or rxGrid.ctx
     K, Lsym, A = rxGrid.shape
     if tuple(txGrid.shape) != (K, Lsym, A):
@@ -91,7 +94,7 @@ def fft2D_submit(radarEstParams, cfar, rxGrid, txGrid, *, ctx=None, reuse_range=
     cf = _cfar_block(cfar)
     ep = est_block(radarEstParams)
     fn = ctx.lib.isac_fft2d_submit_cached_dev if reuse_range else ctx.lib.isac_fft2d_submit_dev
-    ctx.check(fn(ctx.handle, C.byref(ep), C.byref(cf), C.c_void_p(rxGrid.ptr), C.c_void_p(txGrid.ptr), C.c_int32(K), C.c_int32(Lsym), C.c_int32(A)))
+    ctx.check(fn(ctx.handle, C.byref(ep), C.byref(cf), C.c_void_p(rxGrid.ptr or None), C.c_void_p(txGrid.ptr), C.c_int32(K), C.c_int32(Lsym), C.c_int32(A)))
     return ctx
 
 

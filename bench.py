@@ -190,9 +190,10 @@ class Cell:
     `n_buf` buffer sets (transmit grid + waveform + echo grid) = the number of CPIs of THIS cell that can be in
     flight at once."""
 
-    def __init__(self, pkg, device, cell_id, n_ants, n_slots, n_targets, inflight=1, fuse=True, pool=None, n_buf=None, noise_domain="spectral"):
+    def __init__(self, pkg, device, cell_id, n_ants, n_slots, n_targets, inflight=1, fuse=True, pool=None, n_buf=None, noise_domain="spectral", lazy=False):
         L = pkg._lib
         self.fuse = fuse
+        self.lazy = bool(lazy) and fuse           # echo grid kept inside the context (isac_mono_static_sensing_fused_dev with d_echo_grid == NULL): --echo lazy
         self.noise_domain = noise_domain
         self.pkg, self.L = pkg, L
         # device arrays are device-global, so a cell's inputs can be consumed on any context of the same device
@@ -258,8 +259,8 @@ class Cell:
         b = self.n_sub % len(self.echo)
         tx_wave, tx_grid = self.tx_waves[b], self.tx_grids[b]
         echo = self.pkg.sensing.monoStaticSensing(tx_wave, (self.K, self.Lsym, self.A), self.carrier, self.rp, self.los,
-                                                  seed=self.seed + self.n_sub, noise_domain=self.noise_domain, nfft=4096, out=self.echo[b], ctx=c,
-                                                  fuse_fft2d=(self.rp, self.cfar, tx_grid) if self.fuse else None)
+                                                  seed=self.seed + self.n_sub, noise_domain=self.noise_domain, nfft=4096, out=None if self.lazy else self.echo[b], ctx=c,
+                                                  fuse_fft2d=(self.rp, self.cfar, tx_grid) if self.fuse else None, lazy=self.lazy)
         self.pkg.sensing.estimation.fft2D_submit(self.rp, self.cfar, echo, tx_grid, ctx=c, reuse_range=self.fuse)
         self.n_sub += 1
 
@@ -293,7 +294,8 @@ class Cell:
         out = []
         for i in range(reps + 1):
             self.pkg.sensing.monoStaticSensing(self.tx_wave, (self.K, self.Lsym, self.A), self.carrier, self.rp, self.los, seed=self.seed + i,
-                                               noise_domain=self.noise_domain, nfft=4096, out=self.echo[0], ctx=c, fuse_fft2d=(self.rp, self.cfar, self.tx_grid))
+                                               noise_domain=self.noise_domain, nfft=4096, out=None if self.lazy else self.echo[0], ctx=c, fuse_fft2d=(self.rp, self.cfar, self.tx_grid),
+                                               lazy=self.lazy)
             ms = C.c_double(0.0)
             c.check(c.lib.isac_profile_last_kernel_ms(c.handle, C.byref(ms)))
             out.append(ms.value)
@@ -774,6 +776,10 @@ def main():
     ap.add_argument("--no-fuse", dest="fuse", action="store_false", help="separate monoStaticSensing and fft2D range kernels (the range stage re-reads echoGrid)")
     ap.add_argument("--noise-domain", choices=("spectral", "time"), default="spectral",
                     help="Philox AWGN drawn on the demodulated grid (default; same distribution, include/isac.h isac_noise_mode) or per time sample")
+    ap.add_argument("--echo", choices=("lazy", "array", "auto"), default="auto",
+                    help="lazy: the echo grid stays inside the context as a descriptor -- the fused kernel skips its store, the covariance kernel re-forms its operands "
+                         "(include/isac.h 'LAZY echo grid': spectral Philox noise, 49..64 antennas, <= 2 targets; other shapes fall back to a context-owned buffer); "
+                         "array: monoStaticSensing writes echoGrid, fft2D's covariance reads it back (rounds 1-5); auto (default): lazy where it is native")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prime-ms", type=float, default=300.0, help="untimed device priming (hot-path steps) before the warm-up steps; 0 = none")
     ap.add_argument("--pace-ms", type=float, default=-1.0, help="minimum host-side spacing of consecutive CPI submissions; 0 = none, < 0 (default) = 0.93 x the "
@@ -836,6 +842,8 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    lazy_native = args.fuse and args.noise_domain == "spectral" and 48 < args.ants <= 64 and args.targets <= 2
+    args.lazy = args.echo == "lazy" or (args.echo == "auto" and lazy_native)
     pool = SlotPool(pkg, local_rank, args.inflight, ordered=args.schedule == "ordered")          # the GPU's execution slots, shared by all its cells
     if pool.ordered:
         args.pace_ms = 0.0                                   # submission order IS the device order: nothing to stagger
@@ -844,7 +852,7 @@ def main():
     my_cells = d.shard_cells(args.cells, rank, world) if args.cells > 0 else [rank * args.cells_per_gpu + c for c in range(args.cells_per_gpu)]
     n_total_cells = args.cells if args.cells > 0 else args.cells_per_gpu * world
     n_buf = -(-args.inflight // max(len(my_cells), 1))        # CPIs of one cell that can be in flight at once
-    cells = [Cell(pkg, local_rank, cid, args.ants, args.slots, args.targets, fuse=args.fuse, pool=pool, n_buf=n_buf, noise_domain=args.noise_domain)
+    cells = [Cell(pkg, local_rank, cid, args.ants, args.slots, args.targets, fuse=args.fuse, pool=pool, n_buf=n_buf, noise_domain=args.noise_domain, lazy=args.lazy)
              for cid in my_cells]
 
     def barrier():
@@ -974,7 +982,9 @@ def main():
             "config": {"workload": f"{(str(args.cells) + ' cells round-robin over the ranks') if args.cells > 0 else (str(args.cells_per_gpu) + ' cell(s)/GPU')}, {args.ants}-antenna ULA echo -> 2D-FFT -> 2D-CFAR -> MUSIC, "
                                    f"100 MHz / 273 PRB, K=3276 L={14 * args.slots} T={cells[0].T} nIFFT=4096 nFFT=256, "
                                    f"{args.targets} target(s), Philox AWGN drawn on the {'demodulated grid (Philox4x32-10 + SINGLE-precision hardware Box-Muller: the field is defined to float32 accuracy, echo_dev.hpp box_muller32_hw; all signal arithmetic fp64)' if args.noise_domain == 'spectral' else 'time samples (fp64 Box-Muller)'}, "
-                                   f"{'fused synthesis + range kernel' if args.fuse else 'separate echo / range kernels'}, {args.inflight} CPIs in flight",
+                                   f"{'fused synthesis + range kernel' if args.fuse else 'separate echo / range kernels'}, "
+                                   + ("echo grid LAZY (kept inside the context as a descriptor: never written to HBM, the covariance kernel re-forms its operands from the same D, a, seed -- identical CFAR lists and estimates, isac.h 'LAZY echo grid'), " if args.lazy else "echo grid materialised (written by monoStaticSensing, read back by the covariance), ")
+                                   + f"{args.inflight} CPIs in flight",
                        "parallelism": f"cells sharded over {world} GPU(s)"},
             "roofline": roofline_entry(cells[0], args, dom_ms_timed, dom_ms_iso, len(sink or []), stages, echo_b + rdm_b, per_cpi_ms),
         }

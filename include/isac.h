@@ -32,10 +32,10 @@ extern "C" {
 #endif
 
 /* Bumped on EVERY change of a struct layout, enum value or entry-point signature below (1: round 1; 2: ISAC_MAX_EST 1024 -> 4096,
- * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve, isac_prg_precode_dev, isac_cdl_freq_response_dev, isac_cdl_csi_estimate_batch_dev).  A host must
+ * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve, isac_prg_precode_dev, isac_cdl_freq_response_dev, isac_cdl_csi_estimate_batch_dev; 7: the lazy echo grid -- d_echo_grid / d_rx_grid may be NULL --, isac_echo_grid_materialize_dev).  A host must
  * compare isac_abi_version() with the ISAC_ABI_VERSION it was compiled against AND isac_abi_sizeof() with its own sizeof of every
  * struct it passes: the library writes whole structs (isac_est_result is 128 KB) into caller memory. */
-#define ISAC_ABI_VERSION 6
+#define ISAC_ABI_VERSION 7
 #define ISAC_MAX_EST 4096 /* capacity of the estimate vectors in isac_est_result: unique range bins <= nIFFT (<= 4096 for every
                              * NR numerology), unique velocity bins <= nFFT, azimuth peaks <= 180 -- never the binding limit */
 
@@ -202,6 +202,16 @@ int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64* d_tx_wave,
                                        uint64_t seed, isac_c64* d_echo_grid, int32_t* l_out,
                                        const isac_est_params* ep, const isac_cfar_config* cfar,
                                        const isac_c64* d_tx_grid);
+/* LAZY echo grid (round 6).  d_echo_grid == NULL in the call above keeps echoGrid INSIDE the context: monoStaticSensing.m:1 returns the array, but its only consumer on the hot
+ * path is the fft2D call that follows (cellSimulation.m:194-197).  Where the grid is a cheap function of small inputs -- the fused spectral route (Nfft = nIFFT = 4096,
+ * ISAC_NOISE_PHILOX_SPECTRAL), 49..64 antennas, one or two LoS targets -- it is never written:
+ *      echoGrid[k, l, r] = sum_q D_q[k, l] a_q[r] + sig W(seed; k, l, r)        (D: Q demodulated coefficient grids, 12 MB each; W: counter-based Philox + Box-Muller)
+ * the fused kernel runs its range stage from registers and skips the store, and the covariance kernel of the following isac_fft2d_submit_cached_dev (d_rx_grid == NULL there)
+ * re-forms its operand tiles with the same expression -- 1.5 GB of HBM traffic per CPI at the bench shape (K L A 16 B written + read back) disappear; every CFAR list and
+ * estimate is identical, Ra agrees to <= 1e-13 (same terms, another summation order).  Every other shape / noise mode gets a context-owned buffer and runs as with a caller's
+ * array.  The descriptor lives until the next echo call on the context.  isac_echo_grid_materialize_dev writes the grid out for a caller that wants the array after all
+ * (bit for bit what the call above would have stored); dims3 (optional) receives {n_sc, L_out, A}; d_echo_grid == NULL: size query only. */
+int isac_echo_grid_materialize_dev(isac_ctx* ctx, isac_c64* d_echo_grid, int32_t* dims3);
 /* number of whole OFDM symbols in T samples (size query for the call above) */
 int isac_ofdm_symbol_count(const isac_carrier* carrier, int64_t T, int32_t* n_symbols);
 
@@ -257,7 +267,7 @@ int isac_fft2d_submit_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_c
 int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out);
 /* isac_fft2d_submit_dev that REQUIRES and consumes the range rows cached by the preceding
  * isac_mono_static_sensing_fused_dev call on this context (same grids, same parameter blocks); ISAC_ERR_INVALID_ARG when
- * there is no such cache.  Saves the K L A 16 B re-read of rxGrid by the range stage. */
+ * there is no such cache.  Saves the K L A 16 B re-read of rxGrid by the range stage.  d_rx_grid == NULL: the lazy echo grid the fused call kept inside the context (above). */
 int isac_fft2d_submit_cached_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
                                  const isac_c64* d_rx_grid, const isac_c64* d_tx_grid,
                                  int32_t K, int32_t L, int32_t A);

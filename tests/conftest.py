@@ -49,6 +49,19 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+def pytest_terminal_summary(terminalreporter):
+    """Tally of how the fuzz scenes' azimuth lists were checked (tests/test_gpu_fuzz.py::_check_azimuth): 'chain' = the chain's own aziEst against the oracle's,
+    'stage_at_rank' = numerically degenerate signal / noise split, the MUSIC stage compared on the scene's covariance at its numerical rank instead."""
+    tally = {}
+    for rep in terminalreporter.stats.get("passed", []):
+        for k, v in getattr(rep, "user_properties", []):
+            if k == "azimuth":
+                tally[v] = tally.get(v, 0) + 1
+    if tally:
+        n = sum(tally.values())
+        terminalreporter.write_line("fuzz azimuth tally: " + ", ".join(f"{k} {v} ({100.0 * v / n:.1f} %)" for k, v in sorted(tally.items())) + f" of {n} scenes with detections")
+
+
 def make_scene(n_ants=4, n_slots=2, nrb=273, targets=((100.0, 20.0, 1.5),), velocity=(7.0,),
                seed=1, zero_s_slots=True, detection_area=None, with_noise=True, num_slots_param=None):
     """Synthetic cell in the reference's own parameterisation:

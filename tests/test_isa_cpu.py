@@ -87,7 +87,7 @@ def vm_waits(asm):
 
 @pytest.mark.parametrize("q,group", [(1, 4), (2, 2)])
 def test_fused_kernel_keeps_exact_wait_counts(echo_co, q, group):
-    name, meta, asm = echo_co.find("echo_range_sl_kernel", f"ILi{q}ELi1ELi{group}E")
+    name, meta, asm = echo_co.find("echo_range_sl_kernel", f"ILi{q}ELi1ELb1ELi{group}E")
     assert meta["vgpr_count"] <= 128 and meta["agpr_count"] == 0, meta      # four waves per SIMD, two 512-thread workgroups per CU
     assert meta["private_segment_fixed_size"] == 0, meta                     # no spills
     stores = [i for i, ln in enumerate(asm) if ln.startswith("buffer_store_dwordx4")]
@@ -98,6 +98,34 @@ def test_fused_kernel_keeps_exact_wait_counts(echo_co, q, group):
     # the second load group is issued before the first group's stores
     loads = [i for i, ln in enumerate(asm) if ln.startswith("global_load_dwordx4")]
     assert sum(1 for i in loads if i < stores[0]) >= 2 * 2 * group, "the next group's loads must be in flight when the stores start"
+
+
+@pytest.mark.parametrize("q,group", [(1, 4), (2, 2)])
+def test_lazy_fused_kernel_has_no_echo_grid_store(echo_co, q, group):
+    """echo_range_sl_kernel<Q, 1, STORE = false> (lazy echo grid, round 6): the same kernel without the eight echoGrid stores -- nothing else of a column goes to memory
+    but its CUT rows."""
+    name, meta, asm = echo_co.find("echo_range_sl_kernel", f"ILi{q}ELi1ELb0ELi{group}E")
+    assert meta["vgpr_count"] <= 128 and meta["agpr_count"] == 0 and meta["private_segment_fixed_size"] == 0, meta
+    assert not any(ln.startswith("buffer_store_dwordx4") for ln in asm), "the lazy form must not store the echo grid"
+    assert sum(1 for ln in asm if ln.startswith("global_load_dwordx4")) >= 8 * (1 + q)       # txGrid + D loads of the eight elements are still there
+
+
+@pytest.mark.parametrize("q,sched", [(1, 0), (1, 1), (1, 2), (2, 2)])
+def test_lazy_covariance_kernel_shape(music_co, q, sched):
+    """cov_lazy_kernel<Q, SCHED>: two workgroups per CU (<= 256 registers, at most a handful of spilled registers at two targets), the 2 x 30 MFMAs of its two slab steps, no
+    global load of the grid (only the D values: 2 Q per thread and slab), the generator's transcendentals between the MFMAs, no waterfall loop (uniform descriptors)."""
+    name, meta, asm = music_co.find("cov_lazy_kernel", f"ILi{q}ELi{sched}E")
+    assert meta["vgpr_count"] <= 256 and meta["agpr_count"] == 0, meta
+    assert meta["private_segment_fixed_size"] <= (0 if q == 1 else 32), meta
+    mf = [i for i, ln in enumerate(asm) if ln.startswith("v_mfma_f64_16x16x4")]
+    assert len(mf) == 2 * 2 * 30, len(mf)                                  # two tile groups x two unrolled steps x 30
+    for g in range(2):                                                       # inside the slab loops: no waterfall loop (a buffer descriptor that is not provably uniform), no branch at all
+        loop = asm[mf[60 * g]:mf[60 * g + 59] + 1]
+        assert not any(ln.startswith(("s_cbranch", "s_branch")) for ln in loop), "a branch inside the MFMA stream"
+    body = asm[mf[0]:mf[29] + 1]                                             # one slab step of one tile group
+    assert sum(1 for ln in body if ln.startswith(("v_log_f32", "v_sin_f32", "v_cos_f32", "v_sqrt_f32"))) == 16, "four Box-Muller transforms (4 transcendentals each) per step"
+    assert sum(1 for ln in body if ln.startswith("buffer_load_dwordx4")) == 2 * q
+    assert sum(1 for ln in body if ln.startswith("ds_write_b128") or ln.startswith("ds_write2_b64")) >= 4
 
 
 def test_fused_kernel_fallback_forms_exist(echo_co):
@@ -184,7 +212,8 @@ def test_distributed_householder_kernel_exchange_code(music_co):
 
 
 def test_scratch_users_are_the_known_ones(echo_co, music_co):
-    known = ("echo_range_kernelILi4E", "eigh_replay_kernel")       # spill a few registers by design
+    known = ("echo_range_kernelILi4E", "eigh_replay_kernel",       # spill a few registers by design
+             "cov_lazy_kernelILi2ELi2E")                           # two targets, spread generator placement: 3 registers (16 B) beyond the 256 of two waves per SIMD
     for co in (echo_co, music_co):
         for n, m in co.meta.items():
             if m.get("private_segment_fixed_size", 0) > 0:
