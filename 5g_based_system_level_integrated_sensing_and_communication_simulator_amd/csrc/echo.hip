@@ -65,6 +65,45 @@ __global__ __launch_bounds__(256) void beamsum_kernel(const c64* __restrict__ tx
   }
 }
 
+// Low-register form (round 6): the same sums in the same order in <= 32 VGPRs and 1 KB of LDS-free state (the steering coefficients come in through scalar loads), so that a
+// beam-sum workgroup FITS BESIDE the resident workgroups of the compute-bound wide kernels of the CPIs ahead of it in the pipeline -- two echo_range_sl workgroups leave
+// 32 registers per lane and SIMD (4 waves x 120), two cov_lazy / cov_mfma_lds workgroups 32-48 -- and streams txWaveform underneath them instead of taking the chip for
+// 175 us of its own: with the echo grid lazy those kernels hardly touch the HBM (0.85 GB in 256 us, nothing in the covariance), the beam-sum hardly touches the VALU.
+// Fewer loads in flight per lane (UNROLL 4) -- a lower rate by itself, but it no longer has to be fast, only out of the way.
+template <int QT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void beamsum_lr_kernel(const c64* __restrict__ tx, long long T, int A,
+                                                                                                const c64* __restrict__ steer /* [A x QT] compacted LoS */,
+                                                                                                c64* __restrict__ beam /* [QT x T] */) {
+  constexpr int UNROLL = 4;
+  for (long long t0 = (long long)blockIdx.x * 256; t0 < T; t0 += (long long)gridDim.x * 256) {
+    const long long t = t0 + threadIdx.x;
+    const long long tc = t < T ? t : T - 1;                            // unconditional loads (clamped), one conditional store
+    c64 acc[QT];
+#pragma unroll
+    for (int q = 0; q < QT; ++q) acc[q] = mk(0.0, 0.0);
+    const c64* p = tx + tc;
+    int a = 0;
+    for (; a + UNROLL <= A; a += UNROLL) {
+      c64 v[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) v[u] = p[(long long)(a + u) * T];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+        for (int q = 0; q < QT; ++q) acc[q] = fma(v[u], steer[q * A + a + u], acc[q]);      // (uniform address: scalar loads)
+    }
+    for (; a < A; ++a) {
+      c64 v = p[(long long)a * T];
+#pragma unroll
+      for (int q = 0; q < QT; ++q) acc[q] = fma(v, steer[q * A + a], acc[q]);
+    }
+    if (t < T) {
+#pragma unroll
+      for (int q = 0; q < QT; ++q) beam[(long long)q * T + t] = acc[q];
+    }
+  }
+}
+
 // ---------------------------------------------------------------- per-target coefficient vectors
 struct TargetDesc {
   double wd;      // (2*pi)*fd          basicRadarChannel.m:25,44
@@ -617,10 +656,18 @@ static int prepare_echo(isac_ctx* ctx, const c64* d_tx, long long T, const isac_
     else if (bs_unroll >= 16) hipLaunchKernelGGL((beamsum_kernel<QT, (QT <= 4 ? 16 : 8)>), dim3(gbs), dim3(256), sizeof(c64) * A * QT, ctx->stream, d_tx, T, A, st, bm); \
     else hipLaunchKernelGGL((beamsum_kernel<QT, 8>), dim3(gbs), dim3(256), sizeof(c64) * A * QT, ctx->stream, d_tx, T, A, st, bm);           \
   } while (0)
+  static const int bs_lr = std::getenv("ISAC_BEAMSUM_LR") ? std::atoi(std::getenv("ISAC_BEAMSUM_LR")) : 0;   // development switch: the low-register form for <= 2 targets
   for (int q0 = 0; q0 < Q;) {
     int rem = Q - q0;
     const c64* st = d_steer_aq + (size_t)q0 * A;
     c64* bm = (c64*)ctx->beam.p + (size_t)q0 * T;
+    if (bs_lr && Q <= 2) {
+      const unsigned glr = (unsigned)std::min<long long>(gb, bs_lr > 1 ? bs_lr : 1024);
+      if (Q == 2) hipLaunchKernelGGL((beamsum_lr_kernel<2>), dim3(glr), dim3(256), 0, ctx->stream, d_tx, T, A, st, bm);
+      else hipLaunchKernelGGL((beamsum_lr_kernel<1>), dim3(glr), dim3(256), 0, ctx->stream, d_tx, T, A, st, bm);
+      q0 += Q;
+      continue;
+    }
     if (rem >= 8) { ISAC_BEAMSUM(8); q0 += 8; }
     else if (rem >= 4) { ISAC_BEAMSUM(4); q0 += 4; }
     else if (rem >= 2) { ISAC_BEAMSUM(2); q0 += 2; }

@@ -29,12 +29,24 @@ def _targets(q):
     return (((100.0, 20.0, 1.5),), ((120.0, 60.0, 1.5), (-250.0, 80.0, 1.5)), ((120.0, 60.0, 1.5), (-250.0, 80.0, 1.5), (60.0, -30.0, 1.5)))[q - 1], ((7.0,), (10.0, -6.0), (10.0, -6.0, 3.0))[q - 1]
 
 
+def _fft2d(pkg, rp, cf, grid, d_txg, ctx):
+    """(est | None, debug): a scene without a CFAR detection raises NO_DETECTION in both forms (findpeaks NPeaks = 0, music.m:102) -- the |rdm|^2 window, the (empty) lists
+    and Ra are still there to compare."""
+    from importlib import import_module
+    dbg_fn = import_module(pkg.__name__ + ".sensing.estimation.fft2D").fft2D_debug
+    try:
+        return pkg.sensing.estimation.fft2D(rp, cf, grid, d_txg, return_debug=True, reuse_range=True)
+    except pkg.IsacError as e:
+        assert e.name == "NO_DETECTION"
+        return None, dbg_fn(ctx, grid.shape[2])
+
+
 def _both(pkg, ctx, sc, rp, cf, d_wave, d_txg, shape, **kw):
     arr = pkg.sensing.monoStaticSensing(d_wave, shape, sc.carrier, rp, sc.los, nfft=4096, fuse_fft2d=(rp, cf, d_txg), ctx=ctx, **kw)
-    est_a, dbg_a = pkg.sensing.estimation.fft2D(rp, cf, arr, d_txg, return_debug=True, reuse_range=True)
+    est_a, dbg_a = _fft2d(pkg, rp, cf, arr, d_txg, ctx)
     lz = pkg.sensing.monoStaticSensing(d_wave, shape, sc.carrier, rp, sc.los, nfft=4096, fuse_fft2d=(rp, cf, d_txg), ctx=ctx, lazy=True, **kw)
     assert lz.shape == tuple(arr.shape)
-    est_l, dbg_l = pkg.sensing.estimation.fft2D(rp, cf, lz, d_txg, return_debug=True, reuse_range=True)
+    est_l, dbg_l = _fft2d(pkg, rp, cf, lz, d_txg, ctx)
     return arr, (est_a, dbg_a), lz, (est_l, dbg_l)
 
 
@@ -42,7 +54,9 @@ def _same_estimates(a, b):
     (est_a, dbg_a), (est_l, dbg_l) = a, b
     assert np.array_equal(dbg_a.power_window, dbg_l.power_window)
     assert all(np.array_equal(x, y) for x, y in zip(dbg_a.detections, dbg_l.detections))
-    assert np.array_equal(est_a.rngEst, est_l.rngEst) and np.array_equal(est_a.velEst, est_l.velEst) and np.array_equal(est_a.aziEst, est_l.aziEst)
+    assert (est_a is None) == (est_l is None)
+    if est_a is not None:
+        assert np.array_equal(est_a.rngEst, est_l.rngEst) and np.array_equal(est_a.velEst, est_l.velEst) and np.array_equal(est_a.aziEst, est_l.aziEst)
 
 
 @pytest.mark.parametrize("n_ants,q,n_slots,zero_s,seed", [(64, 1, 4, True, 11), (64, 2, 2, False, 12), (56, 1, 2, False, 13), (49, 2, 3, True, 14), (63, 1, 2, True, 15)])
@@ -140,7 +154,7 @@ def test_lazy_grid_at_the_bench_shape(pkg):
     arr, ra, lz, rl = _both(pkg, ctx, sc, rp, cf, d_wave, d_txg, sc.tx_grid.shape, seed=0x5EED0001, noise_domain="spectral")
     assert sc.tx_grid.shape == (3276, 224, 64)
     _same_estimates(ra, rl)
-    assert rl[0].rngEst.size >= 1
+    assert rl[0] is not None and rl[0].rngEst.size >= 1
     assert rel(rl[1].Ra, ra[1].Ra) < 1e-13
     m = lz.materialize()
     assert np.array_equal(m.numpy()[::7, ::5, ::3], arr.numpy()[::7, ::5, ::3])
