@@ -883,6 +883,9 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
     return isac_range_stage_into_cache(ctx, ep, cf, (const c64*)d_echo_grid, (const c64*)d_tx_grid, g.n_sc, lo, rp->n_ants);
   }
   int Q = 0, L_whole = 0;
+  // (tried in round 6 and removed: the front of the call -- beam-sum, coefficient vectors, Q x L demodulation FFTs -- on a lowest-priority third stream per context, so that it
+  //  would yield to the compute-bound kernels of the CPIs ahead: 24 streams on 16 hardware queues collapse the pipelined rate to 4-5 k slots/s whatever GPU_MAX_HW_QUEUES says,
+  //  and with 4-5 contexts (12-15 streams) it is 7-15 % slower than two streams per context; profiles/r06_lazy_first_measurements.txt)
   ISAC_TRY(spectral_prepare(ctx, (const c64*)d_tx_wave, T, rp, los, g, &Q, &L_whole));
   const int A = rp->n_ants;
   if (L_whole <= 0) return fail(ctx, ISAC_ERR_SHORT_WAVEFORM, "waveform shorter than one OFDM symbol");
