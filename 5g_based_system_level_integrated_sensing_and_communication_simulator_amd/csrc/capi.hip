@@ -276,6 +276,7 @@ extern "C" int isac_abi_sizeof(int32_t which) {
     case ISAC_SIZEOF_CARRIER: return (int)sizeof(isac_carrier);
     case ISAC_SIZEOF_MUSIC2D_PARAMS: return (int)sizeof(isac_music2d_params);
     case ISAC_SIZEOF_CSI_REPORT: return (int)sizeof(isac_csi_report);
+    case ISAC_SIZEOF_SENSING_JOB: return (int)sizeof(isac_sensing_job);
     default: return -1;
   }
 }
@@ -745,6 +746,54 @@ extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
   for (int i = 0; i < out->n_azi; ++i) {
     out->azi_est[i] = locs[(size_t)i] * ep->azimuth_scan_granularity - ep->azimuth_scan_scale / 2.0;           // :103
     out->ele_est[i] = NAN;                                                                                  // :104
+  }
+  return ISAC_OK;
+}
+
+// Many cells' (monoStaticSensing -> fft2D) pairs in two calls: job i on ctxs[i] (include/isac.h).  Nothing here that the single calls do not do -- the point is WHERE the loop
+// runs: ~25 launches per job issued back to back from C++ instead of two host-language calls (argument marshalling, ctypes / MEX dispatch) per job.
+extern "C" int isac_sensing_submit_n(isac_ctx* const* ctxs, int32_t n, const isac_sensing_job* jobs, int64_t T, int32_t tx_dim_l, const isac_carrier* carrier,
+                                     const isac_est_params* ep, const isac_cfar_config* cfar, double pace_us, int32_t* status) {
+  if (!ctxs || !jobs || !status || n <= 0 || !carrier || !ep || !cfar || !(pace_us >= 0.0)) return ISAC_ERR_INVALID_ARG;
+  for (int i = 0; i < n; ++i) {
+    if (!ctxs[i]) return ISAC_ERR_INVALID_ARG;
+    for (int j = 0; j < i; ++j)
+      if (ctxs[j] == ctxs[i]) return fail(ctxs[i], ISAC_ERR_INVALID_ARG, "isac_sensing_submit_n: a context appears twice (one pending CPI per context)");
+  }
+  auto t_next = std::chrono::steady_clock::now();
+  const auto pace = std::chrono::nanoseconds((long long)(pace_us * 1e3));
+  for (int i = 0; i < n; ++i) {
+    isac_ctx* c = ctxs[i];
+    const isac_sensing_job& jb = jobs[i];
+    if (pace_us > 0.0) {
+      while (std::chrono::steady_clock::now() < t_next) {}                    // (sub-millisecond spacing: spin, a sleep would overshoot)
+      t_next = std::max(t_next, std::chrono::steady_clock::now()) + pace;
+    }
+    if (c->pending.active) { status[i] = fail(c, ISAC_ERR_INVALID_ARG, "isac_sensing_submit_n: the context still holds a pending CPI (collect it first)"); continue; }
+    if (!jb.rp || !jb.d_tx_wave || !jb.d_tx_grid) { status[i] = fail(c, ISAC_ERR_INVALID_ARG, "isac_sensing_submit_n: incomplete job"); continue; }
+    int32_t lo = 0;
+    int st = isac_mono_static_sensing_fused_dev(c, jb.d_tx_wave, T, tx_dim_l, carrier, jb.rp, jb.los, jb.noise_mode, jb.d_noise_unit, jb.seed, jb.d_echo_grid, &lo, ep, cfar, jb.d_tx_grid);
+    if (st == ISAC_OK) {
+      const int A = jb.rp->n_ants;
+      st = isac_fft2d_submit_cached_dev(c, ep, cfar, jb.d_echo_grid, jb.d_tx_grid, carrier->n_sc, lo, A);
+      if (st == ISAC_ERR_INVALID_ARG && jb.d_echo_grid)                        // nothing cached (the CUT window left the map): the plain call reports it
+        st = isac_fft2d_submit_dev(c, ep, cfar, jb.d_echo_grid, jb.d_tx_grid, carrier->n_sc, lo, A);
+    }
+    status[i] = st;
+  }
+  return ISAC_OK;
+}
+
+extern "C" int isac_sensing_collect_n(isac_ctx* const* ctxs, int32_t n, isac_est_result* out, int32_t* status) {
+  if (!ctxs || !out || !status || n <= 0) return ISAC_ERR_INVALID_ARG;
+  for (int i = 0; i < n; ++i) {
+    if (!ctxs[i]) return ISAC_ERR_INVALID_ARG;
+    if (!ctxs[i]->pending.active) {                                            // never submitted (status[i] holds why) or already collected
+      if (status[i] == ISAC_OK) status[i] = fail(ctxs[i], ISAC_ERR_INVALID_ARG, "isac_sensing_collect_n: no pending CPI on this context");
+      std::memset(&out[i], 0, sizeof(out[i]));
+      continue;
+    }
+    status[i] = isac_fft2d_collect(ctxs[i], &out[i]);
   }
   return ISAC_OK;
 }

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 /* Bumped on EVERY change of a struct layout, enum value or entry-point signature below (1: round 1; 2: ISAC_MAX_EST 1024 -> 4096,
- * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve, isac_prg_precode_dev, isac_cdl_freq_response_dev, isac_cdl_csi_estimate_batch_dev; 7: the lazy echo grid -- d_echo_grid / d_rx_grid may be NULL --, isac_echo_grid_materialize_dev).  A host must
+ * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve, isac_prg_precode_dev, isac_cdl_freq_response_dev, isac_cdl_csi_estimate_batch_dev; 7: the lazy echo grid -- d_echo_grid / d_rx_grid may be NULL --, isac_echo_grid_materialize_dev, isac_sensing_submit_n / isac_sensing_collect_n).  A host must
  * compare isac_abi_version() with the ISAC_ABI_VERSION it was compiled against AND isac_abi_sizeof() with its own sizeof of every
  * struct it passes: the library writes whole structs (isac_est_result is 128 KB) into caller memory. */
 #define ISAC_ABI_VERSION 7
@@ -60,7 +60,7 @@ typedef enum {
 int isac_abi_version(void);
 /* sizeof() of the library's build of struct `which` (ISAC_SIZEOF_*), -1 for an unknown selector. */
 enum { ISAC_SIZEOF_EST_RESULT = 0, ISAC_SIZEOF_EST_PARAMS = 1, ISAC_SIZEOF_CFAR_CONFIG = 2, ISAC_SIZEOF_RADAR_CHANNEL_PARAMS = 3,
-       ISAC_SIZEOF_CARRIER = 4, ISAC_SIZEOF_MUSIC2D_PARAMS = 5, ISAC_SIZEOF_CSI_REPORT = 6 };
+       ISAC_SIZEOF_CARRIER = 4, ISAC_SIZEOF_MUSIC2D_PARAMS = 5, ISAC_SIZEOF_CSI_REPORT = 6, ISAC_SIZEOF_SENSING_JOB = 7 };
 int isac_abi_sizeof(int32_t which);
 int isac_device_count(int* count);
 int isac_ctx_create(int device, isac_ctx** out);
@@ -271,6 +271,27 @@ int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out);
 int isac_fft2d_submit_cached_dev(isac_ctx* ctx, const isac_est_params* ep, const isac_cfar_config* cfar,
                                  const isac_c64* d_rx_grid, const isac_c64* d_tx_grid,
                                  int32_t K, int32_t L, int32_t A);
+
+/* MANY cells' (monoStaticSensing -> fft2D) pairs in TWO library calls (round 6): cellSimulation.m:189-202 runs the pair once per cell (one worker per cell,
+ * networkSimulation.m:47-60), and at small arrays (the reference's default 16 elements, ula.m:45) the pair's kernels take less time than the ~25 calls / launches a host
+ * language spends on it -- a MATLAB / MEX or Python host is then bound by its own loop.  isac_sensing_submit_n enqueues job i on ctxs[i] (n distinct idle contexts of one device:
+ * each holds one pending CPI): isac_mono_static_sensing_fused_dev followed by isac_fft2d_submit_cached_dev (plain submit where nothing was cached), consecutive jobs at least
+ * pace_us apart on the host (0 = none; staggered arrivals keep the in-flight CPIs at different phases).  isac_sensing_collect_n collects them in order.  Per-job status in
+ * status[i] (ISAC_OK / ISAC_ERR_NO_DETECTION / ...; a job that failed to submit is skipped by collect and keeps its status); the return value is ISAC_OK unless the call
+ * itself was malformed.  d_echo_grid == NULL: the job's echo grid stays lazy (above).  Results are those of the single calls, bit for bit. */
+typedef struct {
+  const isac_c64* d_tx_wave;                /* [T x A]                                                        */
+  const isac_c64* d_tx_grid;                /* [n_sc x L x A]                                                 */
+  isac_c64* d_echo_grid;                    /* [n_sc x L x A], or NULL: lazy                                  */
+  const isac_radar_channel_params* rp;      /* this cell's link budget / steering vectors                     */
+  const uint8_t* los;                       /* [rp->n_targets]                                                */
+  const isac_c64* d_noise_unit;             /* injected noise modes only                                      */
+  uint64_t seed;
+  int32_t noise_mode, reserved;
+} isac_sensing_job;
+int isac_sensing_submit_n(isac_ctx* const* ctxs, int32_t n, const isac_sensing_job* jobs, int64_t T, int32_t tx_dim_l, const isac_carrier* carrier,
+                          const isac_est_params* ep, const isac_cfar_config* cfar, double pace_us, int32_t* status);
+int isac_sensing_collect_n(isac_ctx* const* ctxs, int32_t n, isac_est_result* out, int32_t* status);
 
 /* Range stage of fft2D alone (fft2D.m:37-45: conj-multiply, Kaiser window, nIFFT-point IFFT per
  * (symbol, antenna) column, CUT-row selection, range-axis window).  One kernel launch on the

@@ -6,6 +6,8 @@
  *                                       results of both written to <out.bin> for the Python test to compare with the golden fixture.
  *   abi_host time  <A> <reps>           full-size timing (K = 3276, L = 224, T = 983 040): host-pointer CPI (PCIe inclusive) beside the
  *                                       device-resident CPI, printed as one JSON line.
+ *   abi_host batch <A> <n_ctx> <reps>   isac_sensing_submit_n / isac_sensing_collect_n: n_ctx cells' (monoStaticSensing -> fft2D) pairs per call pair, lazy echo grids, from this
+ *                                       plain-C loop -- sensing slots/s of the host a MEX gateway would be (no interpreter in the loop), and the single-call results beside it.
  * File format (little endian): see tests/test_gpu_abi_host.py.  No torch, no Python, no C++: the ABI needs nothing but this header. */
 #include <math.h>
 #include <stdint.h>
@@ -161,10 +163,102 @@ static int timing(int A, int reps) {
   return 0;
 }
 
+static int batch(int A, int n_ctx, int reps) {
+  const int K = 3276, L = 224, Q = 1;
+  if (n_ctx < 1 || n_ctx > 16) return 1;
+  isac_carrier car = {K, 4096, 30, 0};
+  int64_t T = 0;
+  CHECK(isac_ofdm_waveform_length(&car, L, &T));
+  const size_t nw = (size_t)T * A, ng = (size_t)K * L * A;
+  isac_ctx* cs[16];
+  void *d_grid[16], *d_wave[16];
+  cs[0] = ctx;
+  for (int i = 1; i < n_ctx; ++i) if (isac_ctx_create(0, &cs[i]) != ISAC_OK) return 1;
+  const double amp = pow(10.0, (46.0 - 30.0) / 20.0) * sqrt(4096.0 * 4096.0 / ((double)K * A));
+  for (int i = 0; i < n_ctx; ++i) {                                                /* every cell its own transmit grid / waveform */
+    CHECK(isac_dev_alloc(ctx, sizeof(isac_c64) * ng, &d_grid[i]));
+    CHECK(isac_dev_alloc(ctx, sizeof(isac_c64) * nw, &d_wave[i]));
+    CHECK(isac_synth_qpsk_grid_dev(ctx, d_grid[i], K, L, A, 0x5EED0001ull + 1000ull * i, 1));
+    CHECK(isac_ofdm_modulate_dev(ctx, d_grid[i], L, A, &car, amp, d_wave[i], T));
+  }
+  CHECK(isac_sync(ctx));
+  double range = sqrt(100.0 * 100.0 + 20.0 * 20.0 + 28.5 * 28.5), vel = 7.0, lsf = 3.0e-6;
+  isac_c64* steer = malloc(sizeof(isac_c64) * (size_t)A);
+  const double sn = sin(atan2(20.0, 100.0));
+  for (int m = 0; m < A; ++m) { const double ph = -2.0 * M_PI * m * 0.5 * sn; steer[m].re = cos(ph); steer[m].im = sin(ph); }
+  uint8_t los = 1;
+  isac_radar_channel_params rp = {3.5e9, 122.88e6, 1.958675465085905e-12, A, Q, &range, &vel, &lsf, steer};
+  isac_est_params ep;
+  memset(&ep, 0, sizeof(ep));
+  ep.n_ifft = 4096; ep.n_fft = 256; ep.r_res = 1.2198586344401041; ep.v_res = 4.5621831158455395;
+  ep.azimuth_scan_scale = 360; ep.azimuth_scan_granularity = 1; ep.elevation_scan_scale = 180; ep.elevation_scan_granularity = 1;
+  isac_cfar_config cf = {1e-9, {2, 2}, {1, 1}, 42, 411, 118, 140};
+  isac_sensing_job jobs[16];
+  int32_t status[16];
+  isac_est_result* out = malloc(sizeof(isac_est_result) * (size_t)n_ctx);
+  isac_est_result single;
+  for (int i = 0; i < n_ctx; ++i) {
+    memset(&jobs[i], 0, sizeof(jobs[i]));
+    jobs[i].d_tx_wave = d_wave[i]; jobs[i].d_tx_grid = d_grid[i]; jobs[i].d_echo_grid = NULL; jobs[i].rp = &rp; jobs[i].los = &los;
+    jobs[i].noise_mode = ISAC_NOISE_PHILOX_SPECTRAL; jobs[i].seed = 100 + i;
+  }
+  /* ---- the batch against the single calls on the same inputs and seeds: same estimates */
+  CHECK(isac_sensing_submit_n(cs, n_ctx, jobs, T, L, &car, &ep, &cf, 0.0, status));
+  CHECK(isac_sensing_collect_n(cs, n_ctx, out, status));
+  int same = 1;
+  for (int i = 0; i < n_ctx; ++i) {
+    int32_t lo = 0;
+    CHECK(isac_mono_static_sensing_fused_dev(cs[i], d_wave[i], T, L, &car, &rp, &los, ISAC_NOISE_PHILOX_SPECTRAL, NULL, 100 + i, NULL, &lo, &ep, &cf, d_grid[i]));
+    CHECK(isac_fft2d_submit_cached_dev(cs[i], &ep, &cf, NULL, d_grid[i], K, lo, A));
+    const int st = isac_fft2d_collect(cs[i], &single);
+    same &= (st == status[i]) && single.n_rng == out[i].n_rng && single.n_vel == out[i].n_vel && single.n_azi == out[i].n_azi &&
+            !memcmp(single.rng_est, out[i].rng_est, sizeof(double) * (size_t)single.n_rng) && !memcmp(single.azi_est, out[i].azi_est, sizeof(double) * (size_t)single.n_azi);
+  }
+  /* ---- steady rate: every pass submits n_ctx jobs and collects them; a second set of contexts would hide the collect, but a MATLAB host has one thread */
+  for (int r = 0; r < 30; ++r) { CHECK(isac_sensing_submit_n(cs, n_ctx, jobs, T, L, &car, &ep, &cf, 0.0, status)); CHECK(isac_sensing_collect_n(cs, n_ctx, out, status)); }
+  /* (two half-batches in ping-pong when there are at least two contexts: one half is being collected / re-submitted while the other runs -- a single-threaded host keeps the GPU fed) */
+  const int h = n_ctx >= 2 ? n_ctx / 2 : n_ctx, h2 = n_ctx - h;
+  double t0 = now_ms();
+  long long done = 0;
+  if (h2 > 0) CHECK(isac_sensing_submit_n(cs, h, jobs, T, L, &car, &ep, &cf, 0.0, status));
+  for (int r = 0; r < reps; ++r) {
+    for (int i = 0; i < n_ctx; ++i) jobs[i].seed = 1000 + (uint64_t)r * 16 + i;
+    if (h2 > 0) {
+      CHECK(isac_sensing_submit_n(cs + h, h2, jobs + h, T, L, &car, &ep, &cf, 0.0, status + h));
+      CHECK(isac_sensing_collect_n(cs, h, out, status));
+      CHECK(isac_sensing_submit_n(cs, h, jobs, T, L, &car, &ep, &cf, 0.0, status));
+      CHECK(isac_sensing_collect_n(cs + h, h2, out + h, status + h));
+    } else {
+      CHECK(isac_sensing_submit_n(cs, n_ctx, jobs, T, L, &car, &ep, &cf, 0.0, status));
+      CHECK(isac_sensing_collect_n(cs, n_ctx, out, status));
+    }
+    done += n_ctx;
+  }
+  if (h2 > 0) { CHECK(isac_sensing_collect_n(cs, h, out, status)); done += h; }
+  const double ms_batch = (now_ms() - t0) / (double)done;
+  /* the same work as single blocking call pairs from this C loop (one CPI in flight) */
+  t0 = now_ms();
+  for (int r = 0; r < reps; ++r) {
+    int32_t lo = 0;
+    CHECK(isac_mono_static_sensing_fused_dev(ctx, d_wave[0], T, L, &car, &rp, &los, ISAC_NOISE_PHILOX_SPECTRAL, NULL, 5000 + r, NULL, &lo, &ep, &cf, d_grid[0]));
+    CHECK(isac_fft2d_submit_cached_dev(ctx, &ep, &cf, NULL, d_grid[0], K, lo, A));
+    (void)isac_fft2d_collect(ctx, &single);
+  }
+  const double ms_single = (now_ms() - t0) / reps;
+  printf("{\"ants\": %d, \"contexts\": %d, \"reps\": %d, \"batch_ms_per_cpi\": %.4f, \"batch_slots_per_s\": %.1f, \"blocking_single_ms_per_cpi\": %.4f, "
+         "\"blocking_single_slots_per_s\": %.1f, \"batch_equals_single_calls\": %s, \"rngEst0\": %.4f, \"aziEst0\": %.1f}\n",
+         A, n_ctx, reps, ms_batch, 1e3 * (L / 14) / ms_batch, ms_single, 1e3 * (L / 14) / ms_single, same ? "true" : "false",
+         out[0].n_rng ? out[0].rng_est[0] : NAN, out[0].n_azi ? out[0].azi_est[0] : NAN);
+  for (int i = 0; i < n_ctx; ++i) { CHECK(isac_dev_free(ctx, d_grid[i])); CHECK(isac_dev_free(ctx, d_wave[i])); }
+  for (int i = 1; i < n_ctx; ++i) isac_ctx_destroy(cs[i]);
+  return same ? 0 : 7;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: abi_host chain <in> <out> | time <A> <reps>\n"); return 1; }
+  if (argc < 2) { fprintf(stderr, "usage: abi_host chain <in> <out> | time <A> <reps> | batch <A> <n_ctx> <reps>\n"); return 1; }
   if (isac_abi_version() != ISAC_ABI_VERSION || isac_abi_sizeof(ISAC_SIZEOF_EST_RESULT) != (int)sizeof(isac_est_result) ||
-      isac_abi_sizeof(ISAC_SIZEOF_EST_PARAMS) != (int)sizeof(isac_est_params) || isac_abi_sizeof(ISAC_SIZEOF_CFAR_CONFIG) != (int)sizeof(isac_cfar_config)) {
+      isac_abi_sizeof(ISAC_SIZEOF_EST_PARAMS) != (int)sizeof(isac_est_params) || isac_abi_sizeof(ISAC_SIZEOF_CFAR_CONFIG) != (int)sizeof(isac_cfar_config) ||
+      isac_abi_sizeof(ISAC_SIZEOF_SENSING_JOB) != (int)sizeof(isac_sensing_job)) {
     fprintf(stderr, "ABI version / struct size mismatch\n"); return 1;
   }
   const char* dev = getenv("ISAC_DEVICE");
@@ -172,6 +266,7 @@ int main(int argc, char** argv) {
   int rc = 1;
   if (!strcmp(argv[1], "chain") && argc >= 4) rc = chain(argv[2], argv[3]);
   else if (!strcmp(argv[1], "time") && argc >= 4) rc = timing(atoi(argv[2]), atoi(argv[3]));
+  else if (!strcmp(argv[1], "batch") && argc >= 5) rc = batch(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
   isac_ctx_destroy(ctx);
   return rc;
 }

@@ -85,6 +85,54 @@ def test_c_host_pointer_path_timing_beside_device_resident():
     assert 90.0 < res["rngEst0"] < 120.0
 
 
+@pytest.mark.parametrize("ants,n_ctx", [(16, 8), (64, 8)])
+def test_c_host_batched_submit(ants, n_ctx):
+    """isac_sensing_submit_n / isac_sensing_collect_n from the plain-C host: n_ctx cells' (monoStaticSensing -> fft2D) pairs per call pair with lazy echo grids -- the same
+    estimates as the single call pairs on the same inputs and seeds, and the rate a host without an interpreter in its loop reaches (A = 16 is the reference's default
+    array, ula.m:45: per-cell Python calls were host-bound at 62 k slots/s in round 5)."""
+    r = subprocess.run([_exe(), "batch", str(ants), str(n_ctx), "60"], capture_output=True, text=True, timeout=600, env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print("abi_host batch:", json.dumps(res))
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, f"r06_abi_host_batch_a{ants}.json"), "w") as f:
+            json.dump(res, f)
+    assert res["batch_equals_single_calls"] is True
+    assert res["batch_slots_per_s"] > res["blocking_single_slots_per_s"]
+    assert 90.0 < res["rngEst0"] < 120.0
+
+
+def test_submit_n_python_mirror_matches_single_calls():
+    """sensing.submitN / SensingBatch.collect (the Python face of the same two entry points): four cells on four contexts, lazy echo grids and caller-owned ones, one cell with
+    every target blocked (its status is NO_LOS, the others are unaffected) -- results equal the per-cell calls."""
+    from conftest import load_pkg
+    pkg = load_pkg()
+    scs = [make_scene(n_ants=a, n_slots=2, nrb=273, targets=((100.0 + 10 * i, 20.0, 1.5),), velocity=(7.0,), seed=60 + i, zero_s_slots=False, with_noise=False)
+           for i, a in enumerate((64, 64, 64, 64))]
+    ctxs = [pkg.Context() for _ in scs]
+    rps = [pkg.sensing.radarParams(sc.cell, sc.carrier, sc.wave) for sc in scs]
+    cf = pkg.sensing.detection.cfar2D(rps[0])
+    waves = [c.to_device(sc.tx_wave) for c, sc in zip(ctxs, scs)]
+    grids = [c.to_device(sc.tx_grid) for c, sc in zip(ctxs, scs)]
+    los = [np.ones(1, np.uint8), np.ones(1, np.uint8), np.zeros(1, np.uint8), np.ones(1, np.uint8)]
+    echo = [None, ctxs[1].empty(scs[1].tx_grid.shape), None, None]
+    batch = pkg.sensing.submitN(ctxs, waves, grids, scs[0].tx_grid.shape, scs[0].carrier, rps, los, cf, seeds=[11, 12, 13, 14], nfft=4096, echoGrids=echo)
+    res = batch.collect()
+    assert isinstance(res[2], pkg.IsacError) and res[2].name == "NO_LOS"
+    for i in (0, 1, 3):
+        lz = pkg.sensing.monoStaticSensing(waves[i], scs[i].tx_grid.shape, scs[i].carrier, rps[i], los[i], nfft=4096, fuse_fft2d=(rps[i], cf, grids[i]), ctx=ctxs[i],
+                                           lazy=True, seed=11 + i, noise_domain="spectral")
+        try:
+            want = pkg.sensing.estimation.fft2D(rps[i], cf, lz, grids[i], reuse_range=True)
+        except pkg.IsacError as e:
+            assert isinstance(res[i], pkg.IsacError) and res[i].name == e.name
+            continue
+        assert np.array_equal(res[i].rngEst, want.rngEst) and np.array_equal(res[i].velEst, want.velEst) and np.array_equal(res[i].aziEst, want.aziEst)
+    for c in ctxs:
+        c.close()
+
+
 def test_graft_entry_smoke_runs():
     """The driver's own entry point: __graft_entry__.smoke() end to end (it is not otherwise part of the test suite)."""
     import __graft_entry__ as g
