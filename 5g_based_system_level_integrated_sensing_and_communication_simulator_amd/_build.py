@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libisac_hip.so")
-SOURCES = ["capi.hip", "echo.hip", "rdm.hip", "music.hip", "cdl.hip", "cqi.hip", "los.hip"]
+SOURCES = ["capi.hip", "echo.hip", "rdm.hip", "music.hip", "cdl.hip", "cdl_os.hip", "cqi.hip", "los.hip"]
 HEADERS = ["isac_common.hpp", "fft_lds.hpp", "echo_dev.hpp", os.path.join("..", "..", "include", "isac.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",

@@ -974,6 +974,13 @@ int launch_fused_ul(isac_ctx* ctx, const std::vector<CdlSeg>& segs, long long T,
   return ISAC_OK;
 }
 
+}  // namespace
+// cdl_os.hip: the downlink apply in the frequency domain (overlap-save, 4096-point windows) for long waveforms into two receive elements
+bool cdl_os_ok(long long T, int Nt, int Nr, int n_paths, int n_taps, int max_shift);
+int cdl_os_apply(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long T, int Nt, int Nr, int n_paths, const double* taps, int n_taps, const int32_t* shift, int max_shift,
+                 double out_scale);
+namespace {
+
 int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long T, int Nt, int Nr, int n_paths, const double* taps, int n_taps,
                    const int32_t* shift, double out_scale) {
   if (!jobs || !taps || !shift) return fail(ctx, ISAC_ERR_INVALID_ARG, "NULL argument");
@@ -997,6 +1004,8 @@ int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long lon
     ctx->range_cache.touch(jobs[j].d_y, sizeof(c64) * (size_t)T * Nr);   // an output that overlaps a cached grid drops the cached range rows
   }
   if (n_seg_total > 65535) return fail(ctx, ISAC_ERR_CAPACITY, "more than 65535 (job, gain block) segments in one batch");
+  if (!ul && cdl_os_ok(T, Nt, Nr, n_paths, n_taps, max_shift))      // long downlink waveforms: overlap-save in the frequency domain (cdl_os.hip), the waveform's transforms shared by its UEs
+    return cdl_os_apply(ctx, jobs, n_jobs, T, Nt, Nr, n_paths, taps, n_taps, shift, max_shift, out_scale);
   // workspace: DL (unfused kernels only): Z [T x Ncp] per segment;  UL: prefiltered signals [T x Kc] per job;  fused DL: none
   const bool fused = !ul && cdl_fused_ok(T, Nt, Nr, n_paths, n_taps, max_shift), fused_ul = ul && cdl_fused_ul_ok(T, Nt, Nr, n_paths, n_taps, max_shift);
   const size_t ws_elems = (fused || fused_ul) ? 0 : ul ? (size_t)n_jobs * (size_t)T * Kc : n_seg_total * (size_t)T * Ncp;

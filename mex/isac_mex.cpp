@@ -241,8 +241,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     int L = 0;
     check(isac_ofdm_symbol_count(&c, T, &L));
     const mwSize Lo = (mwSize)std::max(L, want);
+    // 13th argument (Fused only) true: LAZY echo grid -- nothing is allocated or written, the grid stays inside the context (include/isac.h 'LAZY echo grid'); the handle
+    // returned is uint64(0), which the next 'fft2D' call accepts as rxGrid and 'materializeEcho' turns into a real array handle
+    const bool lazy = fn == "monoStaticSensingFused" && nrhs > 12 && !mxIsEmpty(prhs[12]) && mxGetScalar(prhs[12]) != 0.0;
     void* d_echo = nullptr;
-    check(isac_dev_alloc(ctx(), sizeof(isac_c64) * c.n_sc * Lo * A, &d_echo));
+    if (!lazy) check(isac_dev_alloc(ctx(), sizeof(isac_c64) * c.n_sc * Lo * A, &d_echo));
     struct Guard { void* p; ~Guard() { if (p) isac_dev_free(g_ctx, p); } } guard{d_echo};
     const isac_c64* d_nz = nullptr;
     DevIn* nz_in = noise ? new DevIn(noise) : nullptr;
@@ -262,7 +265,22 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     delete nz_in;
     check(st);
     guard.p = nullptr;
+    if (lazy) {
+      plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);       // uint64(0): "the context's lazy echo grid"
+      *mxGetUint64s(plhs[0]) = 0;
+      return;
+    }
     plhs[0] = make_handle(d_echo, (mwSize)c.n_sc, Lo, A, true);
+  } else if (fn == "materializeEcho") {
+    // h = isac_mex('materializeEcho'): the lazy echo grid of the last 'monoStaticSensingFused'(..., true) call as a device array handle (isac_echo_grid_materialize_dev)
+    int32_t d3[3] = {0, 0, 0};
+    check(isac_echo_grid_materialize_dev(ctx(), nullptr, d3));
+    void* d_echo = nullptr;
+    check(isac_dev_alloc(ctx(), sizeof(isac_c64) * (size_t)d3[0] * d3[1] * d3[2], &d_echo));
+    int st = isac_echo_grid_materialize_dev(ctx(), (isac_c64*)d_echo, d3);
+    if (st == ISAC_OK) st = isac_sync(ctx());
+    if (st != ISAC_OK) { isac_dev_free(ctx(), d_echo); check(st); }
+    plhs[0] = make_handle(d_echo, (mwSize)d3[0], (mwSize)d3[1], (mwSize)d3[2], true);
   // ------------------------------------------------------------------ estimation
   } else if (fn == "fft2D" || fn == "music2D") {
     // fft2D:   (radarEstParams, cfar, rxGrid | handle, txGrid | handle)                            fft2D.m:1
@@ -276,6 +294,16 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       isac_cfar_config c = cfar_block(arg2);
       g_fused_pending = false;
       check(isac_fft2d(ctx(), &e, &c, cplx(rx), cplx(txg), (int)d[0], (int)d[1], (int)d[2], &r));
+      plhs[0] = est_struct(r);
+      return;
+    }
+    if (fn == "fft2D" && is_handle(rx) && *mxGetUint64s(rx) == 0) {   // uint64(0): the context's lazy echo grid (monoStaticSensingFused(..., true))
+      if (!g_fused_pending || !is_handle(txg)) mexErrMsgIdAndTxt("isac:INVALID_ARG", "fft2D: a lazy echo grid is consumed once, right after the fused call that made it, with txGrid as a handle");
+      g_fused_pending = false;
+      DevArray& t = lookup(txg);
+      isac_cfar_config c = cfar_block(arg2);
+      check(isac_fft2d_submit_cached_dev(ctx(), &e, &c, nullptr, (const isac_c64*)t.p, (int)t.dims[0], (int)t.dims[1], (int)t.dims[2]));
+      check(isac_fft2d_collect(ctx(), &r));
       plhs[0] = est_struct(r);
       return;
     }

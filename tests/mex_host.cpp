@@ -163,6 +163,17 @@ int chain(const char* in, const char* out) {
   mxArray* est3 = call("fft2D", {rp, cfar, h_echo3, h_grid})[0];
   mxArray* echo3 = call("gather", {h_echo3})[0];
   write_est(o, echo3, est3);
+  // (3b) the same with a LAZY echo grid (13th argument): uint64(0) comes back, fft2D takes it, 'materializeEcho' gives the array -- same estimates, same grid
+  {
+    mxArray* one = mxCreateDoubleScalar(1.0);
+    mxArray* h_lazy = call("monoStaticSensingFused", {h_wave, dim, car, rp, m_los, h_noise, none, s_time, rp, cfar, h_grid, one})[0];
+    if (*mxGetUint64s(h_lazy) != 0) { std::fprintf(stderr, "lazy fused call did not return the zero handle\n"); return 9; }
+    mxArray* h_mat = call("materializeEcho", {})[0];
+    mxArray* est3b = call("fft2D", {rp, cfar, h_lazy, h_grid})[0];
+    mxArray* echo3b = call("gather", {h_mat})[0];
+    write_est(o, echo3b, est3b);
+    call("free", {h_mat});
+  }
   // (4) DoA entries on the covariance of the echo grid (fft2D.m:106-107 formed here on the host): music must repeat fft2D's azimuths
   const size_t N = (size_t)h.K * h.L;
   mxArray* ra = mxCreateDoubleMatrix(h.A, h.A, mxCOMPLEX);

@@ -77,6 +77,33 @@ def test_cdl_batch_at_config5_shape_matches_oracle(pkg, profile, uplink, n_ue):
         assert ch.time == pytest.approx(t + 2 * T / FS)
 
 
+@pytest.mark.parametrize("profile,tx,fs,t_len,n_ue", [("CDL-A", (1, 4, 2, 1, 1), 122.88e6, 9000, 3), ("CDL-D", (1, 8, 2, 1, 1), 30.72e6, 20011, 2), ("CDL-A", (2, 8, 2, 1, 1), 61.44e6, 12345, 9),
+                                                       ("CDL-D", (4, 8, 2, 1, 1), 122.88e6, 8192, 1)])
+def test_cdl_overlap_save_shapes_match_oracle(pkg, profile, tx, fs, t_len, n_ue):
+    """The frequency-domain downlink apply (cdl_os.hip: 4096-point overlap-save, the waveform's transforms shared by its UEs) at 8 / 16 / 32 / 64 transmit elements, ragged
+    lengths (the last window mostly zeros), nine UEs on one waveform (two mix chunks), every UE next to a path-gain refresh (two gain blocks: two (job, block) pairs whose
+    windows overlap at the boundary) -- every output sample <= 1e-10 of the oracle."""
+    import oracle.cdl as OC
+    CM = pkg.communication.channelModels
+    ctx = pkg.default_context()
+    nt = int(np.prod(tx))
+    refresh = 1.0 / 640
+    rng = np.random.default_rng(nt + t_len)
+    x = np.asfortranarray(rng.standard_normal((t_len, nt)) + 1j * rng.standard_normal((t_len, nt)))
+    d_x = ctx.to_device(x)
+    chans, t_start = [], []
+    for u in range(n_ue):
+        ch = CM.CDLChannel(profile, 300e-9, 3.5e9, tx, UE, fs, Seed=73 + (u % 3))
+        t0 = (2 + u) * refresh - (1 + (u * t_len) // max(n_ue, 1) % t_len) / fs if u % 2 == 0 else 0.01 * u
+        ch.time = t0
+        chans.append(ch); t_start.append(t0)
+    outs = CM.applyCDLBatch(chans, [d_x] * n_ue, ctx=ctx)
+    for u, (ch, o) in enumerate(zip(chans, outs)):
+        cfg = OC.cdl_config(profile, 3.5e9, tx, UE, fs, seed=73 + (u % 3))
+        want = OC.apply_cdl(cfg, x, t_start[u])
+        assert rel(o.numpy(), want) < RTOL, (profile, tx, u)
+
+
 def test_bench_config5_frame_against_oracle(pkg):
     """bench.py's CommCell (the object `--workload config5` times) stepped for one frame: (a) the precoded PDSCH input of a downlink slot = oracle prgPrecode of the
     same layers and precoders + the oracle's CP-OFDM modulator; (b) one downlink job of the frame's last call (UE, slot 15) and (c) one uplink job (UE, third 'U' slot:

@@ -66,7 +66,7 @@ def test_mex_gateway_runs_the_reference_call_sequences(tmp_path):
     buf = open(fout, "rb").read()
     off = 0
     echo1 = None
-    for path in ("MATLAB arrays", "device handles", "fused entry + cached fft2D"):
+    for path in ("MATLAB arrays", "device handles", "fused entry + cached fft2D", "fused entry with a LAZY echo grid + materializeEcho"):
         echo, (rng, vel, azi), off = _est(buf, off)
         echo = echo.reshape((sc.K, sc.L, sc.A), order="F")
         echo1 = echo if echo1 is None else echo1

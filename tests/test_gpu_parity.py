@@ -726,7 +726,8 @@ def test_cdl_fused_apply_bits_do_not_depend_on_the_grid(tmp_path):
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     runs = {}
-    for tag, extra in (("cu", {}), ("one", {"ISAC_CDL_FUSED_WGS": "1"}), ("seven", {"ISAC_CDL_FUSED_WGS": "7"}), ("unfused", {"ISAC_CDL_UNFUSED": "1"})):
+    td = {"ISAC_CDL_TIME_DOMAIN": "1"}            # (round 6: long downlink waveforms take the overlap-save path by default -- this test is about the time-domain kernels; "os" = the default)
+    for tag, extra in (("cu", td), ("one", dict(td, ISAC_CDL_FUSED_WGS="1")), ("seven", dict(td, ISAC_CDL_FUSED_WGS="7")), ("unfused", dict(td, ISAC_CDL_UNFUSED="1")), ("os", {})):
         r = subprocess.run([sys.executable, "-c", _CDL_FUSED_SNIPPET % (root, PKG_NAME), str(tmp_path / tag)], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         runs[tag] = [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("digest")]
@@ -738,6 +739,12 @@ def test_cdl_fused_apply_bits_do_not_depend_on_the_grid(tmp_path):
         if f.startswith("cu_"):
             a, b = np.load(tmp_path / f), np.load(tmp_path / f.replace("cu_", "unfused_"))
             assert rel(a, b) < 1e-12, f
+            c = np.load(tmp_path / f.replace("cu_", "os_"))          # frequency-domain overlap-save apply (cdl_os.hip) where the shape qualifies, the same kernels elsewhere
+            assert rel(c, a) < 1e-12, f
+    assert runs["os"][0] != runs["cu"][0] and runs["os"][2] != runs["cu"][2]      # 64 and 16 transmit elements, T >= two windows: really another code path
+    assert runs["os"][4:] == runs["cu"][4:]                                        # 6 transmit elements / uplink: the time-domain kernels either way
+    for i in range(0, 10, 2):
+        assert runs["os"][i][1:] == runs["os"][i + 1][1:]                          # overlap-save: a job alone == the job in a batch, bit for bit
 
 
 # ------------------------------------------------------------------ SINR -> CQI

@@ -21,7 +21,7 @@ open(p, "w").write(s)
 PY
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wno-unused-function -Wno-unused-variable -Wno-unused-value -Wno-unused-result -ffp-contract=on"
 cd $W/pkg/csrc
-for f in capi echo rdm music cdl cqi los; do /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $f.o & done; wait
+for f in capi echo rdm music cdl cdl_os cqi los; do /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $f.o & done; wait
 mkdir -p $ROOT/tools/_ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/_ab/libisac_hip_prefix.so *.o -Wl,-soname,libisac_hip.so -Wl,--no-undefined
 echo built tools/_ab/libisac_hip_prefix.so
