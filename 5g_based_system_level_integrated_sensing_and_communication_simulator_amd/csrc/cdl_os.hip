@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void cdl_os_table_kernel(const double* __restr
 
 // K1: forward transforms of the windows of every distinct waveform.  Window j of a waveform covers samples [j S - Mpad, j S - Mpad + N) (zero outside [0, T)).
 __global__ __launch_bounds__(256, 2) void cdl_os_fwd_kernel(const c64* const* __restrict__ waves, long long T, int Nt, int n_seg, int S, int Mpad, const c64* __restrict__ tw,
-                                                            c64* __restrict__ Xf /* [wave][seg][s][N] */) {
+                                                            c64* __restrict__ Xf /* [wave][seg][8-bin tile][s][8]: a mix workgroup's tile of a window is ONE contiguous run */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);
   const int tid = threadIdx.x;
@@ -75,8 +75,9 @@ __global__ __launch_bounds__(256, 2) void cdl_os_fwd_kernel(const c64* const* __
   }, tid);
   fft.init(lds, tw, tid);
   fft.template transform<-1>(lds, tw, tid);
-  c64* dst = Xf + (((long long)w * n_seg + seg) * Nt + s) * kOsN;
-  fft.drain([&](int k, c64 v) { dst[k] = v; }, tid);
+  // (the first layout, [seg][s][f], made every mix workgroup gather its [Nt x 8] tile from Nt cache lines 64 KB apart: 1.28 ms per 40-job launch)
+  c64* dst = Xf + ((long long)w * n_seg + seg) * Nt * kOsN + (long long)s * kOsBins;
+  fft.drain([&](int k, c64 v) { dst[(long long)(k >> 3) * Nt * kOsBins + (k & 7)] = v; }, tid);
 }
 
 // K2: thread (f = tid & 7, half = (tid >> 3) & 1, u = (tid >> 4) & 1, pair = tid >> 5) keeps C(f)[s][u] of ITS pair for the HS = Nt / 2 transmit elements of its half in registers;
@@ -85,46 +86,73 @@ template <int HS>
 __global__ __launch_bounds__(256) void cdl_os_mix_kernel(const OsPair* __restrict__ pairs, const OsChunk* __restrict__ chunks, const c64* __restrict__ Xf,
                                                          const c64* __restrict__ E, int n_paths, int n_seg, c64* __restrict__ Yf /* [task][u][N] */) {
   constexpr int Nt = 2 * HS, Nr = 2;
-  __shared__ __attribute__((aligned(16))) c64 xs[2][Nt * kOsBins];
+  constexpr int XB = 2;                                          // X tiles in flight: one window ahead (four -- three ahead -- cost a resident workgroup per CU: 749 -> 885 us per 40-job launch)
+  __shared__ __attribute__((aligned(16))) c64 xs[XB][Nt * kOsBins];
   const int tid = threadIdx.x;
   const int f = tid & 7, half = (tid >> 3) & 1, u = (tid >> 4) & 1, pl = tid >> 5;
   const int tile = blockIdx.x, f0 = tile * kOsBins;
   const OsChunk ch = chunks[blockIdx.y];
   const bool live = pl < ch.n_pairs;
   const OsPair pr = pairs[ch.pair0 + (live ? pl : 0)];
-  // ---- C(f)[s][u] = sum_n H[n][s][u] E_n(f) for s in this thread's half
+  // ---- C(f)[s][u] = sum_n H[n][s][u] E_n(f) for s in this thread's half.  The path gains of the workgroup's pairs go through LDS one path at a time (coalesced 2 KB runs,
+  // double buffered): read straight from memory they were 736 sixteen-byte gathers per thread with eight distinct addresses per wavefront -- the texture path of the CU, not the
+  // arithmetic, set the pace (1.1 ms per 40-job launch).
+  __shared__ __attribute__((aligned(16))) c64 hs[2][kOsPairs * Nt * Nr];
+  __shared__ const c64* hp[kOsPairs];
+  if (tid < kOsPairs) hp[tid] = tid < ch.n_pairs ? pairs[ch.pair0 + tid].H : nullptr;
+  __syncthreads();
+  auto stage_h = [&](int n, int buf) {
+#pragma unroll
+    for (int r = 0; r < (kOsPairs * Nt * Nr + 255) / 256; ++r) {
+      const int e = tid + 256 * r, p = e / (Nt * Nr), idx = e % (Nt * Nr);
+      if (e < kOsPairs * Nt * Nr) hs[buf][e] = hp[p] ? hp[p][(long long)n * Nt * Nr + idx] : mk(0.0, 0.0);
+    }
+  };
   c64 C[HS];
 #pragma unroll
   for (int i = 0; i < HS; ++i) C[i] = mk(0.0, 0.0);
-  const c64* Hh = pr.H + (long long)(half * HS) * Nr + u;
+  stage_h(0, 0);
+  __syncthreads();
   for (int n = 0; n < n_paths; ++n) {
+    if (n + 1 < n_paths) stage_h(n + 1, (n + 1) & 1);
     const c64 e = E[(long long)n * kOsN + f0 + f];
-    const c64* hn = Hh + (long long)n * Nt * Nr;
+    const c64* hn = hs[n & 1] + (pl * Nt + half * HS) * Nr + u;
 #pragma unroll
     for (int i = 0; i < HS; ++i) C[i] = fma(hn[i * Nr], e, C[i]);
+    __syncthreads();
   }
   // ---- windows
-  const c64* Xw = Xf + (long long)ch.w * n_seg * Nt * kOsN + f0;
+  const c64* Xw = Xf + (long long)ch.w * n_seg * Nt * kOsN + (long long)tile * Nt * kOsBins;
   auto stage = [&](int seg, int buf) {
 #pragma unroll
     for (int r = 0; r < (Nt * kOsBins + 255) / 256; ++r) {
       const int e = tid + 256 * r;
-      if (e < Nt * kOsBins) xs[buf][e] = Xw[((long long)seg * Nt + (e >> 3)) * kOsN + (e & 7)];
+      if (e < Nt * kOsBins) xs[buf][e] = Xw[(long long)seg * Nt * kOsN + e];
     }
   };
   // the windows any pair of this chunk needs: [lo, hi] of the chunk (pairs of one waveform; usually all of them)
   int lo = n_seg, hi = -1;
   for (int p = 0; p < ch.n_pairs; ++p) { lo = min(lo, pairs[ch.pair0 + p].seg_lo); hi = max(hi, pairs[ch.pair0 + p].seg_hi); }
   if (hi < lo) return;
-  stage(lo, 0);
+#pragma unroll
+  for (int a_ = 0; a_ < XB - 1; ++a_)
+    if (lo + a_ <= hi) stage(lo + a_, a_);
   __syncthreads();
   for (int seg = lo; seg <= hi; ++seg) {
-    const int buf = (seg - lo) & 1;
-    if (seg < hi) stage(seg + 1, buf ^ 1);                       // the next window's tile under this window's sums
+    const int buf = (seg - lo) % XB;
+    if (seg + XB - 1 <= hi) stage(seg + XB - 1, (seg - lo + XB - 1) % XB);     // XB - 1 windows ahead (the buffer freed by the barrier at the end of the previous iteration)
     c64 acc = mk(0.0, 0.0);
     const c64* xb = xs[buf] + (half * HS) * kOsBins + f;
+    {
+      constexpr int NA = HS >= 4 ? 4 : 1;                         // four partial sums: a single chain of HS dependent complex multiply-adds leaves the fp64 pipe waiting on itself
+      c64 part[NA];
 #pragma unroll
-    for (int i = 0; i < HS; ++i) acc = fma(C[i], xb[i * kOsBins], acc);
+      for (int a_ = 0; a_ < NA; ++a_) part[a_] = mk(0.0, 0.0);
+#pragma unroll
+      for (int i = 0; i < HS; ++i) part[i % NA] = fma(C[i], xb[i * kOsBins], part[i % NA]);
+#pragma unroll
+      for (int a_ = 0; a_ < NA; ++a_) acc = acc + part[a_];
+    }
     // the two halves of the transmit array: lanes tid and tid ^ 8 (same wavefront)
     acc.re += __shfl_xor(acc.re, 8);
     acc.im += __shfl_xor(acc.im, 8);
