@@ -71,7 +71,15 @@ ISAC_MAX_SUBBANDS = 70
 class CsiReport(C.Structure):
     _fields_ = [("n_subbands_pmi", C.c_int32), ("n_subbands_cqi", C.c_int32), ("n_cqi", C.c_int32), ("reserved", C.c_int32),
                 ("i1", C.c_double * 3), ("i2", C.c_double * ISAC_MAX_SUBBANDS), ("cqi", C.c_double * (ISAC_MAX_SUBBANDS + 1)),
-                ("subband_cqi", C.c_double * (ISAC_MAX_SUBBANDS + 1)), ("sinr_per_subband_cw", C.c_double * (ISAC_MAX_SUBBANDS + 1))]
+                ("subband_cqi", C.c_double * (ISAC_MAX_SUBBANDS + 1)), ("sinr_per_subband_cw", C.c_double * (ISAC_MAX_SUBBANDS + 1)), ("ri_total_sinr", C.c_double)]
+
+
+ISAC_MAX_RBS = 275
+
+
+class SrsReport(C.Structure):
+    _fields_ = [("n_subbands", C.c_int32), ("n_tpmi", C.c_int32), ("n_rb", C.c_int32), ("reserved", C.c_int32),
+                ("pmi", C.c_double * (ISAC_MAX_SUBBANDS + 1)), ("sinr_subband_pmi", C.c_double * (ISAC_MAX_SUBBANDS + 1)), ("cqi_rb", C.c_double * ISAC_MAX_RBS)]
 
 
 class CdlJob(C.Structure):
@@ -99,7 +107,7 @@ EXPORTS = [
     "isac_mono_static_sensing", "isac_mono_static_sensing_fused_dev", "isac_echo_grid_materialize_dev", "isac_ofdm_symbol_count", "isac_ofdm_demodulate_dev", "isac_ofdm_modulate_dev", "isac_ofdm_modulate_windowed_dev", "isac_sentx_append_dev",
     "isac_ofdm_waveform_length", "isac_cfar2d_ca", "isac_fft2d_dev", "isac_fft2d", "isac_fft2d_submit_dev", "isac_fft2d_submit_cached_dev", "isac_fft2d_collect", "isac_sensing_submit_n", "isac_sensing_collect_n", "isac_fft2d_range_stage_dev", "isac_fft2d_get_detections",
     "isac_fft2d_get_power_window", "isac_fft2d_get_covariance", "isac_fft2d_get_music_spectrum",
-    "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_ctx_set_option", "isac_ctx_share_streams", "isac_ctx_reserve", "isac_eigh_top", "isac_beamscan_doa", "isac_music2d_dev", "isac_eigh", "isac_cdl_apply_dev", "isac_cdl_apply_batch_dev", "isac_cdl_path_gains_dev", "isac_cdl_freq_response_dev", "isac_cdl_csi_estimate_batch_dev", "isac_prg_precode_dev", "isac_precoded_sinr_cqi_dev", "isac_type1sp_codebook", "isac_csi_report_dev", "isac_csi_report_batch_dev", "isac_los_check_dev", "isac_winding_number_dev", "isac_synth_qpsk_grid_dev",
+    "isac_rdm_plane_dev", "isac_covariance_dev", "isac_music_doa", "isac_ctx_set_option", "isac_ctx_share_streams", "isac_ctx_reserve", "isac_eigh_top", "isac_beamscan_doa", "isac_music2d_dev", "isac_eigh", "isac_cdl_apply_dev", "isac_cdl_apply_batch_dev", "isac_cdl_path_gains_dev", "isac_cdl_freq_response_dev", "isac_cdl_csi_estimate_batch_dev", "isac_prg_precode_dev", "isac_precoded_sinr_cqi_dev", "isac_type1sp_codebook", "isac_csi_report_dev", "isac_csi_report_batch_dev", "isac_pusch_codebook", "isac_srs_pmi_select_batch_dev", "isac_los_check_dev", "isac_winding_number_dev", "isac_synth_qpsk_grid_dev",
 ]
 
 
@@ -137,7 +145,7 @@ def load():
             raise RuntimeError(f"{_LIB_PATH}: ABI version {lib.isac_abi_version()} but this binding was written for {ISAC_ABI_VERSION}; rebuild the library")
         for which, (name, cls) in enumerate((("isac_est_result", EstResult), ("isac_est_params", EstParams), ("isac_cfar_config", CfarConfig),
                                              ("isac_radar_channel_params", RadarChannelParams), ("isac_carrier", Carrier),
-                                             ("isac_music2d_params", Music2dParams), ("isac_csi_report", CsiReport), ("isac_sensing_job", SensingJob))):
+                                             ("isac_music2d_params", Music2dParams), ("isac_csi_report", CsiReport), ("isac_sensing_job", SensingJob), ("isac_srs_report", SrsReport))):
             if lib.isac_abi_sizeof(C.c_int32(which)) != C.sizeof(cls):
                 raise RuntimeError(f"{_LIB_PATH}: sizeof({name}) = {lib.isac_abi_sizeof(C.c_int32(which))} in the library, {C.sizeof(cls)} in the binding")
         _lib = lib

@@ -3,3 +3,5 @@ from .precodedSINR import precodedSINR, getCQI, cqiFromChannel, DOWNLINK_SINR90P
 from .senTx import SenTx, nrOFDMModulate, determineSlotType, signalAmp  # noqa: F401,E402
 from .csiReport import cqiSelect, cqiSelectBatch, dlPMISelect, type1SinglePanelCodebook  # noqa: F401,E402
 from .prgPrecode import prgPrecode, prgPrecodeGrid  # noqa: F401,E402
+from .pmiSelect import pmiSelect, srsReportBatch, puschCodebook, maxPUSCHPrecodingMatrixIndicator  # noqa: F401,E402
+from .riSelect import riSelect, riSelectBatch  # noqa: F401,E402

@@ -66,14 +66,15 @@ def cqiSelect(carrier, csirs, reportConfig, nLayers, H, nVar, SINRTable, *, ctx=
     pmi = SimpleNamespace(i1=np.array(rep.i1[:3]), i2=np.array(rep.i2[: rep.n_subbands_pmi]))
     cqi = np.array(rep.cqi[: rep.n_cqi])
     info = SimpleNamespace(SINRPerSubbandPerCW=np.array(rep.sinr_per_subband_cw[: rep.n_cqi]), SubbandCQI=np.array(rep.subband_cqi[: rep.n_cqi]))
-    pinfo = SimpleNamespace(W=w, TotalSINR=tot.reshape(w.shape[2:], order="F"))
+    pinfo = SimpleNamespace(W=w, TotalSINR=tot.reshape(w.shape[2:], order="F"), RITotalSINR=rep.ri_total_sinr)
     return cqi, pmi, info, pinfo
 
 
-def cqiSelectBatch(carrier, csirs, reportConfig, nLayers, H_list, nVar_list, SINRTable, *, ctx=None, codebook=None):
+def cqiSelectBatch(carrier, csirs, reportConfig, nLayers, H_list, nVar_list, SINRTable, *, ctx=None, codebook=None, with_ri_total=False):
     """cqiSelect for many UEs that share the CSI-RS / report configuration (uePhy.m:901-908 runs it once per UE; isac_csi_report_batch_dev runs the
     cell's UEs in one call: one upload, one launch per stage, one synchronisation).  H_list: DeviceArrays [nRE x nRx x P] gathered at the CSI-RS REs;
-    nVar_list: one noise variance per UE.  Returns a list of (CQI, PMISet, CQIInfo) per UE.  `codebook`: W from type1SinglePanelCodebook (built if None)."""
+    nVar_list: one noise variance per UE.  Returns a list of (CQI, PMISet, CQIInfo) per UE -- with_ri_total: (CQI, PMISet, CQIInfo, totalSINR of riSelect.m:253-276 at this rank).
+    `codebook`: W from type1SinglePanelCodebook (built if None)."""
     H_list = list(H_list)
     if not H_list:
         return []
@@ -104,7 +105,7 @@ def cqiSelectBatch(carrier, csirs, reportConfig, nLayers, H_list, nVar_list, SIN
     for rep in reps:
         pmi = SimpleNamespace(i1=np.array(rep.i1[:3]), i2=np.array(rep.i2[: rep.n_subbands_pmi]))
         info = SimpleNamespace(SINRPerSubbandPerCW=np.array(rep.sinr_per_subband_cw[: rep.n_cqi]), SubbandCQI=np.array(rep.subband_cqi[: rep.n_cqi]))
-        out.append((np.array(rep.cqi[: rep.n_cqi]), pmi, info))
+        out.append((np.array(rep.cqi[: rep.n_cqi]), pmi, info) + ((rep.ri_total_sinr,) if with_ri_total else ()))
     return out
 
 

@@ -277,6 +277,7 @@ extern "C" int isac_abi_sizeof(int32_t which) {
     case ISAC_SIZEOF_MUSIC2D_PARAMS: return (int)sizeof(isac_music2d_params);
     case ISAC_SIZEOF_CSI_REPORT: return (int)sizeof(isac_csi_report);
     case ISAC_SIZEOF_SENSING_JOB: return (int)sizeof(isac_sensing_job);
+    case ISAC_SIZEOF_SRS_REPORT: return (int)sizeof(isac_srs_report);
     default: return -1;
   }
 }

@@ -1145,7 +1145,8 @@ extern "C" int isac_cdl_csi_estimate_batch_dev(isac_ctx* ctx, int32_t n_ue, cons
   if (n_ue <= 0 || n_paths <= 0 || n_rays <= 0 || Nt <= 0 || Nr <= 0 || ports <= 0 || ports > Nt || n_re <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad dimensions (ports <= Nt)");
   if (n_ue > 65535) return fail(ctx, ISAC_ERR_CAPACITY, "more than 65535 UEs in one batch (grid dimension)");
   const size_t lds = sizeof(c64) * ((size_t)n_paths * n_rays + (size_t)n_paths * ports * Nr + 32 * (size_t)n_paths);
-  if (lds > 64 * 1024) return fail(ctx, ISAC_ERR_UNSUPPORTED, "CSI estimate: n_paths x (n_rays + ports Nr + 32) complex values must fit 64 KB of LDS");
+  if (lds > 160 * 1024) return fail(ctx, ISAC_ERR_UNSUPPORTED, "CSI estimate: n_paths x (n_rays + ports Nr + 32) complex values must fit 160 KB of LDS");
+  if (lds > 64 * 1024) ISAC_TRY(allow_lds(ctx, (const void*)cdl_csi_estimate_kernel, lds));     // the uplink estimate (2 ports x 64 receive elements x 24 paths: 69 KB)
   std::vector<CdlCsiUe> tab((size_t)n_ue);
   for (int j = 0; j < n_ue; ++j) {
     if (!d_base[j] || !d_rate[j] || !d_Hf[j]) return fail(ctx, ISAC_ERR_INVALID_ARG, "incomplete UE entry");

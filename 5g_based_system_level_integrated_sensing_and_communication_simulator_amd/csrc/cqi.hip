@@ -456,6 +456,7 @@ struct CsiShape {                                                         // wha
 void csi_all_nan(const CsiShape& sh, isac_csi_report* out) {              // cqiSelect.m:633-647
   const int n = sh.cqi_sb.n == 1 ? 0 : sh.cqi_sb.n;
   out->n_cqi = n + 1;
+  out->ri_total_sinr = NAN;                                               // riSelect.m:253: the rank's total stays NaN when i1 is NaN
   for (int i = 0; i <= n; ++i) out->cqi[i] = out->subband_cqi[i] = out->sinr_per_subband_cw[i] = NAN;
 }
 
@@ -504,6 +505,22 @@ int csi_finish(const CsiShape& sh, const double* tot_p, const double* sp_p, cons
       if (sum > bs) { bs = sum; bi = i2; }
     }
     out->i2[s] = bi + 1;
+  }
+  // ---- riSelect.m:253-271: totalSINR of this rank -- per layer the mean over the PMI subbands (NaN omitted) of SINRPerSubband(s, l, i2(s), i1) x rank, layers below 1 left out
+  {
+    double total = 0.0;
+    for (int l = 0; l < NL; ++l) {
+      double sum = 0.0;
+      int cnt = 0;
+      for (int s = 0; s < pmi_sb.n; ++s) {
+        if (std::isnan(out->i2[s])) continue;
+        const double v = sbv(sp, pmi_sb.n, s, l, (int)out->i2[s] - 1) * (double)NL;
+        if (!std::isnan(v)) { sum += v; ++cnt; }
+      }
+      const double mean = cnt ? sum / cnt : NAN;
+      if (mean >= 1.0) total += mean;
+    }
+    out->ri_total_sinr = total;
   }
   // ---- SINR per CQI subband for the selected PMI, one codeword (<= 4 layers)   cqiSelect.m:578-630
   std::vector<double> cw((size_t)cqi_sb.n, NAN);
@@ -682,4 +699,156 @@ extern "C" int isac_csi_report_batch_dev(isac_ctx* ctx, int32_t n_ue, const isac
   ISAC_ENTER(ctx);
   return csi_report_batch(ctx, n_ue, d_H_list, n_re, Nr, P, re_k, re_l, n_size_bwp, n_start_bwp, subband_size, pmi_subband, cqi_subband, W, n_layers, dims, nvar,
                           sinr_table_db, n_table, out, total_sinr_out, nullptr);
+}
+
+
+// ------------------------------------------------------------------ uplink channel quality from SRS (gNBPhy.m:1023-1060 -> pmiSelect.m:28-65, sinrPerSubband.m:12-36)
+namespace isac {
+
+// per (subband, TPMI): sum over the subband's REs of the per-RE SINR summed over the layers (precodedSINR.m:16: real(sum(1 ./ diag(den) - 1))), in ascending RE order by one
+// thread per (subband, TPMI, UE) -- a few thousand additions each, fixed order
+__global__ __launch_bounds__(64) void srs_subband_sum_kernel(const double* __restrict__ sinr_all /* per UE: [n_re x NL x nE] */, long long ue_stride, long long n_re, int NL, int nE,
+                                                            const int* __restrict__ ptr /* [n_sb + 1] */, const int* __restrict__ idx /* REs grouped by subband */, int n_sb,
+                                                            double* __restrict__ res_all /* per UE: [n_sb x nE] */) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_sb * nE) return;
+  const int sb = t % n_sb, e = t / n_sb;
+  const double* x = sinr_all + ue_stride * blockIdx.y + n_re * (long long)NL * e;
+  double acc = 0.0;
+  for (int q = ptr[sb]; q < ptr[sb + 1]; ++q) {
+    const int i = idx[q];
+    double v = 0.0;
+    for (int l = 0; l < NL; ++l) v += x[i + n_re * l];
+    acc += v;
+  }
+  res_all[(long long)n_sb * nE * blockIdx.y + t] = acc;
+}
+
+}  // namespace isac
+
+extern "C" int isac_pusch_codebook(int32_t n_layers, int32_t n_ports, isac_c64* W, int64_t cap_elems, int32_t* n_tpmi) {
+  if (n_layers < 1 || n_layers > 4 || !n_tpmi) return ISAC_ERR_INVALID_ARG;
+  if (n_ports == 4) return ISAC_ERR_UNSUPPORTED;                         // TS 38.211 Tables 6.3.1.5-2/-3/-5/-6/-7: not restated (the reference's UE has two antennas)
+  if ((n_ports != 1 && n_ports != 2) || n_layers > n_ports) return ISAC_ERR_INVALID_ARG;
+  const double r2 = 1.0 / std::sqrt(2.0);                                // as MATLAB forms it (one ulp below sqrt(0.5))
+  // maxPUSCHPrecodingMatrixIndicator.m:29-70: 1 port -> 0; 2 ports: 1 layer -> 5 (Table 6.3.1.5-1), 2 layers -> 2 (Table 6.3.1.5-4)
+  const int nE = n_ports == 1 ? 1 : (n_layers == 1 ? 6 : 3);
+  *n_tpmi = nE;
+  if (!W) return ISAC_OK;
+  if (cap_elems < (int64_t)nE * n_ports * n_layers) return ISAC_ERR_CAPACITY;
+  auto put = [&](int e, int p, int l, double re, double im) { W[(size_t)p + (size_t)n_ports * ((size_t)l + (size_t)n_layers * e)] = isac_c64{re, im}; };
+  if (n_ports == 1) { put(0, 0, 0, 1.0, 0.0); return ISAC_OK; }
+  if (n_layers == 1) {                                                   // Table 6.3.1.5-1: 1/sqrt2 [1 0]', [0 1]', [1 1]', [1 -1]', [1 j]', [1 -j]'
+    const double w1[6][2] = {{0, 0}, {1, 0}, {1, 0}, {-1, 0}, {0, 1}, {0, -1}};
+    for (int e = 0; e < 6; ++e) { put(e, 0, 0, e == 1 ? 0.0 : r2, 0.0); put(e, 1, 0, r2 * w1[e][0], r2 * w1[e][1]); }
+    return ISAC_OK;
+  }
+  // Table 6.3.1.5-4: 1/sqrt2 [1 0; 0 1], 1/2 [1 1; 1 -1], 1/2 [1 1; j -j]   (rows = ports, columns = layers)
+  put(0, 0, 0, r2, 0); put(0, 1, 0, 0, 0); put(0, 0, 1, 0, 0); put(0, 1, 1, r2, 0);
+  put(1, 0, 0, 0.5, 0); put(1, 1, 0, 0.5, 0); put(1, 0, 1, 0.5, 0); put(1, 1, 1, -0.5, 0);
+  put(2, 0, 0, 0.5, 0); put(2, 1, 0, 0, 0.5); put(2, 0, 1, 0.5, 0); put(2, 1, 1, 0, -0.5);
+  return ISAC_OK;
+}
+
+extern "C" int isac_srs_pmi_select_batch_dev(isac_ctx* ctx, int32_t n_ue, const isac_c64* const* d_H_list, int64_t n_re, int32_t R, int32_t P, const int32_t* re_k, int32_t n_rb,
+                                             int32_t band_size, int32_t n_layers, const double* nvar, const double* sinr_table_db, int32_t n_table, isac_srs_report* out) {
+  ISAC_ENTER(ctx);
+  if (!d_H_list || !re_k || !nvar || !out || n_ue <= 0 || n_re <= 0 || R <= 0 || P <= 0 || n_rb <= 0 || n_rb > ISAC_MAX_RBS || band_size <= 0 || n_layers < 1 || n_layers > 4 ||
+      (n_table > 0 && !sinr_table_db))
+    return fail(ctx, ISAC_ERR_INVALID_ARG, "isac_srs_pmi_select_batch_dev: bad arguments");
+  int nE = 0;
+  const int stc = isac_pusch_codebook(n_layers, P, nullptr, 0, &nE);
+  if (stc != ISAC_OK) return fail(ctx, stc, "isac_srs_pmi_select_batch_dev: PUSCH codebook for this (layers, ports) not available (one or two SRS ports)");
+  std::vector<isac_c64> W((size_t)P * n_layers * nE);
+  ISAC_TRY(isac_pusch_codebook(n_layers, P, W.data(), (int64_t)W.size(), &nE));
+  const int NL = n_layers;
+  const int n_sb = (n_rb + band_size - 1) / band_size;                   // sinrPerSubband.m:24
+  if (n_sb > ISAC_MAX_SUBBANDS) return fail(ctx, ISAC_ERR_CAPACITY, "more SRS subbands than ISAC_MAX_SUBBANDS");
+  // REs grouped by subband (sinrPerSubband.m:18-20: subband s = subcarriers 12 band_size s + 1 .. 12 band_size (s + 1); a fractional last band takes the rest)
+  std::vector<int> ptr((size_t)n_sb + 1, 0), idx((size_t)n_re), of((size_t)n_re);
+  for (long long i = 0; i < n_re; ++i) {
+    const int sb = re_k[i] / (12 * band_size);
+    if (re_k[i] < 0 || re_k[i] >= 12 * n_rb || sb >= n_sb) return fail(ctx, ISAC_ERR_INVALID_ARG, "isac_srs_pmi_select_batch_dev: SRS subcarrier outside the carrier");
+    of[(size_t)i] = sb;
+    ++ptr[(size_t)sb + 1];
+  }
+  for (int s2 = 0; s2 < n_sb; ++s2) ptr[(size_t)s2 + 1] += ptr[(size_t)s2];
+  { std::vector<int> cur(ptr.begin(), ptr.end() - 1); for (long long i = 0; i < n_re; ++i) idx[(size_t)cur[(size_t)of[(size_t)i]]++] = (int)i; }
+  // ---- one staged upload: W | ptr | idx | H pointers | noise variances
+  auto pad = [](size_t b) { return (b + 63) & ~(size_t)63; };
+  const size_t o_w = 0, o_ptr = o_w + pad(sizeof(isac_c64) * W.size()), o_idx = o_ptr + pad(sizeof(int) * ptr.size()), o_h = o_idx + pad(sizeof(int) * idx.size()),
+               o_nv = o_h + pad(sizeof(void*) * (size_t)n_ue), meta = o_nv + pad(sizeof(double) * (size_t)n_ue);
+  std::vector<char> host(meta, 0);
+  std::memcpy(host.data() + o_w, W.data(), sizeof(isac_c64) * W.size());
+  std::memcpy(host.data() + o_ptr, ptr.data(), sizeof(int) * ptr.size());
+  std::memcpy(host.data() + o_idx, idx.data(), sizeof(int) * idx.size());
+  std::memcpy(host.data() + o_h, d_H_list, sizeof(void*) * (size_t)n_ue);
+  std::memcpy(host.data() + o_nv, nvar, sizeof(double) * (size_t)n_ue);
+  ISAC_TRY(ensure(ctx, ctx->stage_c, meta + 64));
+  char* dm = (char*)ctx->stage_c.p;
+  ISAC_TRY(stage_upload(ctx, dm, host.data(), meta));
+  const size_t sinr_elems = (size_t)n_re * NL * nE, res_stride = (size_t)n_sb * nE;
+  ISAC_TRY(ensure(ctx, ctx->stage_a, sizeof(double) * sinr_elems * (size_t)n_ue));
+  ISAC_TRY(ensure(ctx, ctx->stage_b, sizeof(double) * res_stride * (size_t)n_ue + 64));
+  double* d_sinr = (double*)ctx->stage_a.p;
+  double* d_res = (double*)ctx->stage_b.p;
+  const c64* const* d_hl = (const c64* const*)(dm + o_h);
+  const double* d_nv = (const double*)(dm + o_nv);
+  switch (NL) {
+    case 1: ISAC_TRY(launch_pmi_sinr<1>(ctx, d_hl, n_re, R, P, (const c64*)(dm + o_w), nE, d_nv, d_sinr, (long long)sinr_elems, n_ue)); break;
+    case 2: ISAC_TRY(launch_pmi_sinr<2>(ctx, d_hl, n_re, R, P, (const c64*)(dm + o_w), nE, d_nv, d_sinr, (long long)sinr_elems, n_ue)); break;
+    case 3: ISAC_TRY(launch_pmi_sinr<3>(ctx, d_hl, n_re, R, P, (const c64*)(dm + o_w), nE, d_nv, d_sinr, (long long)sinr_elems, n_ue)); break;
+    default: ISAC_TRY(launch_pmi_sinr<4>(ctx, d_hl, n_re, R, P, (const c64*)(dm + o_w), nE, d_nv, d_sinr, (long long)sinr_elems, n_ue)); break;
+  }
+  hipLaunchKernelGGL(srs_subband_sum_kernel, dim3(cdiv((long long)res_stride, 64), (unsigned)n_ue), dim3(64), 0, ctx->stream, (const double*)d_sinr, (long long)sinr_elems,
+                     (long long)n_re, NL, nE, (const int*)(dm + o_ptr), (const int*)(dm + o_idx), n_sb, d_res);
+  ISAC_HIP(hipGetLastError());
+  const size_t res_bytes = sizeof(double) * res_stride * (size_t)n_ue;
+  ISAC_TRY(ensure_pinned_buf(ctx, ctx->pinned_csi, ctx->pinned_csi_cap, res_bytes));
+  ISAC_HIP(hipMemcpyAsync(ctx->pinned_csi, d_res, res_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  const double* res = (const double*)ctx->pinned_csi;
+  // ---- host half per UE: sinrPerSubband.m:33, pmiSelect.m:54-58, gNBPhy.m:1035-1058
+  for (int u = 0; u < n_ue; ++u) {
+    isac_srs_report& o = out[u];
+    std::memset(&o, 0, sizeof(o));
+    o.n_subbands = n_sb; o.n_tpmi = nE; o.n_rb = n_rb;
+    const double* r = res + res_stride * (size_t)u;
+    std::vector<double> sb_sinr((size_t)n_sb * nE, NAN), pmi((size_t)n_sb, NAN);
+    const bool no_estimate = !(nvar[u] != 0.0);                          // pmiSelect.m:40: noiseest == 0 -> pmi = NaN, sinr = NaN
+    for (int s2 = 0; s2 < n_sb && !no_estimate; ++s2) {
+      const int cnt = ptr[(size_t)s2 + 1] - ptr[(size_t)s2];
+      for (int e = 0; e < nE; ++e) sb_sinr[(size_t)s2 + (size_t)n_sb * e] = cnt ? r[(size_t)s2 + (size_t)n_sb * e] / (double)cnt : NAN;      // 0 / 0 = NaN as in MATLAB
+      if (!cnt) continue;
+      int best = 0;
+      for (int e = 1; e < nE; ++e) if (sb_sinr[(size_t)s2 + (size_t)n_sb * e] > sb_sinr[(size_t)s2 + (size_t)n_sb * best]) best = e;   // max(): the first maximiser
+      pmi[(size_t)s2] = (double)best;
+    }
+    // gNBPhy.m:1035-1040: subbands without SRS take floor(mean(pmi of the others)) and the mean of the other subbands' SINR rows
+    int n_ok = 0;
+    double pm = 0.0;
+    for (int s2 = 0; s2 < n_sb; ++s2) if (!std::isnan(pmi[(size_t)s2])) { pm += pmi[(size_t)s2]; ++n_ok; }
+    if (n_ok > 0 && n_ok < n_sb) {
+      std::vector<double> row((size_t)nE, 0.0);
+      for (int e = 0; e < nE; ++e) { double a = 0.0; for (int s2 = 0; s2 < n_sb; ++s2) if (!std::isnan(pmi[(size_t)s2])) a += sb_sinr[(size_t)s2 + (size_t)n_sb * e]; row[(size_t)e] = a / n_ok; }
+      const double fill = std::floor(pm / n_ok);
+      for (int s2 = 0; s2 < n_sb; ++s2) if (std::isnan(pmi[(size_t)s2])) { pmi[(size_t)s2] = fill; for (int e = 0; e < nE; ++e) sb_sinr[(size_t)s2 + (size_t)n_sb * e] = row[(size_t)e]; }
+    }
+    for (int s2 = 0; s2 < n_sb; ++s2) {
+      o.pmi[s2] = pmi[(size_t)s2];
+      o.sinr_subband_pmi[s2] = std::isnan(pmi[(size_t)s2]) ? NAN : sb_sinr[(size_t)s2 + (size_t)n_sb * (int)pmi[(size_t)s2]];
+    }
+    // gNBPhy.m:1045-1058: per-RB CQI
+    std::vector<double> cq((size_t)n_rb, 0.0);
+    for (int i = 0; i + 1 < n_sb; ++i) {
+      const double s_db = 10.0 * std::log10(o.sinr_subband_pmi[i]);
+      int c = 0, j = 0;                                                  // find(sinrTable(sinrTable <= x), 1, 'last'): find() runs on the filtered VALUES -- the 1-based
+      for (int t = 0; t < n_table; ++t)                                  // position, within the entries <= x, of the last one that is not zero
+        if (sinr_table_db[t] <= s_db) { ++j; if (sinr_table_db[t] != 0.0) c = j; }
+      if (c > 0) for (int rb = i * band_size; rb < (i + 1) * band_size && rb < n_rb; ++rb) cq[(size_t)rb] = c - 1;
+    }
+    if (n_sb >= 2) for (int rb = (n_sb - 1) * band_size; rb < n_rb; ++rb) cq[(size_t)rb] = cq[(size_t)(n_sb - 1) * band_size - 1];
+    for (int rb = 0; rb < n_rb; ++rb) o.cqi_rb[rb] = cq[(size_t)rb] <= 1.0 ? 1.0 : cq[(size_t)rb];
+  }
+  return ISAC_OK;
 }

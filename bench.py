@@ -339,6 +339,9 @@ class CommCell:
     from slot to slot and from frame to frame (path gains formed on the device per gain block)."""
     DL_SLOTS, UL_SLOTS, CSI_OCCASIONS, SLOT_T, LAYERS, PRG_PRBS = 16, 4, 4, 61440, 2, 4
     WITH_UL = os.environ.get("ISAC_C5_NO_UL") is None
+    WITH_RI = os.environ.get("ISAC_C5_NO_RI") is None            # round 6: rank selection per CSI report (uePhy.m:900)
+    WITH_SRS = os.environ.get("ISAC_C5_NO_SRS") is None          # round 6: the gNB's SRS measurement of every UE (gNBPhy.m:1023-1060)
+    SRS_BAND = 16
     DEVICE_CSI = os.environ.get("ISAC_C5_HOST_CSI") is None
 
     def __init__(self, pkg, ctxs_cdl, ctx_csi, cell_id, n_ants, n_ues):
@@ -399,6 +402,11 @@ class CommCell:
                 self.ul_gains.append(ctx_cdl.empty((self.UL_SLOTS * len(g) * 4 * st.base.shape[0] * st.base.shape[2] * st.base.shape[3],)))
         self.last_cqi = None
         self.last_reports = None
+        self.last_ranks = self.last_srs = None
+        if self.WITH_UL and self.WITH_SRS:                    # setupSRS.m:8-24: two SRS ports, full bandwidth, 16-PRB measurement subbands (subbandSize.m: 16 or 32 at 273 PRBs)
+            self.srs_k1 = np.arange(1, K + 1)
+            self.h_srs = [ctx_csi.empty((K, n_ants, 2)) for _ in range(n_ues)]
+            self.nvar_ul = 10.0 ** (-(23.0 - pl_db - (-174.0 + 10.0 * np.log10(100e6) + 5.0)) / 10.0)   # 23 dBm UE, 5 dB gNB noise figure
         for c_ in self.ctxs:
             c_.sync()
         ctx_csi.sync()
@@ -427,10 +435,26 @@ class CommCell:
                 for g in self.groups:                         # 5 slots): one library call per delay-profile group
                     self.CM.csiEstimateBatch([self.chans[u] for u in g], self.csi_k, 3276, 30e3, 4, ctx=self.ctx_csi,
                                              times=[t_frame[u] + o * 5 * self.T / self.chans[u].SampleRate for u in g], outs=[self.h_est[u] for u in g])
-            rep = self.PL.cqiSelectBatch(self.carrier, SimpleNamespace(k=self.csi_k, l=self.csi_l), self.report, 1, self.h_est, self.nvar, DOWNLINK_SINR90PC,
-                                         ctx=self.ctx_csi, codebook=self.codebook)
+            if self.WITH_RI:                                  # uePhy.m:900-908: riSelect (the PMI search at every rank the two-antenna UE supports), the report at that rank
+                sel = self.PL.riSelectBatch(self.carrier, SimpleNamespace(k=self.csi_k, l=self.csi_l), self.report, self.h_est, self.nvar, DOWNLINK_SINR90PC, ctx=self.ctx_csi)
+                rep, self.last_ranks = [r_[1:] for r_ in sel], [r_[0] for r_ in sel]
+            else:
+                rep = self.PL.cqiSelectBatch(self.carrier, SimpleNamespace(k=self.csi_k, l=self.csi_l), self.report, 1, self.h_est, self.nvar, DOWNLINK_SINR90PC,
+                                             ctx=self.ctx_csi, codebook=self.codebook)
         self.last_cqi = [None if np.isnan(c[0][0]) else int(c[0][0]) for c in rep]
         self.last_reports = rep                              # (cqi, pmi, info) per UE of the frame's last occasion: what the per-cell record carries to rank 0
+
+    def srs_reports(self):
+        """The gNB's uplink measurement (gNBPhy.m:1023-1060): per UE the channel estimate at the SRS symbol of the frame's last 'U' slot -- the perfect estimate,
+        formed on the device from that slot's UL path gains (the estimator is toolbox code; as nrChannelEstimate's output it covers every subcarrier) -- through
+        pmiSelect (6 TPMIs of the two-port codebook x 3 276 REs x the 64-element array) to TPMI per subband and CQI per RB.  The reference's SRS period is 8 slots
+        on a DDDSU pattern (setupSRS.m:13: a UE's SRS meets a 'U' slot once per 40 slots); here once per frame and UE: twice that rate."""
+        if not (self.WITH_UL and self.WITH_SRS):
+            return
+        for g in self.groups:
+            self.CM.csiEstimateBatch([self.ul_chans[u] for u in g], self.srs_k1, 3276, 30e3, 2, ctx=self.ctx_csi,
+                                     times=[self.ul_chans[u].time - self.T / self.ul_chans[u].SampleRate for u in g], outs=[self.h_srs[u] for u in g])
+        self.last_srs = self.PL.srsReportBatch(1, self.h_srs, self.srs_k1 - 1, self.nvar_ul, self.SRS_BAND, 273, UPLINK_SINR90PC, ctx=self.ctx_csi)
 
     def gemm_launch(self):
         """(jobs, issued 3M flops, bytes) of one contraction launch of the larger delay-profile group: what `roofline` prices."""
@@ -441,6 +465,7 @@ class CommCell:
 
 
 DOWNLINK_SINR90PC = np.array([-3.46, 1.54, 6.54, 11.05, 13.54, 16.04, 17.54, 20.04, 22.04, 24.43, 26.93, 27.43, 29.43, 32.43, 35.43])   # setupSINRtoCQIMappingTable.m:7-11
+UPLINK_SINR90PC = np.array([-5.46, -0.46, 4.54, 9.05, 11.54, 14.04, 15.54, 18.04, 20.04, 22.43, 24.93, 25.43, 27.43, 30.43, 33.43])
 
 
 def run_config5(args, pkg, rank, world, local_rank, dist, torch):
@@ -471,6 +496,7 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
             cc.enqueue_frame()
         for cc in comm:
             cc.csi_reports()
+            cc.srs_reports()
 
     for _ in range(args.warmup):
         frame()
@@ -483,7 +509,7 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
     barrier()
     dt = time.perf_counter() - t0
     os.write(2, f"bench.py: rank {rank}/{world}: device {local_rank}, {len(mine)} cell(s) {mine}, timed region {1e3 * dt:.3f} ms for {args.steps} frame(s), config5\n".encode())
-    recs = np.array([d.make_record(cid, sc.last, dt, ue_reports=cc.last_reports) for cid, sc, cc in zip(mine, sense, comm)]).reshape(-1, d.RECORD_LEN)
+    recs = np.array([d.make_record(cid, sc.last, dt, ue_reports=cc.last_reports, ue_ranks=cc.last_ranks, ue_srs=cc.last_srs, srs_band=CommCell.SRS_BAND) for cid, sc, cc in zip(mine, sense, comm)]).reshape(-1, d.RECORD_LEN)
     on_gpu = dist is not None and dist.get_backend() == "nccl"
     allr = d.gather_records(recs, dist, torch.device("cuda", local_rank) if on_gpu else None)
     dt_max = float(np.nanmax(allr[:, 6])) if allr.size else dt
@@ -518,12 +544,15 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
                                   f"echo -> 2D-FFT -> 2D-CFAR -> MUSIC), {CommCell.DL_SLOTS} DL slot waveforms [{cc.T} x {args.ants}] (precoded PDSCH: {CommCell.LAYERS} layers, one precoder per "
                                   f"{CommCell.PRG_PRBS}-PRB PRG) through every UE's CDL-D / CDL-A channel ({CommCell.DL_SLOTS * args.ues} applies), "
                                   + (f"{CommCell.UL_SLOTS} UL slots x every UE's packet [{cc.T} x 2] into the {args.ants}-element array ({CommCell.UL_SLOTS * args.ues} applies), " if CommCell.WITH_UL else "")
-                                  + f"{CommCell.CSI_OCCASIONS} CSI reports per UE (Type-I PMI search + subband CQI, 546 CSI-RS REs x 32 entries; channel estimate of each occasion "
-                                  f"{'formed on the device from its path gains' if CommCell.DEVICE_CSI else 'evaluated once on the host'})",
+                                  + f"{CommCell.CSI_OCCASIONS} CSI reports per UE ("
+                                  + ("riSelect over ranks 1-2 + " if CommCell.WITH_RI else "") + "Type-I PMI search + subband CQI, 546 CSI-RS REs x 32 entries; channel estimate of each occasion "
+                                  f"{'formed on the device from its path gains' if CommCell.DEVICE_CSI else 'evaluated once on the host'})"
+                                  + (f", one SRS measurement per UE (pmiSelect: 6 TPMIs x 3276 REs x {args.ants} receive elements -> TPMI per {CommCell.SRS_BAND}-PRB subband + CQI per RB)" if CommCell.WITH_UL and CommCell.WITH_SRS else ""),
                       "parallelism": f"cells sharded over {world} GPU(s)"},
            "per_frame_and_rank": {"cells": len(mine), "cdl_applies": n_applies, "csi_reports": len(mine) * args.ues * CommCell.CSI_OCCASIONS, "sensing_cpis": len(mine),
                                   "ul_applies": sum(c_.n_ues for c_ in comm) * CommCell.UL_SLOTS if CommCell.WITH_UL else 0, "precoded": True,
-                                  "csi_h": "device, per occasion" if CommCell.DEVICE_CSI else "host, once at set-up"},
+                                  "csi_h": "device, per occasion" if CommCell.DEVICE_CSI else "host, once at set-up",
+                                  "rank_selection": CommCell.WITH_RI, "srs_reports": sum(c_.n_ues for c_ in comm) if CommCell.WITH_UL and CommCell.WITH_SRS else 0},
            "roofline": {"bound": "mfma", "kernel": "cdl_fused_kernel<NCT,NSLOT> (DL apply of a batch in one persistent launch: contraction X [T x Nt] against the path gains of every job, 3M form on "
                                                     "v_mfma_f64_16x16x4_f64, + 16-tap delay filters + integer delays on the CU; Z never in HBM)" if not os.environ.get("ISAC_CDL_UNFUSED") else
                                                     "cdl_gemm_kernel<NCT,false> (DL contraction of a batch; ISAC_CDL_UNFUSED: the delay filter is a second launch, Z through HBM)",

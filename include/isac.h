@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 /* Bumped on EVERY change of a struct layout, enum value or entry-point signature below (1: round 1; 2: ISAC_MAX_EST 1024 -> 4096,
- * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve, isac_prg_precode_dev, isac_cdl_freq_response_dev, isac_cdl_csi_estimate_batch_dev; 7: the lazy echo grid -- d_echo_grid / d_rx_grid may be NULL --, isac_echo_grid_materialize_dev, isac_sensing_submit_n / isac_sensing_collect_n).  A host must
+ * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve, isac_prg_precode_dev, isac_cdl_freq_response_dev, isac_cdl_csi_estimate_batch_dev; 7: the lazy echo grid -- d_echo_grid / d_rx_grid may be NULL --, isac_echo_grid_materialize_dev, isac_sensing_submit_n / isac_sensing_collect_n, isac_csi_report.ri_total_sinr, isac_pusch_codebook, isac_srs_pmi_select_batch_dev).  A host must
  * compare isac_abi_version() with the ISAC_ABI_VERSION it was compiled against AND isac_abi_sizeof() with its own sizeof of every
  * struct it passes: the library writes whole structs (isac_est_result is 128 KB) into caller memory. */
 #define ISAC_ABI_VERSION 7
@@ -60,7 +60,7 @@ typedef enum {
 int isac_abi_version(void);
 /* sizeof() of the library's build of struct `which` (ISAC_SIZEOF_*), -1 for an unknown selector. */
 enum { ISAC_SIZEOF_EST_RESULT = 0, ISAC_SIZEOF_EST_PARAMS = 1, ISAC_SIZEOF_CFAR_CONFIG = 2, ISAC_SIZEOF_RADAR_CHANNEL_PARAMS = 3,
-       ISAC_SIZEOF_CARRIER = 4, ISAC_SIZEOF_MUSIC2D_PARAMS = 5, ISAC_SIZEOF_CSI_REPORT = 6, ISAC_SIZEOF_SENSING_JOB = 7 };
+       ISAC_SIZEOF_CARRIER = 4, ISAC_SIZEOF_MUSIC2D_PARAMS = 5, ISAC_SIZEOF_CSI_REPORT = 6, ISAC_SIZEOF_SENSING_JOB = 7, ISAC_SIZEOF_SRS_REPORT = 8 };
 int isac_abi_sizeof(int32_t which);
 int isac_device_count(int* count);
 int isac_ctx_create(int device, isac_ctx** out);
@@ -488,6 +488,9 @@ typedef struct {
   double cqi[ISAC_MAX_SUBBANDS + 1];              /* CQI: wideband index, then the subband differential values (Subband)  */
   double subband_cqi[ISAC_MAX_SUBBANDS + 1];      /* CQIInfo.SubbandCQI: absolute indices                                 */
   double sinr_per_subband_cw[ISAC_MAX_SUBBANDS + 1]; /* CQIInfo.SINRPerSubbandPerCW (linear)                              */
+  double ri_total_sinr;                           /* riSelect.m:253-271's totalSINR(rank) of THIS report's rank: per layer the mean over the PMI subbands (NaN omitted) of
+                                                   * SINRPerSubband(subband, layer, selected i2, i1) x rank, summed over the layers whose mean is >= 1; NaN when i1 is NaN.
+                                                   * Rank selection (uePhy.m:900 -> riSelect) = reports at ranks 1..min(Nr, P): the rank whose value beats the best so far by > 0.1 */
 } isac_csi_report;
 int isac_csi_report_dev(isac_ctx* ctx, const isac_c64* d_H, int64_t n_re, int32_t Nr, int32_t P, const int32_t* re_k,
                         const int32_t* re_l, int32_t n_size_bwp, int32_t n_start_bwp, int32_t subband_size, int32_t pmi_subband,
@@ -501,6 +504,26 @@ int isac_csi_report_batch_dev(isac_ctx* ctx, int32_t n_ue, const isac_c64* const
                               const int32_t* re_l, int32_t n_size_bwp, int32_t n_start_bwp, int32_t subband_size, int32_t pmi_subband,
                               int32_t cqi_subband, const isac_c64* W, int32_t n_layers, const int32_t dims[4], const double* nvar,
                               const double* sinr_table_db, int32_t n_table, isac_csi_report* out, double* total_sinr_out);
+
+/* ------------------------------------------------------------------ uplink channel quality from SRS (gNBPhy.m:1023-1060; round 6)
+ * nrPUSCHCodebook(nlayers, nports, tpmi).' for every TPMI (TS 38.211 Tables 6.3.1.5-1 and -4: one or two antenna ports -- the reference's UE has two, ueParameters; four ports:
+ * ISAC_ERR_UNSUPPORTED): W [P x n_layers x nE] column-major, nE = maxPUSCHPrecodingMatrixIndicator + 1 (maxPUSCHPrecodingMatrixIndicator.m:29-70).  W == NULL: size query. */
+int isac_pusch_codebook(int32_t n_layers, int32_t n_ports, isac_c64* W, int64_t cap_elems, int32_t* n_tpmi);
+/* communication.phyLayer.pmiSelect(rank, Hest(:, srsSymbols, :, :), nVar, subbandSize) (pmiSelect.m:28-65: LMMSE SINR of every SRS resource element for every TPMI through
+ * precodedSINR, summed over the layers; sinrPerSubband.m:12-36: per subband of band_size PRBs the sum over its REs / their count; the first maximiser) and what gNBPhy.m:1035-1058
+ * makes of it: subbands without SRS take floor(mean) of the other PMIs and the mean of their SINR rows, the SINR of each subband's PMI goes through the SINR table to a per-RB CQI
+ * (last subband = its neighbour's value, minimum 1).  For n_ue UEs that share the SRS positions (one launch per stage, one copy back, one synchronisation).
+ * d_H_list: HOST array of n_ue device pointers [n_re x R x P] (RE fastest): the channel estimates at the SRS resource elements; re_k (host): 0-based subcarrier of each RE;
+ * n_rb = NRBsUL; nvar: HOST [n_ue] (0 -> the reference's "no estimate": everything NaN). */
+#define ISAC_MAX_RBS 275
+typedef struct {
+  int32_t n_subbands, n_tpmi, n_rb, reserved;
+  double pmi[ISAC_MAX_SUBBANDS + 1];                 /* 0-based TPMI per subband (after the NaN replacement of gNBPhy.m:1036-1040)    */
+  double sinr_subband_pmi[ISAC_MAX_SUBBANDS + 1];    /* sinrSubband(i, pmi(i) + 1)                                                  */
+  double cqi_rb[ISAC_MAX_RBS];                       /* cqiRBs (gNBPhy.m:1047-1058)                                                 */
+} isac_srs_report;
+int isac_srs_pmi_select_batch_dev(isac_ctx* ctx, int32_t n_ue, const isac_c64* const* d_H_list, int64_t n_re, int32_t R, int32_t P, const int32_t* re_k, int32_t n_rb,
+                                  int32_t band_size, int32_t n_layers, const double* nvar, const double* sinr_table_db, int32_t n_table, isac_srs_report* out);
 
 /* ------------------------------------------------------------------ line-of-sight blockage
  * Batched openStreetMapCity.checkLoS (+networkTopology/+blockages/openStreetMapCity.m:67-93): for every link

@@ -252,3 +252,32 @@ def cqi_select(report, n_layers: int, h, csirs_k, csirs_l, n_var: float, sinr_ta
         sub_cqi = cqi_all[:1]
         sinr_cw = sinr_cw[:1]
     return cqi, pmi, SimpleNamespace(SINRPerSubbandPerCW=sinr_cw[:, 0], SubbandCQI=sub_cqi), info
+
+
+def ri_select(report, h, csirs_k, csirs_l, n_var: float, ri_restriction=None):
+    """riSelect.m:207-280, Type1SinglePanel.  Returns (RI or NaN, PMISet of that rank, totalSINR [maxRank])."""
+    n_rx, n_ports = h.shape[2], h.shape[3]
+    max_rank = min(n_rx, n_ports)                                                        # :219-220
+    restr = np.ones(8) if ri_restriction is None else np.asarray(ri_restriction)
+    valid = [r for r in range(1, max_rank + 1) if r <= restr.size and restr[r - 1]]      # :226-231
+    sb = subband_info(report.PMIMode, report.NStartBWP, report.NSizeBWP, report.SubbandSize)
+    if not valid or np.asarray(csirs_k).size == 0:                                       # :232-242
+        return np.nan, SimpleNamespace(i1=np.full(3, np.nan), i2=np.full(sb.NumSubbands, np.nan)), np.full(max_rank, np.nan)
+    best, ri, pmi_set = -np.inf, np.nan, None
+    total = np.full(max_rank, np.nan)                                                    # :246-247
+    pmi = None
+    for rank in valid:
+        pmi, info = dl_pmi_select(report, rank, h, csirs_k, csirs_l, n_var)              # :254
+        sub = np.full((sb.NumSubbands, rank), np.nan)
+        if not np.any(np.isnan(pmi.i1)):
+            i11, i12, i13 = (int(v) - 1 for v in pmi.i1)
+            for s in range(sb.NumSubbands):                                              # :261-268
+                if not np.isnan(pmi.i2[s]):
+                    sub[s, :] = info.SINRPerSubband[s, :, int(pmi.i2[s]) - 1, i11, i12, i13] * rank
+            layer = _nanmean_matlab(sub, 0)                                              # :272 mean(., 1, 'omitnan')
+            total[rank - 1] = np.sum(layer[layer >= 1])                                  # :276
+        if total[rank - 1] > best + 0.1:                                                 # :278-282
+            best, ri, pmi_set = total[rank - 1], rank, pmi
+    if np.all(np.isnan(total)):                                                          # :287-290
+        ri, pmi_set = np.nan, pmi
+    return ri, pmi_set, total

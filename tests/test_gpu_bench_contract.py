@@ -60,7 +60,7 @@ def test_config5_workload_line():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["dtype"] == "f64" and d["data"] == "synthetic" and "configs[4]" in d["config"]["workload"]
     assert d["per_frame_and_rank"] == {"cells": 2, "cdl_applies": 2 * 4 * 16, "csi_reports": 2 * 4 * 4, "sensing_cpis": 2, "ul_applies": 2 * 4 * 4, "precoded": True,
-                                       "csi_h": "device, per occasion"}                # (round 5: 'U' slots, precoded PDSCH input, per-occasion device CSI)
+                                       "csi_h": "device, per occasion", "rank_selection": True, "srs_reports": 2 * 4}   # (round 5: 'U' slots, precoded PDSCH input, per-occasion device CSI; round 6: riSelect, SRS)
     assert abs(d["value"] - 2 * 20 / (d["ms_per_step"] / 1e3)) <= 1e-3 * d["value"]
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6 and 0.0 < rf["frac"] < 1.0
@@ -71,5 +71,8 @@ def test_config5_workload_line():
     for c in d["cells"]:
         assert len(c["ues"]) == 4 and all(u["cqi"] is None or 0 <= u["cqi"] <= 15 for u in c["ues"])
         assert all(len(u["sbCQI"]) == 18 and len(u["sbI2"]) == 18 and len(u["i1"]) == 3 for u in c["ues"])
+        # round 6: the rank of each report (two-antenna UEs: 1 or 2) and the gNB's SRS measurement (ceil(273 / 16) = 18 subbands: TPMI 0..5 of the two-port codebook, CQI 1..15)
+        assert all(u["ri"] in (1, 2) and len(u["ulTPMI"]) == 18 and len(u["ulCQI"]) == 18 for u in c["ues"])
+        assert all(0 <= t <= 5 for u in c["ues"] for t in u["ulTPMI"]) and all(1 <= q <= 15 for u in c["ues"] for q in u["ulCQI"])
         if c["valid"]:
             assert len(c["rngEst"]) == c["nRng"] >= 1 and len(c["velEst"]) == c["nVel"] and len(c["aziEst"]) == c["nAzi"]
