@@ -439,6 +439,7 @@ extern "C" int isac_timer_stop_ms(isac_ctx* ctx, double* elapsed_ms) {
 extern "C" int isac_profile_enable(isac_ctx* ctx, int on) {
   ISAC_ENTER(ctx);
   ctx->profile = on != 0;
+  ctx->profile_cov = on == 2;
   ctx->profile_recorded = false;
   return ISAC_OK;
 }

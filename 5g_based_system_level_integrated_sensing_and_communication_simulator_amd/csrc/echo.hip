@@ -902,7 +902,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
   ISAC_TRY(isac_get_w512_pack(ctx, &tw));            // Fft4096W's packed LDS tables (the fused kernel needs nothing else of the 4096 table)
   ISAC_TRY(isac_get_windows(ctx, g.n_sc, ep->n_ifft, &wk, &wr));
   const double n0s = std::sqrt(rp->n0 / 2.0);
-  if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));   // isac_profile_*: brackets exactly the fused kernel below
+  if (ctx->profile && !ctx->profile_cov) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));   // isac_profile_*: brackets exactly the fused kernel below
   timeline_mark(ctx, 2, ctx->stream);
   {
     const double sig = n0s * std::sqrt((double)g.nfft);
@@ -944,7 +944,7 @@ extern "C" int isac_mono_static_sensing_fused_dev(isac_ctx* ctx, const isac_c64*
 #undef ISAC_SPEC
     ISAC_HIP(hipGetLastError());
   }
-  if (ctx->profile) { ISAC_HIP(hipEventRecord(ctx->ev_k1, ctx->stream)); ctx->profile_recorded = true; }
+  if (ctx->profile && !ctx->profile_cov) { ISAC_HIP(hipEventRecord(ctx->ev_k1, ctx->stream)); ctx->profile_recorded = true; }
   timeline_mark(ctx, 3, ctx->stream);
   RangeCache& rc = ctx->range_cache;
   rc.rx = d_echo_grid; rc.tx = d_tx_grid; rc.K = g.n_sc; rc.L = L_out; rc.A = A; rc.n_ifft = ep->n_ifft; rc.row_lo = row_lo; rc.nr = nr;   // (rc.rx == NULL: the native lazy grid)

@@ -141,6 +141,7 @@ struct isac_ctx {
   bool tl_on = false;
   hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;   // isac_profile_*: around the dominant kernel of the last fused echo call
   bool profile = false, profile_recorded = false;
+  bool profile_cov = false;                    // isac_profile_enable(ctx, 2): the event pair brackets the wide covariance launch of fft2D instead of the fused echo kernel
   int music_route = 0;             // ISAC_OPT_MUSIC_ROUTE: 0 = signal-subspace eigensolver for MUSIC (default), 1 = always the full eigendecomposition
   long long eig_epoch = 0;         // launches of eigh_tridiag_dist_kernel on this context (its exchange stamps carry the epoch: no reset between launches)
   bool tail_unjoined = false;      // wide order: ev_done of the last submit has not been waited for by the main stream (ISAC_ENTER joins lazily)

@@ -2794,6 +2794,9 @@ extern "C" int isac_covariance_dev(isac_ctx* ctx, const isac_c64* d_grid, int64_
   ISAC_ENTER(ctx);
   return isac_covariance_on(ctx, ctx->stream, d_grid, N, A, d_Ra);
 }
+// isac_profile_enable(ctx, 2): HIP events around exactly the wide covariance launch (bench.py's roofline entry when that launch is the longest of the CPI)
+#define ISAC_PROF_COV0(st) do { if (ctx->profile_cov) ISAC_HIP(hipEventRecord(ctx->ev_k0, st)); } while (0)
+#define ISAC_PROF_COV1(st) do { if (ctx->profile_cov) { ISAC_HIP(hipEventRecord(ctx->ev_k1, st)); ctx->profile_recorded = true; } } while (0)
 template <int NB>
 static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long long N, int A, c64* Ra) {
   using P = CovPlan<NB>;
@@ -2812,16 +2815,20 @@ static int launch_cov_small(isac_ctx* ctx, hipStream_t st, const c64* G, long lo
     if (staged) {
       const size_t lds = sizeof(c64) * kCovLdsBufs * NB * 16 * kCovPitch;
       ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cov_mfma_lds_kernel<NB>), lds));
+      ISAC_PROF_COV0(st);
       hipLaunchKernelGGL((cov_mfma_lds_kernel<NB>), dim3((unsigned)gx), dim3(256), lds, st, G, N, A, per, (double*)ctx->cov_part.p);
       ISAC_HIP(hipGetLastError());
+      ISAC_PROF_COV1(st);
     }
   }
   if (!staged) {
   static const bool wg_times = std::getenv("ISAC_COV_WGTIMES") != nullptr;       // dev probe: per-workgroup wall-clock spans, printed per launch
   static long long* d_dbg = nullptr;
   if (wg_times && !d_dbg) ISAC_HIP(hipMalloc(&d_dbg, sizeof(long long) * 3 * 4096));
+  ISAC_PROF_COV0(st);
   hipLaunchKernelGGL((cov_mfma_small_kernel<NB>), dim3((unsigned)gx), dim3(256), 0, st, G, N, A, per, (double*)ctx->cov_part.p, wg_times ? d_dbg : nullptr);
   ISAC_HIP(hipGetLastError());
+  ISAC_PROF_COV1(st);
   if (wg_times) {
     std::vector<long long> h((size_t)3 * gx);
     ISAC_HIP(hipStreamSynchronize(st));
@@ -2865,9 +2872,11 @@ static int launch_cov_lazy(isac_ctx* ctx, hipStream_t st, const LazyCovArgs& a, 
     ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));                                                    \
     hipLaunchKernelGGL(kern, dim3((unsigned)gx), dim3(256), lds, st, a, n_slabs, per, part);                               \
   } while (0)
+  ISAC_PROF_COV0(st);
   if (sched == 0) ISAC_LAZY(0); else if (sched == 1) ISAC_LAZY(1); else ISAC_LAZY(2);
 #undef ISAC_LAZY
   ISAC_HIP(hipGetLastError());
+  ISAC_PROF_COV1(st);
   return ISAC_OK;
 }
 
@@ -2924,6 +2933,7 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
     n_chunks = (total + per - 1) / per;
     ISAC_TRY(ensure(ctx, ctx->cov_part, sizeof(double) * (size_t)n_chunks * n_pairs * 16 * 2 * 256));
     static const bool burst_form = std::getenv("ISAC_COV_BLOCK_BURST") != nullptr;    // development switch: cov_mfma_block_kernel for every N
+    ISAC_PROF_COV0(st);
     if (!burst_form && N * 512 < (1ll << 31)) {       // (32 antennas per staging descriptor: 32-bit offsets up to N x 31 x 16 B)
       const size_t lds = sizeof(c64) * kCovUImgs * kCovUImg;
       ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cov_mfma_block_pl_kernel), (size_t)(lds)));
@@ -2936,6 +2946,7 @@ int isac_covariance_on(isac_ctx* ctx, hipStream_t st, const isac_c64* d_grid, in
                          n_blk, n_pairs, per, (double*)ctx->cov_part.p);
     }
     ISAC_HIP(hipGetLastError());
+    ISAC_PROF_COV1(st);
     hipLaunchKernelGGL(cov_block_reduce_kernel, dim3(16, n_pairs), dim3(256, 4), 0, st, (const double*)ctx->cov_part.p, (int)n_chunks,
                        n_blk, n_pairs, A, 1.0 / (double)N, (c64*)d_Ra);
     ISAC_HIP(hipGetLastError());

@@ -51,25 +51,32 @@ FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X fp64 matrix (= vector) dense peak
 DOMINANT_KERNEL = "echo_range_"          # echo_range_sl_kernel<Q, NZ> (one / two LoS targets) or echo_range_kernel<Q, NZ>
 
 
-def profile_facts():
+def profile_facts(lazy=False):
     """What the committed rocprofv3 summaries (profiles/, newest round) say -- read, not hard-coded:
-      top_by_time  the kernel with the largest share of GPU time in rNN_kernel_stats_single_stream.csv (blocking call order, one stream);
-      traffic      HBM bytes per launch of the dominant kernel at the A = 64 / 224-symbol shape from the separate --pmc passes:
+      top_by_time  the kernel with the largest share of GPU time in rNN[_mode]_kernel_stats_single_stream.csv (blocking call order, one stream);
+      traffic      HBM bytes per launch of the fused kernel (and of the covariance launch: traffic_cov) at the A = 64 / 224-symbol shape from the separate --pmc passes:
                    2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half, MI355X_MICROARCH.md) + WRITE_SIZE, KB -> B.
+    Since round 6 the summaries exist per echo-grid mode (rNN_lazy_* / rNN_array_*, tools/prof_r06.sh); the mode of this run is read, older un-moded files otherwise.
     Not measurable from inside this process; quoted "from profile" and only for the shape it was collected at."""
     import csv
     import glob
     import re
-    out = {"top_by_time": None, "traffic": None, "traffic_source": None}
+    out = {"top_by_time": None, "traffic": None, "traffic_source": None, "traffic_cov": None}
     pdir = os.path.join(ROOT, "profiles")
+    mode = "lazy" if lazy else "array"
+    store_tag = "Lb0E" if lazy else "Lb1E"                    # echo_range_sl_kernel<Q, NZ, STORE, GROUP>: the STORE = false instantiation is the lazy one
 
     def newest(suffix):
         best = None
-        for f in glob.glob(os.path.join(pdir, "r[0-9][0-9]_" + suffix)):
-            m = re.match(r"r(\d\d)_", os.path.basename(f))
-            if m and (best is None or int(m.group(1)) > best[0]):
-                best = (int(m.group(1)), f)
+        for f in glob.glob(os.path.join(pdir, "r[0-9][0-9]*_" + mode + "_" + suffix)) + glob.glob(os.path.join(pdir, "r[0-9][0-9]_" + suffix)):
+            m = re.match(r"r(\d\d)([a-z]?)_", os.path.basename(f))
+            key = (int(m.group(1)), m.group(2)) if m else None
+            if key and (best is None or key > best[0]):
+                best = (key, f)
         return best[1] if best else None
+
+    def is_dom(name):
+        return DOMINANT_KERNEL in name and ("echo_range_sl_kernel" not in name or store_tag in name or "Lb" not in name)
 
     def short(name):
         m = re.match(r"_ZN4isac\d+([A-Za-z0-9_]+?)(?:I|E)", name.strip('"'))
@@ -79,23 +86,29 @@ def profile_facts():
         if f:
             rows = list(csv.DictReader(open(f)))
             top = max(rows, key=lambda r: float(r["total_us"]))
-            dom = [r for r in rows if DOMINANT_KERNEL in r["kernel"]]
+            dom = [r for r in rows if is_dom(r["kernel"])]
+            cov = [r for r in rows if ("cov_lazy_kernel" if lazy else "cov_mfma_") in r["kernel"]]
             out["top_by_time"] = {"kernel": short(top["kernel"]), "share": round(float(top["pct"]) / 100.0, 4), "avg_us": float(top["avg_us"]),
                                   "dominant_hbm_kernel_share": round(float(dom[0]["pct"]) / 100.0, 4) if dom else None,
                                   "dominant_hbm_kernel_avg_us": float(dom[0]["avg_us"]) if dom else None,
+                                  "covariance_kernel_avg_us": float(cov[0]["avg_us"]) if cov else None,
                                   "source": "profiles/" + os.path.basename(f), "from_committed_profile": True}
         ff, fw = newest("pmc_fetch_size.csv"), newest("pmc_write_size.csv")
         if ff and fw:
-            def kb(path, counter):
+            def kb(path, counter, pred):
                 for r in csv.DictReader(open(path)):
-                    if DOMINANT_KERNEL in r["kernel"] and r["counter"] == counter:
+                    if pred(r["kernel"]) and r["counter"] == counter:
                         return float(r["avg_value"])
                 return None
-            fe, wr = kb(ff, "FETCH_SIZE"), kb(fw, "WRITE_SIZE")
+            fe, wr = kb(ff, "FETCH_SIZE", is_dom), kb(fw, "WRITE_SIZE", is_dom)
             if fe is not None and wr is not None:
                 out["traffic"] = int((2.0 * fe + wr) * 1024)
                 out["traffic_source"] = (f"from profile: profiles/{os.path.basename(ff)} (x2, gfx950) + profiles/{os.path.basename(fw)}, "
                                          "separate --pmc passes, A = 64 / 224-symbol shape")
+            is_cov = lambda n: ("cov_lazy_kernel" if lazy else "cov_mfma_") in n          # noqa: E731
+            fe, wr = kb(ff, "FETCH_SIZE", is_cov), kb(fw, "WRITE_SIZE", is_cov)
+            if fe is not None and wr is not None:
+                out["traffic_cov"] = int((2.0 * fe + wr) * 1024)
     except Exception as e:                                     # a malformed summary must not break the benchmark
         out["error"] = repr(e)
     return out
@@ -302,10 +315,47 @@ class Cell:
         c.sync()
         return float(np.mean(out[1:]))
 
+    def time_covariance_kernel_isolated(self, reps=10):
+        """Average duration of the wide covariance launch of fft2D (cov_lazy_kernel with a lazy echo grid, cov_mfma_lds_kernel / cov_mfma_block_pl_kernel on an array) with
+        nothing else on the GPU: blocking CPIs on the cell's first context, the library's event pair around exactly that launch (isac_profile_enable(ctx, 2))."""
+        c = self.ctx
+        c.check(c.lib.isac_profile_enable(c.handle, 2))
+        out = []
+        for i in range(reps + 1):
+            b = 0
+            echo = self.pkg.sensing.monoStaticSensing(self.tx_wave, (self.K, self.Lsym, self.A), self.carrier, self.rp, self.los, seed=self.seed + i,
+                                                      noise_domain=self.noise_domain, nfft=4096, out=None if self.lazy else self.echo[b], ctx=c,
+                                                      fuse_fft2d=(self.rp, self.cfar, self.tx_grid) if self.fuse else None, lazy=self.lazy)
+            self.pkg.sensing.estimation.fft2D_submit(self.rp, self.cfar, echo, self.tx_grid, ctx=c, reuse_range=self.fuse)
+            try:
+                self.pkg.sensing.estimation.fft2D_collect(c)
+            except self.pkg.IsacError as e:
+                if e.name != "NO_DETECTION":
+                    raise
+            ms = C.c_double(0.0)
+            if c.lib.isac_profile_last_kernel_ms(c.handle, C.byref(ms)) == 0:
+                out.append(ms.value)
+        c.check(c.lib.isac_profile_enable(c.handle, 0))
+        return float(np.mean(out[1:])) if len(out) > 1 else None
+
+    def covariance_issued_flops(self):
+        """fp64 MFMA flops the covariance launch issues on useful samples: 8 A^2 K L nominal x the share of 16 x 16 tiles computed (the upper triangle: of the 64 x 64
+        block pairs and, inside a diagonal pair, of its tiles) x 3/4 (three real MFMAs per complex tile step).  Padding (the lazy form's masked partner rows, +6.5 % at
+        K = 3276; antennas padded to a multiple of 16) is NOT counted."""
+        nominal = 8.0 * self.A * self.A * self.K * self.Lsym
+        nt = (self.A + 15) // 16
+        if self.A <= 64:
+            share = (nt * (nt + 1) / 2) / (nt * nt)
+        else:
+            nb = (self.A + 63) // 64
+            share = (nb * 10 + (nb * (nb - 1) // 2) * 16) / (nb * nb * 16)
+        return nominal * share * 0.75, nominal
+
     def dominant_kernel_bytes(self):
-        """Algorithmic HBM bytes of one launch of the fused kernel: txGrid read once + echoGrid written once = 2 K L A 16 B
-        (SURVEY 8d's RDM+CFAR read of txGrid + monoStaticSensing's write of echoGrid; rxGrid is never re-read)."""
-        return 2 * self.K * self.Lsym * self.A * 16
+        """Algorithmic HBM bytes of one launch of the fused kernel.  Array form: txGrid read once + echoGrid written once = 2 K L A 16 B (SURVEY 8d's RDM+CFAR read of
+        txGrid + monoStaticSensing's write of echoGrid; rxGrid is never re-read).  LAZY form: the kernel does not store echoGrid -- txGrid read once = K L A 16 B (its
+        range-stage rows, 84 MB by the counters, are not counted)."""
+        return (1 if self.lazy else 2) * self.K * self.Lsym * self.A * 16
 
 
 def csirs_positions(nrb):
@@ -678,11 +728,11 @@ def cpu_baseline(cell, budget_s=12.0):
     return best
 
 
-def roofline_entry(cell, args, ms_timed, ms_iso, n_launches, stages, cpi_bytes, per_cpi_ms):
+def roofline_entry(cell, args, ms_timed, ms_iso, n_launches, stages, cpi_bytes, per_cpi_ms, ms_cov_iso=None):
     """`roofline` for the dominant HBM-bound kernel: the fused echo-synthesis + range-stage kernel (the largest share of the wide kernels'
     time and of the bytes moved).  achieved = algorithmic bytes per launch / average launch duration measured with HIP events inside
     this run; `top_by_time` and `traffic` come from the committed rocprofv3 summaries (profile_facts)."""
-    facts = profile_facts()
+    facts = profile_facts(args.lazy)
     whole = {"algorithmic_bytes": cpi_bytes, "ms": round(per_cpi_ms, 4), "achieved_GBps": round(cpi_bytes / 1e9 / (per_cpi_ms / 1e3), 1),
              "frac": round(cpi_bytes / 1e9 / (per_cpi_ms / 1e3) / HBM_PEAK_GBS, 4),
              "note": "SURVEY 8d bytes per CPI (txWaveform + echoGrid + rxGrid + txGrid) / driver-visible time per CPI"}
@@ -696,6 +746,32 @@ def roofline_entry(cell, args, ms_timed, ms_iso, n_launches, stages, cpi_bytes, 
     # (reported separately below; the end-to-end figure under concurrency is `whole_cpi`).
     ms = ms_iso
     at_shape = (args.ants == 64 and args.slots == 16 and args.targets == 1)
+    cov_entry = None
+    if ms_cov_iso:
+        issued, nominal = cell.covariance_issued_flops()
+        cov_name = ("cov_lazy_kernel<Q,2> (operand tiles re-formed from D, a, seed: Philox rounds / Box-Muller / synthesis in the MFMA gaps)" if args.lazy else
+                    "cov_mfma_lds_kernel<4>" if 48 < args.ants <= 64 else "cov_mfma_small_kernel" if args.ants <= 64 else "cov_mfma_block_pl_kernel (64 x 64 block pairs)")
+        cov_entry = {"bound": "mfma", "kernel": cov_name + ": Ra = X X^H / N on v_mfma_f64_16x16x4_f64, 3M form, upper-triangular tiles (fft2D.m:106-107)",
+                     "achieved": round(issued / 1e12 / (ms_cov_iso / 1e3), 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(issued / 1e12 / (ms_cov_iso / 1e3) / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": facts.get("traffic_cov") if at_shape else None,
+                     "traffic_source": facts["traffic_source"] if at_shape else None,
+                     "avg_launch_ms": round(ms_cov_iso, 4), "launches_averaged": 10,
+                     "avg_launch_ms_rocprofv3": None if not (at_shape and facts["top_by_time"] and facts["top_by_time"].get("covariance_kernel_avg_us")) else round(facts["top_by_time"]["covariance_kernel_avg_us"] / 1e3, 4),
+                     "duration_note": "two clocks for the same launch: the library's HIP event pair in THIS run (`avg_launch_ms`, what `achieved` / `frac` use) and the kernel duration of the committed "
+                                      "rocprofv3 trace (`avg_launch_ms_rocprofv3`, another box); the event pair reads 10-15 % longer (it includes the launch gaps either side of the kernel)",
+                     "issued_flops_per_launch": issued, "nominal_flops_per_launch": nominal,
+                     "flops_note": "issued = 8 A^2 K L x (upper-triangular 16 x 16 tiles / all tiles) x 3/4 (three real MFMAs per complex tile step); masked padding rows not counted",
+                     "timing": "HIP events recorded by the library around exactly this launch (isac_profile_enable(ctx, 2)), blocking CPIs, device otherwise idle"}
+    if cov_entry and ms_cov_iso > ms:
+        # the LONGEST launch of the CPI is the covariance (lazy echo grid: the fused kernel no longer stores echoGrid, the covariance pays for the generator; more than 64
+        # antennas: the block-pair kernel): `roofline` describes that kernel, the fused kernel follows as `second_kernel`
+        facts_cov = dict(facts["top_by_time"]) if isinstance(facts.get("top_by_time"), dict) else facts.get("top_by_time")
+        cov_entry.update({"top_by_time": facts_cov, "other_stages": stages, "whole_cpi": whole,
+                          "second_kernel": {"bound": "hbm", "kernel": "echo_range_sl_kernel (fused synthesis + range stage" + (", echoGrid NOT stored" if args.lazy else "") + ")",
+                                            "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": nb, "achieved_GBps": round(nb / 1e9 / (ms / 1e3), 1),
+                                            "frac": round(nb / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
+                                            "algorithmic_bytes_note": "txGrid read once (lazy: no echoGrid store)" if args.lazy else "txGrid read once + echoGrid written once"}})
+        return cov_entry
     return {"bound": "hbm", "kernel": ("echo_range_sl_kernel" if args.targets <= 2 else "echo_range_kernel") + f"<{args.targets if args.targets <= 4 else 0},1> (fused: per-target rank-1 echo synthesis + Philox AWGN on the demodulated grid -> echoGrid; "
                                       "rx.*conj(tx), Kaiser, 4096-pt range IFFT, CUT rows)",
             "achieved": round(nb / 1e9 / (ms / 1e3), 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nb / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
@@ -703,12 +779,17 @@ def roofline_entry(cell, args, ms_timed, ms_iso, n_launches, stages, cpi_bytes, 
             "traffic_source": facts["traffic_source"] if at_shape else None,
             "top_by_time": facts["top_by_time"],
             "avg_launch_ms": round(ms, 4), "launches_averaged": 10,
+            "avg_launch_ms_rocprofv3": None if not (at_shape and facts["top_by_time"] and facts["top_by_time"].get("dominant_hbm_kernel_avg_us")) else round(facts["top_by_time"]["dominant_hbm_kernel_avg_us"] / 1e3, 4),
+            "frac_on_rocprofv3_duration": None if not (at_shape and facts["top_by_time"] and facts["top_by_time"].get("dominant_hbm_kernel_avg_us")) else round(nb / 1e9 / (facts["top_by_time"]["dominant_hbm_kernel_avg_us"] / 1e6) / HBM_PEAK_GBS, 4),
+            "duration_note": "two clocks for the same launch: the library's HIP event pair in THIS run (`avg_launch_ms`, what `achieved` / `frac` use) and the kernel duration of the committed "
+                             "rocprofv3 trace (`avg_launch_ms_rocprofv3`, another box); the event pair reads 10-15 % longer (it includes the launch gaps either side of the kernel)",
             "avg_launch_ms_in_timed_region": None if not ms_timed else round(ms_timed, 4), "launches_in_timed_region": n_launches,
             "frac_in_timed_region": None if not ms_timed else round(nb / 1e9 / (ms_timed / 1e3) / HBM_PEAK_GBS, 4),
             "timing": "HIP events recorded by the library around every launch of this kernel, on the stream of the launch: `avg_launch_ms` with the "
                       "device to itself (10 launches right after the timed region; this is what rocprofv3 reports for the single-stream run, "
                       "profiles/rNN_kernel_stats_single_stream.csv), `..._in_timed_region` with the other in-flight CPIs' kernels sharing the GPU",
-            "algorithmic_bytes_per_launch": nb, "algorithmic_bytes_note": "txGrid read once + echoGrid written once = 2 K L A 16 B; echoGrid is not re-read by the range stage",
+            "algorithmic_bytes_per_launch": nb, "algorithmic_bytes_note": ("LAZY echo grid: txGrid read once = K L A 16 B (no echoGrid store)" if args.lazy else "txGrid read once + echoGrid written once = 2 K L A 16 B; echoGrid is not re-read by the range stage"),
+            "covariance_kernel": cov_entry,
             # the same bytes moved by plain copy kernels on this part (1 : 1 read / write mix), tools/cbench.hip: the guide's flat form (one float4 per thread) and the
             # kernel's own column shape.  Round 4 quoted a persistent grid-stride probe (5.35-5.53 TB/s) -- that was the probe's shape, not the part's limit.
             "copy_rate_reference": {"GBps": COPY_RATE_GBS, "frac_of_copy_rate": round(nb / 1e9 / (ms / 1e3) / COPY_RATE_GBS, 4),
@@ -964,6 +1045,7 @@ def main():
         cell.profile_sink = None
     dom_ms_timed = float(np.mean(sink)) if sink else None                       # fused kernel, launches of the timed region (other CPIs co-running)
     dom_ms_iso = cells[0].time_dominant_kernel_isolated() if (rank == 0 and args.fuse and not args.trace_only) else None
+    cov_ms_iso = cells[0].time_covariance_kernel_isolated() if (rank == 0 and args.fuse and not args.trace_only) else None
     blocking_ms = None
     if rank == 0 and not args.trace_only:                    # latency of one blocking CPI (submit + collect, nothing else in flight)
         cells[0].step()
@@ -1015,7 +1097,7 @@ def main():
                                    + ("echo grid LAZY (kept inside the context as a descriptor: never written to HBM, the covariance kernel re-forms its operands from the same D, a, seed -- identical CFAR lists and estimates, isac.h 'LAZY echo grid'), " if args.lazy else "echo grid materialised (written by monoStaticSensing, read back by the covariance), ")
                                    + f"{args.inflight} CPIs in flight",
                        "parallelism": f"cells sharded over {world} GPU(s)"},
-            "roofline": roofline_entry(cells[0], args, dom_ms_timed, dom_ms_iso, len(sink or []), stages, echo_b + rdm_b, per_cpi_ms),
+            "roofline": roofline_entry(cells[0], args, dom_ms_timed, dom_ms_iso, len(sink or []), stages, echo_b + rdm_b, per_cpi_ms, cov_ms_iso),
         }
         res["cells"] = [d.record_json(r) for r in allr[:64]]                      # every cell's whole estResults, gathered from every rank
         if world > 1:

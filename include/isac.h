@@ -85,7 +85,8 @@ int isac_timer_stop_ms(isac_ctx* ctx, double* elapsed_ms); /* synchronises */
 /* Per-kernel timing hook (bench.py's roofline entry): when enabled, the context brackets the dominant kernel of every
  * isac_mono_static_sensing_fused_dev call -- the fused echo-synthesis + range-stage kernel -- and the contraction launch of every
  * isac_cdl_apply[_batch]_dev call with a pair of HIP events on the stream it is launched on; isac_profile_last_kernel_ms waits for the
- * most recent pair and returns its duration. */
+ * most recent pair and returns its duration.  on == 2 (round 6): the pair brackets the wide covariance launch of fft2D / isac_covariance_dev (cov_lazy_kernel,
+ * cov_mfma_lds_kernel, cov_mfma_block_pl_kernel, ...) instead of the fused echo kernel -- the longest launch of a CPI with a lazy echo grid and at more than 64 antennas. */
 int isac_profile_enable(isac_ctx* ctx, int on);
 int isac_profile_last_kernel_ms(isac_ctx* ctx, double* ms);
 
