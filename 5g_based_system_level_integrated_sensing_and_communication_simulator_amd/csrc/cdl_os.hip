@@ -27,6 +27,8 @@ int isac_get_twiddles(isac_ctx* ctx, int n, const isac::c64** out);  // capi.hip
 
 namespace isac {
 
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
 constexpr int kOsN = 4096;           // transform length
 constexpr int kOsBins = 8;           // bins per mix workgroup
 constexpr int kOsPairs = 8;          // (job, gain block) pairs per mix workgroup
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(256) void cdl_os_table_kernel(const double* __restr
 
 // K1: forward transforms of the windows of every distinct waveform.  Window j of a waveform covers samples [j S - Mpad, j S - Mpad + N) (zero outside [0, T)).
 __global__ __launch_bounds__(256, 2) void cdl_os_fwd_kernel(const c64* const* __restrict__ waves, long long T, int Nt, int n_seg, int S, int Mpad, const c64* __restrict__ tw,
-                                                            c64* __restrict__ Xf /* [wave][seg][8-bin tile][s][8]: a mix workgroup's tile of a window is ONE contiguous run */) {
+                                                            int tb_log2 /* bins per mix tile: 3 (cdl_os_mix_kernel) or 4 (cdl_os_mix_mfma_kernel) */,
+                                                            c64* __restrict__ Xf /* [wave][seg][bin tile][s][tile bins]: a mix workgroup's tile of a window is ONE contiguous run */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   c64* lds = reinterpret_cast<c64*>(smem_raw);
   const int tid = threadIdx.x;
@@ -76,8 +79,9 @@ __global__ __launch_bounds__(256, 2) void cdl_os_fwd_kernel(const c64* const* __
   fft.init(lds, tw, tid);
   fft.template transform<-1>(lds, tw, tid);
   // (the first layout, [seg][s][f], made every mix workgroup gather its [Nt x 8] tile from Nt cache lines 64 KB apart: 1.28 ms per 40-job launch)
-  c64* dst = Xf + ((long long)w * n_seg + seg) * Nt * kOsN + (long long)s * kOsBins;
-  fft.drain([&](int k, c64 v) { dst[(long long)(k >> 3) * Nt * kOsBins + (k & 7)] = v; }, tid);
+  const int tb = 1 << tb_log2;
+  c64* dst = Xf + ((long long)w * n_seg + seg) * Nt * kOsN + (long long)s * tb;
+  fft.drain([&](int k, c64 v) { dst[(long long)(k >> tb_log2) * Nt * tb + (k & (tb - 1))] = v; }, tid);
 }
 
 // K2: thread (f = tid & 7, half = (tid >> 3) & 1, u = (tid >> 4) & 1, pair = tid >> 5) keeps C(f)[s][u] of ITS pair for the HS = Nt / 2 transmit elements of its half in registers;
@@ -162,6 +166,149 @@ __global__ __launch_bounds__(256) void cdl_os_mix_kernel(const OsPair* __restric
   }
 }
 
+// K2m (64 transmit elements): C(f) on the matrix pipe, Y(f) with every X value feeding four products.
+// The first form (cdl_os_mix_kernel above) makes one 16-byte LDS read per complex multiply-add -- its thread owns one (pair, receive element, bin): 749 us per 40-job launch,
+// the LDS pipe setting the pace.  Here a workgroup owns 16 bins and up to four pairs of one waveform; wave (h, g) owns transmit elements [32 h, 32 h + 32) of pairs 2 g, 2 g + 1:
+//   phase A  C[s][f] = sum_n H[n][s][u] E[n][f] per (pair, u) as [32 x n_paths] x [n_paths x 16] products on v_mfma_f64_16x16x4_f64 (3M complex form: 36 MFMAs per pair, wave and
+//            k-step-of-four paths; A = H straight from L2 -- 32 contiguous bytes per lane --, B = E[n][f0 .. f0 + 15]).  The accumulator layout (row = s, column = bin) leaves every
+//            lane with ONE bin and eight transmit elements of four (pair, u) combinations:
+//   phase B  per window the X tile [64 x 16 bins] goes through LDS once; a lane reads its eight X values and makes 32 complex multiply-adds (one LDS read per four), sums over
+//            the 8 in-lane elements, the four row groups of the wave (two shuffles) and the two waves h (LDS), and stores 16 consecutive bins.
+// Every pair's arithmetic is independent of what else the workgroup holds (separate accumulators; windows outside a pair's own range are computed and dropped).
+constexpr int kOsMBins = 16, kOsMPairs = 4;
+__global__ __launch_bounds__(256, 2) void cdl_os_mix_mfma_kernel(const OsPair* __restrict__ pairs, const OsChunk* __restrict__ chunks, const c64* __restrict__ Xf,
+                                                                 const c64* __restrict__ E, int n_paths, int n_seg, c64* __restrict__ Yf /* [task][u][N] */) {
+  constexpr int Nt = 64, Nr = 2;
+  __shared__ __attribute__((aligned(16))) c64 xs[2][Nt * kOsMBins];          // the window's X tile [s][16 bins], double buffered
+  __shared__ __attribute__((aligned(16))) c64 ys[2][2][4][kOsMBins];         // [window parity][g][(pp, u)][bin]: wave h = 1 -> wave h = 0
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = wid & 1, g = wid >> 1;
+  const int li = lane & 15, kq = lane >> 4;
+  const int tile = blockIdx.x, f0 = tile * kOsMBins;
+  const OsChunk ch = chunks[blockIdx.y];
+  bool live[2];
+  OsPair pr[2];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp) {
+    live[pp] = g + 2 * pp < ch.n_pairs;                                       // pair p of the chunk -> wave group p & 1, slot p >> 1: two or three pairs keep both groups busy
+    pr[pp] = pairs[ch.pair0 + (live[pp] ? g + 2 * pp : 0)];
+  }
+  // ---- phase A
+  v4f64 a1[2][2][2], a2[2][2][2], a3[2][2][2];                               // [pp][u][mt]: sum Hr Er, sum Hi Ei, sum (Hr + Hi)(Er + Ei)
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) a1[pp][u][mt] = a2[pp][u][mt] = a3[pp][u][mt] = v4f64{0.0, 0.0, 0.0, 0.0};
+  const int ksteps = (n_paths + 3) >> 2;
+  for (int st = 0; st < ksteps; ++st) {
+    const int n = 4 * st + kq;
+    const bool nok = n < n_paths;
+    const c64 e = nok ? E[(long long)n * kOsN + f0 + li] : mk(0.0, 0.0);
+    const double es = e.re + e.im;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      if (!live[pp]) continue;                                                // (wave-uniform)
+      const c64* Hn = pr[pp].H + ((long long)(nok ? n : 0) * Nt + 32 * h + li) * Nr;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        c64 hv[2];
+        hv[0] = Hn[(16 * mt) * Nr + 0];
+        hv[1] = Hn[(16 * mt) * Nr + 1];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const double hr = nok ? hv[u].re : 0.0, hi = nok ? hv[u].im : 0.0;
+          a1[pp][u][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(hr, e.re, a1[pp][u][mt], 0, 0, 0);
+          a2[pp][u][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(hi, e.im, a2[pp][u][mt], 0, 0, 0);
+          a3[pp][u][mt] = __builtin_amdgcn_mfma_f64_16x16x4f64(hr + hi, es, a3[pp][u][mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // C[(pp, u)][mt][r] of transmit element s = 32 h + 16 mt + kq + 4 r at bin f0 + li
+  double cr[4][2][4], ci[4][2][4];
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          cr[2 * pp + u][mt][r] = a1[pp][u][mt][r] - a2[pp][u][mt][r];
+          ci[2 * pp + u][mt][r] = (a3[pp][u][mt][r] - a1[pp][u][mt][r]) - a2[pp][u][mt][r];
+        }
+  // ---- phase B
+  int lo = n_seg, hi = -1;
+  for (int p = 0; p < ch.n_pairs; ++p) { lo = min(lo, pairs[ch.pair0 + p].seg_lo); hi = max(hi, pairs[ch.pair0 + p].seg_hi); }
+  if (hi < lo) return;
+  const c64* Xw = Xf + (long long)ch.w * n_seg * Nt * kOsN + (long long)tile * Nt * kOsMBins;
+  constexpr int kXL = Nt * kOsMBins / 256;                                    // 16-byte loads per thread and tile
+#pragma unroll
+  for (int r = 0; r < kXL; ++r) xs[0][tid + 256 * r] = Xw[(long long)lo * Nt * kOsN + tid + 256 * r];
+  __syncthreads();
+  // the combination this lane reduces across the waves and stores: (pp, u) = kq
+  const int my_pp = kq >> 1, my_u = kq & 1;
+  const bool my_live = my_pp ? live[1] : live[0];                            // (selects, not a dynamically indexed array: that would live in scratch)
+  const int my_task0 = my_pp ? pr[1].task0 : pr[0].task0, my_lo = my_pp ? pr[1].seg_lo : pr[0].seg_lo, my_hi = my_pp ? pr[1].seg_hi : pr[0].seg_hi;
+  for (int seg = lo; seg <= hi; ++seg) {
+    const int buf = (seg - lo) & 1;
+    const bool more = seg + 1 <= hi;
+    c64 nx[kXL];                                                              // (unconditional: the last window re-reads itself, nothing is stored)
+#pragma unroll
+    for (int r = 0; r < kXL; ++r) nx[r] = Xw[(long long)(more ? seg + 1 : seg) * Nt * kOsN + tid + 256 * r];
+    c64 part = mk(0.0, 0.0);
+    auto window = [&](auto nc_c) {                                            // NC = 2 x (live pairs of this wave): combinations (pp, u) = c >> 1, c & 1
+      constexpr int NC = decltype(nc_c)::value;
+      double yr[NC], yi[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) yr[c] = yi[c] = 0.0;
+      const c64* xb = xs[buf] + (32 * h + kq) * kOsMBins + li;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const c64 x = xb[(16 * mt + 4 * r) * kOsMBins];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            yr[c] = ::fma(cr[c][mt][r], x.re, yr[c]);
+            yr[c] = ::fma(-ci[c][mt][r], x.im, yr[c]);
+            yi[c] = ::fma(cr[c][mt][r], x.im, yi[c]);
+            yi[c] = ::fma(ci[c][mt][r], x.re, yi[c]);
+          }
+        }
+      // sum over the four row groups of the wave, scattered: after the exchange with lane ^ 16 a lane keeps the combinations with (c & 1) == bit 0 of kq, after lane ^ 32
+      // the one with (c >> 1) == bit 1 of kq -- row group kq ends with combination kq (NC = 2: combination kq & 1 in both halves).  Fixed order: (own + ^16) + (^32's).
+      const int b0 = kq & 1, b1 = kq >> 1;
+      c64 keep[NC / 2];
+#pragma unroll
+      for (int j = 0; j < NC / 2; ++j) {
+        const double kr = b0 ? yr[2 * j + 1] : yr[2 * j], ki = b0 ? yi[2 * j + 1] : yi[2 * j];
+        const double sr = b0 ? yr[2 * j] : yr[2 * j + 1], si = b0 ? yi[2 * j] : yi[2 * j + 1];
+        keep[j] = mk(kr + __shfl_xor(sr, 16), ki + __shfl_xor(si, 16));
+      }
+      if constexpr (NC == 4) {
+        const c64 k2 = b1 ? keep[1] : keep[0], s2 = b1 ? keep[0] : keep[1];
+        part = mk(k2.re + __shfl_xor(s2.re, 32), k2.im + __shfl_xor(s2.im, 32));
+      } else {
+        part = mk(keep[0].re + __shfl_xor(keep[0].re, 32), keep[0].im + __shfl_xor(keep[0].im, 32));
+      }
+    };
+    if (live[1]) window(std::integral_constant<int, 4>{});
+    else if (live[0]) window(std::integral_constant<int, 2>{});
+    if (h == 1) ys[seg & 1][g][kq][li] = part;
+    if (more) {
+#pragma unroll
+      for (int r = 0; r < kXL; ++r) xs[buf ^ 1][tid + 256 * r] = nx[r];
+    }
+    __syncthreads();
+    if (h == 0 && my_live && seg >= my_lo && seg <= my_hi)
+      Yf[((long long)(my_task0 + seg - my_lo) * Nr + my_u) * kOsN + f0 + li] = part + ys[seg & 1][g][kq][li];
+  }
+}
+
 // K3: inverse transform of one (pair, window, receive element); output index i <-> sample t = seg S - Mpad + i; the first Mpad samples are the aliased ones.
 __global__ __launch_bounds__(256, 2) void cdl_os_inv_kernel(const OsPair* __restrict__ pairs, const OsTask* __restrict__ tasks, long long T, int Nr, int S, int Mpad,
                                                             const c64* __restrict__ tw, const c64* __restrict__ Yf, double scale /* out_scale / N */) {
@@ -203,6 +350,9 @@ int cdl_os_apply(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long 
                  double out_scale) {
   const int Mpad = (max_shift + n_taps - 1 + 7) / 8 * 8, S = kOsN - Mpad;
   const int n_seg = (int)((T + S - 1) / S);
+  static const bool no_mfma = std::getenv("ISAC_CDL_OS_VALU") != nullptr;       // development switch: the first (all-VALU) mix kernel for every shape
+  const bool mfma_mix = Nt == 64 && !no_mfma;
+  const size_t per_chunk = mfma_mix ? kOsMPairs : kOsPairs;
   // ---- distinct waveforms, (job, gain block) pairs, chunks of up to eight pairs on one waveform, (pair, window) tasks
   std::vector<const c64*> waves;
   std::map<const void*, int> wave_of;
@@ -235,12 +385,16 @@ int cdl_os_apply(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long 
   std::vector<OsPair> ordered;
   std::vector<OsChunk> chunks;
   ordered.reserve(pairs.size());
-  for (size_t w = 0; w < by_wave.size(); ++w)
-    for (size_t i = 0; i < by_wave[w].size(); i += kOsPairs) {
-      OsChunk c{(int)ordered.size(), (int)std::min<size_t>(kOsPairs, by_wave[w].size() - i), (int)w, 0};
+  for (size_t w = 0; w < by_wave.size(); ++w) {
+    // pairs with the same window range side by side (a workgroup walks the union of its pairs' ranges): stable, so the order inside a range is the batch order
+    std::stable_sort(by_wave[w].begin(), by_wave[w].end(), [&](int a, int b) { return pairs[(size_t)a].seg_lo != pairs[(size_t)b].seg_lo ? pairs[(size_t)a].seg_lo < pairs[(size_t)b].seg_lo : pairs[(size_t)a].seg_hi < pairs[(size_t)b].seg_hi; });
+    const size_t nw = by_wave[w].size(), n_ch = (nw + per_chunk - 1) / per_chunk, even = mfma_mix ? (nw + n_ch - 1) / n_ch : per_chunk;   // (MFMA form: chunks of even size -- five pairs go 3 + 2, not 4 + 1)
+    for (size_t i = 0; i < nw; i += even) {
+      OsChunk c{(int)ordered.size(), (int)std::min<size_t>(even, nw - i), (int)w, 0};
       for (int k = 0; k < c.n_pairs; ++k) ordered.push_back(pairs[(size_t)by_wave[w][i + k]]);
       chunks.push_back(c);
     }
+  }
   std::vector<OsTask> tasks;
   tasks.reserve((size_t)n_tasks);
   for (size_t p = 0; p < ordered.size(); ++p)
@@ -274,13 +428,17 @@ int cdl_os_apply(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long 
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cdl_os_fwd_kernel), lds));
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cdl_os_inv_kernel), lds));
   hipLaunchKernelGGL(cdl_os_fwd_kernel, dim3((unsigned)n_seg, (unsigned)Nt, (unsigned)waves.size()), dim3(256), lds, ctx->stream, (const c64* const*)(dm + o_waves), T, Nt, n_seg, S,
-                     Mpad, tw, d_X);
+                     Mpad, tw, mfma_mix ? 4 : 3, d_X);
   ISAC_HIP(hipGetLastError());
   if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));          // isac_profile_*: brackets the mix launch (the arithmetic of the apply)
   const dim3 gm(kOsN / kOsBins, (unsigned)chunks.size());
 #define ISAC_OS_MIX(HS) hipLaunchKernelGGL((cdl_os_mix_kernel<HS>), gm, dim3(256), 0, ctx->stream, (const OsPair*)(dm + o_pairs), (const OsChunk*)(dm + o_chunks), (const c64*)d_X, \
                                            (const c64*)d_E, n_paths, n_seg, d_Y)
-  switch (Nt) { case 8: ISAC_OS_MIX(4); break; case 16: ISAC_OS_MIX(8); break; case 32: ISAC_OS_MIX(16); break; default: ISAC_OS_MIX(32); break; }
+  if (mfma_mix)
+    hipLaunchKernelGGL(cdl_os_mix_mfma_kernel, dim3(kOsN / kOsMBins, (unsigned)chunks.size()), dim3(256), 0, ctx->stream, (const OsPair*)(dm + o_pairs), (const OsChunk*)(dm + o_chunks),
+                       (const c64*)d_X, (const c64*)d_E, n_paths, n_seg, d_Y);
+  else
+    switch (Nt) { case 8: ISAC_OS_MIX(4); break; case 16: ISAC_OS_MIX(8); break; case 32: ISAC_OS_MIX(16); break; default: ISAC_OS_MIX(32); break; }
 #undef ISAC_OS_MIX
   ISAC_HIP(hipGetLastError());
   if (ctx->profile) { ISAC_HIP(hipEventRecord(ctx->ev_k1, ctx->stream)); ctx->profile_recorded = true; }
