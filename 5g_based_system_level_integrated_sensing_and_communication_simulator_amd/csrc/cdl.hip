@@ -977,6 +977,7 @@ int launch_fused_ul(isac_ctx* ctx, const std::vector<CdlSeg>& segs, long long T,
 }  // namespace
 // cdl_os.hip: the downlink apply in the frequency domain (overlap-save, 4096-point windows) for long waveforms into two receive elements
 bool cdl_os_ok(long long T, int Nt, int Nr, int n_paths, int n_taps, int max_shift);
+bool cdl_os_ul_ok(long long T, int Nt, int Nr, int n_paths, int n_taps, int max_shift);   // uplink: one or two transmit elements into many receive elements
 int cdl_os_apply(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long T, int Nt, int Nr, int n_paths, const double* taps, int n_taps, const int32_t* shift, int max_shift,
                  double out_scale);
 namespace {
@@ -1005,6 +1006,8 @@ int cdl_apply_jobs(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long lon
   }
   if (n_seg_total > 65535) return fail(ctx, ISAC_ERR_CAPACITY, "more than 65535 (job, gain block) segments in one batch");
   if (!ul && cdl_os_ok(T, Nt, Nr, n_paths, n_taps, max_shift))      // long downlink waveforms: overlap-save in the frequency domain (cdl_os.hip), the waveform's transforms shared by its UEs
+    return cdl_os_apply(ctx, jobs, n_jobs, T, Nt, Nr, n_paths, taps, n_taps, shift, max_shift, out_scale);
+  if (ul && cdl_os_ul_ok(T, Nt, Nr, n_paths, n_taps, max_shift))    // long uplink waveforms: the same overlap-save form, one workgroup per (job, gain block, receive element)
     return cdl_os_apply(ctx, jobs, n_jobs, T, Nt, Nr, n_paths, taps, n_taps, shift, max_shift, out_scale);
   // workspace: DL (unfused kernels only): Z [T x Ncp] per segment;  UL: prefiltered signals [T x Kc] per job;  fused DL: none
   const bool fused = !ul && cdl_fused_ok(T, Nt, Nr, n_paths, n_taps, max_shift), fused_ul = ul && cdl_fused_ul_ok(T, Nt, Nr, n_paths, n_taps, max_shift);

@@ -24,6 +24,7 @@
 #include "fft_lds.hpp"
 
 int isac_get_twiddles(isac_ctx* ctx, int n, const isac::c64** out);  // capi.hip
+int isac_get_w512_pack(isac_ctx* ctx, const isac::c64** out);        // capi.hip
 
 namespace isac {
 
@@ -335,6 +336,90 @@ __global__ __launch_bounds__(256, 2) void cdl_os_inv_kernel(const OsPair* __rest
   }, tid);
 }
 
+// K4 (UPLINK: one or two transmit elements into many receive elements; gNBPhy.m:833-864, cdl.m:78-85): one workgroup per (pair, receive element u).
+// With two transmit elements Y_u(f) = C_0u(f) X_0(f) + C_1u(f) X_1(f) is two multiply-adds per bin: the mix needs no kernel of its own -- the workgroup forms the combined
+// impulse responses c_su[m] = sum_n H[n][s][u] g_n[m - shift_n] (<= Mpad taps), transforms them ONCE (C_su(f) stays in registers: 16 bins per thread and s), and then per window
+// loads the two X spectra (shared by the 64 workgroups of the pair: L2), forms Y_u(f) in the transform's own registers, inverts and stores the window's valid samples.
+// Nothing but X(f) (131 KB per window and waveform) and y leaves the CU: per job 2 x 18 forward + 64 x (2 + 18) in-LDS transforms instead of 1.09 GF on the matrix pipe.
+template <int NS, class FFT, int NU, int MINW>
+__global__ __launch_bounds__(FFT::NT, MINW) void cdl_os_ul_kernel(const OsPair* __restrict__ pairs, long long T, int Nr, int n_seg, int S, int Mpad, int n_paths, int n_taps,
+                                                           const double* __restrict__ taps, const int* __restrict__ shift, const c64* __restrict__ tw,
+                                                           const c64* __restrict__ Xf /* [wave][seg][s][N] */, double scale /* out_scale / N */) {
+  // NU receive elements per workgroup share every window's X spectra (one fetch from L2 per NU inverse transforms: with NU = 1 the 64 workgroups of a pair read 131 KB per
+  // window each -- 126 GB per config-5 frame, the L2 / Infinity-Cache rate, not the transforms, set the pace: 22 ms)
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  c64* lds = reinterpret_cast<c64*>(smem_raw);
+  __shared__ __attribute__((aligned(16))) c64 hsm[NU][64 * NS];
+  __shared__ int ssh[64];
+  const int tid = threadIdx.x;
+  const int u0 = blockIdx.x * NU;
+  const OsPair pr = pairs[blockIdx.y];
+#pragma unroll
+  for (int a = 0; a < NU; ++a)
+    if (tid < n_paths * NS) hsm[a][tid] = pr.H[(long long)tid * Nr + (u0 + a < Nr ? u0 + a : Nr - 1)];     // H[n][s][u] at (n NS + s) Nr + u
+  if (tid < n_paths) ssh[tid] = shift[tid];
+  FFT fft;
+  fft.init(lds, tw, tid);                                                     // (a barrier inside: hsm / ssh are visible afterwards)
+  c64 C[NU][NS][FFT::PER];
+#pragma unroll
+  for (int a = 0; a < NU; ++a)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int j = 0; j < FFT::PER; ++j) {
+        c64 acc = mk(0.0, 0.0);
+        const int i = tid + FFT::NT * j;
+        if (FFT::NT * j < kOsN / 4 && i < Mpad) {                                // Mpad <= 1024: only the first elements of a thread can be non-zero
+          for (int n = 0; n < n_paths; ++n) {
+            const int k = i - ssh[n];
+            if (k >= 0 && k < n_taps) {
+              const double g = taps[n * n_taps + k];
+              const c64 h = hsm[a][n * NS + s];
+              acc.re = ::fma(h.re, g, acc.re);
+              acc.im = ::fma(h.im, g, acc.im);
+            }
+          }
+        }
+        fft.x[j] = acc;
+      }
+      __syncthreads();
+      fft.template transform<-1>(lds, tw, tid);
+#pragma unroll
+      for (int j = 0; j < FFT::PER; ++j) C[a][s][j] = fft.x[j];
+    }
+  for (int seg = pr.seg_lo; seg <= pr.seg_hi; ++seg) {
+    c64 xw[NS][FFT::PER];
+    const c64* X = Xf + ((long long)pr.w * n_seg + seg) * NS * kOsN + tid;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j = 0; j < FFT::PER; ++j) xw[s][j] = X[(long long)s * kOsN + FFT::NT * j];
+    const long long t0 = (long long)seg * S - Mpad;
+    const long long w0 = (long long)seg * S, w1 = w0 + S;
+    const long long lo = pr.o0 > w0 ? pr.o0 : w0;
+    long long hi = pr.o1 < w1 ? pr.o1 : w1;
+    hi = hi < T ? hi : T;
+#pragma unroll
+    for (int a = 0; a < NU; ++a) {
+#pragma unroll
+      for (int j = 0; j < FFT::PER; ++j) {
+        c64 v = C[a][0][j] * xw[0][j];
+        if constexpr (NS == 2) v = fma(C[a][1][j], xw[1][j], v);
+        fft.x[j] = v;
+      }
+      __syncthreads();
+      fft.template transform<+1>(lds, tw, tid);
+      if (u0 + a < Nr) {
+        c64* y = pr.Y + T * (long long)(u0 + a);
+        fft.drain([&](int i, c64 v) {
+          const long long t = t0 + i;
+          if (t >= lo && t < hi) y[t] = v * scale;
+        }, tid);
+      }
+    }
+  }
+}
+
 }  // namespace isac
 
 using namespace isac;
@@ -345,13 +430,20 @@ bool cdl_os_ok(long long T, int Nt, int Nr, int n_paths, int n_taps, int max_shi
   return !off && Nr == 2 && (Nt == 8 || Nt == 16 || Nt == 32 || Nt == 64) && n_paths >= 1 && n_paths <= 64 && Mpad <= kOsN / 4 && T >= 2 * (kOsN - Mpad);
 }
 
+bool cdl_os_ul_ok(long long T, int Nt, int Nr, int n_paths, int n_taps, int max_shift) {
+  static const bool off = std::getenv("ISAC_CDL_TIME_DOMAIN") != nullptr || std::getenv("ISAC_CDL_UL_TIME_DOMAIN") != nullptr;   // development switches
+  const int Mpad = (max_shift + n_taps - 1 + 7) / 8 * 8;
+  return !off && (Nt == 1 || Nt == 2) && Nr > Nt && Nr <= 65535 && n_paths >= 1 && n_paths <= 64 && Mpad <= kOsN / 4 && T >= 2 * (kOsN - Mpad);
+}
+
 // jobs: the batch of isac_cdl_apply_batch_dev (cdl.hip); one launch sequence for all of them.
 int cdl_os_apply(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long T, int Nt, int Nr, int n_paths, const double* taps, int n_taps, const int32_t* shift, int max_shift,
                  double out_scale) {
   const int Mpad = (max_shift + n_taps - 1 + 7) / 8 * 8, S = kOsN - Mpad;
   const int n_seg = (int)((T + S - 1) / S);
   static const bool no_mfma = std::getenv("ISAC_CDL_OS_VALU") != nullptr;       // development switch: the first (all-VALU) mix kernel for every shape
-  const bool mfma_mix = Nt == 64 && !no_mfma;
+  const bool ul = Nr > Nt;                                                      // uplink form: cdl_os_ul_kernel, no mix launch, no Y spectra
+  const bool mfma_mix = !ul && Nt == 64 && !no_mfma;
   const size_t per_chunk = mfma_mix ? kOsMPairs : kOsPairs;
   // ---- distinct waveforms, (job, gain block) pairs, chunks of up to eight pairs on one waveform, (pair, window) tasks
   std::vector<const c64*> waves;
@@ -401,8 +493,8 @@ int cdl_os_apply(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long 
     for (int s = ordered[p].seg_lo; s <= ordered[p].seg_hi; ++s) tasks.push_back(OsTask{(int)p, s});
   // ---- workspace: E | X spectra | Y spectra;  metadata through the pinned staging ring
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  const size_t e_bytes = pad(sizeof(c64) * (size_t)n_paths * kOsN), x_bytes = pad(sizeof(c64) * waves.size() * (size_t)n_seg * Nt * kOsN),
-               y_bytes = pad(sizeof(c64) * (size_t)n_tasks * Nr * kOsN);
+  const size_t e_bytes = ul ? 0 : pad(sizeof(c64) * (size_t)n_paths * kOsN), x_bytes = pad(sizeof(c64) * waves.size() * (size_t)n_seg * Nt * kOsN),
+               y_bytes = ul ? 0 : pad(sizeof(c64) * (size_t)n_tasks * Nr * kOsN);
   ISAC_TRY(ensure(ctx, ctx->stage_b, e_bytes + x_bytes + y_bytes));
   c64* d_E = (c64*)ctx->stage_b.p;
   c64* d_X = (c64*)((char*)ctx->stage_b.p + e_bytes);
@@ -422,9 +514,34 @@ int cdl_os_apply(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long 
   ISAC_TRY(stage_upload(ctx, dm, host.data(), meta));
   const c64* tw = nullptr;
   ISAC_TRY(isac_get_twiddles(ctx, kOsN, &tw));
+  const size_t lds = sizeof(c64) * Fft4096::LDS_ELEMS;
+  if (ul) {
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cdl_os_fwd_kernel), lds));
+    hipLaunchKernelGGL(cdl_os_fwd_kernel, dim3((unsigned)n_seg, (unsigned)Nt, (unsigned)waves.size()), dim3(256), lds, ctx->stream, (const c64* const*)(dm + o_waves), T, Nt, n_seg, S,
+                       Mpad, tw, 12, d_X);                                      // (one 4096-bin "tile": the plain [wave][seg][s][N] layout)
+    ISAC_HIP(hipGetLastError());
+    if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));
+    const c64* tw_ul = nullptr;
+    ISAC_TRY(isac_get_w512_pack(ctx, &tw_ul));
+    // (one receive element per workgroup: sharing a window's X spectra between two or four of them -- NU = 2 / 4 -- needs their C(f) in registers as well and spills (268 / 948
+    //  bytes per lane at the 256-register ceiling of a 512-thread workgroup); measured, the launch is bound by the in-LDS transforms themselves -- ~50 per microsecond on the
+    //  whole device, the rate of the fused echo kernel -- whatever the occupancy or the X prefetch: 22-24 ms per config-5 frame for all forms)
+#define ISAC_OS_UL(NS)                                                                                                                                                       \
+  do {                                                                                                                                                                       \
+    const size_t l_ = sizeof(c64) * Fft4096W::LDS_ELEMS;                                                                                                                     \
+    const dim3 gu_((unsigned)Nr, (unsigned)ordered.size());                                                                                                                  \
+    ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cdl_os_ul_kernel<NS, Fft4096W, 1, 2>), l_));                                                                       \
+    hipLaunchKernelGGL((cdl_os_ul_kernel<NS, Fft4096W, 1, 2>), gu_, dim3(Fft4096W::NT), l_, ctx->stream, (const OsPair*)(dm + o_pairs), T, Nr, n_seg, S, Mpad, n_paths,      \
+                       n_taps, (const double*)(dm + o_taps), (const int*)(dm + o_shift), tw_ul, (const c64*)d_X, out_scale / (double)kOsN);                                  \
+  } while (0)
+    if (Nt == 1) ISAC_OS_UL(1); else ISAC_OS_UL(2);
+#undef ISAC_OS_UL
+    ISAC_HIP(hipGetLastError());
+    if (ctx->profile) { ISAC_HIP(hipEventRecord(ctx->ev_k1, ctx->stream)); ctx->profile_recorded = true; }
+    return ISAC_OK;
+  }
   hipLaunchKernelGGL(cdl_os_table_kernel, dim3(kOsN / 256, (unsigned)n_paths), dim3(256), 0, ctx->stream, (const double*)(dm + o_taps), (const int*)(dm + o_shift), n_paths, n_taps, d_E);
   ISAC_HIP(hipGetLastError());
-  const size_t lds = sizeof(c64) * Fft4096::LDS_ELEMS;
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cdl_os_fwd_kernel), lds));
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cdl_os_inv_kernel), lds));
   hipLaunchKernelGGL(cdl_os_fwd_kernel, dim3((unsigned)n_seg, (unsigned)Nt, (unsigned)waves.size()), dim3(256), lds, ctx->stream, (const c64* const*)(dm + o_waves), T, Nt, n_seg, S,

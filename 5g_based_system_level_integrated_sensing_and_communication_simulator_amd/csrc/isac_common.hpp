@@ -113,7 +113,7 @@ struct StageSlot {
   hipEvent_t ev = nullptr;
   bool busy = false;
 };
-constexpr int kStageSlots = 32;     // (a batched CDL call stages two blocks: with 8 slots the host could run only 4 calls ahead of the device and short launches starved it)
+constexpr int kStageSlots = 128;    // (a batched CDL call stages two or three blocks and a slot is free again only when the stream has REACHED its copy: with 8 slots the host ran 4 calls ahead of the device, with 32 about ten -- 5 ms of config 5's frame; 128: the host issues a frame's applies in 40 ms against 94 ms of GPU work)
 
 struct Fft2dPending {  // state between isac_fft2d_submit_dev and isac_fft2d_collect
   bool active = false;

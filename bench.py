@@ -392,6 +392,7 @@ class CommCell:
     WITH_RI = os.environ.get("ISAC_C5_NO_RI") is None            # round 6: rank selection per CSI report (uePhy.m:900)
     WITH_SRS = os.environ.get("ISAC_C5_NO_SRS") is None          # round 6: the gNB's SRS measurement of every UE (gNBPhy.m:1023-1060)
     SRS_BAND = 16
+    BATCH_OCCASIONS = os.environ.get("ISAC_C5_CSI_PER_OCCASION") is None   # round 6: a cell's four CSI-RS occasions of the frame as one batch
     DEVICE_CSI = os.environ.get("ISAC_C5_HOST_CSI") is None
 
     def __init__(self, pkg, ctxs_cdl, ctx_csi, cell_id, n_ants, n_ues):
@@ -436,6 +437,7 @@ class CommCell:
         pl_db = 32.4 + 20.0 * np.log10(3.5) + 30.0 * np.log10(np.maximum(r, 10.0))
         self.nvar = 10.0 ** (-(46.0 - pl_db - (-174.0 + 10.0 * np.log10(100e6) + 7.0)) / 10.0)
         self.h_est = [ctx_csi.to_device(freq_response(ch, self.csi_k, K, 30e3, 4)) for ch in self.chans]
+        self.h_est_occ = [[ctx_csi.empty(tuple(self.h_est[u].shape)) for u in range(n_ues)] for _ in range(self.CSI_OCCASIONS)]
         # uplink: every UE's packet of a 'U' slot through its UL channel (UE 2 elements -> gNB array), cdl.m:78-85
         self.ul_chans = [CM.CDLChannel(DelayProfile="CDL-D" if lo else "CDL-A", TransmitAntennaArraySize=(1, 1, 2, 1, 1), ReceiveAntennaArraySize=nt_shape, Seed=73) for lo in self.los]
         self.ul_waves, self.ul_rx, self.ul_gains = [], [], []
@@ -476,25 +478,50 @@ class CommCell:
             for gi, g in enumerate(self.groups):              # appears four times advances its time from slot to slot)
                 self.CM.applyCDLBatch([self.ul_chans[u] for _ in range(self.UL_SLOTS) for u in g], [self.ul_waves[u] for _ in range(self.UL_SLOTS) for u in g],
                                       ctx=self.ctxs[gi % len(self.ctxs)], outs=self.ul_rx[gi], gains=self.ul_gains[gi])
+        # channel times the frame's reports refer to, fixed HERE (the reports may run on another host thread while the next frame's applies advance the channels):
+        # the frame's first DL slot (CSI-RS occasions count from it) and the frame's last 'U' slot (SRS)
+        self.t_frame = [ch.time - self.DL_SLOTS * self.T / ch.SampleRate for ch in self.chans]
+        self.t_srs = [ch.time - self.T / ch.SampleRate for ch in self.ul_chans] if self.WITH_UL else None
 
-    def csi_reports(self):
+    def reports(self, t_frame=None, t_srs=None):
+        self.csi_reports(t_frame)
+        self.srs_reports(t_srs)
+
+    def csi_reports(self, t_frame=None):
         """The frame's CSI-RS occasions: every UE's report, one batched call (one synchronisation of the CSI context) per occasion."""
-        t_frame = [ch.time - self.DL_SLOTS * self.T / ch.SampleRate for ch in self.chans]        # channel time at the frame's first DL slot (enqueue_frame has advanced it)
-        for o in range(self.CSI_OCCASIONS):
+        t_frame = t_frame or self.t_frame                    # channel time at the frame's first DL slot (enqueue_frame has advanced the channels past the frame)
+        csirs = SimpleNamespace(k=self.csi_k, l=self.csi_l)
+        if self.BATCH_OCCASIONS and self.DEVICE_CSI:
+            # round 6: the frame's four occasions of the cell in ONE pass -- every (occasion, UE) is an entry of the batched calls (its own channel time, its own estimate):
+            # one estimate call per delay-profile group, one report call per rank: 2 synchronisations per cell and frame instead of 8 (each is a host round trip of ~0.2 ms
+            # that the GPU does not hide: the applies queued on the other streams do not run ahead of a blocked host)
+            for g in self.groups:
+                self.CM.csiEstimateBatch([self.chans[u] for o in range(self.CSI_OCCASIONS) for u in g], self.csi_k, 3276, 30e3, 4, ctx=self.ctx_csi,
+                                         times=[t_frame[u] + o * 5 * self.T / self.chans[u].SampleRate for o in range(self.CSI_OCCASIONS) for u in g],
+                                         outs=[self.h_est_occ[o][u] for o in range(self.CSI_OCCASIONS) for u in g])
+            h_all = [self.h_est_occ[o][u] for o in range(self.CSI_OCCASIONS) for u in range(self.n_ues)]
+            nvar_all = np.tile(self.nvar, self.CSI_OCCASIONS)
+            if self.WITH_RI:
+                sel = self.PL.riSelectBatch(self.carrier, csirs, self.report, h_all, nvar_all, DOWNLINK_SINR90PC, ctx=self.ctx_csi)[-self.n_ues:]
+                rep, self.last_ranks = [r_[1:] for r_ in sel], [r_[0] for r_ in sel]
+            else:
+                rep = self.PL.cqiSelectBatch(self.carrier, csirs, self.report, 1, h_all, nvar_all, DOWNLINK_SINR90PC, ctx=self.ctx_csi, codebook=self.codebook)[-self.n_ues:]
+        else:
+          for o in range(self.CSI_OCCASIONS):
             if self.DEVICE_CSI:                               # this occasion's channel estimates, formed on the device from this occasion's path gains (CSI-RS period
                 for g in self.groups:                         # 5 slots): one library call per delay-profile group
                     self.CM.csiEstimateBatch([self.chans[u] for u in g], self.csi_k, 3276, 30e3, 4, ctx=self.ctx_csi,
                                              times=[t_frame[u] + o * 5 * self.T / self.chans[u].SampleRate for u in g], outs=[self.h_est[u] for u in g])
             if self.WITH_RI:                                  # uePhy.m:900-908: riSelect (the PMI search at every rank the two-antenna UE supports), the report at that rank
-                sel = self.PL.riSelectBatch(self.carrier, SimpleNamespace(k=self.csi_k, l=self.csi_l), self.report, self.h_est, self.nvar, DOWNLINK_SINR90PC, ctx=self.ctx_csi)
+                sel = self.PL.riSelectBatch(self.carrier, csirs, self.report, self.h_est, self.nvar, DOWNLINK_SINR90PC, ctx=self.ctx_csi)
                 rep, self.last_ranks = [r_[1:] for r_ in sel], [r_[0] for r_ in sel]
             else:
-                rep = self.PL.cqiSelectBatch(self.carrier, SimpleNamespace(k=self.csi_k, l=self.csi_l), self.report, 1, self.h_est, self.nvar, DOWNLINK_SINR90PC,
+                rep = self.PL.cqiSelectBatch(self.carrier, csirs, self.report, 1, self.h_est, self.nvar, DOWNLINK_SINR90PC,
                                              ctx=self.ctx_csi, codebook=self.codebook)
         self.last_cqi = [None if np.isnan(c[0][0]) else int(c[0][0]) for c in rep]
         self.last_reports = rep                              # (cqi, pmi, info) per UE of the frame's last occasion: what the per-cell record carries to rank 0
 
-    def srs_reports(self):
+    def srs_reports(self, t_srs=None):
         """The gNB's uplink measurement (gNBPhy.m:1023-1060): per UE the channel estimate at the SRS symbol of the frame's last 'U' slot -- the perfect estimate,
         formed on the device from that slot's UL path gains (the estimator is toolbox code; as nrChannelEstimate's output it covers every subcarrier) -- through
         pmiSelect (6 TPMIs of the two-port codebook x 3 276 REs x the 64-element array) to TPMI per subband and CQI per RB.  The reference's SRS period is 8 slots
@@ -503,7 +530,7 @@ class CommCell:
             return
         for g in self.groups:
             self.CM.csiEstimateBatch([self.ul_chans[u] for u in g], self.srs_k1, 3276, 30e3, 2, ctx=self.ctx_csi,
-                                     times=[self.ul_chans[u].time - self.T / self.ul_chans[u].SampleRate for u in g], outs=[self.h_srs[u] for u in g])
+                                     times=[(t_srs or self.t_srs)[u] for u in g], outs=[self.h_srs[u] for u in g])
         self.last_srs = self.PL.srsReportBatch(1, self.h_srs, self.srs_k1 - 1, self.nvar_ul, self.SRS_BAND, 273, UPLINK_SINR90PC, ctx=self.ctx_csi)
 
     def gemm_launch(self):
@@ -512,6 +539,19 @@ class CommCell:
         n_paths = self.chans[self.groups[gi][0]].path_delays().size
         cols = -(-(2 * n_paths) // 16) * 16
         return gi, len(self.groups[gi]), 6.0 * self.T * cols * self.A * len(self.groups[gi]), n_paths
+
+    def os_mix_flops(self, gi, n_jobs):
+        """fp64 flops of one cdl_os_mix_mfma_kernel launch over n_jobs jobs of group gi, counted with ONE gain block per job (a job that crosses a gain refresh forms C(f)
+        twice: the count is a lower bound): phase A on the matrix pipe -- per job 2 u x 4 row tiles x ceil(paths / 4) k-steps x 256 bin tiles x 3 MFMAs of 2 x 16 x 16 x 4 flops --,
+        phase B on the VALU -- windows x 4096 bins x 128 complex multiply-adds x 8 flops."""
+        ch = self.chans[self.groups[gi][0]]
+        g, shift = ch.filter_taps()
+        mpad = -(-(int(np.max(shift)) + g.shape[1] - 1) // 8) * 8
+        n_seg = -(-self.T // (4096 - mpad))
+        ksteps = -(-g.shape[0] // 4)
+        fa = n_jobs * 2 * 4 * ksteps * 256 * 3 * 2.0 * 16 * 16 * 4
+        fb = n_jobs * n_seg * 4096 * 128 * 8.0
+        return fa, fb, n_seg
 
 
 DOWNLINK_SINR90PC = np.array([-3.46, 1.54, 6.54, 11.05, 13.54, 16.04, 17.54, 20.04, 22.04, 24.43, 26.93, 27.43, 29.43, 32.43, 35.43])   # setupSINRtoCQIMappingTable.m:7-11
@@ -540,22 +580,38 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
         if dist is not None:
             dist.barrier()
 
+    # The reports of a cell (CSI: riSelect + cqiSelect of its four occasions; SRS) are host round trips -- uploads, small launches, a copy back, a synchronisation, the
+    # host half of the report -- that a GPU busy with the applies does not hide while the issuing thread is blocked in them.  They run on a second HOST thread
+    # (the reference's cells are parallel workers, networkSimulation.m:47-60; ctypes drops the GIL inside the library), one cell at a time, on their own context;
+    # the main thread keeps enqueueing sensing CPIs and applies.  A frame's reports are all waited for before the timed region ends.  ISAC_C5_REPORT_THREAD=0: inline.
+    from concurrent.futures import ThreadPoolExecutor
+    threaded = os.environ.get("ISAC_C5_REPORT_THREAD", "1") != "0"
+    reporter = ThreadPoolExecutor(max_workers=1) if threaded else None
+    pending = []
+
     def frame():
         for sc, cc in zip(sense, comm):
             pool.submit(sc)
             cc.enqueue_frame()
-        for cc in comm:
-            cc.csi_reports()
-            cc.srs_reports()
+            if reporter is not None:
+                pending.append(reporter.submit(cc.reports, cc.t_frame, cc.t_srs))      # (the frame's time stamps travel with the job: the next frame's enqueue overwrites them)
+            else:
+                cc.reports()
+
+    def reports_done():
+        while pending:
+            pending.pop().result()
 
     for _ in range(args.warmup):
         frame()
     pool.drain()
+    reports_done()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         frame()
     pool.drain()
+    reports_done()
     barrier()
     dt = time.perf_counter() - t0
     os.write(2, f"bench.py: rank {rank}/{world}: device {local_rank}, {len(mine)} cell(s) {mine}, timed region {1e3 * dt:.3f} ms for {args.steps} frame(s), config5\n".encode())
@@ -587,6 +643,28 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
         cc.csi_reports()
     ms_csi = 1e3 * (time.perf_counter() - t1) / (3 * cc.CSI_OCCASIONS * cc.n_ues)
     n_applies = sum(c_.n_ues for c_ in comm) * CommCell.DL_SLOTS
+    time_domain = bool(os.environ.get("ISAC_CDL_TIME_DOMAIN") or os.environ.get("ISAC_CDL_UNFUSED")) or args.ants != 64
+    if time_domain:
+        roof = {"bound": "mfma", "kernel": "cdl_fused_kernel<NCT,NSLOT> (DL apply of a batch in one persistent launch: contraction X [T x Nt] against the path gains of every job, 3M form on "
+                                           "v_mfma_f64_16x16x4_f64, + 16-tap delay filters + integer delays on the CU; Z never in HBM)" if not os.environ.get("ISAC_CDL_UNFUSED") else
+                                           "cdl_gemm_kernel<NCT,false> (DL contraction of a batch; ISAC_CDL_UNFUSED: the delay filter is a second launch, Z through HBM)",
+                "achieved": round(flops / 1e12 / (ms_k / 1e3), 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / 1e12 / (ms_k / 1e3) / FP64_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None, "avg_launch_ms": round(ms_k, 4), "launches_averaged": 10, "jobs_per_launch": n_jobs, "paths": n_paths,
+                "issued_flops_per_launch": flops, "flops_note": "contraction only (the launch also runs the delay filters on the VALU: + 16 % flops, not counted): 3 real MFMAs x 2 flops per complex multiply-add, padded to 16-column tiles: 6 T cols Nt per job",
+                "whole_batch_call_ms": round(ms_call, 4), "whole_batch_note": "path gains + apply of the same batch, HIP events around the call",
+                "timing": "HIP events recorded by the library around the apply launch (isac_profile_*), device otherwise idle"}
+    else:
+        fa, fb, n_seg = cc.os_mix_flops(gi, n_jobs)
+        roof = {"bound": "mfma", "kernel": "cdl_os_mix_mfma_kernel (overlap-save DL apply, the arithmetic of the path: per 16-bin tile C(f) = sum_n H_n E_n(f) on v_mfma_f64_16x16x4_f64 -- 3M complex form --, "
+                                           "then Y(f) = C(f) X(f) for every 4096-sample window on the fp64 VALU; forward / inverse transforms are separate HBM-bound launches)",
+                "achieved": round((fa + fb) / 1e12 / (ms_k / 1e3), 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round((fa + fb) / 1e12 / (ms_k / 1e3) / FP64_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None, "avg_launch_ms": round(ms_k, 4), "launches_averaged": 10, "jobs_per_launch": n_jobs, "paths": n_paths, "windows": n_seg,
+                "issued_flops_per_launch": fa + fb, "mfma_flops": fa, "valu_flops": fb,
+                "flops_note": "matrix-pipe flops of C(f) (three real MFMAs per complex product, paths padded to a multiple of four) + vector flops of Y(f) (8 per complex multiply-add), one gain "
+                              "block per job (a lower bound); the part's fp64 vector and matrix peaks are the same 78.6 TFLOP/s.  The time-domain formulation of rounds 4-5 issued 1.09 GF per "
+                              "job on the matrix pipe for the same result: this launch needs %.2f GF per job" % ((fa + fb) / n_jobs / 1e9),
+                "whole_batch_call_ms": round(ms_call, 4), "whole_batch_note": "path gains + forward transforms + mix + inverse transforms of the same batch, HIP events around the call",
+                "timing": "HIP events recorded by the library around the mix launch (isac_profile_*), device otherwise idle"}
     res = {"metric": "sensing slots/sec (CDL echo->2D-FFT->2D-CFAR)", "value": round(n_cells * 20 * args.steps / dt_max, 2), "unit": "slots/sec (whole cells: sensing CPI + CDL applies + CSI reports)",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_max / args.steps, 3), "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -603,14 +681,7 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
                                   "ul_applies": sum(c_.n_ues for c_ in comm) * CommCell.UL_SLOTS if CommCell.WITH_UL else 0, "precoded": True,
                                   "csi_h": "device, per occasion" if CommCell.DEVICE_CSI else "host, once at set-up",
                                   "rank_selection": CommCell.WITH_RI, "srs_reports": sum(c_.n_ues for c_ in comm) if CommCell.WITH_UL and CommCell.WITH_SRS else 0},
-           "roofline": {"bound": "mfma", "kernel": "cdl_fused_kernel<NCT,NSLOT> (DL apply of a batch in one persistent launch: contraction X [T x Nt] against the path gains of every job, 3M form on "
-                                                    "v_mfma_f64_16x16x4_f64, + 16-tap delay filters + integer delays on the CU; Z never in HBM)" if not os.environ.get("ISAC_CDL_UNFUSED") else
-                                                    "cdl_gemm_kernel<NCT,false> (DL contraction of a batch; ISAC_CDL_UNFUSED: the delay filter is a second launch, Z through HBM)",
-                        "achieved": round(flops / 1e12 / (ms_k / 1e3), 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / 1e12 / (ms_k / 1e3) / FP64_MFMA_PEAK_TFLOPS, 4),
-                        "traffic": None, "avg_launch_ms": round(ms_k, 4), "launches_averaged": 10, "jobs_per_launch": n_jobs, "paths": n_paths,
-                        "issued_flops_per_launch": flops, "flops_note": "contraction only (the launch also runs the delay filters on the VALU: + 16 % flops, not counted): 3 real MFMAs x 2 flops per complex multiply-add, padded to 16-column tiles: 6 T cols Nt per job",
-                        "whole_batch_call_ms": round(ms_call, 4), "whole_batch_note": "path gains + apply of the same batch, HIP events around the call",
-                        "timing": "HIP events recorded by the library around the apply launch (isac_profile_*), device otherwise idle"},
+           "roofline": roof,
            "comm_seams": {"cdl_apply_ms_per_job": round(ms_call / n_jobs, 4), "csi_report_ms_per_ue": round(ms_csi, 4),
                           "csi_note": "host wall per UE of the batched report (one synchronisation per cell and occasion), device otherwise idle"},
            "cells": [d.record_json(r) for r in allr[:64]],

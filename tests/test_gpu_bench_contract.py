@@ -31,10 +31,22 @@ def test_bench_line_carries_the_contract_fields():
     assert "workload" in d["config"] and "64-antenna" in d["config"]["workload"] and "K=3276 L=224" in d["config"]["workload"]
     assert abs(d["value"] - 16.0 * 6 / (d["ms_per_step"] * 6 / 1e3)) <= 1e-3 * d["value"]        # slots = 16 per CPI
     rf = d["roofline"]
-    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and 0.0 < rf["frac"] < 1.0     # (no lower bar: under pytest-xdist other tests share the GPU)
-    assert rf["traffic"] is None or rf["traffic"] >= rf["algorithmic_bytes_per_launch"]
-    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / 1e9 / (rf["avg_launch_ms"] / 1e3)) <= 1e-2 * rf["achieved"]
+    assert rf["bound"] in ("hbm", "mfma") and 0.0 < rf["frac"] < 1.0                             # (no lower bar: under pytest-xdist other tests share the GPU)
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    if rf["bound"] == "mfma":
+        # round 6, lazy echo grid (the default at this shape): the longest launch of the CPI is the covariance -- priced on its issued fp64 MFMA flops; the fused
+        # echo + range kernel follows as `second_kernel`, priced on the bytes it still moves (txGrid read; no echoGrid store)
+        assert "LAZY" in d["config"]["workload"] and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.6 and "cov_lazy_kernel" in rf["kernel"]
+        assert abs(rf["achieved"] - rf["issued_flops_per_launch"] / 1e12 / (rf["avg_launch_ms"] / 1e3)) <= 1e-2 * rf["achieved"]
+        sk = rf["second_kernel"]
+        assert sk["bound"] == "hbm" and sk["algorithmic_bytes_per_launch"] == 3276 * 224 * 64 * 16 and 0.0 < sk["frac"] < 1.0
+        assert rf["avg_launch_ms"] > sk["avg_launch_ms"]
+        assert rf["traffic"] is None or rf["traffic"] < 0.1 * sk["algorithmic_bytes_per_launch"]    # the covariance reads D and writes partial tiles: tens of MB
+    else:
+        assert rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+        assert rf["traffic"] is None or rf["traffic"] >= rf["algorithmic_bytes_per_launch"]
+        assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / 1e9 / (rf["avg_launch_ms"] / 1e3)) <= 1e-2 * rf["achieved"]
+    assert rf["whole_cpi"]["algorithmic_bytes"] == 2 * 3276 * 224 * 64 * 16 + (983040 + 3276 * 224) * 64 * 16    # SURVEY 8d's 3.261 GB per CPI, whatever the echo-grid mode
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"] and cb["sample"]
     assert d["value"] > 10 * cb["value"]                           # north_star: >= 10x the CPU path on the same host

@@ -104,6 +104,34 @@ def test_cdl_overlap_save_shapes_match_oracle(pkg, profile, tx, fs, t_len, n_ue)
         assert rel(o.numpy(), want) < RTOL, (profile, tx, u)
 
 
+@pytest.mark.parametrize("profile,rx,fs,t_len,n_ue,tx", [("CDL-A", (1, 4, 2, 1, 1), 122.88e6, 9000, 3, UE), ("CDL-D", (1, 8, 2, 1, 1), 30.72e6, 20011, 2, UE), ("CDL-A", (2, 8, 2, 1, 1), 61.44e6, 12345, 5, UE),
+                                                          ("CDL-D", (4, 8, 2, 1, 1), 122.88e6, 8192, 1, UE), ("CDL-A", (1, 3, 1, 1, 1), 122.88e6, 7777, 2, (1, 1, 1, 1, 1))])
+def test_cdl_overlap_save_uplink_shapes_match_oracle(pkg, profile, rx, fs, t_len, n_ue, tx):
+    """The frequency-domain UPLINK apply (cdl_os_ul_kernel: one workgroup per (job, gain block, receive element), the combined impulse response transformed once, Y(f) formed
+    in the inverse transform's registers) at 8 / 16 / 32 / 64 receive elements and a single-antenna UE into three, ragged lengths, every UE with its own waveform, UEs next to
+    a path-gain refresh (two gain blocks whose windows overlap at the boundary) -- every output sample <= 1e-10 of the oracle."""
+    import oracle.cdl as OC
+    CM = pkg.communication.channelModels
+    ctx = pkg.default_context()
+    nt, nr = int(np.prod(tx)), int(np.prod(rx))
+    refresh = 1.0 / 640
+    rng = np.random.default_rng(nr + t_len)
+    xs = [np.asfortranarray(rng.standard_normal((t_len, nt)) + 1j * rng.standard_normal((t_len, nt))) for _ in range(n_ue)]
+    d_xs = [ctx.to_device(x) for x in xs]
+    chans, t_start = [], []
+    for u in range(n_ue):
+        ch = CM.CDLChannel(profile, 300e-9, 3.5e9, tx, rx, fs, Seed=73 + (u % 3))
+        t0 = (2 + u) * refresh - (1 + (u * t_len) // max(n_ue, 1) % t_len) / fs if u % 2 == 0 else 0.01 * u
+        ch.time = t0
+        chans.append(ch); t_start.append(t0)
+    outs = CM.applyCDLBatch(chans, d_xs, ctx=ctx)
+    for u, (ch, o) in enumerate(zip(chans, outs)):
+        cfg = OC.cdl_config(profile, 3.5e9, tx, rx, fs, seed=73 + (u % 3))
+        want = OC.apply_cdl(cfg, xs[u], t_start[u])
+        assert o.numpy().shape == (t_len, nr)
+        assert rel(o.numpy(), want) < RTOL, (profile, rx, u)
+
+
 def test_bench_config5_frame_against_oracle(pkg):
     """bench.py's CommCell (the object `--workload config5` times) stepped for one frame: (a) the precoded PDSCH input of a downlink slot = oracle prgPrecode of the
     same layers and precoders + the oracle's CP-OFDM modulator; (b) one downlink job of the frame's last call (UE, slot 15) and (c) one uplink job (UE, third 'U' slot:

@@ -742,7 +742,8 @@ def test_cdl_fused_apply_bits_do_not_depend_on_the_grid(tmp_path):
             c = np.load(tmp_path / f.replace("cu_", "os_"))          # frequency-domain overlap-save apply (cdl_os.hip) where the shape qualifies, the same kernels elsewhere
             assert rel(c, a) < 1e-12, f
     assert runs["os"][0] != runs["cu"][0] and runs["os"][2] != runs["cu"][2]      # 64 and 16 transmit elements, T >= two windows: really another code path
-    assert runs["os"][4:] == runs["cu"][4:]                                        # 6 transmit elements / uplink: the time-domain kernels either way
+    assert runs["os"][4:6] == runs["cu"][4:6] and runs["os"][8:] == runs["cu"][8:]  # 6 transmit elements / a 4 000-sample uplink (less than two windows): the time-domain kernels either way
+    assert runs["os"][6] != runs["cu"][6]                                          # uplink 2 -> 64, T = 9 001: the overlap-save uplink kernel (cdl_os_ul_kernel)
     for i in range(0, 10, 2):
         assert runs["os"][i][1:] == runs["os"][i + 1][1:]                          # overlap-save: a job alone == the job in a batch, bit for bit
 

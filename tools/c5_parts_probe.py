@@ -40,10 +40,26 @@ def everything():
     for sc, cc in zip(sense, comm):
         pool.submit(sc); cc.enqueue_frame()
     for cc in comm:
-        cc.csi_reports()
+        cc.csi_reports(); cc.srs_reports()
+def srs_only():
+    for cc in comm:
+        cc.srs_reports()
 run("DL applies only (3 360 jobs, 84 calls)", dl_only)
 run("UL applies only (840 jobs, 42 calls)", ul_only)
 run("DL + UL applies", cdl_all)
 run("sensing CPIs only (21)", sensing_only)
 run("CSI estimates + reports only (840)", csi_only)
-run("whole frame", everything)
+run("SRS estimates + reports only (210)", srs_only)
+def no_reports():
+    for sc, cc in zip(sense, comm):
+        pool.submit(sc); cc.enqueue_frame()
+def interleaved():
+    for sc, cc in zip(sense, comm):
+        pool.submit(sc); cc.enqueue_frame(); cc.csi_reports(); cc.srs_reports()
+def reports_only():
+    for cc in comm:
+        cc.csi_reports(); cc.srs_reports()
+run("sensing + DL + UL (no reports)", no_reports)
+run("CSI + SRS reports only", reports_only)
+run("whole frame, reports after all applies", everything)
+run("whole frame, reports interleaved per cell", interleaved)
