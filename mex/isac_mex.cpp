@@ -577,6 +577,38 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       std::memcpy(mxGetDoubles(plhs[3]) + (size_t)u * ncqi, rep[(size_t)u].subband_cqi, sizeof(double) * (size_t)ncqi);
       std::memcpy(mxGetDoubles(plhs[4]) + (size_t)u * ncqi, rep[(size_t)u].sinr_per_subband_cw, sizeof(double) * (size_t)ncqi);
     }
+    if (nlhs > 5) {                                                  // sixth output (round 6): riSelect.m:253-276's totalSINR of this rank, one value per UE
+      plhs[5] = mxCreateDoubleMatrix(1, (mwSize)nu, mxREAL);
+      for (int u = 0; u < nu; ++u) mxGetDoubles(plhs[5])[u] = rep[(size_t)u].ri_total_sinr;
+    }
+  } else if (fn == "srsReportBatch") {
+    // [pmi (nSB x n, 0-based TPMI), sinrSubbandPMI (nSB x n), cqiRBs (nRB x n)] = (Hre [nRE x R x P x n] at the SRS resource elements, k (1-based subcarrier of each RE),
+    //   NRBsUL, bandSize, nLayers, nVar [n], SINRTable): gNBPhy.m:1023-1058 (pmiSelect + the NaN-subband / per-RB CQI step) for the UEs that share the SRS positions
+    if (nrhs < 8) mexErrMsgIdAndTxt("isac:INVALID_ARG", "srsReportBatch: (Hre, k, NRBsUL, bandSize, nLayers, nVar, SINRTable)");
+    const mxArray *h = prhs[1], *kk = prhs[2], *nv = prhs[6], *tab = prhs[7];
+    const int n_rb = (int)mxGetScalar(prhs[3]), band = (int)mxGetScalar(prhs[4]), nl = (int)mxGetScalar(prhs[5]);
+    const mwSize* hd = mxGetDimensions(h);
+    const mwSize nhd = mxGetNumberOfDimensions(h);
+    const int64_t n_re = (int64_t)hd[0];
+    const int R = nhd > 1 ? (int)hd[1] : 1, P = nhd > 2 ? (int)hd[2] : 1, nu = nhd > 3 ? (int)hd[3] : 1;
+    if ((int)mxGetNumberOfElements(nv) != nu || (int64_t)mxGetNumberOfElements(kk) != n_re) mexErrMsgIdAndTxt("isac:INVALID_ARG", "srsReportBatch: one subcarrier per RE, one noise variance per UE");
+    if (n_rb < 1 || n_rb > ISAC_MAX_RBS) mexErrMsgIdAndTxt("isac:INVALID_ARG", "srsReportBatch: NRBsUL out of range");
+    std::vector<int32_t> k((size_t)n_re);
+    for (int64_t i = 0; i < n_re; ++i) k[(size_t)i] = (int32_t)mxGetDoubles(kk)[i] - 1;
+    DevIn d_h(h);
+    std::vector<const isac_c64*> hl((size_t)nu);
+    for (int u = 0; u < nu; ++u) hl[(size_t)u] = d_h.p + (size_t)u * (size_t)n_re * R * P;
+    std::vector<isac_srs_report> rep((size_t)nu);
+    check(isac_srs_pmi_select_batch_dev(ctx(), nu, hl.data(), n_re, R, P, k.data(), n_rb, band, nl, mxGetDoubles(nv), mxGetDoubles(tab), (int)mxGetNumberOfElements(tab), rep.data()));
+    const int nsb = rep[0].n_subbands;
+    plhs[0] = mxCreateDoubleMatrix((mwSize)nsb, (mwSize)nu, mxREAL);
+    plhs[1] = mxCreateDoubleMatrix((mwSize)nsb, (mwSize)nu, mxREAL);
+    plhs[2] = mxCreateDoubleMatrix((mwSize)n_rb, (mwSize)nu, mxREAL);
+    for (int u = 0; u < nu; ++u) {
+      std::memcpy(mxGetDoubles(plhs[0]) + (size_t)u * nsb, rep[(size_t)u].pmi, sizeof(double) * (size_t)nsb);
+      std::memcpy(mxGetDoubles(plhs[1]) + (size_t)u * nsb, rep[(size_t)u].sinr_subband_pmi, sizeof(double) * (size_t)nsb);
+      std::memcpy(mxGetDoubles(plhs[2]) + (size_t)u * n_rb, rep[(size_t)u].cqi_rb, sizeof(double) * (size_t)n_rb);
+    }
   } else if (fn == "senTxAppend") {
     // tLen = isac_mex('senTxAppend', gridHandle, waveHandle, txGrid [K x 14 x A], currSlot, isDLslot, carrierInfo, signalAmp, windowing,
     //                   slotsAlready, samplesAlready)                                          gNBPhy.m:591-612

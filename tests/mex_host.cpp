@@ -330,7 +330,8 @@ int comm(const char* in, const char* out) {
     const mwSize hd4[4] = {(mwSize)n_re, (mwSize)nrx, (mwSize)P, (mwSize)nu};
     mxArray* h4 = mxCreateNumericArray(4, hd4, mxDOUBLE_CLASS, mxCOMPLEX);
     for (int u = 0; u < nu; ++u) std::memcpy(mxGetComplexDoubles(h4) + H.size() * u, H.data(), sizeof(isac_c64) * H.size());
-    std::vector<mxArray*> rb = call("csiReportBatch", {h4, real_mat(k, n_re, 1), real_mat(l, n_re, 1), rc, scalar(nl), real_row(nv3, 3), real_mat(tab, nt, 1)}, 5);
+    std::vector<mxArray*> rb = call("csiReportBatch", {h4, real_mat(k, n_re, 1), real_mat(l, n_re, 1), rc, scalar(nl), real_row(nv3, 3), real_mat(tab, nt, 1)}, 6);
+    write_vec(o, rb[5]);                                             // riSelect's totalSINR of this rank for the three noise variances
     for (int u = 0; u < nu; ++u) {
       std::vector<mxArray*> r1 = call("csiReport", {cplx_array(H.data(), n_re, nrx, P), real_mat(k, n_re, 1), real_mat(l, n_re, 1), rc, scalar(nl), scalar(nv3[u]),
                                                     real_mat(tab, nt, 1)}, 5);
@@ -343,6 +344,21 @@ int comm(const char* in, const char* out) {
         }
       }
     }
+  }
+  {   // ---- srsReportBatch(Hre, k, NRBsUL, bandSize, nLayers, nVar, SINRTable)                         gNBPhy.m:1023-1058 -> pmiSelect.m
+    int32_t d[7];
+    rd(d, sizeof(d), f);
+    const int n_re = d[0], R = d[1], P = d[2], nu = d[3], n_rb = d[4], band = d[5], nl = d[6];
+    auto k = rdv<double>(f, (size_t)n_re);
+    auto nv = rdv<double>(f, (size_t)nu);
+    auto H = rdv<isac_c64>(f, (size_t)n_re * R * P * nu);
+    int32_t nt; rd(&nt, sizeof(nt), f);
+    auto tab = rdv<double>(f, (size_t)nt);
+    const mwSize hd4[4] = {(mwSize)n_re, (mwSize)R, (mwSize)P, (mwSize)nu};
+    mxArray* h4 = mxCreateNumericArray(4, hd4, mxDOUBLE_CLASS, mxCOMPLEX);
+    std::memcpy(mxGetComplexDoubles(h4), H.data(), sizeof(isac_c64) * H.size());
+    std::vector<mxArray*> r = call("srsReportBatch", {h4, real_mat(k, n_re, 1), scalar(n_rb), scalar(band), scalar(nl), real_row(nv.data(), nu), real_mat(tab, nt, 1)}, 3);
+    for (int i = 0; i < 3; ++i) write_vec(o, r[(size_t)i]);
   }
   {   // ---- senTx accumulation: allocDevice x2, senTxAppend per PDSCH slot, gather                      gNBPhy.m:591-612
     int32_t d[6]; double amp;

@@ -149,6 +149,22 @@ def test_mex_gateway_communication_and_topology_entries(tmp_path):
         f.write(k.astype(np.float64).tobytes()); f.write(l.astype(np.float64).tobytes()); f.write(hre.tobytes(order="F"))
         tab = np.asarray(OQ.DOWNLINK_SINR90PC, dtype=np.float64)
         f.write(struct.pack("<i", tab.size)); f.write(tab.tobytes())
+        # ---- srsReportBatch: 52 PRB, 8 receive elements, 2 SRS ports, comb 2 on RBs 4..47 (leading / trailing bands take the mean PMI), three UEs
+        import oracle.srs as OS
+        nrb_s, band_s, R_s, P_s, nu_s = 52, 4, 8, 2, 3
+        mask = np.zeros(12 * nrb_s, dtype=bool); mask[12 * 4:12 * 48:2] = True
+        k_s = np.flatnonzero(mask)
+        rs = np.random.default_rng(17)
+        hs_full, nv_s = [], [0.02, 0.2, 1.0]
+        for u in range(nu_s):
+            g_ = (rs.standard_normal((4, R_s, P_s)) + 1j * rs.standard_normal((4, R_s, P_s))) / np.sqrt(8)
+            ph = np.exp(-2j * np.pi * np.outer(np.arange(12 * nrb_s), rs.uniform(0, 60, 4)) / 4096)
+            hs_full.append(np.einsum("kt,trp->krp", ph, g_) * [0.1, 0.5, 2.0][u] * mask[:, None, None])
+        f.write(struct.pack("<7i", k_s.size, R_s, P_s, nu_s, nrb_s, band_s, 1))
+        f.write((k_s + 1).astype(np.float64).tobytes()); f.write(np.asarray(nv_s, dtype=np.float64).tobytes())
+        f.write(np.asfortranarray(np.stack([h[k_s] for h in hs_full], axis=3)).tobytes(order="F"))
+        tab_ul = np.asarray(OQ.UPLINK_SINR90PC, dtype=np.float64)
+        f.write(struct.pack("<i", tab_ul.size)); f.write(tab_ul.tobytes())
         # ---- senTx accumulation: 24 PRB, 3 antennas, DDDSU, windowing 18
         nrb2, A2, tdd, win, nfft2 = 24, 3, "DDDSU", 18, 512
         slots = [s for s in range(5) if tdd[s % 5] != "U"]
@@ -223,6 +239,21 @@ def test_mex_gateway_communication_and_topology_entries(tmp_path):
     assert _same(cqi, want_cqi) and _same(i1, want_pmi.i1) and _same(i2, want_pmi.i2) and _same(sbc, want_ci.SubbandCQI)
     b_ = np.asarray(want_ci.SINRPerSubbandPerCW, dtype=np.float64).reshape(-1)
     assert np.array_equal(np.isnan(sps), np.isnan(b_)) and np.abs(sps[~np.isnan(sps)] - b_[~np.isnan(b_)]).max() <= 1e-10 * np.nanmax(np.abs(b_))
+    # csiReportBatch's sixth output: riSelect's totalSINR of the rank for the three noise variances
+    ri_tot, off_b = _vec(buf, off_b)
+    for u, nv_ in enumerate((nvar, 4.0 * nvar, 0.25 * nvar)):
+        pmi_u, info_u = OP.dl_pmi_select(rep, layers, hc, k, l, nv_)
+        i11, i12, i13 = (int(v) - 1 for v in pmi_u.i1)
+        sub_ = np.stack([info_u.SINRPerSubband[s_, :, int(pmi_u.i2[s_]) - 1, i11, i12, i13] * layers for s_ in range(pmi_u.i2.size)])
+        lay = np.nanmean(sub_, axis=0)
+        assert abs(ri_tot[u] - np.sum(lay[lay >= 1])) <= 1e-10 * max(1.0, abs(ri_tot[u]))
+    # srsReportBatch
+    g_pmi, off_b = _vec(buf, off_b); g_sel, off_b = _vec(buf, off_b); g_cqi, off_b = _vec(buf, off_b)
+    n_sb = -(-nrb_s // band_s)
+    for u in range(nu_s):
+        w_pmi, w_sel, w_cqi = OS.srs_report(1, hs_full[u][:, None, :, :], nv_s[u], band_s, nrb_s, OQ.UPLINK_SINR90PC)
+        assert np.array_equal(g_pmi[u * n_sb:(u + 1) * n_sb], w_pmi) and np.array_equal(g_cqi[u * nrb_s:(u + 1) * nrb_s], w_cqi)
+        assert np.abs(g_sel[u * n_sb:(u + 1) * n_sb] - w_sel).max() <= 1e-10 * np.abs(w_sel).max()
     # senTx accumulators
     (n,) = struct.unpack_from("<Q", buf, off_b); off_b += 8
     grid = np.frombuffer(buf, dtype=np.complex128, count=n, offset=off_b).reshape(ref.grid.shape, order="F"); off_b += 16 * n
