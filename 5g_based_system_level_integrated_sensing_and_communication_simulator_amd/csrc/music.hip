@@ -810,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void cov_mfma_lds_kernel(const c64* __restr
 //     wave share 8 subcarriers) per target, issued two slabs ahead;
 //   * the generator is cut into 19 pieces (counter set-up + 10 Philox rounds, 4 Box-Muller transforms, 4 x (synthesis + mask + LDS store), the D loads) that sit in the gaps of the
 //     step's 30 MFMAs like the staging instructions did (SCHED picks the placement).
-// Bound: fp64 MFMA issue + the generator's VALU (v_mfma_f64 and VALU of one wave overlap only inside the 64-cycle shadow of the wave's own MFMA, section 3d of DESIGN.md).
+// Bound: fp64 MFMA issue + the generator's VALU (v_mfma_f64 and VALU of one wave overlap only inside the 64-cycle shadow of the wave's own MFMA, section 3d of DESIGN_HISTORY.md).
 struct LazyCovArgs {
   const c64* D;               // [K x L_whole x QT] per-target demodulated coefficient grids
   const c64* steer_rq;        // [A x QT]: a_q[r] at r QT + q

@@ -1178,7 +1178,7 @@ def main():
                                     else ("--n1-value" if args.n1_value is not None else None),
                                     "efficiency_vs_n1": None if n1 is None else round(res["value"] / (world * n1), 4),
                                     "note": f"efficiency = value / (N x N=1 value of {per_gpu}); no multi-GPU scaling curve has been measured on hardware yet "
-                                            "(DESIGN.md section 6) -- the driver computes its own from the per-N lines"}
+                                            "(DESIGN.md section 7) -- the driver computes its own from the per-N lines"}
         if world == 1 and not args.trace_only and not args.no_cold and args.workload == "config2":
             res["cold"] = cold_block(args)
         if not args.no_cpu_baseline and world == 1 and not args.trace_only:

@@ -1,7 +1,7 @@
 """ISA-level regression checks of the hot kernels (no GPU needed: the gfx950 code objects are taken out of the freshly built objects).
 
 The measured gains of round 3 came from properties of the generated code that nothing in the numerical tests would notice if a compiler
-update or an innocent edit lost them again:
+update or an innocent edit lost them again (DESIGN_HISTORY.md section 3c):
   * no vector-memory instruction of the fused echo + range kernel sits behind an `s_waitcnt vmcnt(0)` while its eight stores are issued
     (a branch around a load / store makes the wait-count pass give up: every wait becomes vmcnt(0));
   * the covariance block kernel keeps its loads in flight, its accumulators in place and its diagonal form compile-time (no selects);
@@ -226,7 +226,7 @@ def cdl_co(tmp_path_factory):
 
 
 def test_fused_cdl_kernels_code_generation(cdl_co):
-    """cdl_fused_kernel / cdl_fused_ul_kernel: two waves per SIMD (<= 256 registers), no scratch inside the tile loop (the compiler once turned
+    """cdl_fused_kernel / cdl_fused_ul_kernel (DESIGN_HISTORY.md section 3g): two waves per SIMD (<= 256 registers), no scratch inside the tile loop (the compiler once turned
     the gather's slot array into a dynamically indexed scratch array and its lane selects into exec-masked branches: 2.6 k -> 7.9 k cycles per column tile), and the
     contraction as one straight-line run of MFMAs per tile / chunk."""
     # downlink, CDL-A shape: 3 column tiles, 4 delay slots

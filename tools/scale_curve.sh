@@ -2,7 +2,7 @@
 # The first multi-GPU run as ONE command: the N = 1 / 2 / 4 / 8 lines of BASELINE configs[2] (7 cells, strong; 7 cells per GPU, weak) and
 # configs[4] (21 cells x 10 UEs) with the in-run N = 1 leg, + the efficiencies bench.py computes from it.  Needs an 8-GPU node; on fewer GPUs the larger N are skipped.
 #   tools/scale_curve.sh [steps] [out_dir]
-# NOTE: no scaling curve has been measured on hardware yet (one-GPU build boxes; DESIGN.md section 6): this script is what produces it.
+# NOTE: no scaling curve has been measured on hardware yet (one-GPU build boxes; DESIGN.md section 7): this script is what produces it.
 set -u
 STEPS=${1:-20}; OUT=${2:-gpurun_out/scale_curve}; mkdir -p "$OUT"
 NGPU=$(python - <<'PY'
