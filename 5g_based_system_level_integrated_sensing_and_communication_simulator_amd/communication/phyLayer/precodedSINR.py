@@ -4,10 +4,13 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from ... import _lib as L
 
+_DEBUG_UPLOAD = os.environ.get("ISAC_DEBUG_UPLOAD") is not None
 DOWNLINK_SINR90PC = np.array([-3.46, 1.54, 6.54, 11.05, 13.54, 16.04, 17.54, 20.04, 22.04, 24.43, 26.93, 27.43, 29.43, 32.43, 35.43])
 UPLINK_SINR90PC = np.array([-5.46, -0.46, 4.54, 9.05, 11.54, 14.04, 15.54, 18.04, 20.04, 22.43, 24.93, 25.43, 27.43, 30.43, 33.43])
 
@@ -30,6 +33,14 @@ def _run(H, sigma, W, table, want_per_re, ctx):
                                                  tab.ctypes.data_as(C.c_void_p) if tab is not None else None,
                                                  C.c_int32(0 if tab is None else tab.size), C.c_void_p(per.ptr if per is not None else 0),
                                                  C.byref(mean), C.byref(cqi)))
+    if _DEBUG_UPLOAD and not isinstance(H, L.DeviceArray):      # development switch (ISAC_DEBUG_UPLOAD=1): read the channel estimate back and compare it with what was uploaded
+        import sys
+        back, src = d_h.numpy().reshape(-1, order="F"), L.as_c128_f(H).reshape(-1, order="F")
+        bad = np.flatnonzero(back != src)
+        if bad.size:
+            z = int(np.count_nonzero(back[bad] == 0))
+            sys.stderr.write(f"ISAC_DEBUG_UPLOAD: {bad.size} of {src.size} elements of the uploaded H differ on the device ({z} of them are zero there); first {bad[0]} last {bad[-1]} "
+                             f"(byte offsets {16 * int(bad[0])} .. {16 * int(bad[-1]) + 15}); device pointer {d_h.ptr:#x}\n")
     return (per.numpy() if per is not None else None), mean.value, cqi.value
 
 

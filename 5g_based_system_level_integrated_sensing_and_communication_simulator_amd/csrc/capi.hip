@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <numeric>
 
 #include "isac_common.hpp"
@@ -20,7 +21,7 @@ int isac_eigh_dev(isac_ctx* ctx, const c64* d_H, int A, hipStream_t st, bool liv
 int isac_eigh_replay_recover(isac_ctx* ctx, int n, hipStream_t st);   // music.hip
 static int eig_status(isac_ctx* ctx, int A, bool ql_ran = true /* false: the signal-subspace kernel delivered, the QL pipeline returned at once */) {
   int sweeps = 0;
-  ISAC_HIP(hipMemcpy(&sweeps, (const char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(int), hipMemcpyDeviceToHost));
+  ISAC_TRY(copy_d2h(ctx, &sweeps, (const char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(int)));
   static const bool force = std::getenv("ISAC_EIG_FORCE_REPLAY_TIMEOUT") != nullptr;   // test hook: take the recovery path on every call ...
   if (force && ql_ran && sweeps >= 0 && A > 16 && ctx->eig_scratch.p) {
     ISAC_HIP(hipMemset(ctx->eig_v.p, 0xFF, sizeof(c64) * (size_t)A * A));               // ... with the eigenvectors destroyed first
@@ -29,7 +30,7 @@ static int eig_status(isac_ctx* ctx, int A, bool ql_ran = true /* false: the sig
   if (sweeps == -2) {                                // live replay blocks gave up waiting: Z and the rotations are intact, replay them offline
     ISAC_TRY(isac_eigh_replay_recover(ctx, A, ctx->stream));
     ISAC_HIP(hipStreamSynchronize(ctx->stream));
-    ISAC_HIP(hipMemcpy(&sweeps, (const char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(int), hipMemcpyDeviceToHost));
+    ISAC_TRY(copy_d2h(ctx, &sweeps, (const char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(int)));
   }
   if (sweeps < 0) return isac::fail(ctx, ISAC_ERR_HIP, sweeps == -1 ? "eigensolver: QL recurrence exceeded its rotation storage (no convergence)"
                                                      : sweeps == -3 ? "eigensolver: the signal-subspace vectors are not finite (NaN / Inf in the covariance)"
@@ -341,6 +342,8 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
     if (b->p) (void)hipFree(b->p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   if (ctx->pinned_csi) (void)hipHostFree(ctx->pinned_csi);
+  if (ctx->bounce) (void)hipHostFree(ctx->bounce);
+  for (auto& e : ctx->ev_bounce) if (e) (void)hipEventDestroy(e);
   (void)hipEventDestroy(ctx->ev_fork);
   (void)hipEventDestroy(ctx->ev_join);
   (void)hipEventDestroy(ctx->ev_cfar);
@@ -377,10 +380,40 @@ extern "C" int isac_sync(isac_ctx* ctx) {
   return ISAC_OK;
 }
 
+// Caller-visible device memory comes from a per-device POOL of blocks the process has allocated before (round 6): isac_dev_free parks a block, isac_dev_alloc hands out the
+// smallest parked block that fits (up to 25 % + 64 KB of slack), and only what the pool cannot serve goes to hipMalloc.  A host that allocates per call (the Python tests,
+// a MATLAB session creating and clearing handles) then works on memory the process already owns instead of memory fresh from the driver -- see copy_h2d (isac_common.hpp) for
+// the fuzz observation behind this -- and saves the ~100 us of a hipMalloc / hipFree pair.  Parked memory is capped (ISAC_DEV_POOL_MB, default 16 384; 0 disables the pool);
+// beyond the cap the largest parked block is returned to the driver.
+namespace {
+struct DevPool {
+  std::mutex m;
+  std::multimap<size_t, void*> parked[16];
+  std::map<void*, size_t> size_of[16];
+  size_t parked_bytes[16] = {0};
+  size_t cap = 16384ull << 20;
+  DevPool() { if (const char* e = std::getenv("ISAC_DEV_POOL_MB")) cap = (size_t)std::strtoull(e, nullptr, 10) << 20; }
+};
+DevPool& dev_pool() { static DevPool p; return p; }
+}  // namespace
 extern "C" int isac_dev_alloc(isac_ctx* ctx, size_t bytes, void** dptr) {
   if (!ctx || !dptr) return ISAC_ERR_INVALID_ARG;
   ISAC_ENTER(ctx);
-  ISAC_HIP(hipMalloc(dptr, bytes ? bytes : 16));
+  DevPool& P = dev_pool();
+  const int dev = ctx->device & 15;
+  const size_t want = ((bytes ? bytes : 16) + 255) & ~(size_t)255;
+  if (P.cap) {
+    std::lock_guard<std::mutex> lk(P.m);
+    auto it = P.parked[dev].lower_bound(want);
+    if (it != P.parked[dev].end() && it->first <= want + want / 4 + 65536) {
+      *dptr = it->second;
+      P.parked_bytes[dev] -= it->first;
+      P.parked[dev].erase(it);
+      return ISAC_OK;
+    }
+  }
+  ISAC_HIP(hipMalloc(dptr, want));
+  if (P.cap) { std::lock_guard<std::mutex> lk(P.m); P.size_of[dev][*dptr] = want; }
   return ISAC_OK;
 }
 extern "C" int isac_dev_free(isac_ctx* ctx, void* dptr) {
@@ -388,6 +421,31 @@ extern "C" int isac_dev_free(isac_ctx* ctx, void* dptr) {
   if (!dptr) return ISAC_OK;
   ctx->range_cache.touch(dptr, 0);                 // freeing one of the cached grids drops the cached range rows
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  DevPool& P = dev_pool();
+  const int dev = ctx->device & 15;
+  if (P.cap) {
+    // (hipFree waits for the whole device; a parked block may be handed out again at once, so the same guarantee is kept: nothing on this device still uses it)
+    ISAC_HIP(hipDeviceSynchronize());
+    std::vector<void*> release;
+    {
+      std::lock_guard<std::mutex> lk(P.m);
+      auto so = P.size_of[dev].find(dptr);
+      if (so == P.size_of[dev].end()) { release.push_back(dptr); }                     // not ours (allocated with the pool disabled): straight back to the driver
+      else {
+        P.parked[dev].emplace(so->second, dptr);
+        P.parked_bytes[dev] += so->second;
+        while (P.parked_bytes[dev] > P.cap && !P.parked[dev].empty()) {                // over the cap: the largest parked block goes back
+          auto big = std::prev(P.parked[dev].end());
+          P.parked_bytes[dev] -= big->first;
+          P.size_of[dev].erase(big->second);
+          release.push_back(big->second);
+          P.parked[dev].erase(big);
+        }
+      }
+    }
+    for (void* r : release) ISAC_HIP(hipFree(r));
+    return ISAC_OK;
+  }
   ISAC_HIP(hipFree(dptr));
   return ISAC_OK;
 }
@@ -395,14 +453,14 @@ extern "C" int isac_memcpy_h2d(isac_ctx* ctx, void* dst_dev, const void* src_hos
   if (!ctx || (!dst_dev && bytes) || (!src_host && bytes)) return ISAC_ERR_INVALID_ARG;
   ISAC_ENTER(ctx);
   ctx->range_cache.touch(dst_dev, bytes);          // overwriting a cached grid drops the cached range rows
-  ISAC_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_TRY(copy_h2d(ctx, dst_dev, src_host, bytes));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   return ISAC_OK;
 }
 extern "C" int isac_memcpy_d2h(isac_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
   if (!ctx || (!dst_host && bytes) || (!src_dev && bytes)) return ISAC_ERR_INVALID_ARG;
   ISAC_ENTER(ctx);
-  ISAC_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_TRY(copy_d2h(ctx, dst_host, src_dev, bytes));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   return ISAC_OK;
 }
@@ -681,8 +739,8 @@ extern "C" int isac_fft2d_collect(isac_ctx* ctx, isac_est_result* out) {
     std::memcpy(cut.data(), h + off_cut, sizeof(int) * (size_t)total);
     std::memcpy(pw.data(), h + off_pow, sizeof(double) * (size_t)total);
   } else {
-    ISAC_HIP(hipMemcpy(cut.data(), d_pcut_full, sizeof(int) * (size_t)total, hipMemcpyDeviceToHost));
-    ISAC_HIP(hipMemcpy(pw.data(), d_ppow_full, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost));
+    ISAC_TRY(copy_d2h(ctx, cut.data(), d_pcut_full, sizeof(int) * (size_t)total));
+    ISAC_TRY(copy_d2h(ctx, pw.data(), d_ppow_full, sizeof(double) * (size_t)total));
   }
   const int* ant_off = hdr + 3;
   // ---- host post-processing, fft2D.m:63-99
@@ -842,7 +900,7 @@ extern "C" int isac_fft2d_get_power_window(isac_ctx* ctx, double* P, int64_t cap
   const long long n = (long long)l.nr * l.nc * l.A;
   if (!P) return ISAC_OK;
   if (cap_elems < n) return fail(ctx, ISAC_ERR_CAPACITY, "power window larger than capacity");
-  ISAC_HIP(hipMemcpy(P, ctx->pwin.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  ISAC_TRY(copy_d2h(ctx, P, ctx->pwin.p, sizeof(double) * (size_t)n));
   return ISAC_OK;
 }
 
@@ -850,7 +908,7 @@ extern "C" int isac_fft2d_get_covariance(isac_ctx* ctx, isac_c64* Ra, int32_t A)
   if (!ctx || !Ra) return ISAC_ERR_INVALID_ARG;
   ISAC_ENTER(ctx);
   if (!ctx->last.valid || ctx->last.A != A) return fail(ctx, ISAC_ERR_INVALID_ARG, "no completed fft2D call with this A");
-  ISAC_HIP(hipMemcpy(Ra, ctx->cov.p, sizeof(c64) * (size_t)A * A, hipMemcpyDeviceToHost));
+  ISAC_TRY(copy_d2h(ctx, Ra, ctx->cov.p, sizeof(c64) * (size_t)A * A));
   return ISAC_OK;
 }
 
@@ -870,17 +928,17 @@ extern "C" int isac_eigh(isac_ctx* ctx, const isac_c64* H, int32_t A, double* w,
   ISAC_ENTER(ctx);
   if (!H || !w || A <= 0) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)A * A));
-  ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, H, sizeof(c64) * (size_t)A * A, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_TRY(copy_h2d(ctx, ctx->stage_c.p, H, sizeof(c64) * (size_t)A * A));
   ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));
   std::vector<double> wv((size_t)A);
   std::vector<c64> vv((size_t)A * A);
-  ISAC_HIP(hipMemcpyAsync(wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));
-  ISAC_HIP(hipMemcpyAsync(vv.data(), ctx->eig_v.p, sizeof(c64) * (size_t)A * A, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_TRY(copy_d2h(ctx, wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A));
+  ISAC_TRY(copy_d2h(ctx, vv.data(), ctx->eig_v.p, sizeof(c64) * (size_t)A * A));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_TRY(eig_status(ctx, A));
   if (std::getenv("ISAC_DEBUG")) {
     int inf[16] = {-1, 0, 0, 0, 0, 0};
-    ISAC_HIP(hipMemcpy(inf, (char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(inf), hipMemcpyDeviceToHost));
+    ISAC_TRY(copy_d2h(ctx, inf, (char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(inf)));
     if (A > 64 && A <= 256)
       std::fprintf(stderr, "[isac] eigh A=%d distributed tridiagonalisation, phases(x64 clk): column + p published=%d exchange wait=%d vector work=%d rank-2 update=%d\n", A,
                    inf[12], inf[13], inf[14], inf[15]);
@@ -906,14 +964,14 @@ static int doa_scan(isac_ctx* ctx, int mode, int32_t num_dets, const isac_est_pa
   if (!ep || !Ra || A <= 0 || !n_est) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   *n_est = 0;
   ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)A * A));
-  ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, Ra, sizeof(c64) * (size_t)A * A, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_TRY(copy_h2d(ctx, ctx->stage_c.p, Ra, sizeof(c64) * (size_t)A * A));
   const bool sub = mode == 0 && !ep->array_is_upa && isac_music_subspace_ok(ctx, A);   // MUSIC: the L signal vectors are enough
   if (sub) ISAC_TRY(isac_music_tridiag_bisect_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));
   else ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));                               // music.m:19
   int L = num_dets;
   if (num_dets < 0) {                                                                              // music.m:21-22
     std::vector<double> wv((size_t)A);
-    ISAC_HIP(hipMemcpyAsync(wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));
+    ISAC_TRY(copy_d2h(ctx, wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A));
     ISAC_HIP(hipStreamSynchronize(ctx->stream));
     std::sort(wv.begin(), wv.end());
     L = determine_num_targets(wv);
@@ -927,7 +985,7 @@ static int doa_scan(isac_ctx* ctx, int mode, int32_t num_dets, const isac_est_pa
   ISAC_TRY(ensure(ctx, ctx->spec, sizeof(double) * (size_t)n_steps));
   ISAC_TRY(isac_music_scan_dev(ctx, A, nullptr, L, d_sind, n_steps, 0.5, (double*)ctx->spec.p, nullptr, mode, sub ? isac_music_ctl(ctx) : nullptr));
   std::vector<double> spec((size_t)n_steps);
-  ISAC_HIP(hipMemcpyAsync(spec.data(), ctx->spec.p, sizeof(double) * (size_t)n_steps, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_TRY(copy_d2h(ctx, spec.data(), ctx->spec.p, sizeof(double) * (size_t)n_steps));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_TRY(eig_status(ctx, A));
   double mx = 0.0;
@@ -952,24 +1010,24 @@ extern "C" int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_
   if (!H || !w || A <= 0 || n_top < 0 || n_top > A || (n_top > 0 && !U)) return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments");
   if (A < 3 || A > 256) return fail(ctx, ISAC_ERR_UNSUPPORTED, "isac_eigh_top: orders 3..256 (use isac_eigh)");
   ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)A * A));
-  ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, H, sizeof(c64) * (size_t)A * A, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_TRY(copy_h2d(ctx, ctx->stage_c.p, H, sizeof(c64) * (size_t)A * A));
   ISAC_TRY(isac_music_tridiag_bisect_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));
-  ISAC_HIP(hipMemcpyAsync(w, ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_TRY(copy_d2h(ctx, w, ctx->eig_w.p, sizeof(double) * (size_t)A));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));                      // (the fallback below overwrites eig_w with unsorted values)
   if (n_top == 0) return ISAC_OK;
   ISAC_TRY(isac_music_subspace_dev(ctx, A, nullptr, n_top, nullptr));
   int ctl[2] = {0, 0};
-  ISAC_HIP(hipMemcpyAsync(ctl, isac_music_ctl(ctx), sizeof(ctl), hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_TRY(copy_d2h(ctx, ctl, isac_music_ctl(ctx), sizeof(ctl)));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_TRY(eig_status(ctx, A, ctl[0] != 1));
   if (std::getenv("ISAC_DEBUG")) {
     int inf[15] = {0};
-    ISAC_HIP(hipMemcpy(inf, (char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(inf), hipMemcpyDeviceToHost));
+    ISAC_TRY(copy_d2h(ctx, inf, (char*)ctx->eig_w.p + sizeof(double) * (size_t)A, sizeof(inf)));
     std::fprintf(stderr, "[isac] eigh_top A=%d n_top=%d phases(x64 clk): tridiag=%d (n <= 64: reflector=%d matvec=%d matvec+update=%d) | subspace: set-up=%d solves=%d "
                  "gram-schmidt=%d back-transform=%d\n", A, n_top, inf[1], inf[12], inf[13], inf[14], inf[8], inf[9], inf[10], inf[11]);
   }
   if (ctl[0] == 1 && n_top < A) {                                   // the subspace kernel delivered the vectors, descending eigenvalue order
-    ISAC_HIP(hipMemcpyAsync(U, ctx->eig_v.p, sizeof(c64) * (size_t)A * n_top, hipMemcpyDeviceToHost, ctx->stream));
+    ISAC_TRY(copy_d2h(ctx, U, ctx->eig_v.p, sizeof(c64) * (size_t)A * n_top));
     ISAC_HIP(hipStreamSynchronize(ctx->stream));
     return ISAC_OK;
   }
@@ -977,8 +1035,8 @@ extern "C" int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_
   std::vector<double> wv((size_t)A);
   std::vector<c64> vv((size_t)A * A);
   if (n_top == A) ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->stage_c.p, A, nullptr));
-  ISAC_HIP(hipMemcpyAsync(wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));   // (the context's streams are
-  ISAC_HIP(hipMemcpyAsync(vv.data(), ctx->eig_v.p, sizeof(c64) * (size_t)A * A, hipMemcpyDeviceToHost, ctx->stream));  //  non-blocking: stay on them)
+  ISAC_TRY(copy_d2h(ctx, wv.data(), ctx->eig_w.p, sizeof(double) * (size_t)A));   // (the context's streams are
+  ISAC_TRY(copy_d2h(ctx, vv.data(), ctx->eig_v.p, sizeof(c64) * (size_t)A * A));  //  non-blocking: stay on them)
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_TRY(eig_status(ctx, A));
   std::vector<int> order((size_t)A);
@@ -1104,7 +1162,7 @@ extern "C" int isac_music2d_dev(isac_ctx* ctx, const isac_est_params* ep, const 
   ISAC_TRY(isac_covariance_on(ctx, ctx->stream, d_rx_grid, (int64_t)K * L, A, (isac_c64*)ctx->cov.p));
   ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, A, nullptr));
   std::vector<double> wa((size_t)A);
-  ISAC_HIP(hipMemcpyAsync(wa.data(), ctx->eig_w.p, sizeof(double) * (size_t)A, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_TRY(copy_d2h(ctx, wa.data(), ctx->eig_w.p, sizeof(double) * (size_t)A));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_TRY(eig_status(ctx, A));
   std::sort(wa.begin(), wa.end());
@@ -1117,7 +1175,7 @@ extern "C" int isac_music2d_dev(isac_ctx* ctx, const isac_est_params* ep, const 
   ISAC_TRY(ensure(ctx, ctx->spec, sizeof(double) * (size_t)std::max(n_steps, std::max(r_steps, v_steps))));
   ISAC_TRY(isac_music_scan_dev(ctx, A, nullptr, Lsig, d_sind, n_steps, 0.5, (double*)ctx->spec.p, nullptr));
   std::vector<double> spec((size_t)n_steps);
-  ISAC_HIP(hipMemcpyAsync(spec.data(), ctx->spec.p, sizeof(double) * (size_t)n_steps, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_TRY(copy_d2h(ctx, spec.data(), ctx->spec.p, sizeof(double) * (size_t)n_steps));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   auto to_db = [](std::vector<double>& v) {
     double mx = 0.0;
@@ -1141,7 +1199,7 @@ extern "C" int isac_music2d_dev(isac_ctx* ctx, const isac_est_params* ep, const 
   ISAC_TRY(isac_covariance_on(ctx, ctx->stream, (const isac_c64*)d_h, (int64_t)K, L, (isac_c64*)ctx->cov.p));  // G/K        :71-72
   ISAC_TRY(isac_eigh_dev(ctx, (const c64*)ctx->cov.p, L, nullptr));                                            // :77-89
   std::vector<double> wg((size_t)L);
-  ISAC_HIP(hipMemcpyAsync(wg.data(), ctx->eig_w.p, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_TRY(copy_d2h(ctx, wg.data(), ctx->eig_w.p, sizeof(double) * (size_t)L));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   ISAC_TRY(eig_status(ctx, L));
   std::vector<int> order((size_t)L);
@@ -1152,19 +1210,19 @@ extern "C" int isac_music2d_dev(isac_ctx* ctx, const isac_est_params* ep, const 
   ISAC_TRY(ensure(ctx, ctx->stage_b, sizeof(c64) * (size_t)K * Lu + sizeof(int) * (size_t)Lu + 64));
   c64* d_U = (c64*)ctx->stage_b.p;
   int* d_top = (int*)((char*)ctx->stage_b.p + sizeof(c64) * (size_t)K * Lu);
-  ISAC_HIP(hipMemcpyAsync(d_top, top.data(), sizeof(int) * (size_t)Lu, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_TRY(copy_h2d(ctx, d_top, top.data(), sizeof(int) * (size_t)Lu));
   ISAC_TRY(isac_music2d_signal_vectors(ctx, d_h, K, L, d_top, Lu, d_U));
   // range scan  ar = exp(-2j*pi*scs*2*r*n/c)                                                :92,:98-102
   const double coef_r = ((-2.0 * M_PI) * mp->scs_hz) * 2.0;
   ISAC_TRY(isac_music2d_scan(ctx, d_U, K, K, nullptr, Lu, 0, coef_r, c0, 0.0, r_gran, r_steps, (double*)ctx->spec.p));
   std::vector<double> pr((size_t)r_steps), pv((size_t)v_steps);
-  ISAC_HIP(hipMemcpyAsync(pr.data(), ctx->spec.p, sizeof(double) * (size_t)r_steps, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_TRY(copy_d2h(ctx, pr.data(), ctx->spec.p, sizeof(double) * (size_t)r_steps));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   // velocity scan  av = exp(2j*pi*T*2*v*m/lambda), Uvs = conj(V(:,top))                       :93,:104-108
   const double coef_v = ((2.0 * M_PI) * mp->t_sri) * 2.0;
   ISAC_TRY(isac_music2d_scan(ctx, (const c64*)ctx->eig_v.p, L, L, d_top, Lu, 1, coef_v, lambda, -mp->v_max / 2.0, v_gran, v_steps,
                              (double*)ctx->spec.p));
-  ISAC_HIP(hipMemcpyAsync(pv.data(), ctx->spec.p, sizeof(double) * (size_t)v_steps, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_TRY(copy_d2h(ctx, pv.data(), ctx->spec.p, sizeof(double) * (size_t)v_steps));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   to_db(pr);                                                            // :111-117
   to_db(pv);
@@ -1194,7 +1252,7 @@ extern "C" int isac_basic_radar_channel(isac_ctx* ctx, const isac_c64* tx_wave, 
   if (st == ISAC_OK && upload_now(ctx, d_tx, tx_wave, bytes) != ISAC_OK) st = fail(ctx, ISAC_ERR_HIP, "upload failed");
   if (st == ISAC_OK)
     st = isac_basic_radar_channel_dev(ctx, (const isac_c64*)d_tx, T, rp, los, noise_mode, (const isac_c64*)d_nz, seed, (isac_c64*)d_rx);
-  if (st == ISAC_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(rx_wave, d_rx, bytes, hipMemcpyDeviceToHost) != hipSuccess))
+  if (st == ISAC_OK && copy_d2h(ctx, rx_wave, d_rx, bytes) != ISAC_OK)
     st = fail(ctx, ISAC_ERR_HIP, "download failed");
   (void)hipFree(d_tx); (void)hipFree(d_nz); (void)hipFree(d_rx);
   return st;
@@ -1223,7 +1281,7 @@ extern "C" int isac_mono_static_sensing(isac_ctx* ctx, const isac_c64* tx_wave, 
   if (st == ISAC_OK)
     st = isac_mono_static_sensing_dev(ctx, (const isac_c64*)d_tx, T, tx_dim_l, carrier, rp, los, noise_mode,
                                       (const isac_c64*)d_nz, seed, (isac_c64*)d_g, l_out);
-  if (st == ISAC_OK && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(echo_grid, d_g, gbytes, hipMemcpyDeviceToHost) != hipSuccess))
+  if (st == ISAC_OK && copy_d2h(ctx, echo_grid, d_g, gbytes) != ISAC_OK)
     st = fail(ctx, ISAC_ERR_HIP, "download failed");
   (void)hipFree(d_tx); (void)hipFree(d_nz); (void)hipFree(d_g);
   return st;

@@ -283,7 +283,7 @@ extern "C" int isac_precoded_sinr_cqi_dev(isac_ctx* ctx, const isac_c64* d_H, in
   if (!d_H || !W || n_re <= 0 || Nr <= 0 || Nr > kMaxRx || P <= 0 || n_layers <= 0 || n_layers > kMaxLayers || !(sigma > 0))
     return fail(ctx, ISAC_ERR_INVALID_ARG, "bad arguments (1 <= layers <= 8, 1 <= Nr <= 16, sigma > 0)");
   ISAC_TRY(ensure(ctx, ctx->stage_c, sizeof(c64) * (size_t)P * n_layers + 64));
-  ISAC_HIP(hipMemcpyAsync(ctx->stage_c.p, W, sizeof(c64) * (size_t)P * n_layers, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_TRY(copy_h2d(ctx, ctx->stage_c.p, W, sizeof(c64) * (size_t)P * n_layers));
   double* out = d_sinr_per_re;
   if (!out) {
     ISAC_TRY(ensure(ctx, ctx->stage_a, sizeof(double) * (size_t)n_re));
@@ -312,6 +312,33 @@ extern "C" int isac_precoded_sinr_cqi_dev(isac_ctx* ctx, const isac_c64* d_H, in
     ISAC_HIP(hipMemcpyAsync(ctx->pinned_csi, d_mean, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     ISAC_HIP(hipStreamSynchronize(ctx->stream));
     const double m = *(const double*)ctx->pinned_csi;
+    static const bool dbg_mean = std::getenv("ISAC_DEBUG_MEAN") != nullptr;     // development switch: re-read the per-RE values, recompute the mean on the host, report a disagreement
+    if (dbg_mean) {
+      std::vector<double> hv((size_t)n_re);
+      ISAC_TRY(copy_d2h(ctx, hv.data(), out, sizeof(double) * (size_t)n_re));
+      double part[256] = {0.0};
+      for (long long i = 0; i < n_re; ++i) part[i & 255] += hv[(size_t)i];
+      double hm = 0.0;                                                           // (same association as mean_kernel: per-thread strided sums, lanes by shfl_down tree, then the four waves)
+      double wsum[4] = {0, 0, 0, 0};
+      for (int w = 0; w < 4; ++w) { double t[64]; for (int l = 0; l < 64; ++l) t[l] = part[64 * w + l]; for (int o = 32; o > 0; o >>= 1) for (int l = 0; l < o; ++l) t[l] += t[l + o]; wsum[w] = t[0]; }
+      hm = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (double)n_re;
+      double dm2 = 0.0;
+      ISAC_TRY(copy_d2h(ctx, &dm2, d_mean, sizeof(double)));
+      int zeros = 0, nans = 0; long long first_zero = -1, last_zero = -1;
+      for (long long i = 0; i < n_re; ++i) { if (hv[(size_t)i] == 0.0) { ++zeros; if (first_zero < 0) first_zero = i; last_zero = i; } if (hv[(size_t)i] != hv[(size_t)i]) ++nans; }
+      if (zeros) {                                                               // a per-RE SINR of exactly zero = an all-zero channel row: the uploaded H was (partly) zero when the kernel read it
+        std::vector<c64> hh((size_t)n_re * Nr * P);
+        ISAC_TRY(copy_d2h(ctx, hh.data(), d_H, sizeof(c64) * hh.size()));
+        long long hz = 0, hz_first = -1, hz_last = -1;
+        for (size_t i = 0; i < hh.size(); ++i) if (hh[i].re == 0.0 && hh[i].im == 0.0) { ++hz; if (hz_first < 0) hz_first = (long long)i; hz_last = (long long)i; }
+        std::fprintf(stderr, "ISAC_DEBUG_MEAN: %d of %lld per-RE SINRs are exactly zero (REs %lld .. %lld); H on the device NOW has %lld zero elements of %zu (elements %lld .. %lld, bytes %lld .. %lld) at %p\n",
+                     zeros, (long long)n_re, first_zero, last_zero, hz, hh.size(), hz_first, hz_last, 16 * hz_first, 16 * hz_last + 15, (const void*)d_H);
+      }
+      if (!(std::fabs(hm - m) <= 1e-12 * std::fabs(hm)) || dm2 != m) {
+        std::fprintf(stderr, "ISAC_DEBUG_MEAN: pinned %.17g device-word-now %.17g host-recomputed %.17g  n_re %lld Nr %d P %d NL %d  zeros %d (first %lld) nans %d  out %p user_buf %d\n",
+                     m, dm2, hm, (long long)n_re, Nr, P, n_layers, zeros, first_zero, nans, (void*)out, d_sinr_per_re ? 1 : 0);
+      }
+    }
     if (mean_sinr) *mean_sinr = m;
     if (cqi) {                                           // cqiSelect.m:705-721 getCQI
       int c = 0;

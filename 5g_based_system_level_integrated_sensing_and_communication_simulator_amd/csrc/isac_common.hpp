@@ -157,6 +157,7 @@ struct isac_ctx {
   isac::DevBuf beam, coef, phase_rx, steer, dgrid, ymid, pwin, flags, det_cut, det_pow, det_cnt, cov_part, cov,
       eig_w, eig_v, eig_scratch, spec, misc, stage_a, stage_b, stage_c, sind_tab, seg, cdl_h;
   void* pinned = nullptr; size_t pinned_cap = 0;                       // results of isac_fft2d_submit* (read by isac_fft2d_collect) -- no other entry point may touch it
+  void* bounce = nullptr; size_t bounce_cap = 0; hipEvent_t ev_bounce[2] = {nullptr, nullptr};   // pinned bounce buffer of the host-array copies (copy_h2d / copy_d2h)
   void* pinned_csi = nullptr; size_t pinned_csi_cap = 0;               // results of isac_csi_report*: its own buffer, so a CSI call between submit and collect cannot clobber a pending CPI
   isac::Fft2dLast last;
   isac::Fft2dPending pending;
@@ -266,11 +267,58 @@ inline int ensure_pinned(isac_ctx* ctx, size_t bytes) {
 // returns once a PAGEABLE source has been staged -- its DMA may still be in flight -- and the context's streams are non-blocking (no implicit synchronisation with the NULL
 // stream): a kernel launched on them right away could read the destination before the data has landed.  Seen once in ~4 700 fuzz cases under 16 concurrent processes
 // (the |rdm|^2 window of a host-array fft2D call off by 1e-2, profiles/r05_fuzz_campaigns.txt); the copy therefore runs ON the context's stream and is waited for.
-inline int upload_now(isac_ctx* ctx, void* dst, const void* src, size_t bytes) {
-  ISAC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+// Round 6: no PAGEABLE host memory is handed to the runtime any more.  Caller arrays (MATLAB / NumPy memory) go through a pinned bounce buffer of the context in 8 MB chunks,
+// two in flight: memcpy into the chunk, hipMemcpyAsync from it on the context's stream, one synchronisation at the end.  The fuzz campaigns of rounds 5-6 under 16
+// concurrent processes saw ~1 case in 250 in which a kernel read a (partly) ZERO channel estimate right after the estimate had been uploaded into freshly allocated
+// device memory from a pageable array and the stream had been synchronised (profiles/r06_fuzz_campaigns.txt); the runtime's own staging of pageable copies and the
+// driver's handling of fresh allocations are the two things such a case passes through that the hot path (pinned buffers, memory allocated once) never does.
+constexpr size_t kBounceChunk = 8u << 20;
+inline int bounce_ready(isac_ctx* ctx, size_t bytes) {
+  const size_t want = bytes < kBounceChunk ? (bytes < 4096 ? 4096 : bytes) : 2 * kBounceChunk;
+  if (ctx->bounce_cap < want) {
+    ISAC_HIP(hipStreamSynchronize(ctx->stream));
+    ISAC_TRY(ensure_pinned_buf(ctx, ctx->bounce, ctx->bounce_cap, want));
+  }
+  for (auto& e : ctx->ev_bounce) if (!e) ISAC_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  return ISAC_OK;
+}
+inline int copy_h2d(isac_ctx* ctx, void* dst, const void* src, size_t bytes) {           // complete when it returns
+  if (!bytes) return ISAC_OK;
+  ISAC_TRY(bounce_ready(ctx, bytes));
+  bool used[2] = {false, false};
+  int half = 0;
+  for (size_t off = 0; off < bytes; off += kBounceChunk, half ^= 1) {
+    const size_t n = bytes - off < kBounceChunk ? bytes - off : kBounceChunk;
+    char* b = (char*)ctx->bounce + (ctx->bounce_cap >= 2 * kBounceChunk ? (size_t)half * kBounceChunk : 0);
+    if (used[half]) ISAC_HIP(hipEventSynchronize(ctx->ev_bounce[half]));          // the chunk's previous copy has left the bounce buffer
+    std::memcpy(b, (const char*)src + off, n);
+    ISAC_HIP(hipMemcpyAsync((char*)dst + off, b, n, hipMemcpyHostToDevice, ctx->stream));
+    ISAC_HIP(hipEventRecord(ctx->ev_bounce[half], ctx->stream));
+    used[half] = true;
+  }
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   return ISAC_OK;
 }
+inline int copy_d2h(isac_ctx* ctx, void* dst, const void* src, size_t bytes) {           // waits for the stream first: everything enqueued before is in the copy
+  if (!bytes) return ISAC_OK;
+  ISAC_TRY(bounce_ready(ctx, bytes));
+  const bool two = ctx->bounce_cap >= 2 * kBounceChunk;
+  size_t pend_off[2] = {0, 0}, pend_n[2] = {0, 0};
+  int half = 0;
+  for (size_t off = 0; off < bytes; off += kBounceChunk, half ^= 1) {
+    const size_t n = bytes - off < kBounceChunk ? bytes - off : kBounceChunk;
+    const int h = two ? half : 0;
+    char* b = (char*)ctx->bounce + (size_t)h * kBounceChunk;
+    if (pend_n[h]) { ISAC_HIP(hipEventSynchronize(ctx->ev_bounce[h])); std::memcpy((char*)dst + pend_off[h], b, pend_n[h]); pend_n[h] = 0; }
+    ISAC_HIP(hipMemcpyAsync(b, (const char*)src + off, n, hipMemcpyDeviceToHost, ctx->stream));
+    ISAC_HIP(hipEventRecord(ctx->ev_bounce[h], ctx->stream));
+    pend_off[h] = off; pend_n[h] = n;
+  }
+  ISAC_HIP(hipStreamSynchronize(ctx->stream));
+  for (int h = 0; h < 2; ++h) if (pend_n[h]) std::memcpy((char*)dst + pend_off[h], (char*)ctx->bounce + (size_t)h * kBounceChunk, pend_n[h]);
+  return ISAC_OK;
+}
+inline int upload_now(isac_ctx* ctx, void* dst, const void* src, size_t bytes) { return copy_h2d(ctx, dst, src, bytes); }
 
 // Small host block -> device scratch through the context's pinned staging ring: asynchronous, no stream synchronisation; the host waits only when the
 // ring wraps onto a slot whose copy has not left it yet.  stage_acquire hands out the next slot's host memory, stage_commit enqueues its copy.

@@ -709,14 +709,14 @@ extern "C" int isac_cfar2d_ca(isac_ctx* ctx, const double* P, int32_t n_rows, in
   ISAC_TRY(ensure(ctx, ctx->stage_a, pb));
   ISAC_TRY(ensure(ctx, ctx->stage_b, cb));
   ISAC_TRY(ensure(ctx, ctx->stage_c, (size_t)n_cut));
-  ISAC_HIP(hipMemcpyAsync(ctx->stage_a.p, P, pb, hipMemcpyHostToDevice, ctx->stream));
-  ISAC_HIP(hipMemcpyAsync(ctx->stage_b.p, cut_idx, cb, hipMemcpyHostToDevice, ctx->stream));
+  ISAC_TRY(copy_h2d(ctx, ctx->stage_a.p, P, pb));
+  ISAC_TRY(copy_h2d(ctx, ctx->stage_b.p, cut_idx, cb));
   hipLaunchKernelGGL(cfar_list_kernel, dim3(cdiv(n_cut, 256)), dim3(256), 0, ctx->stream, (const double*)ctx->stage_a.p, n_rows,
                      n_cols, (const int*)ctx->stage_b.p, n_cut, gr, gc, hr, hc, cfar_alpha(n_train, pfa), (double)n_train,
                      (unsigned char*)ctx->stage_c.p);
   ISAC_HIP(hipGetLastError());
   std::vector<unsigned char> flags((size_t)n_cut);
-  ISAC_HIP(hipMemcpyAsync(flags.data(), ctx->stage_c.p, (size_t)n_cut, hipMemcpyDeviceToHost, ctx->stream));
+  ISAC_TRY(copy_d2h(ctx, flags.data(), ctx->stage_c.p, (size_t)n_cut));
   ISAC_HIP(hipStreamSynchronize(ctx->stream));
   int n = 0;
   for (int i = 0; i < n_cut; ++i)

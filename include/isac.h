@@ -70,7 +70,11 @@ const char* isac_last_error(const isac_ctx* ctx);
 int isac_ctx_get_stream(isac_ctx* ctx, void** hip_stream);
 int isac_sync(isac_ctx* ctx);
 
-/* device memory + copies (so a host language needs nothing but this library) */
+/* device memory + copies (so a host language needs nothing but this library).
+ * Round 6: isac_dev_alloc / isac_dev_free work on a per-device POOL of blocks the process has allocated before (a freed block is parked and handed out again to the next request
+ * it fits with at most 25 % + 64 KB of slack; parked memory is capped at ISAC_DEV_POOL_MB, default 16 384, 0 = no pool): a host that allocates per call works on memory the process
+ * already owns.  isac_dev_free still waits for the device, as hipFree does.  isac_memcpy_h2d / _d2h (and every entry point that takes HOST arrays) move caller memory through a pinned
+ * bounce buffer of the context -- no pageable memory is handed to the runtime; both are complete when they return.  Why: profiles/r06_fuzz_campaigns.txt. */
 int isac_dev_alloc(isac_ctx* ctx, size_t bytes, void** dptr);
 int isac_dev_free(isac_ctx* ctx, void* dptr);
 int isac_memcpy_h2d(isac_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);

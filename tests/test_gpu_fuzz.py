@@ -56,6 +56,11 @@ def _scene(seed, wide=None):
 DEGENERATE_GAP = 1e-12      # relative eigenvalue gap below which MUSIC's signal / noise split is decided by rounding (see _check_azimuth)
 
 
+def _fold90(a):
+    a = np.asarray(a, dtype=np.float64)
+    return np.where(a == -90.0, 90.0, a)
+
+
 def _check_azimuth(pkg, record_property, sc, rp, got, want, ra_dev, ra_ref):
     """MUSIC separates the L = numDets largest eigenvalues from the rest (music.m:21-25).  A perturbation of the size of fp64 rounding (eps w0) rotates the split subspace by
     ~ eps w0 / gap: with a relative gap >= 1e-12 that is <= 2e-4 rad -- invisible on the 1-degree scan -- and the chain's azimuth list is compared as it is ("chain").
@@ -67,7 +72,13 @@ def _check_azimuth(pkg, record_property, sc, rp, got, want, ra_dev, ra_ref):
     w = np.sort(np.linalg.eigvalsh(ra_ref))[::-1]
     n_sig = min(int(want.rngEst.size), sc.A - 1)
     if n_sig < 1 or (w[n_sig - 1] - w[n_sig]) >= DEGENERATE_GAP * w[0]:
-        assert np.array_equal(got.aziEst, want.aziEst)
+        if not np.array_equal(got.aziEst, want.aziEst):
+            # +90 and -90 degrees are ONE steering vector at half-wavelength spacing (exp(-j pi m sind(+-90)) = (-1)^m): the two scan points carry the same spectrum value up
+            # to the rounding of their sincos arguments, so which of them findpeaks' descending sort lists first is rounding-defined (seed 1062: [90, -90] vs [-90, 90]).
+            # Everything else about the list must agree.
+            assert np.array_equal(_fold90(got.aziEst), _fold90(want.aziEst)) and np.array_equal(np.sort(got.aziEst), np.sort(want.aziEst)), (got.aziEst, want.aziEst)
+            record_property("azimuth", "chain_pm90_tie")
+            return
         record_property("azimuth", "chain")
         return
     l_eff = min(int((w > 1e-9 * w[0]).sum()), sc.A - 1)
@@ -78,6 +89,10 @@ def _check_azimuth(pkg, record_property, sc, rp, got, want, ra_dev, ra_ref):
         return
     a = O.music_doa(l_eff, sc.rp, ra_ref)
     b = pkg.sensing.estimation.doaEstimation.music(l_eff, rp, ra_dev)
+    if b[0] == a[0] and not np.array_equal(b[1], a[1]):                    # the +-90 degree pair again (one steering vector, see above): order rounding-defined
+        assert np.array_equal(_fold90(b[1]), _fold90(a[1])) and np.array_equal(np.sort(b[1]), np.sort(a[1])), (b[1], a[1])
+        record_property("azimuth", "stage_at_rank_pm90_tie")
+        return
     assert b[0] == a[0] and np.array_equal(b[1], a[1])
     record_property("azimuth", "stage_at_rank")
 
