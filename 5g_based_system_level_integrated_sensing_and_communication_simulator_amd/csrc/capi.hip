@@ -389,7 +389,8 @@ namespace {
 struct DevPool {
   std::mutex m;
   std::multimap<size_t, void*> parked[16];
-  std::map<void*, size_t> size_of[16];
+  struct Blk { size_t bytes; bool parked; };
+  std::map<void*, Blk> size_of[16];                // every block the pool has handed out or holds
   size_t parked_bytes[16] = {0};
   size_t cap = 16384ull << 20;
   DevPool() { if (const char* e = std::getenv("ISAC_DEV_POOL_MB")) cap = (size_t)std::strtoull(e, nullptr, 10) << 20; }
@@ -408,12 +409,13 @@ extern "C" int isac_dev_alloc(isac_ctx* ctx, size_t bytes, void** dptr) {
     if (it != P.parked[dev].end() && it->first <= want + want / 4 + 65536) {
       *dptr = it->second;
       P.parked_bytes[dev] -= it->first;
+      P.size_of[dev][it->second].parked = false;
       P.parked[dev].erase(it);
       return ISAC_OK;
     }
   }
   ISAC_HIP(hipMalloc(dptr, want));
-  if (P.cap) { std::lock_guard<std::mutex> lk(P.m); P.size_of[dev][*dptr] = want; }
+  if (P.cap) { std::lock_guard<std::mutex> lk(P.m); P.size_of[dev][*dptr] = DevPool::Blk{want, false}; }
   return ISAC_OK;
 }
 extern "C" int isac_dev_free(isac_ctx* ctx, void* dptr) {
@@ -431,9 +433,11 @@ extern "C" int isac_dev_free(isac_ctx* ctx, void* dptr) {
       std::lock_guard<std::mutex> lk(P.m);
       auto so = P.size_of[dev].find(dptr);
       if (so == P.size_of[dev].end()) { release.push_back(dptr); }                     // not ours (allocated with the pool disabled): straight back to the driver
+      else if (so->second.parked) return fail(ctx, ISAC_ERR_INVALID_ARG, "isac_dev_free: this block has been freed already");
       else {
-        P.parked[dev].emplace(so->second, dptr);
-        P.parked_bytes[dev] += so->second;
+        so->second.parked = true;
+        P.parked[dev].emplace(so->second.bytes, dptr);
+        P.parked_bytes[dev] += so->second.bytes;
         while (P.parked_bytes[dev] > P.cap && !P.parked[dev].empty()) {                // over the cap: the largest parked block goes back
           auto big = std::prev(P.parked[dev].end());
           P.parked_bytes[dev] -= big->first;

@@ -1,21 +1,26 @@
-// CDL downlink apply in the FREQUENCY domain: overlap-save with 4096-point transforms (gfx950; round 6).
+// CDL channel apply in the FREQUENCY domain: overlap-save with 4096-point transforms, downlink and uplink (gfx950; round 6).
 //
-// Reference seam: rxWaveform = obj.ChannelModel(rxWaveform) at +communication/+phyLayer/uePhy.m:729-731, nrCDLChannel configured in
-// +parameters/+channelModels/+communication/cdl.m:57-64.  TR 38.901 7.7.1 with sample-and-hold path gains:
+// Reference seam: rxWaveform = obj.ChannelModel(rxWaveform) at +communication/+phyLayer/uePhy.m:729-731 (DL) and gNBPhy.m:833-864 (UL), nrCDLChannel configured in
+// +parameters/+channelModels/+communication/cdl.m:57-64 / :78-85.  TR 38.901 7.7.1 with sample-and-hold path gains:
 //     y[t, u] = scale * sum_n sum_k g_n[k] sum_s H_b(t)[n][s][u] x[t - shift_n - k, s]
 // Inside one gain block b the channel is linear and time invariant (the gains of an OUTPUT sample's block multiply every tap that reaches it):
 //     y_u = sum_s c_{s,u} * x_s ,   c_{s,u}[m] = sum_n H_b[n][s][u] g_n[m - shift_n] ,   0 <= m <= max_shift + n_taps - 1  (<= 476 samples at 122.88 MHz)
-// The time-domain kernels (cdl.hip) contract X [T x 64] against all 23 paths (1.09 GF issued per CDL-A job at config 5's shape, 3M form) and filter afterwards.  Here:
-//   K1  cdl_os_fwd_kernel   X_s(f) of every 4096-sample window (step S = 4096 - Mpad) of every DISTINCT waveform of the batch -- the UEs of a cell and slot receive one waveform
-//                           (uePhy.m:729-731 inside the per-UE loop): its 18 x 64 transforms are shared by all of them;
-//   K2  cdl_os_mix_kernel   per (8-bin tile, up to eight (job, gain block) pairs on one waveform): C(f)[s][u] = sum_n H[n][s][u] E_n(f) formed in registers
-//                           (E_n(f) = sum_k g_n[k] exp(-2 pi j f (shift_n + k) / 4096): one small table per delay profile), then  Y(f)[u] = sum_s C(f)[s][u] X_s(f)  for every window,
-//                           the X tile of a window staged ONCE in LDS for all eight pairs;
-//   K3  cdl_os_inv_kernel   y of every (pair, window, receive element): inverse transform, the first Mpad (aliased) samples dropped, the samples of the pair's gain block kept.
-// Per CDL-A job at config 5's shape: 2 x 4096 x (23 x 64 + 18 x 64) complex multiply-adds = 0.17 GF on the VALU + 36 inverse transforms, plus a fifth of the waveform's
-// forward transforms -- against 1.09 GF of MFMA issue + 0.18 GF of filter FMAs.  Every output sample is produced by exactly one (pair, window): no accumulation across launches,
-// results independent of the batch composition.  Envelope: downlink with two receive elements, 8 / 16 / 32 / 64 transmit elements, T >= 2 windows; everything else (and
-// ISAC_CDL_TIME_DOMAIN=1) stays on the time-domain kernels.  Against the oracle <= 1e-10 (tests/test_gpu_cdl_config5.py), against the time-domain kernels <= 1e-12.
+// The time-domain kernels (cdl.hip) contract X [T x 64] against all 23 paths (1.09 GF issued per CDL-A job at config 5's shape, 3M form) and filter afterwards.  Here, per
+// (job, gain block) PAIR and 4096-sample window (step S = 4096 - Mpad):
+//   DOWNLINK (8 / 16 / 32 / 64 -> 2)
+//   K1  cdl_os_fwd_kernel        X_s(f) of every window of every DISTINCT waveform of the batch -- the UEs of a cell and slot receive one waveform (uePhy.m:729-731 inside the
+//                                per-UE loop): its 18 x 64 transforms are shared by all of them;
+//   K2  cdl_os_mix_mfma_kernel   (64 transmit elements) per (16-bin tile, up to four pairs on one waveform): C(f) = sum_n H_n E_n(f) on v_mfma_f64_16x16x4_f64 (E_n(f) = the transfer
+//                                function of path n's delay filter: one table per delay profile, cdl_os_table_kernel), then Y(f) = C(f) X(f) per window with one LDS read per four
+//                                complex multiply-adds;   cdl_os_mix_kernel: the first, all-VALU form (8-bin tiles, eight pairs), kept for 8 / 16 / 32 transmit elements;
+//   K3  cdl_os_inv_kernel        y of every (pair, window, receive element): inverse transform, the first Mpad (aliased) samples dropped, the samples of the pair's gain block kept.
+//   UPLINK (1 / 2 -> many)
+//   K1 with the plain [s][4096] layout, then cdl_os_ul_kernel: one workgroup per (pair, receive element) -- the combined impulse responses transformed once, Y_u(f) formed in the
+//   inverse transform's registers; no mix launch, no Y spectra.
+// Per CDL-A downlink job at config 5's shape 0.15 GF (matrix + vector pipe) + 36 inverse transforms + a fifth of the waveform's forward transforms -- against 1.09 GF of MFMA issue
+// + 0.18 GF of filter FMAs.  Every output sample is produced by exactly one (pair, window): no accumulation across launches, results independent of the batch composition.
+// Envelope: T >= 2 windows, Mpad <= 1024; everything else (and ISAC_CDL_TIME_DOMAIN=1 / ISAC_CDL_UL_TIME_DOMAIN=1) stays on the time-domain kernels.  Against the oracle <= 1e-10
+// (tests/test_gpu_cdl_config5.py), against the time-domain kernels <= 1e-12.
 #include <algorithm>
 #include <cstring>
 #include <map>
