@@ -569,7 +569,8 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
     ctxs_cdl, ctx_csi = [pkg.Context(local_rank) for _ in range(max(1, n_cdl_ctx))], pkg.Context(local_rank)
     ctx_cdl = ctxs_cdl[0]
     n_buf = -(-args.inflight // max(len(mine), 1))
-    sense = [Cell(pkg, local_rank, c, args.ants, args.slots, args.targets, pool=pool, n_buf=min(n_buf, 2)) for c in mine]
+    lazy_native = 48 < args.ants <= 64 and args.targets <= 2 and args.echo != "array"      # the sensing CPIs keep their echo grids lazy where that is native (bench --echo)
+    sense = [Cell(pkg, local_rank, c, args.ants, args.slots, args.targets, pool=pool, n_buf=min(n_buf, 2), lazy=lazy_native) for c in mine]
     comm = [CommCell(pkg, ctxs_cdl, ctx_csi, c, args.ants, args.ues) for c in mine]
 
     def barrier():
