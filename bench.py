@@ -615,6 +615,8 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
     reports_done()
     barrier()
     dt = time.perf_counter() - t0
+    if reporter is not None:
+        reporter.shutdown(wait=True)
     os.write(2, f"bench.py: rank {rank}/{world}: device {local_rank}, {len(mine)} cell(s) {mine}, timed region {1e3 * dt:.3f} ms for {args.steps} frame(s), config5\n".encode())
     recs = np.array([d.make_record(cid, sc.last, dt, ue_reports=cc.last_reports, ue_ranks=cc.last_ranks, ue_srs=cc.last_srs, srs_band=CommCell.SRS_BAND) for cid, sc, cc in zip(mine, sense, comm)]).reshape(-1, d.RECORD_LEN)
     on_gpu = dist is not None and dist.get_backend() == "nccl"

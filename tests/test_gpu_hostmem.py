@@ -34,19 +34,22 @@ def test_round_trip_through_the_bounce_buffer(pkg, n_bytes):
 
 def test_pool_hands_a_parked_block_out_again(pkg):
     ctx = pkg.default_context()
-    a = ctx.empty((1 << 16,), np.complex128)            # 1 MB
+    n = 77_777                                          # (an element count no other test uses: the pool serves the smallest parked block that fits, oldest first)
+    a = ctx.empty((n,), np.complex128)                  # 1.24 MB
     p = a.ptr
     a.free()
-    b = ctx.empty((1 << 16,), np.complex128)
+    b = ctx.empty((n,), np.complex128)
     assert b.ptr == p                                   # the parked block, not a new allocation
-    c = ctx.empty((1 << 16,), np.complex128)
+    c = ctx.empty((n,), np.complex128)
     assert c.ptr != p                                   # b still holds it
-    big = ctx.empty((1 << 22,), np.complex128)          # 64 MB: nothing parked fits
+    big = ctx.empty((n * 64,), np.complex128)           # 80 MB: the parked 1.24 MB block cannot serve it
     assert big.ptr not in (b.ptr, c.ptr)
-    small = ctx.empty((100,), np.complex128)
     b.free()
-    again = ctx.empty(((1 << 16) - 1000,), np.complex128)    # within the 25 % + 64 KB slack of the parked 1 MB block
-    assert again.ptr == p and small.ptr != p
+    again = ctx.empty((n - 1000,), np.complex128)       # within the 25 % + 64 KB slack of the parked block
+    assert again.ptr == p
+    import ctypes as C
+    again.free()
+    assert ctx.lib.isac_dev_free(ctx.handle, C.c_void_p(p)) != 0     # freeing a parked block again is refused (ISAC_ERR_INVALID_ARG), not queued twice
 
 
 def test_allocate_upload_compute_free_cycles(pkg):
