@@ -254,6 +254,11 @@ class Context:
         False = memset of the row flags + one CFAR workgroup per antenna + a separate count kernel (ISAC_OPT_TAIL_FUSION, include/isac.h)."""
         self.check(self.lib.isac_ctx_set_option(self.handle, C.c_int32(1), C.c_int32(1 if on else 0)))
 
+    def set_cdl_share_spectra(self, on: bool):
+        """ISAC_OPT_CDL_SHARE_SPECTRA: consecutive overlap-save downlink batches on the SAME waveform arrays share their forward transforms (the caller promises the
+        waveforms are not rewritten in between; see include/isac.h)."""
+        self.check(self.lib.isac_ctx_set_option(self.handle, C.c_int32(3), C.c_int32(1 if on else 0)))
+
     def set_wide_order(self, on: bool):
         """ISAC_OPT_WIDE_ORDER: fft2D's covariance on the main stream, every narrow kernel on the second (see include/isac.h)."""
         self.check(self.lib.isac_ctx_set_option(self.handle, C.c_int32(2), C.c_int32(1 if on else 0)))

@@ -337,7 +337,7 @@ extern "C" int isac_ctx_destroy(isac_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->beam, &ctx->coef, &ctx->phase_rx, &ctx->steer, &ctx->dgrid,
                     &ctx->ymid, &ctx->pwin, &ctx->flags, &ctx->det_cut, &ctx->det_pow, &ctx->det_cnt, &ctx->cov_part,
                     &ctx->cov, &ctx->eig_w, &ctx->eig_v, &ctx->eig_scratch, &ctx->spec, &ctx->misc, &ctx->stage_a, &ctx->stage_b, &ctx->seg,
-                    &ctx->stage_c, &ctx->sind_tab, &ctx->cdl_h, &ctx->echo_own};
+                    &ctx->stage_c, &ctx->sind_tab, &ctx->cdl_h, &ctx->echo_own, &ctx->os_x};
   for (DevBuf* b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -1109,6 +1109,7 @@ extern "C" int isac_ctx_set_option(isac_ctx* ctx, int32_t option, int32_t value)
     case ISAC_OPT_MUSIC_ROUTE: ctx->music_route = value; return ISAC_OK;          // 0 = signal-subspace eigensolver (default), 1 = full eig
     case ISAC_OPT_TAIL_FUSION: ctx->tail_fusion = value; return ISAC_OK;          // 1 = one Doppler + CFAR launch (default), 0 = separate kernels
     case ISAC_OPT_WIDE_ORDER: ctx->wide_order = value; return ISAC_OK;            // 1 = covariance on the main stream, the narrow kernels on the second
+    case ISAC_OPT_CDL_SHARE_SPECTRA: ctx->cdl_share_spectra = value; ctx->os_valid = false; return ISAC_OK;   // 1 = consecutive downlink batches on the same waveforms share their forward transforms
     default: return fail(ctx, ISAC_ERR_INVALID_ARG, "unknown option");
   }
 }

@@ -444,7 +444,11 @@ bool cdl_os_ul_ok(long long T, int Nt, int Nr, int n_paths, int n_taps, int max_
 // jobs: the batch of isac_cdl_apply_batch_dev (cdl.hip); one launch sequence for all of them.
 int cdl_os_apply(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long T, int Nt, int Nr, int n_paths, const double* taps, int n_taps, const int32_t* shift, int max_shift,
                  double out_scale) {
-  const int Mpad = (max_shift + n_taps - 1 + 7) / 8 * 8, S = kOsN - Mpad;
+  int Mpad = (max_shift + n_taps - 1 + 7) / 8 * 8;
+  // ISAC_OPT_CDL_SHARE_SPECTRA: every delay profile takes the same window step (Mpad rounded up to 512 where the profile needs no more: CDL-A .. CDL-E at 122.88 MHz need
+  // 300-480 samples), so that the spectra of one batch serve the next batch of ANOTHER profile on the same waveforms
+  if (ctx->cdl_share_spectra && Nr <= Nt && Mpad <= 512) Mpad = 512;
+  const int S = kOsN - Mpad;
   const int n_seg = (int)((T + S - 1) / S);
   static const bool no_mfma = std::getenv("ISAC_CDL_OS_VALU") != nullptr;       // development switch: the first (all-VALU) mix kernel for every shape
   const bool ul = Nr > Nt;                                                      // uplink form: cdl_os_ul_kernel, no mix launch, no Y spectra
@@ -500,10 +504,17 @@ int cdl_os_apply(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long 
   auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t e_bytes = ul ? 0 : pad(sizeof(c64) * (size_t)n_paths * kOsN), x_bytes = pad(sizeof(c64) * waves.size() * (size_t)n_seg * Nt * kOsN),
                y_bytes = ul ? 0 : pad(sizeof(c64) * (size_t)n_tasks * Nr * kOsN);
-  ISAC_TRY(ensure(ctx, ctx->stage_b, e_bytes + x_bytes + y_bytes));
+  // the X spectra live in a buffer of their own when they may be reused by the next call (a scratch buffer shared with other entry points could not promise that)
+  const bool share = ctx->cdl_share_spectra && !ul;
+  const int tb_log2 = ul ? 12 : (mfma_mix ? 4 : 3);
+  std::vector<const void*> wave_ids(waves.begin(), waves.end());
+  const bool reuse = share && ctx->os_valid && ctx->os_T == T && ctx->os_nt == Nt && ctx->os_mpad == Mpad && ctx->os_tb == tb_log2 && ctx->os_waves == wave_ids &&
+                     ctx->os_x.cap >= x_bytes;
+  if (share && !reuse) { ctx->os_valid = false; ISAC_TRY(ensure(ctx, ctx->os_x, x_bytes)); }
+  ISAC_TRY(ensure(ctx, ctx->stage_b, e_bytes + (share ? 0 : x_bytes) + y_bytes));
   c64* d_E = (c64*)ctx->stage_b.p;
-  c64* d_X = (c64*)((char*)ctx->stage_b.p + e_bytes);
-  c64* d_Y = (c64*)((char*)ctx->stage_b.p + e_bytes + x_bytes);
+  c64* d_X = share ? (c64*)ctx->os_x.p : (c64*)((char*)ctx->stage_b.p + e_bytes);
+  c64* d_Y = (c64*)((char*)ctx->stage_b.p + e_bytes + (share ? 0 : x_bytes));
   const size_t o_pairs = 0, o_chunks = o_pairs + pad(sizeof(OsPair) * ordered.size()), o_tasks = o_chunks + pad(sizeof(OsChunk) * chunks.size()),
                o_waves = o_tasks + pad(sizeof(OsTask) * tasks.size()), o_taps = o_waves + pad(sizeof(void*) * waves.size()), o_shift = o_taps + pad(sizeof(double) * (size_t)n_paths * n_taps),
                meta = o_shift + pad(sizeof(int) * (size_t)n_paths);
@@ -549,9 +560,12 @@ int cdl_os_apply(isac_ctx* ctx, const isac_cdl_job* jobs, int n_jobs, long long 
   ISAC_HIP(hipGetLastError());
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cdl_os_fwd_kernel), lds));
   ISAC_TRY(allow_lds(ctx, reinterpret_cast<const void*>(cdl_os_inv_kernel), lds));
-  hipLaunchKernelGGL(cdl_os_fwd_kernel, dim3((unsigned)n_seg, (unsigned)Nt, (unsigned)waves.size()), dim3(256), lds, ctx->stream, (const c64* const*)(dm + o_waves), T, Nt, n_seg, S,
-                     Mpad, tw, mfma_mix ? 4 : 3, d_X);
-  ISAC_HIP(hipGetLastError());
+  if (!reuse) {
+    hipLaunchKernelGGL(cdl_os_fwd_kernel, dim3((unsigned)n_seg, (unsigned)Nt, (unsigned)waves.size()), dim3(256), lds, ctx->stream, (const c64* const*)(dm + o_waves), T, Nt, n_seg, S,
+                       Mpad, tw, tb_log2, d_X);
+    ISAC_HIP(hipGetLastError());
+    if (share) { ctx->os_waves = wave_ids; ctx->os_T = T; ctx->os_nt = Nt; ctx->os_mpad = Mpad; ctx->os_tb = tb_log2; ctx->os_valid = true; }
+  }
   if (ctx->profile) ISAC_HIP(hipEventRecord(ctx->ev_k0, ctx->stream));          // isac_profile_*: brackets the mix launch (the arithmetic of the apply)
   const dim3 gm(kOsN / kOsBins, (unsigned)chunks.size());
 #define ISAC_OS_MIX(HS) hipLaunchKernelGGL((cdl_os_mix_kernel<HS>), gm, dim3(256), 0, ctx->stream, (const OsPair*)(dm + o_pairs), (const OsChunk*)(dm + o_chunks), (const c64*)d_X, \

@@ -163,6 +163,12 @@ struct isac_ctx {
   isac::Fft2dPending pending;
   isac::RangeCache range_cache;
   isac::LazyEcho lazy;               // the echo grid of the last fused monoStaticSensing call when the caller passed no array for it
+  // overlap-save CDL apply (cdl_os.hip): the forward spectra of the last downlink batch, kept in a buffer of their own so that the NEXT batch on this context can reuse them when
+  // ISAC_OPT_CDL_SHARE_SPECTRA is set and it names the same waveforms (the UEs of a cell receive one waveform whatever their delay profile: uePhy.m:724-731)
+  isac::DevBuf os_x;
+  std::vector<const void*> os_waves;
+  long long os_T = 0; int os_nt = 0, os_mpad = 0, os_tb = 0; bool os_valid = false;
+  int cdl_share_spectra = 0;
   isac::DevBuf echo_own;             // ... and its storage when it has to exist in memory (LazyEcho::native == false)
   isac::StageSlot stage_ring[isac::kStageSlots];   // pinned->device parameter uploads (stage_acquire / stage_commit)
   int stage_next = 0;

@@ -393,12 +393,14 @@ class CommCell:
     WITH_SRS = os.environ.get("ISAC_C5_NO_SRS") is None          # round 6: the gNB's SRS measurement of every UE (gNBPhy.m:1023-1060)
     SRS_BAND = 16
     BATCH_OCCASIONS = os.environ.get("ISAC_C5_CSI_PER_OCCASION") is None   # round 6: a cell's four CSI-RS occasions of the frame as one batch
+    SHARE = os.environ.get("ISAC_C5_NO_SHARE") is None                     # round 6: the two delay-profile groups of a cell share the forward transforms of their slot waveforms
     DEVICE_CSI = os.environ.get("ISAC_C5_HOST_CSI") is None
 
     def __init__(self, pkg, ctxs_cdl, ctx_csi, cell_id, n_ants, n_ues):
         CM, self.PL, L = pkg.communication.channelModels, pkg.communication.phyLayer, pkg._lib
         ctx_cdl = ctxs_cdl[0]
         self.CM, self.ctx, self.ctxs, self.ctx_csi, self.n_ues, self.A = CM, ctx_cdl, list(ctxs_cdl), ctx_csi, n_ues, n_ants
+        self.cell_id = cell_id
         rng = np.random.default_rng(0xC5000 + cell_id)
         self.los = rng.random(n_ues) < 0.5
         nt_shape = (n_ants // 16, 8, 2, 1, 1) if n_ants >= 16 else (1, n_ants // 2, 2, 1, 1)
@@ -472,7 +474,10 @@ class CommCell:
             for gi, (g, rx, gn) in enumerate(zip(self.groups, self.rx, self.gains)):
                 slots = range(s0, min(s0 + self.SLOTS_PER_CALL, self.DL_SLOTS))
                 # (one context per delay-profile group: the filter launch of one group runs beside the contraction launch of the other)
-                self.CM.applyCDLBatch([self.chans[u] for s_ in slots for u in g], [self.waves[s_] for s_ in slots for u in g], ctx=self.ctxs[gi % len(self.ctxs)],
+                # (round 6: both delay-profile groups of a cell on ONE context -- with ISAC_OPT_CDL_SHARE_SPECTRA the second group's call reuses the forward transforms of the
+                #  first: the UEs of a cell receive the same slot waveforms; ISAC_C5_NO_SHARE=1: one context per group as in rounds 4-5)
+                c_ = self.ctxs[(self.cell_id if self.SHARE else gi) % len(self.ctxs)]
+                self.CM.applyCDLBatch([self.chans[u] for s_ in slots for u in g], [self.waves[s_] for s_ in slots for u in g], ctx=c_,
                                       outs=[rx[(s_ - s0) * len(g) + i] for s_ in slots for i in range(len(g))], gains=gn)
         if self.WITH_UL:                                      # the frame's four 'U' slots: every UE's packet into the gNB array, one call per group (a channel that
             for gi, g in enumerate(self.groups):              # appears four times advances its time from slot to slot)
@@ -568,6 +573,9 @@ def run_config5(args, pkg, rank, world, local_rank, dist, torch):
     n_cdl_ctx = int(os.environ.get("ISAC_C5_CDL_CONTEXTS", "2"))
     ctxs_cdl, ctx_csi = [pkg.Context(local_rank) for _ in range(max(1, n_cdl_ctx))], pkg.Context(local_rank)
     ctx_cdl = ctxs_cdl[0]
+    if CommCell.SHARE:
+        for c_ in ctxs_cdl:
+            c_.set_cdl_share_spectra(True)
     n_buf = -(-args.inflight // max(len(mine), 1))
     lazy_native = 48 < args.ants <= 64 and args.targets <= 2 and args.echo != "array"      # the sensing CPIs keep their echo grids lazy where that is native (bench --echo)
     sense = [Cell(pkg, local_rank, c, args.ants, args.slots, args.targets, pool=pool, n_buf=min(n_buf, 2), lazy=lazy_native) for c in mine]

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 /* Bumped on EVERY change of a struct layout, enum value or entry-point signature below (1: round 1; 2: ISAC_MAX_EST 1024 -> 4096,
- * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve, isac_prg_precode_dev, isac_cdl_freq_response_dev, isac_cdl_csi_estimate_batch_dev; 7: the lazy echo grid -- d_echo_grid / d_rx_grid may be NULL --, isac_echo_grid_materialize_dev, isac_sensing_submit_n / isac_sensing_collect_n, isac_csi_report.ri_total_sinr, isac_pusch_codebook, isac_srs_pmi_select_batch_dev).  A host must
+ * noise modes 3 / 4, the fused / cached / windowed / CDL / CSI entry points; 3: isac_abi_sizeof, isac_ctx_set_option, isac_eigh_top; 4: ISAC_OPT_WIDE_ORDER, isac_ctx_share_streams; 5: isac_cdl_apply_batch_dev, isac_cdl_path_gains_dev, isac_csi_report_batch_dev; 6: isac_ctx_reserve, isac_prg_precode_dev, isac_cdl_freq_response_dev, isac_cdl_csi_estimate_batch_dev; 7: the lazy echo grid -- d_echo_grid / d_rx_grid may be NULL --, isac_echo_grid_materialize_dev, isac_sensing_submit_n / isac_sensing_collect_n, isac_csi_report.ri_total_sinr, isac_pusch_codebook, isac_srs_pmi_select_batch_dev, ISAC_OPT_CDL_SHARE_SPECTRA).  A host must
  * compare isac_abi_version() with the ISAC_ABI_VERSION it was compiled against AND isac_abi_sizeof() with its own sizeof of every
  * struct it passes: the library writes whole structs (isac_est_result is 128 KB) into caller memory. */
 #define ISAC_ABI_VERSION 7
@@ -350,7 +350,14 @@ int isac_eigh_top(isac_ctx* ctx, const isac_c64* H, int32_t A, int32_t n_top, do
  *                The main stream is NOT joined behind that sequence at submit time; any later call on the SAME context other than
  *                isac_fft2d_collect first makes the main stream wait for the pending submit's completion event, so a host that
  *                re-uses a context without collecting loses the overlap but never races its own buffers. */
-enum { ISAC_OPT_MUSIC_ROUTE = 0, ISAC_OPT_TAIL_FUSION = 1, ISAC_OPT_WIDE_ORDER = 2 };
+/* ISAC_OPT_CDL_SHARE_SPECTRA (round 6)  overlap-save downlink applies (isac_cdl_apply_batch_dev on long waveforms):
+ *   0 (default)  every call transforms the waveforms of its batch;
+ *   1            the forward spectra of a call stay in the context, and the NEXT downlink batch on this context reuses them when it names exactly the same waveform pointers
+ *                (same order), length and transmit-element count -- the UEs of a cell receive ONE slot waveform whatever their delay profile (uePhy.m:724-731), so the second
+ *                profile's call of a cell-slot skips a third of the path.  All profiles then share one window step (Mpad = 512 samples where they need no more).  The CALLER
+ *                promises that those waveforms were not rewritten between the two calls; any other call pattern simply transforms again.  Same results to rounding (the window
+ *                boundaries move: <= 1e-12 against the default). */
+enum { ISAC_OPT_MUSIC_ROUTE = 0, ISAC_OPT_TAIL_FUSION = 1, ISAC_OPT_WIDE_ORDER = 2, ISAC_OPT_CDL_SHARE_SPECTRA = 3 };
 int isac_ctx_set_option(isac_ctx* ctx, int32_t option, int32_t value);
 
 /* A host that keeps several CPIs in flight on one device uses one context per CPI (buffers, scratch, pending result).  By default each

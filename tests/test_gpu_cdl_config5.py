@@ -132,6 +132,46 @@ def test_cdl_overlap_save_uplink_shapes_match_oracle(pkg, profile, rx, fs, t_len
         assert rel(o.numpy(), want) < RTOL, (profile, rx, u)
 
 
+def test_shared_forward_spectra_between_delay_profile_groups(pkg):
+    """ISAC_OPT_CDL_SHARE_SPECTRA: the CDL-D UEs and the CDL-A UEs of a cell receive the same two slot waveforms; their two batched calls on one context share the forward
+    transforms (common window step, Mpad = 512) -- every output <= 1e-10 of the oracle and <= 1e-12 of the un-shared calls; a call on OTHER waveforms in between transforms anew,
+    and so does the same pointer list after the option is switched off."""
+    import oracle.cdl as OC
+    CM = pkg.communication.channelModels
+    T = 61909
+    rng = np.random.default_rng(99)
+    xs = [np.asfortranarray(rng.standard_normal((T, 64)) + 1j * rng.standard_normal((T, 64))) for _ in range(3)]
+    outs = {}
+    for share in (True, False):
+        ctx = pkg.Context(0)
+        ctx.set_cdl_share_spectra(share)
+        d_xs = [ctx.to_device(x) for x in xs]
+        res = []
+        for profile, n_ue in (("CDL-D", 2), ("CDL-A", 3)):
+            chans = [CM.CDLChannel(profile, 300e-9, 3.5e9, GNB64, UE, FS, Seed=73 + u) for u in range(n_ue)]
+            for ch in chans:
+                ch.time = 0.004
+            o = CM.applyCDLBatch([chans[u] for s_ in range(2) for u in range(n_ue)], [d_xs[s_] for s_ in range(2) for u in range(n_ue)], ctx=ctx)
+            res.append([a.numpy() for a in o])
+        # other waveforms: (x2, x0) -- a different pointer list, transformed anew; then the first list again
+        ch = CM.CDLChannel("CDL-A", 300e-9, 3.5e9, GNB64, UE, FS, Seed=80)
+        ch.time = 0.004
+        o2 = CM.applyCDLBatch([ch, ch], [d_xs[2], d_xs[0]], ctx=ctx)
+        res.append([a.numpy() for a in o2])
+        outs[share] = res
+    for a_l, b_l in zip(outs[True], outs[False]):
+        for a, b in zip(a_l, b_l):
+            assert rel(a, b) < 1e-12
+    for gi, (profile, n_ue) in enumerate((("CDL-D", 2), ("CDL-A", 3))):
+        for j in range(2 * n_ue):
+            s_, u = divmod(j, n_ue)
+            cfg = OC.cdl_config(profile, 3.5e9, GNB64, UE, FS, seed=73 + u)
+            want = OC.apply_cdl(cfg, xs[s_], 0.004 + s_ * T / FS)
+            assert rel(outs[True][gi][j], want) < RTOL, (profile, s_, u)
+    cfg = OC.cdl_config("CDL-A", 3.5e9, GNB64, UE, FS, seed=80)
+    assert rel(outs[True][2][0], OC.apply_cdl(cfg, xs[2], 0.004)) < RTOL and rel(outs[True][2][1], OC.apply_cdl(cfg, xs[0], 0.004 + T / FS)) < RTOL
+
+
 def test_bench_config5_frame_against_oracle(pkg):
     """bench.py's CommCell (the object `--workload config5` times) stepped for one frame: (a) the precoded PDSCH input of a downlink slot = oracle prgPrecode of the
     same layers and precoders + the oracle's CP-OFDM modulator; (b) one downlink job of the frame's last call (UE, slot 15) and (c) one uplink job (UE, third 'U' slot:
