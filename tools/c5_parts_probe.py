@@ -7,6 +7,9 @@ import bench
 pkg = importlib.import_module(bench.PKG)
 pool = bench.SlotPool(pkg, 0, 8)
 ctxs = [pkg.Context(0) for _ in range(int(os.environ.get("ISAC_C5_CDL_CONTEXTS", "2")))]; ctx_csi = pkg.Context(0)
+if bench.CommCell.SHARE:
+    for c_ in ctxs:
+        c_.set_cdl_share_spectra(True)
 N = 21
 sense = [bench.Cell(pkg, 0, c, 64, 16, 1, pool=pool, n_buf=1) for c in range(N)]
 comm = [bench.CommCell(pkg, ctxs, ctx_csi, c, 64, 10) for c in range(N)]
