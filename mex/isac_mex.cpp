@@ -188,6 +188,18 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     auto it = g_arrays.find(h);
     if (it != g_arrays.end()) { check(isac_dev_free(ctx(), it->second.p)); g_arrays.erase(it); }
   // ------------------------------------------------------------------ context preparation
+  } else if (fn == "setOption") {
+    // isac_mex('setOption', name, value): 'musicRoute' | 'tailFusion' | 'wideOrder' | 'cdlShareSpectra' -> isac_ctx_set_option (include/isac.h: per-context algorithm switches;
+    // 'cdlShareSpectra' = 1 lets consecutive applyCDLBatch calls on the same waveform handles share their forward transforms)
+    if (nrhs < 3) mexErrMsgIdAndTxt("isac:INVALID_ARG", "usage: isac_mex('setOption', name, value)");
+    char* nm = mxArrayToString(prhs[1]);
+    const std::string name = nm ? nm : "";
+    mxFree(nm);
+    int opt = -1;
+    if (name == "musicRoute") opt = ISAC_OPT_MUSIC_ROUTE; else if (name == "tailFusion") opt = ISAC_OPT_TAIL_FUSION; else if (name == "wideOrder") opt = ISAC_OPT_WIDE_ORDER;
+    else if (name == "cdlShareSpectra") opt = ISAC_OPT_CDL_SHARE_SPECTRA;
+    if (opt < 0) mexErrMsgIdAndTxt("isac:INVALID_ARG", "setOption: unknown option name");
+    check(isac_ctx_set_option(ctx(), opt, (int32_t)mxGetScalar(prhs[2])));
   } else if (fn == "reserve") {
     // ms = isac_mex('reserve', waveformLength, txDimension, carrierInfo, radarParams, radarEstParams, cfar [, warm_ms])
     // One or more dry runs of monoStaticSensing -> fft2D at the caller's shape (isac_ctx_reserve): the reference calls that chain once per cell and
